@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the DistillBEV hot path on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RCCL = torch.distributed backend "nccl").  Samples are independent
+on the whole path, so ranks shard samples (weak scaling, fixed per-GPU batch); the only
+collective is the gradient all-reduce of the training-step workload.  W untimed warm-up
+steps, then exactly K timed steps bracketed by barrier + synchronize; MAX over ranks;
+rank 0 prints ONE JSON line (contract in the task statement; `roofline` and
+`cpu_baseline` objects added).  Inputs are synthetic, seeded, resident in HBM before the
+timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def _workloads():
+    import bench_workloads as W
+    return W.WORKLOADS
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback "
+                         "(only the cpu_baseline leg runs on the host)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=dev)
+    n_gpus = world
+
+    W = _workloads()
+    name = args.workload or W["default"]
+    wl = W[name](dev, rank, world)
+    steps = args.steps if args.steps is not None else wl.default_steps
+    warmup = args.warmup if args.warmup is not None else wl.default_warmup
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for _ in range(warmup):
+        wl.step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    wl.begin_timed()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = wl.roofline()          # live HIP-event timing of the dominant kernel (this rank)
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        cpu = wl.cpu_baseline()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+
+    if rank == 0:
+        units = wl.units_per_step * world * steps
+        line = {
+            "metric": "distill-train samples/sec (6-cam nuScenes, BEVDepth-R50) at 1/2/4/8 MI355X",
+            "value": units / dt,
+            "unit": "samples/s",
+            "n_gpus": n_gpus,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": wl.config(world),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""Workloads of bench.py.  Lives outside the product package because the cpu_baseline
+leg imports the oracle (only tests/, smoke() and this leg may)."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from distill_bev_amd import _lib as L
+from distill_bev_amd import lss as LSS
+from distill_bev_amd import synthetic as syn
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def _grid():
+    return LSS.gen_dx_bx([-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8], [-10.0, 10.0, 20.0])
+
+
+class _Base:
+    default_steps = 50
+    default_warmup = 10
+    units_per_step = 1
+
+    def begin_timed(self):
+        pass
+
+    def cpu_baseline(self):
+        return None
+
+
+class BevPoolCfg1(_Base):
+    """BASELINE.json configs[1]: the `bev_pool` op (reference call surface
+    mmdet3d/ops/bev_pool/bev_pool.py:83-97: rank, argsort, gather, interval detection,
+    extension forward; autograd backward) on 6-cam x D=59 x 16x44 frustum points,
+    C=64 -> 128x128 BEV.  One step = forward + backward over the per-GPU batch of
+    B=8 samples x F=2 frames = 16 six-camera frames in ONE bev_pool call."""
+    B, F, C = 8, 2, 64
+    units_per_step = 8  # samples per step per GPU
+
+    def __init__(self, dev, rank, world):
+        from distill_bev_amd.bev_pool import bev_pool
+        self.dev, self.rank = dev, rank
+        self.bev_pool = bev_pool
+        rng = np.random.default_rng(1234 + rank)
+        nf = self.B * self.F
+        rig = {k: torch.from_numpy(v) for k, v in syn.camera_rig(nf, rng).items()}
+        dx, bx, nx = _grid()
+        geom = LSS.get_geometry(LSS.create_frustum(), rig["rots"], rig["trans"], rig["intrins"],
+                                rig["post_rots"], rig["post_trans"])
+        coords, kept = LSS.voxel_coords_torch(geom, dx, bx, nx)
+        self.n = int(coords.shape[0])
+        self.coords = coords.to(dev)
+        g = torch.Generator().manual_seed(1234 + rank)
+        self.feats = torch.randn((self.n, self.C), generator=g).to(dev).requires_grad_(True)
+        self.nf = nf
+        self.gout = torch.randn((nf, self.C, 1, 128, 128), generator=g).to(dev)
+        ranks = coords[:, 0] * (128 * nf) + coords[:, 1] * nf + coords[:, 3]
+        self.n_int = int(torch.unique(ranks).numel())
+        self._geom_cpu = geom
+        self._kept_cpu = kept
+
+    def step(self):
+        self.feats.grad = None
+        out = self.bev_pool(self.feats, self.coords, self.nf, 1, 128, 128)
+        out.backward(self.gout)
+
+    def begin_timed(self):
+        L.enable_timing("dbev_bev_pool_forward")
+
+    def algorithmic_bytes(self):
+        # 4nC + 16n + 8 n_int + 4 B*Z*X*Y*C per forward launch
+        return 4 * self.n * self.C + 16 * self.n + 8 * self.n_int + 4 * self.nf * 128 * 128 * self.C
+
+    def roofline(self):
+        ms = L.timing_ms("dbev_bev_pool_forward")
+        L.disable_timing()
+        if not ms:
+            return None
+        avg_s = float(np.mean(ms)) * 1e-3
+        ach = self.algorithmic_bytes() / avg_s / 1e9
+        return {"bound": "hbm", "kernel": "bev_pool_fwd_vec4 (+ zero-fill of out), per dbev_bev_pool_forward call",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": len(ms),
+                "algorithmic_bytes_per_launch": self.algorithmic_bytes()}
+
+    def config(self, world):
+        return {"workload": "bev_pool fwd+bwd (BASELINE configs[1]): 16 six-cam frames "
+                            "(B=8 samples x 2 frames) x 59x16x44 pts, C=64 -> 128x128 BEV per GPU",
+                "global_batch": self.B * world, "frames_per_sample": self.F,
+                "points_kept_per_gpu": self.n, "intervals_per_gpu": self.n_int,
+                "parallelism": f"dp{world}"}
+
+    def cpu_baseline(self):
+        """Reference CPU path of the same splat (vt_mine.voxel_pooling op sequence restated
+        in oracle/lss_torch.py), forward + autograd backward, on ONE sample (2 frames),
+        all host cores."""
+        from oracle import lss_torch as OT
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        dx, bx, nx = _grid()
+        geom = self._geom_cpu[:2]
+        x = torch.randn((2, 6, 59, 16, 44, self.C)).requires_grad_(True)
+        g = torch.randn((2, self.C, 128, 128))
+        OT.voxel_pooling_cumsum(geom, x, dx, bx, nx).backward(g)  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            x.grad = None
+            OT.voxel_pooling_cumsum(geom, x, dx, bx, nx).backward(g)
+            reps += 1
+            if time.perf_counter() - t0 > 10.0 or reps >= 20:
+                break
+        dt = (time.perf_counter() - t0) / reps
+        return {"value": 1.0 / dt, "unit": "samples/s", "cores": ncores, "kind": "port",
+                "sample": f"{reps} x (splat fwd+bwd of 1 sample = 2 six-cam frames, C=64), "
+                          "torch CPU restatement of view_transformer_mine.voxel_pooling "
+                          "(argsort + cumsum trick), all host threads"}
+
+
+WORKLOADS = {"bev_pool": BevPoolCfg1, "default": "bev_pool"}

@@ -1,0 +1,125 @@
+"""ctypes binding of libdbev_hip.so (C ABI declared in include/dbev_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or was not built,
+``lib()`` raises.  Device pointers are passed as integers (``tensor.data_ptr()``);
+the HIP stream is torch's *current* stream so the kernels order correctly with the
+surrounding PyTorch-ROCm ops (the reference launched on the default stream,
+bev_pool_cuda.cu:88 -- noted in SURVEY 8b).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdbev_hip.so")
+_lib = None
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPES).  Must list EVERY symbol
+# include/dbev_hip.h declares (tests/test_abi.py cross-checks against the header).
+_SIGNATURES = {
+    "dbev_abi_version": [],
+    "dbev_target_arch": [],
+    "dbev_bev_pool_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "dbev_bev_pool_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+}
+_RESTYPES = {"dbev_target_arch": ctypes.c_char_p}
+
+
+class DbevHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DbevHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C distill_bev_amd/csrc` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the hot path.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is missing -> loud
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        _lib = h
+    return _lib
+
+
+# ---- optional live timing of individual ABI calls (bench.py roofline) ----
+_timers = {}
+
+
+def enable_timing(name):
+    """Record a HIP-event pair (on torch's current stream = the launch stream) around
+    every subsequent call of ABI entry `name`; read back with timing_ms()."""
+    _timers[name] = []
+
+
+def disable_timing(name=None):
+    if name is None:
+        _timers.clear()
+    else:
+        _timers.pop(name, None)
+
+
+def timing_ms(name):
+    """Per-call durations in ms of the recorded calls (synchronises)."""
+    torch.cuda.synchronize()
+    return [s.elapsed_time(e) for s, e in _timers.get(name, [])]
+
+
+def call(name, *args):
+    """Invoke ABI entry `name`, raising on a non-zero return code."""
+    fn = getattr(lib(), name)
+    rec = _timers.get(name)
+    if rec is not None:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        rec.append((s, e))
+    else:
+        rc = fn(*args)
+    check(rc, name)
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DbevHipError(f"{what} failed with code {rc}"
+                           + (" (invalid argument)" if rc == 10001 else " (hipError_t)"))
+
+
+def require_cuda(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise DbevHipError("libdbev_hip ops need device (HBM) tensors; got a CPU tensor. "
+                               "There is no CPU fallback in the product path.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise DbevHipError("all tensors of one op must live on the same GPU")
+    return dev
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

@@ -1,0 +1,56 @@
+"""Lift-Splat-Shoot geometry helpers -- host-side mirror of
+``mmdet3d/models/necks/view_transformer_mine.py`` (vt_mine).
+
+Frustum and ego-frame geometry are a few KB..MB of per-step camera arithmetic and
+stay in torch (same op sequence as vt_mine.py:98-139, so the fp32 values -- and the
+voxel indices derived from them -- are the reference's own).  The heavy part (voxel
+index, CSR build, lift x splat) lives in the HIP library (lift_splat.py).
+"""
+import torch
+
+
+def gen_dx_bx(xbound, ybound, zbound):
+    """vt_mine.py:14-18."""
+    dx = torch.Tensor([row[2] for row in [xbound, ybound, zbound]])
+    bx = torch.Tensor([row[0] + row[2] / 2.0 for row in [xbound, ybound, zbound]])
+    nx = torch.Tensor([(row[1] - row[0]) / row[2] for row in [xbound, ybound, zbound]])
+    return dx, bx, nx
+
+
+def create_frustum(input_size=(256, 704), downsample=16, dbound=(1.0, 60.0, 1.0)):
+    """vt_mine.py:98-109 -> f32[D, fH, fW, 3] (x_pix, y_pix, depth).  Built on the CPU
+    (torch.linspace's CPU kernel defines the reference bits) and moved by the caller."""
+    ogfH, ogfW = input_size
+    fH, fW = ogfH // downsample, ogfW // downsample
+    ds = torch.arange(*dbound, dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+    D = ds.shape[0]
+    xs = torch.linspace(0, ogfW - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+    ys = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+    return torch.stack((xs, ys, ds), -1).contiguous()
+
+
+def get_geometry(frustum, rots, trans, intrins, post_rots, post_trans):
+    """vt_mine.py:111-139 -> f32[B, N, D, fH, fW, 3] ego-frame location of every frustum
+    point (undo image augmentation, un-project with depth, camera -> ego)."""
+    B, N, _ = trans.shape
+    points = frustum - post_trans.view(B, N, 1, 1, 1, 3)
+    points = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(points.unsqueeze(-1))
+    points = torch.cat((points[..., :2, :] * points[..., 2:3, :], points[..., 2:3, :]), 5)
+    combine = rots.matmul(torch.inverse(intrins))
+    points = combine.view(B, N, 1, 1, 1, 3, 3).matmul(points).squeeze(-1)
+    points = points + trans.view(B, N, 1, 1, 1, 3)
+    return points
+
+
+def voxel_coords_torch(geom, dx, bx, nx):
+    """vt_mine.py:150-160 with torch ops (used by the bev_pool call surface of
+    view_transformer.py:140-169): returns (coords int64[n_kept, 4] = (x, y, z, b),
+    kept bool[Nprime])."""
+    B = geom.shape[0]
+    n_pts = geom.numel() // 3
+    idx = ((geom - (bx - dx / 2.0)) / dx).long().view(n_pts, 3)
+    batch_ix = torch.arange(B, device=geom.device, dtype=torch.long).repeat_interleave(n_pts // B)
+    idx = torch.cat((idx, batch_ix.view(-1, 1)), 1)
+    kept = ((idx[:, 0] >= 0) & (idx[:, 0] < nx[0]) & (idx[:, 1] >= 0) & (idx[:, 1] < nx[1])
+            & (idx[:, 2] >= 0) & (idx[:, 2] < nx[2]))
+    return idx[kept], kept

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ FROM THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py [lss] [voxel] [fgmask] [pillars] [gauss]
+
+Each section imports (or compiles) the reference's own implementation of one
+hot-path function, runs it on small seeded inputs and stores inputs + outputs
+as .npz.  Fixtures are data only; no reference source is copied.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_import as R  # noqa: E402
+from distill_bev_amd import synthetic as syn  # noqa: E402
+
+
+def _save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+
+
+# --------------------------------------------------------------------------
+def make_lss():
+    vt = R.vt_mine()
+    torch.manual_seed(0)
+
+    # ---- small case: grid 8x8x2, D=7, 3x5 feature map, 2 cams, B=2, C=4 ----
+    grid = dict(xbound=[-8.0, 8.0, 2.0], ybound=[-8.0, 8.0, 2.0],
+                zbound=[-4.0, 4.0, 4.0], dbound=[1.0, 8.0, 1.0])
+    data = dict(input_size=(48, 80))
+    m = vt.ViewTransformerLiftSplatShoot(grid_config=grid, data_config=data,
+                                         numC_input=8, numC_Trans=4, downsample=16)
+    rng = np.random.default_rng(11)
+    B, N = 2, 2
+    rig = syn.camera_rig(B, rng, n_cams=N, input_size=(48, 80), src_size=(100, 160))
+    # make the small rig see the small grid: shrink focal length, move cams
+    rig["intrins"][..., 0, 0] = 60.0
+    rig["intrins"][..., 1, 1] = 60.0
+    rig["intrins"][..., 0, 2] = 80.0
+    rig["intrins"][..., 1, 2] = 50.0
+    rig["post_trans"][..., 1] = -2.0
+    t = {k: torch.from_numpy(v) for k, v in rig.items()}
+    D, fH, fW = m.frustum.shape[:3]
+    C = 4
+    geom = m.get_geometry(t["rots"], t["trans"], t["intrins"], t["post_rots"], t["post_trans"])
+    # adversarial geometry: points exactly on cell borders, in (-1,0) cells (trunc vs floor)
+    geom = geom.clone()
+    g = geom.view(-1, 3)
+    g[0] = torch.tensor([-8.0, -8.0, -4.0])          # exactly lower corner -> (0,0,0)
+    g[1] = torch.tensor([-8.5, 0.0, 0.0])            # x in (-1,0) cell -> trunc gives 0 (kept!)
+    g[2] = torch.tensor([-10.0, 0.0, 0.0])           # x = -1 cell exactly -> idx -1 -> dropped
+    g[3] = torch.tensor([8.0, 0.0, 0.0])             # exactly upper bound -> idx 8 -> dropped
+    g[4] = torch.tensor([7.999999, 7.999999, 3.9999])
+    g[5] = torch.tensor([0.0, 0.0, -7.9])            # z in (-1,0) cell -> kept by trunc
+    g[6] = g[7] = torch.tensor([1.0, 1.0, 1.0])      # duplicates in one voxel
+    x = torch.randn(B, N, D, fH, fW, C)
+    x.requires_grad_(True)
+    out = m.voxel_pooling(geom, x)
+    out_acc = m.voxel_pooling_accelerated(geom, x.detach())
+    gout = torch.randn_like(out)
+    (gx,) = torch.autograd.grad(out, x, gout)
+    idx = ((geom - (m.bx - m.dx / 2.)) / m.dx).long()
+    _save("lss_small.npz",
+          xbound=np.array(grid["xbound"]), ybound=np.array(grid["ybound"]),
+          zbound=np.array(grid["zbound"]), dbound=np.array(grid["dbound"]),
+          input_size=np.array(data["input_size"]),
+          frustum=m.frustum.detach().numpy(), dx=m.dx.numpy(), bx=m.bx.numpy(), nx=m.nx.numpy(),
+          rots=rig["rots"], trans=rig["trans"], intrins=rig["intrins"],
+          post_rots=rig["post_rots"], post_trans=rig["post_trans"],
+          geom=geom.numpy(), x=x.detach().numpy(), idx=idx.numpy(),
+          out=out.detach().numpy(), out_accelerated=out_acc.numpy(),
+          grad_out=gout.numpy(), grad_x=gx.numpy())
+
+    # ---- lift + splat through the Module's own forward (depthnet 1x1 conv) ----
+    m2 = vt.ViewTransformerLiftSplatShoot(grid_config=grid, data_config=data,
+                                          numC_input=8, numC_Trans=4, downsample=16,
+                                          accelerate=False)
+    feat_in = torch.randn(B, N, 8, fH, fW)
+    with torch.no_grad():
+        bev = m2((feat_in, t["rots"], t["trans"], t["intrins"], t["post_rots"], t["post_trans"]))
+        xx = m2.depthnet(feat_in.view(B * N, 8, fH, fW))
+        depth = m2.get_depth_dist(xx[:, :m2.D])
+        img_feat = xx[:, m2.D:m2.D + 4]
+        geom2 = m2.get_geometry(t["rots"], t["trans"], t["intrins"], t["post_rots"], t["post_trans"])
+    _save("lss_lift_small.npz", depth=depth.numpy(), img_feat=img_feat.numpy(),
+          geom=geom2.numpy(), bev=bev.numpy(), dx=m2.dx.numpy(), bx=m2.bx.numpy(), nx=m2.nx.numpy())
+
+    # ---- full-size config (CFG_D grid): statistics + hashes only ----
+    mf = vt.ViewTransformerLiftSplatShoot(numC_input=8, numC_Trans=64, downsample=16)
+    rng = np.random.default_rng(1234)
+    rigf = syn.camera_rig(1, rng)
+    tf = {k: torch.from_numpy(v) for k, v in rigf.items()}
+    geomf = mf.get_geometry(tf["rots"], tf["trans"], tf["intrins"], tf["post_rots"], tf["post_trans"])
+    idxf = ((geomf - (mf.bx - mf.dx / 2.)) / mf.dx).long()
+    nxl = mf.nx.long()
+    kept = ((idxf[..., 0] >= 0) & (idxf[..., 0] < nxl[0]) & (idxf[..., 1] >= 0) & (idxf[..., 1] < nxl[1])
+            & (idxf[..., 2] >= 0) & (idxf[..., 2] < nxl[2]))
+    lin = (idxf[..., 1] * nxl[0] + idxf[..., 0])[kept]
+    cnt = torch.bincount(lin, minlength=int(nxl[0] * nxl[1]))
+    _save("lss_full_stats.npz",
+          frustum_sha256=np.frombuffer(hashlib.sha256(mf.frustum.detach().numpy().tobytes()).digest(), dtype=np.uint8),
+          frustum_corner=mf.frustum.detach().numpy()[[0, -1]][:, [0, -1]][:, :, [0, -1]],
+          dx=mf.dx.numpy(), bx=mf.bx.numpy(), nx=mf.nx.numpy(),
+          rots=rigf["rots"], trans=rigf["trans"], intrins=rigf["intrins"],
+          post_rots=rigf["post_rots"], post_trans=rigf["post_trans"],
+          geom_sample=geomf.numpy().reshape(-1, 3)[::997].copy(),
+          idx_sample=idxf.numpy().reshape(-1, 3)[::997].copy(),
+          n_kept=np.array(int(kept.sum())), n_cells=np.array(int((cnt > 0).sum())),
+          max_per_cell=np.array(int(cnt.max())),
+          idx_sha256=np.frombuffer(hashlib.sha256(idxf.numpy().astype(np.int32).tobytes()).digest(), dtype=np.uint8),
+          geom_full=geomf.numpy().astype(np.float32)[:, :, ::6].copy())
+    print("full: kept", int(kept.sum()), "cells", int((cnt > 0).sum()), "max/cell", int(cnt.max()))
+
+
+SECTIONS = {"lss": make_lss}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(SECTIONS)
+    for s in which:
+        SECTIONS[s]()
