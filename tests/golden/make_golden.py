@@ -124,7 +124,99 @@ def make_lss():
     print("full: kept", int(kept.sum()), "cells", int((cnt > 0).sum()), "max/cell", int(cnt.max()))
 
 
-SECTIONS = {"lss": make_lss}
+# --------------------------------------------------------------------------
+def make_voxel():
+    """dynamic / hard voxelization from the reference's own voxelization_cpu.cpp
+    (compiled by oracle/build_ref.py into oracle/_ref)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_ref
+    build_ref.main()
+    ref = build_ref.load_ref()
+    assert ref is not None
+    rng = np.random.default_rng(7)
+    vs = [0.2, 0.2, 8.0]
+    rg = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+
+    def hard(points, max_points, max_voxels, vs=vs, rg=rg):
+        pts = torch.from_numpy(points)
+        voxels = pts.new_zeros((max_voxels, max_points, pts.size(1)))
+        coors = pts.new_zeros((max_voxels, 3), dtype=torch.int)
+        num = pts.new_zeros((max_voxels,), dtype=torch.int)
+        m = ref.hard_voxelize(pts, voxels, coors, num, vs, rg, max_points, max_voxels, 3, True)
+        return voxels[:m].numpy(), coors[:m].numpy(), num[:m].numpy()
+
+    def dyn(points, vs=vs, rg=rg):
+        pts = torch.from_numpy(points)
+        coors = pts.new_zeros((pts.size(0), 3), dtype=torch.int)
+        ref.dynamic_voxelize(pts, coors, vs, rg, 3)
+        return coors.numpy()
+
+    # case A: 3000 nuScenes-like points + adversarial border points
+    pa = syn.lidar_points(3000, rng)
+    border = np.array([
+        [-51.2, -51.2, -5.0, 1, 0],       # exactly the lower corner -> (0,0,0)
+        [51.2, 0.0, 0.0, 1, 0],           # exactly the upper x bound -> out
+        [51.19999, 51.19999, 2.99999, 1, 0],
+        [-51.2000001, 0.0, 0.0, 1, 0],    # rounds to -51.2 in fp32 -> in
+        [-51.21, 0.0, 0.0, 1, 0],         # just outside
+        [0.0, 0.0, 3.0, 1, 0],            # z upper bound -> out
+        [0.0, 0.0, -5.0, 1, 0],
+        [0.2, 0.2, 0.0, 1, 0], [0.2, 0.2, 0.1, 2, 0], [0.2, 0.2, 0.2, 3, 0],   # same pillar
+        [-0.0, -0.0, 0.0, 1, 0],
+        [0.19999999, 0.4, 0.0, 1, 0], [0.6000000238, 0.6, 0.0, 1, 0],
+    ], dtype=np.float32)
+    pa = np.concatenate([border, pa], 0)
+    # duplicates far apart in the array (first-come ordering across the whole cloud)
+    pa[1500:1520, :3] = pa[100:120, :3]
+    va, ca, na = hard(pa, 2, 2000)       # max_voxels overflow + max_points overflow
+    va2, ca2, na2 = hard(pa, 20, 30000)  # no overflow
+    _save("voxel_small.npz", points=pa, voxel_size=np.array(vs, np.float32),
+          coors_range=np.array(rg, np.float32), dyn_coors=dyn(pa),
+          hard5_voxels=va, hard5_coors=ca, hard5_num=na, hard5_max_points=np.array(2),
+          hard5_max_voxels=np.array(2000),
+          hard20_voxels=va2, hard20_coors=ca2, hard20_num=na2)
+    # case B: a 3-D grid (z has several cells) with 4 features, coarse voxels -> many points/voxel
+    vs3 = [1.0, 2.0, 0.5]
+    rg3 = [-8.0, -8.0, -2.0, 8.0, 8.0, 2.0]
+    pb = rng.uniform(-9, 9, (2000, 4)).astype(np.float32)
+    pb[:, 2] = rng.uniform(-2.5, 2.5, 2000)
+    vb, cb, nb = hard(pb, 3, 100, vs3, rg3)
+    _save("voxel_3d.npz", points=pb, voxel_size=np.array(vs3, np.float32),
+          coors_range=np.array(rg3, np.float32), dyn_coors=dyn(pb, vs3, rg3),
+          hard_voxels=vb, hard_coors=cb, hard_num=nb, max_points=np.array(3), max_voxels=np.array(100))
+    # case C (BASELINE configs[2] size): 30k points -> hashes + counts only
+    pc = syn.lidar_points(30000, np.random.default_rng(1234))
+    vc, cc, nc = hard(pc, 20, 30000)
+    dc = dyn(pc)
+    _save("voxel_30k_stats.npz", n_voxels=np.array(vc.shape[0]),
+          n_invalid=np.array(int((dc[:, 0] < 0).sum())),
+          dyn_sha256=np.frombuffer(hashlib.sha256(dc.tobytes()).digest(), dtype=np.uint8),
+          hard_coors_sha256=np.frombuffer(hashlib.sha256(cc.tobytes()).digest(), dtype=np.uint8),
+          hard_num_sha256=np.frombuffer(hashlib.sha256(nc.tobytes()).digest(), dtype=np.uint8),
+          hard_voxels_sha256=np.frombuffer(hashlib.sha256(vc.tobytes()).digest(), dtype=np.uint8))
+    print("30k: voxels", vc.shape[0], "invalid", int((dc[:, 0] < 0).sum()))
+
+
+# --------------------------------------------------------------------------
+def make_pillars():
+    """PointPillarsScatter.forward_batch from the imported reference module."""
+    ps = R.pillar_scatter()
+    rng = np.random.default_rng(5)
+    B, C, ny, nx, M = 3, 8, 16, 12, 150
+    lin = rng.choice(B * ny * nx, M, replace=False)
+    b, rem = np.divmod(lin, ny * nx)
+    y, x = np.divmod(rem, nx)
+    coors = np.stack([b, np.zeros_like(b), y, x], 1).astype(np.int32)
+    order = np.argsort(lin)
+    coors = coors[order]
+    feats = rng.normal(size=(M, C)).astype(np.float32)
+    m = ps.PointPillarsScatter(C, [ny, nx])
+    canvas = m(torch.from_numpy(feats), torch.from_numpy(coors), B)
+    _save("pillars_scatter_small.npz", feats=feats, coors=coors, canvas=canvas.numpy(),
+          B=np.array(B), ny=np.array(ny), nx=np.array(nx))
+
+
+SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)

@@ -97,7 +97,7 @@ def test_bev_pool_deterministic_and_full_size_properties():
     out1 = bev_pool(ft, ct, 1, 1, 128, 128)
     out2 = bev_pool(ft, ct, 1, 1, 128, 128)
     assert torch.equal(out1, out2)
-    tot = out1.double().sum(dim=(0, 2, 3, 4)).cpu().numpy()
+    tot = out1.detach().double().sum(dim=(0, 2, 3, 4)).cpu().numpy()
     assert np.allclose(tot, feats.astype(np.float64).sum(0), rtol=0, atol=1e-2)
     ref = O.bev_pool(feats, coords, 1, 1, 128, 128, exact=True)
     assert np.abs(out1.detach().cpu().numpy() - ref).max() < 1e-4
