@@ -27,8 +27,20 @@ _SIGNATURES = {
     "dbev_target_arch": [],
     "dbev_bev_pool_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_bev_pool_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "dbev_dynamic_voxelize": [_p, _p, _i, _i, _p, _p, _i, _p],
+    "dbev_hard_voxelize_workspace_bytes": [_i, _p, _p],
+    "dbev_hard_voxelize": [_p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _sz, _p],
+    "dbev_dynamic_scatter_workspace_bytes": [_i, _i, _i, _i],
+    "dbev_dynamic_scatter_prepare": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "dbev_dynamic_scatter_reduce": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "dbev_dynamic_scatter_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "dbev_pillars_scatter": [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p],
+    "dbev_pillars_scatter_backward": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
 }
-_RESTYPES = {"dbev_target_arch": ctypes.c_char_p}
+_RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
+             "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
+             "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t}
+_NO_CHECK = set(_RESTYPES)
 
 
 class DbevHipError(RuntimeError):
@@ -89,7 +101,16 @@ def call(name, *args):
         rec.append((s, e))
     else:
         rc = fn(*args)
+    if name in _NO_CHECK:
+        return rc
     check(rc, name)
+    return 0
+
+
+def host_floats(values):
+    """ctypes float array for the *_host arguments of the ABI."""
+    vals = [float(v) for v in values]
+    return (ctypes.c_float * len(vals))(*vals)
 
 
 def exported_symbols():

@@ -1,0 +1,125 @@
+// PointPillarsScatter for gfx950 -- replaces the per-sample python loop of
+// mmdet3d/models/middle_encoders/pillar_scatter.py:62-102 (zero canvas, boolean-mask gather,
+// index_put, stack) with one output-stationary pass over the whole batch canvas:
+//   step 1: cellmap[b, y, x] = pillar row id or -1                 (4 B per BEV cell)
+//   step 2: every canvas element is written exactly once -- the pillar's feature or 0 --
+//           so there is no separate 4*C*ny*nx*B-byte memset and no scattered store.
+// NCHW output (the reference layout) goes through an LDS transpose tile so that both the
+// pillar-row reads (4C contiguous bytes) and the canvas writes (64 consecutive x) coalesce;
+// channels_last output ([B, ny, nx, C] physical) is a straight row copy.
+// HBM roofline: M(4C+16) + 4 C ny nx B bytes; write dominated.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void ps_cellmap(const int* __restrict__ coors, int m, int B, int ny,
+                                                  int nx, int* __restrict__ cellmap) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= m) return;
+  const int b = coors[v * 4 + 0], y = coors[v * 4 + 2], x = coors[v * 4 + 3];
+  if (b < 0 || b >= B || y < 0 || y >= ny || x < 0 || x >= nx) return;
+  // duplicates: the later row wins (sequential index_put semantics)
+  atomicMax(&cellmap[(b * ny + y) * nx + x], v);
+}
+
+constexpr int TILE_X = 64;
+
+// grid: (ceil(nx/64), ny, B); block 256.  dynamic LDS: TILE_X * (C + 1) floats.
+__global__ __launch_bounds__(256) void ps_canvas_nchw(const float* __restrict__ feats,
+                                                      const int* __restrict__ cellmap,
+                                                      float* __restrict__ canvas, int C, int ny, int nx) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ int vids[TILE_X];
+  const int x0 = blockIdx.x * TILE_X, y = blockIdx.y, b = blockIdx.z;
+  const int t = threadIdx.x;
+  if (t < TILE_X) vids[t] = (x0 + t < nx) ? cellmap[(b * ny + y) * nx + x0 + t] : -1;
+  __syncthreads();
+  const int ld = C + 1;
+  for (int i = t; i < TILE_X * C; i += 256) {
+    const int cx = i / C, ch = i - cx * C;
+    const int v = vids[cx];
+    tile[cx * ld + ch] = v >= 0 ? feats[static_cast<size_t>(v) * C + ch] : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < TILE_X * C; i += 256) {
+    const int ch = i / TILE_X, cx = i - ch * TILE_X;
+    if (x0 + cx < nx)
+      canvas[((static_cast<size_t>(b) * C + ch) * ny + y) * nx + x0 + cx] = tile[cx * ld + ch];
+  }
+}
+
+__global__ __launch_bounds__(256) void ps_canvas_nhwc(const float* __restrict__ feats,
+                                                      const int* __restrict__ cellmap,
+                                                      float* __restrict__ canvas, int C, long long ncell) {
+  const long long total = ncell * C;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long cell = i / C;
+    const int ch = static_cast<int>(i - cell * C);
+    const int v = cellmap[cell];
+    canvas[i] = v >= 0 ? feats[static_cast<size_t>(v) * C + ch] : 0.f;
+  }
+}
+
+// backward: grad_feats[v, c] = grad_canvas[b, c, y, x] (rows that lost a duplicate race get 0)
+__global__ __launch_bounds__(256) void ps_backward(const float* __restrict__ grad_canvas,
+                                                   const int* __restrict__ coors,
+                                                   const int* __restrict__ cellmap, int m, int C, int B,
+                                                   int ny, int nx, int channels_last,
+                                                   float* __restrict__ grad_feats) {
+  const long long total = static_cast<long long>(m) * C;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int v = static_cast<int>(i / C);
+    const int ch = static_cast<int>(i - static_cast<long long>(v) * C);
+    const int b = coors[v * 4 + 0], y = coors[v * 4 + 2], x = coors[v * 4 + 3];
+    float g = 0.f;
+    if (b >= 0 && b < B && y >= 0 && y < ny && x >= 0 && x < nx &&
+        cellmap[(b * ny + y) * nx + x] == v) {
+      g = channels_last ? grad_canvas[((static_cast<size_t>(b) * ny + y) * nx + x) * C + ch]
+                        : grad_canvas[((static_cast<size_t>(b) * C + ch) * ny + y) * nx + x];
+    }
+    grad_feats[i] = g;
+  }
+}
+
+}  // namespace
+
+extern "C" int dbev_pillars_scatter(const float* voxel_features, const int32_t* coors, int num_voxels,
+                                    int C, int B, int ny, int nx, float* canvas, int channels_last,
+                                    int32_t* cellmap, dbevStream_t stream) {
+  if (num_voxels < 0 || C <= 0 || B <= 0 || ny <= 0 || nx <= 0 || cellmap == nullptr) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const long long ncell = static_cast<long long>(B) * ny * nx;
+  DBEV_HIP_TRY(hipMemsetAsync(cellmap, 0xff, sizeof(int) * ncell, s));  // -1
+  if (num_voxels > 0)
+    hipLaunchKernelGGL(ps_cellmap, dim3(dbev_ceil_div(num_voxels, 256)), dim3(256), 0, s, coors, num_voxels,
+                       B, ny, nx, cellmap);
+  if (channels_last) {
+    long long blocks = (ncell * C + 255) / 256;
+    if (blocks > DBEV_MAX_GRID * 8) blocks = DBEV_MAX_GRID * 8;
+    hipLaunchKernelGGL(ps_canvas_nhwc, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, voxel_features,
+                       cellmap, canvas, C, ncell);
+  } else {
+    const size_t lds = sizeof(float) * TILE_X * (C + 1);
+    if (lds > 160 * 1024) return DBEV_EINVAL;
+    hipLaunchKernelGGL(ps_canvas_nchw, dim3(dbev_ceil_div(nx, TILE_X), ny, B), dim3(256), lds, s,
+                       voxel_features, cellmap, canvas, C, ny, nx);
+  }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_pillars_scatter_backward(const float* grad_canvas, const int32_t* coors,
+                                             const int32_t* cellmap, int num_voxels, int C, int B, int ny,
+                                             int nx, int channels_last, float* grad_feats,
+                                             dbevStream_t stream) {
+  if (num_voxels < 0 || C <= 0 || B <= 0 || ny <= 0 || nx <= 0) return DBEV_EINVAL;
+  if (num_voxels == 0) return 0;
+  long long blocks = (static_cast<long long>(num_voxels) * C + 255) / 256;
+  if (blocks > DBEV_MAX_GRID * 4) blocks = DBEV_MAX_GRID * 4;
+  hipLaunchKernelGGL(ps_backward, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, dbev_stream(stream),
+                     grad_canvas, coors, cellmap, num_voxels, C, B, ny, nx, channels_last, grad_feats);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,169 @@
+// exclusive scan + segment sort (see prims.h).
+#include "prims.h"
+
+namespace dbev {
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;                       // consecutive items per thread
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096 items per block
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one int per thread across a 256-thread block; returns exclusive prefix,
+// block total in *total (valid for all threads).
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* lds /*>=5 ints*/) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int incl = wave_incl_scan(v, lane);
+  if (lane == 63) lds[w] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_THREADS / 64; ++i) {
+    const int x = lds[i];
+    if (i < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__device__ __forceinline__ int f_of(int x, bool as_flags) { return as_flags ? (x > 0 ? 1 : 0) : x; }
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const int* __restrict__ in,
+                                                               int* __restrict__ tile_sums,
+                                                               long long n, bool as_flags) {
+  __shared__ int lds[8];
+  const long long base = static_cast<long long>(blockIdx.x) * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const long long i = base + k;
+    if (i < n) s += f_of(in[i], as_flags);
+  }
+  int tot;
+  block_excl_scan(s, &tot, lds);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of the tile sums in place; writes grand total to tile_sums[nt]
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_offsets(int* __restrict__ tile_sums, int nt) {
+  __shared__ int lds[8];
+  int carry = 0;
+  for (int b = 0; b < nt; b += SCAN_THREADS) {
+    const int i = b + threadIdx.x;
+    const int v = i < nt ? tile_sums[i] : 0;
+    int tot;
+    const int ex = block_excl_scan(v, &tot, lds);
+    if (i < nt) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) tile_sums[nt] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep(const int* __restrict__ in,
+                                                               int* __restrict__ out,
+                                                               const int* __restrict__ tile_offs,
+                                                               long long n, int nt, bool as_flags,
+                                                               int* __restrict__ total_out) {
+  __shared__ int lds[8];
+  const long long base = static_cast<long long>(blockIdx.x) * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const long long i = base + k;
+    v[k] = i < n ? f_of(in[i], as_flags) : 0;
+    s += v[k];
+  }
+  int tot;
+  int ex = block_excl_scan(s, &tot, lds) + tile_offs[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const long long i = base + k;
+    if (i < n) out[i] = ex;
+    ex += v[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int grand = tile_offs[nt];
+    out[n] = grand;
+    if (total_out) *total_out = grand;
+  }
+}
+
+// one wave per segment
+__global__ __launch_bounds__(256) void segment_sort_kernel(const int* __restrict__ starts,
+                                                           const unsigned* __restrict__ src,
+                                                           unsigned* __restrict__ dst, int n_seg) {
+  const int seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (seg >= n_seg) return;
+  const int st = starts[seg];
+  const int L = starts[seg + 1] - st;
+  if (L <= 0) return;
+  if (L <= 64) {
+    unsigned v = lane < L ? src[st + lane] : 0xFFFFFFFFu;
+    if (L > 1) {
+#pragma unroll
+      for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const unsigned o = __shfl_xor(v, j);
+          const bool up = (lane & k) == 0;
+          const bool lower = (lane & j) == 0;
+          v = (lower == up) ? (v < o ? v : o) : (v > o ? v : o);
+        }
+      }
+    }
+    if (lane < L) dst[st + lane] = v;
+  } else {
+    // long segment (rare: dense BEV cells next to the cameras): rank by counting.
+    // values are distinct, so ranks are a permutation.
+    const unsigned* p = src + st;
+    for (int i = lane; i < L; i += 64) {
+      const unsigned v = p[i];
+      int rank = 0;
+      for (int j = 0; j < L; ++j) rank += p[j] < v ? 1 : 0;
+      dst[st + rank] = v;
+    }
+  }
+}
+
+}  // namespace
+
+size_t scan_workspace_ints(long long n) { return static_cast<size_t>((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
+
+int exclusive_scan_i32(const int* in, int* out, long long n, bool as_flags, int* total_out, int* ws,
+                       hipStream_t s) {
+  if (n < 0) return DBEV_EINVAL;
+  const int nt = static_cast<int>((n + SCAN_TILE - 1) / SCAN_TILE);
+  if (nt == 0) {
+    DBEV_HIP_TRY(hipMemsetAsync(out, 0, sizeof(int), s));
+    if (total_out) DBEV_HIP_TRY(hipMemsetAsync(total_out, 0, sizeof(int), s));
+    return 0;
+  }
+  hipLaunchKernelGGL(scan_tile_sums, dim3(nt), dim3(SCAN_THREADS), 0, s, in, ws, n, as_flags);
+  hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, s, ws, nt);
+  hipLaunchKernelGGL(scan_downsweep, dim3(nt), dim3(SCAN_THREADS), 0, s, in, out, ws, n, nt, as_flags,
+                     total_out);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+int segment_sort_u32(const int* starts, const unsigned* src, unsigned* dst, int n_seg, hipStream_t s) {
+  if (n_seg <= 0) return 0;
+  hipLaunchKernelGGL(segment_sort_kernel, dim3(dbev_ceil_div(n_seg, 4)), dim3(256), 0, s, starts, src,
+                     dst, n_seg);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace dbev

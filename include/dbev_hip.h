@@ -69,6 +69,88 @@ int dbev_bev_pool_backward(const float* out_grad, const int32_t* geom_feats,
                            float* x_grad, int n, int c, int n_intervals,
                            int b, int d, int h, int w, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * voxel_layer  (replaces mmdet3d/ops/voxel/src/voxelization.cpp:6-11 bindings,
+ *               voxelization.h:58-140, kernels voxelization_cuda.cu / scatter_points_cuda.cu)
+ * Results are those of the reference's CPU implementation (voxelization_cpu.cpp), bit exact.
+ * voxel_size_host[3] / coors_range_host[6] are HOST arrays (the reference passes
+ * std::vector<float> by value).
+ * ---------------------------------------------------------------------------------- */
+
+/* dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3)  (voxelization.h:86-95)
+ *   points f32[num_points, num_features] (xyz first) ; coors i32[num_points, 3] caller-allocated,
+ *   every row written: (z, y, x) cell of the point or (-1,-1,-1) if out of range. */
+int dbev_dynamic_voxelize(const float* points, int32_t* coors, int num_points, int num_features,
+                          const float* voxel_size_host, const float* coors_range_host, int ndim,
+                          dbevStream_t stream);
+
+/* hard_voxelize(points, voxels, coors, num_points_per_voxel, voxel_size, coors_range,
+ *               max_points, max_voxels, NDim=3, deterministic=true) -> voxel_num
+ *   (voxelization.h:58-84).  Output buffers are caller-allocated at capacity
+ *   voxels f32[max_voxels, max_points, F], coors i32[max_voxels, 3], num_points i32[max_voxels]
+ *   and fully (re)written (zero beyond the data, as voxelize.py:57-62 provides).
+ *   The reference returns voxel_num to the host (a sync); here it is stored to the DEVICE
+ *   int *voxel_num_out so the call stays asynchronous.  Always the deterministic result
+ *   (first-come order of voxelization_cpu.cpp:70-98). */
+size_t dbev_hard_voxelize_workspace_bytes(int num_points, const float* voxel_size_host,
+                                          const float* coors_range_host);
+int dbev_hard_voxelize(const float* points, float* voxels, int32_t* coors,
+                       int32_t* num_points_per_voxel, int32_t* voxel_num_out, int num_points,
+                       int num_features, const float* voxel_size_host, const float* coors_range_host,
+                       int max_points, int max_voxels, int ndim, void* workspace,
+                       size_t workspace_bytes, dbevStream_t stream);
+
+/* dynamic_point_to_voxel_forward(feats, coors, reduce_type) ->
+ *        [reduced_feats, out_coors, coors_map, reduce_count]          (voxelization.h:108-121)
+ * split in two asynchronous calls because M (number of voxels) is data dependent:
+ *   prepare: coors i32[N,3] (z,y,x; any negative entry = invalid point) on a grid of
+ *            grid_z x grid_y x grid_x cells (all valid coords must be < grid) ->
+ *              out_coors i32[<=N,3]   unique coords in ascending (z,y,x) order
+ *                                     (= at::unique_dim sorted with the (-1,-1,-1) row dropped)
+ *              coors_map i32[N]       row of out_coors for each point, -1 if invalid
+ *              reduce_count i32[N]    points per voxel (entries >= M are 0)
+ *              voxel_point_start i32[N+1], voxel_point_list i32[N]
+ *                                     CSR: ids of the points of voxel v, ascending
+ *              num_voxels_out         DEVICE int: M
+ *            all caller-allocated at capacity N.
+ *   reduce : reduced f32[M, C] = max / sum / mean over each voxel's points (lanes = channels,
+ *            sequential point-id order => deterministic; no float atomics). */
+size_t dbev_dynamic_scatter_workspace_bytes(int num_points, int grid_z, int grid_y, int grid_x);
+int dbev_dynamic_scatter_prepare(const int32_t* coors, int num_points, int grid_z, int grid_y,
+                                 int grid_x, int32_t* out_coors, int32_t* coors_map,
+                                 int32_t* reduce_count, int32_t* voxel_point_start,
+                                 int32_t* voxel_point_list, int32_t* num_voxels_out,
+                                 void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_dynamic_scatter_reduce(const float* feats, const int32_t* voxel_point_start,
+                                const int32_t* voxel_point_list, float* reduced, int num_voxels,
+                                int num_feats, int reduce_type, dbevStream_t stream);
+
+/* dynamic_point_to_voxel_backward(grad_feats, grad_reduced_feats, feats, reduced_feats,
+ *                                 coors_idx, reduce_count, reduce_type)  (voxelization.h:123-140)
+ *   grad_feats f32[N, C] caller-allocated, every element written.  max: the lowest point id
+ *   attaining the voxel max receives the gradient (scatter_points_cuda.cu:154-157). */
+int dbev_dynamic_scatter_backward(float* grad_feats, const float* grad_reduced, const float* feats,
+                                  const float* reduced, const int32_t* coors_map,
+                                  const int32_t* reduce_count, const int32_t* voxel_point_start,
+                                  const int32_t* voxel_point_list, int num_points, int num_voxels,
+                                  int num_feats, int reduce_type, dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * PointPillarsScatter.forward_batch (mmdet3d/models/middle_encoders/pillar_scatter.py:62-102;
+ * pure torch in the reference, a python loop over samples)
+ *   voxel_features f32[M, C]; coors i32[M, 4] = (b, z, y, x)
+ *   canvas f32[B, C, ny, nx] (channels_last=0, the reference layout) or physical
+ *   [B, ny, nx, C] (channels_last=1); every element written (0 where no pillar).
+ *   cellmap i32[B*ny*nx]: caller-allocated scratch, returned filled with the pillar row of
+ *   each BEV cell (-1 = empty); it is the saved state of the backward.
+ * ---------------------------------------------------------------------------------- */
+int dbev_pillars_scatter(const float* voxel_features, const int32_t* coors, int num_voxels, int C,
+                         int B, int ny, int nx, float* canvas, int channels_last, int32_t* cellmap,
+                         dbevStream_t stream);
+int dbev_pillars_scatter_backward(const float* grad_canvas, const int32_t* coors,
+                                  const int32_t* cellmap, int num_voxels, int C, int B, int ny, int nx,
+                                  int channels_last, float* grad_feats, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,186 @@
+"""GPU parity: voxelization / dynamic_scatter / PointPillarsScatter (C ABI, HIP) against
+the fixtures made from the reference's own CPU code and against oracle/voxel.c."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from distill_bev_amd import synthetic as syn
+from oracle import voxel as V
+
+pytestmark = pytest.mark.gpu
+VS, RG = [0.2, 0.2, 8.0], [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_dynamic_voxelize_bit_exact_fixtures():
+    from distill_bev_amd.voxel import voxelization
+    dev = _dev()
+    for name in ("voxel_small.npz", "voxel_3d.npz"):
+        g = load_golden(name)
+        coors = voxelization(torch.from_numpy(g["points"]).to(dev), g["voxel_size"].tolist(),
+                             g["coors_range"].tolist(), -1, -1)
+        assert coors.dtype == torch.int32
+        assert np.array_equal(coors.cpu().numpy(), g["dyn_coors"])
+
+
+def test_hard_voxelize_bit_exact_fixtures_incl_overflow():
+    from distill_bev_amd.voxel import voxelization
+    dev = _dev()
+    g = load_golden("voxel_small.npz")
+    pts = torch.from_numpy(g["points"]).to(dev)
+    vs, rg = g["voxel_size"].tolist(), g["coors_range"].tolist()
+    v, c, n = voxelization(pts, vs, rg, int(g["hard5_max_points"]), int(g["hard5_max_voxels"]))
+    assert np.array_equal(c.cpu().numpy(), g["hard5_coors"])
+    assert np.array_equal(n.cpu().numpy(), g["hard5_num"])
+    assert np.array_equal(v.cpu().numpy(), g["hard5_voxels"])
+    v, c, n = voxelization(pts, vs, rg, 20, 30000)
+    assert np.array_equal(c.cpu().numpy(), g["hard20_coors"])
+    assert np.array_equal(n.cpu().numpy(), g["hard20_num"])
+    assert np.array_equal(v.cpu().numpy(), g["hard20_voxels"])
+    g = load_golden("voxel_3d.npz")
+    v, c, n = voxelization(torch.from_numpy(g["points"]).to(dev), g["voxel_size"].tolist(),
+                           g["coors_range"].tolist(), int(g["max_points"]), int(g["max_voxels"]))
+    assert np.array_equal(v.cpu().numpy(), g["hard_voxels"])
+    assert np.array_equal(c.cpu().numpy(), g["hard_coors"])
+    assert np.array_equal(n.cpu().numpy(), g["hard_num"])
+
+
+def test_voxelize_30k_config2_hashes():
+    """BASELINE configs[2] size: 30k-point cloud, hashes of the reference CPU outputs."""
+    from distill_bev_amd.voxel import Voxelization
+    dev = _dev()
+    g = load_golden("voxel_30k_stats.npz")
+    pts = torch.from_numpy(syn.lidar_points(30000, np.random.default_rng(1234))).to(dev)
+    dyn = Voxelization(VS, RG, -1, (-1, -1))
+    d = dyn(pts).cpu().numpy()
+    assert hashlib.sha256(d.tobytes()).digest() == g["dyn_sha256"].tobytes()
+    hard = Voxelization(VS, RG, 20, (30000, 40000))
+    hard.train()
+    v, c, n = hard(pts)
+    assert v.shape[0] == int(g["n_voxels"])
+    assert hashlib.sha256(c.cpu().numpy().tobytes()).digest() == g["hard_coors_sha256"].tobytes()
+    assert hashlib.sha256(n.cpu().numpy().tobytes()).digest() == g["hard_num_sha256"].tobytes()
+    assert hashlib.sha256(v.cpu().numpy().tobytes()).digest() == g["hard_voxels_sha256"].tobytes()
+
+
+def test_voxelize_edge_cases_empty_all_out_nan():
+    from distill_bev_amd.voxel import voxelization
+    dev = _dev()
+    e = voxelization(torch.zeros((0, 5), device=dev), VS, RG, -1, -1)
+    assert e.shape == (0, 3)
+    v, c, n = voxelization(torch.zeros((0, 5), device=dev), VS, RG, 5, 100)
+    assert v.shape == (0, 5, 5) and c.shape == (0, 3) and n.shape == (0,)
+    out = torch.full((10, 5), 1000.0, device=dev)
+    out[3, 0] = float("nan"); out[4, 1] = float("inf")
+    assert (voxelization(out, VS, RG, -1, -1) == -1).all()
+    v, c, n = voxelization(out, VS, RG, 5, 100)
+    assert v.shape[0] == 0
+    # every point in ONE pillar, more than 64 (long segment-sort path) and > max_points
+    one = torch.zeros((300, 5), device=dev)
+    one[:, 3] = torch.arange(300, device=dev)
+    v, c, n = voxelization(one, VS, RG, 35, 100)
+    assert v.shape[0] == 1 and int(n[0]) == 35
+    assert torch.equal(v[0, :, 3], torch.arange(35, device=dev, dtype=torch.float32))
+
+
+@pytest.mark.parametrize("reduce_type", ["max", "mean", "sum"])
+@pytest.mark.parametrize("C", [5, 64, 70])
+def test_dynamic_scatter_fwd_bwd_vs_oracle(reduce_type, C):
+    from distill_bev_amd.voxel import dynamic_scatter
+    dev = _dev()
+    rng = np.random.default_rng(C)
+    n = 6000
+    pts = syn.lidar_points(n, rng)
+    coors = V.dynamic_voxelize(pts, [0.8, 0.8, 8.0], RG)
+    coors[11] = [-1, 3, 3]
+    coors[100:180] = coors[99]                      # one voxel with > 64 points
+    feats = rng.normal(size=(n, C)).astype(np.float32)
+    feats[150] = feats[120]                         # exact tie inside that voxel
+    red, oc, cmap, cnt = V.dynamic_scatter_forward(feats, coors, reduce_type)
+    ft = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    vf, vc = dynamic_scatter(ft, torch.from_numpy(coors).to(dev), reduce_type)
+    assert np.array_equal(vc.cpu().numpy(), oc)                 # bit exact, lexicographic order
+    if reduce_type == "mean":
+        assert np.abs(vf.detach().cpu().numpy() - red).max() < 1e-6
+    else:
+        assert np.array_equal(vf.detach().cpu().numpy(), red)   # max exact; sum: same order as oracle
+    gr = rng.normal(size=red.shape).astype(np.float32)
+    vf.backward(torch.from_numpy(gr).to(dev))
+    gref = V.dynamic_scatter_backward(gr, feats, red, cmap, cnt, reduce_type)
+    if reduce_type == "mean":
+        assert np.abs(ft.grad.cpu().numpy() - gref).max() < 1e-6
+    else:
+        assert np.array_equal(ft.grad.cpu().numpy(), gref)
+
+
+def test_dynamic_scatter_module_batched_and_empty():
+    from distill_bev_amd.voxel import DynamicScatter, dynamic_scatter
+    dev = _dev()
+    rng = np.random.default_rng(1)
+    ds = DynamicScatter(VS, RG, True)
+    parts, feats = [], []
+    for b in range(3):
+        pts = syn.lidar_points(2000 + 100 * b, rng)
+        c = V.dynamic_voxelize(pts, VS, RG)
+        parts.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+        feats.append(pts)
+    coors = np.concatenate(parts); f = np.concatenate(feats)
+    vf, vc = ds(torch.from_numpy(f).to(dev), torch.from_numpy(coors).to(dev))
+    off = 0
+    for b in range(3):
+        red, oc, _, _ = V.dynamic_scatter_forward(feats[b], parts[b][:, 1:], "mean")
+        m = red.shape[0]
+        assert np.array_equal(vc[off:off + m, 1:].cpu().numpy(), oc)
+        assert (vc[off:off + m, 0] == b).all()
+        assert np.abs(vf[off:off + m].cpu().numpy() - red).max() < 1e-5
+        off += m
+    assert off == vf.shape[0]
+    e, ec = dynamic_scatter(torch.zeros((0, 4), device=dev), torch.zeros((0, 3), dtype=torch.int32, device=dev), "max")
+    assert e.shape == (0, 4)
+    allbad = torch.full((5, 3), -1, dtype=torch.int32, device=dev)
+    r, rc = dynamic_scatter(torch.ones((5, 4), device=dev), allbad, "max")
+    assert r.shape == (0, 4) and rc.shape == (0, 3)
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_pillars_scatter_fixture_and_backward(channels_last):
+    from distill_bev_amd.pillars import PointPillarsScatter
+    dev = _dev()
+    g = load_golden("pillars_scatter_small.npz")
+    m = PointPillarsScatter(g["feats"].shape[1], [int(g["ny"]), int(g["nx"])], channels_last=channels_last)
+    f = torch.from_numpy(g["feats"]).to(dev).requires_grad_(True)
+    canvas = m(f, torch.from_numpy(g["coors"]).to(dev), int(g["B"]))
+    assert canvas.shape == g["canvas"].shape
+    assert np.array_equal(canvas.detach().cpu().numpy(), g["canvas"])
+    go = torch.randn_like(canvas)
+    canvas.backward(go)
+    co = g["coors"]
+    gref = go.cpu().numpy()[co[:, 0], :, co[:, 2], co[:, 3]]
+    assert np.array_equal(f.grad.cpu().numpy(), gref)
+
+
+def test_pillars_scatter_full_size_vs_oracle():
+    """CFG_TB canvas: 64 x 512 x 512, B=2, ~22k pillars per sample."""
+    from distill_bev_amd.pillars import pillars_scatter
+    from distill_bev_amd.voxel import dynamic_scatter
+    dev = _dev()
+    rng = np.random.default_rng(2)
+    feats, coors = [], []
+    for b in range(2):
+        pts = syn.lidar_points(30000, rng)
+        c = V.dynamic_voxelize(pts, VS, RG)
+        _, oc, _, _ = V.dynamic_scatter_forward(pts, c, "max")
+        coors.append(np.concatenate([np.full((oc.shape[0], 1), b, np.int32), oc], 1))
+        feats.append(rng.normal(size=(oc.shape[0], 64)).astype(np.float32))
+    f = np.concatenate(feats); co = np.concatenate(coors)
+    ref = V.pillars_scatter(f, co, 2, 512, 512)
+    for cl in (False, True):
+        out = pillars_scatter(torch.from_numpy(f).to(dev), torch.from_numpy(co).to(dev), 2, 512, 512, cl)
+        assert np.array_equal(out.cpu().numpy(), ref)
