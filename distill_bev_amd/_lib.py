@@ -36,8 +36,15 @@ _SIGNATURES = {
     "dbev_dynamic_scatter_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dbev_pillars_scatter": [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p],
     "dbev_pillars_scatter_backward": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "dbev_lift_splat_workspace_bytes": [_i, _i],
+    "dbev_lift_splat_prepare": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "dbev_lift_splat_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "dbev_lift_splat_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dbev_splat_forward": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "dbev_splat_backward": [_p, _p, _p, _i, _i, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
+             "dbev_lift_splat_workspace_bytes": ctypes.c_size_t,
              "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
              "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t}
 _NO_CHECK = set(_RESTYPES)
@@ -105,6 +112,11 @@ def call(name, *args):
         return rc
     check(rc, name)
     return 0
+
+
+def host_ints(values):
+    vals = [int(v) for v in values]
+    return (ctypes.c_int32 * len(vals))(*vals)
 
 
 def host_floats(values):

@@ -151,6 +151,53 @@ int dbev_pillars_scatter_backward(const float* grad_canvas, const int32_t* coors
                                   const int32_t* cellmap, int num_voxels, int C, int B, int ny, int nx,
                                   int channels_last, float* grad_feats, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused Lift-Splat (LSS view transform).  Replaces, for the training step, the sequence
+ *   volume = depth.unsqueeze(1) * feat.unsqueeze(2)            (bevdet_distill_more.py:413-416)
+ *   ViewTransformerLiftSplatShoot.voxel_pooling(geom, volume)   (view_transformer_mine.py:141-181)
+ * and (same grouping, other call surfaces) voxel_pooling_accelerated (:184-240) and
+ * mmdet3d.ops.bev_pool (view_transformer.py:140-169).  The reference has no native entry
+ * point for the fused op; these are new ones behind the same Python call sites.
+ *
+ * Point id p = (((b*N + n)*D + d)*H + h)*W + w, n_points = B*N*D*H*W.
+ * BEV cell id = ((b*Y + y)*X + x)*Z + z  (so out[cell, c] is the channels-last image of the
+ * reference's output tensor f32[B, C*Z, Y, X] with channel = z*C + c).
+ * ---------------------------------------------------------------------------------- */
+size_t dbev_lift_splat_workspace_bytes(int n_points, int n_cells);
+
+/* geom f32[n_points, 3] ego-frame (x,y,z) of every frustum point (get_geometry output);
+ * dx/bx/nx: HOST arrays of the module's grid parameters (nx = cells in X, Y, Z).
+ *   point_cell i32[n_points]   BEV cell of the point, -1 if outside the grid
+ *                              index = ((geom - (bx - dx/2)) / dx) truncated TOWARD ZERO, fp32
+ *   cell_start i32[n_cells+1], cell_points i32[n_points]   CSR: ascending point ids per cell
+ *   n_kept_out DEVICE int: number of points inside the grid
+ * n_cells = batch*X*Y*Z. */
+int dbev_lift_splat_prepare(const float* geom, int n_points, int batch, const float* dx_host,
+                            const float* bx_host, const int32_t* nx_host, int32_t* point_cell,
+                            int32_t* cell_start, int32_t* cell_points, int32_t* n_kept_out,
+                            void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
+/* depth f32[BN, D, H, W] (softmaxed depth distribution); feat_nhwc f32[BN, H, W, C]
+ * (channels-last image features); out f32[n_cells, C], every cell written:
+ *   out[cell, :] = sum over the cell's points p of depth[p] * feat[bn(p), h(p), w(p), :].
+ * C must be a multiple of 4 and <= 256. */
+int dbev_lift_splat_forward(const float* depth, const float* feat_nhwc, const int32_t* cell_start,
+                            const int32_t* cell_points, float* out, int BN, int D, int H, int W, int C,
+                            int n_cells, dbevStream_t stream);
+
+/* grad_out f32[n_cells, C] -> grad_depth f32[BN, D, H, W], grad_feat_nhwc f32[BN, H, W, C];
+ * every element of both written (0 for points outside the grid). */
+int dbev_lift_splat_backward(const float* grad_out, const float* depth, const float* feat_nhwc,
+                             const int32_t* point_cell, float* grad_depth, float* grad_feat_nhwc, int BN,
+                             int D, int H, int W, int C, dbevStream_t stream);
+
+/* voxel_pooling(geom, x) for a caller that holds the volume x f32[n_points, C]:
+ * out[cell, :] = sum of x[p, :] over the cell's points; backward = gather (0 if dropped). */
+int dbev_splat_forward(const float* x, const int32_t* cell_start, const int32_t* cell_points, float* out,
+                       int n_points, int C, int n_cells, dbevStream_t stream);
+int dbev_splat_backward(const float* grad_out, const int32_t* point_cell, float* grad_x, int n_points,
+                        int C, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
