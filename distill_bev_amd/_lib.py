@@ -42,8 +42,16 @@ _SIGNATURES = {
     "dbev_lift_splat_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_splat_forward": [_p, _p, _p, _p, _i, _i, _i, _p],
     "dbev_splat_backward": [_p, _p, _p, _i, _i, _p],
+    "dbev_fg_scale_mask": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
+    "dbev_abs_mean_maps_workspace_bytes": [_i, _i, _i],
+    "dbev_abs_mean_maps": [_p, _i, _i, _i, _p, _p, _p, _sz, _p],
+    "dbev_fgd_masked_mse_workspace_bytes": [_i, _i, _i],
+    "dbev_fgd_masked_mse_forward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p],
+    "dbev_fgd_masked_mse_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
+             "dbev_abs_mean_maps_workspace_bytes": ctypes.c_size_t,
+             "dbev_fgd_masked_mse_workspace_bytes": ctypes.c_size_t,
              "dbev_lift_splat_workspace_bytes": ctypes.c_size_t,
              "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
              "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t}

@@ -198,6 +198,47 @@ int dbev_splat_forward(const float* x, const int32_t* cell_start, const int32_t*
 int dbev_splat_backward(const float* grad_out, const int32_t* point_cell, float* grad_x, int n_points,
                         int C, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Foreground-masked feature distillation (FGD).  The reference implements these steps in
+ * Python/numpy/torch inside mmdet3d/models/detectors/bevdet_distill.py; there is no native
+ * entry point to replace -- these are new ones behind the same Python methods.
+ * ---------------------------------------------------------------------------------- */
+
+/* foreground_scale_mask (bevdet_distill.py:755-843; geometry box_np_ops.py:426-446,719-753).
+ *   planes    f32[sumM, 6, 4]  (nx, ny, nz, d) of the six inward faces of every box, boxes of all
+ *                              samples concatenated (host-computed, float32, box_np_ops order)
+ *   box_scale f32[sumM]        sqrt(cell_area / (w*l)) per box
+ *   box_offsets i32[B+1]       boxes of sample b are [box_offsets[b], box_offsets[b+1])
+ *   xs f32[W], ys f32[H]       cell query coordinates (lower-left cell corners, z = 0.5)
+ * -> fg, fg_scale, bg_scale f32[B, H, W] ([b, iy, ix], i.e. the reference's un-transposed
+ *    masks after its reshape(W,H).transpose()); fg_count i32[B] scratch (cells inside a box).
+ * A cell is foreground iff ((px*nx + py*ny) + pz*nz) + d < 0 for all six planes of some box
+ * (fp32, no FMA: bit-identical to the reference's numpy test); fg_scale takes the value of the
+ * LOWEST-index box containing the cell; bg_scale = float(1.0 / (H*W - n_fg)). */
+int dbev_fg_scale_mask(const float* planes, const float* box_scale, const int32_t* box_offsets,
+                       const float* xs, const float* ys, int B, int H, int W, float* fg,
+                       float* fg_scale, float* bg_scale, int32_t* fg_count, dbevStream_t stream);
+
+/* x f32[B, C, HW] -> pix_mean f32[B, HW] = mean_c |x| ; ch_mean f32[B, C] = mean_hw |x|
+ * (inputs of the spatial / channel attention softmaxes, bevdet_distill.py:1084-1097). */
+size_t dbev_abs_mean_maps_workspace_bytes(int B, int C, int HW);
+int dbev_abs_mean_maps(const float* x, int B, int C, int HW, float* pix_mean, float* ch_mean,
+                       void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
+/* S, T f32[B, C, HW] (adapted student / teacher); Wfg, Wbg, Wfp f32[B, HW] per-pixel weights
+ * (Wfp may be NULL), Cc f32[B, C] per-channel factor of the third term (may be NULL = 1).
+ *   out3[0] = sum (S-T)^2 Wfg ; out3[1] = sum (S-T)^2 Wbg ; out3[2] = sum (S-T)^2 Wfp Cc[c]
+ * (kd_fg / kd_bg / kd_fp of bevdet_distill.py:1253-1262,1282-1287 before * weight / B).
+ * backward: dS = 2 (S-T) (g[0] Wfg + g[1] Wbg + g[2] Cc[c] Wfp), g = DEVICE f32[3].
+ * HW must be a multiple of 4. */
+size_t dbev_fgd_masked_mse_workspace_bytes(int B, int C, int HW);
+int dbev_fgd_masked_mse_forward(const float* S, const float* T, const float* Wfg, const float* Wbg,
+                                const float* Wfp, const float* Cc, int B, int C, int HW, float* out3,
+                                void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_fgd_masked_mse_backward(const float* S, const float* T, const float* Wfg, const float* Wbg,
+                                 const float* Wfp, const float* Cc, const float* grad_scale3, int B,
+                                 int C, int HW, float* dS, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -216,7 +216,59 @@ def make_pillars():
           B=np.array(B), ny=np.array(ny), nx=np.array(nx))
 
 
-SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars}
+# --------------------------------------------------------------------------
+def make_fgmask():
+    """foreground / scale masks: the reference's own box_np_ops.points_in_rbbox (imported,
+    numba stubbed to plain python) driven exactly as bevdet_distill.py:755-843 drives it
+    (0-dim float32 torch tensors for the cell coordinates, boxes flattened to z in [0,1])."""
+    bnp = R.box_np_ops()
+    grid_size = torch.tensor([1024, 1024, 40])
+    pc_range = torch.tensor([-51.2, -51.2, -5.0, 51.2, 51.2, 3.0])
+    voxel_size = torch.tensor([0.1, 0.1, 0.2])
+    rng = np.random.default_rng(21)
+    for H in (128, 64):
+        W = H
+        osf = grid_size[0] // W
+        xs = [i * voxel_size[0] * osf + pc_range[0] for i in range(W)]
+        ys = [i * voxel_size[1] * osf + pc_range[1] for i in range(H)]
+        gx, gy = np.meshgrid(xs, ys, indexing="ij")
+        gx = gx.reshape(-1, 1); gy = gy.reshape(-1, 1)
+        coords = np.hstack((gx, gy, np.ones_like(gx) * 0.5))
+        points = torch.tensor(coords).numpy()
+        boxes_all, masks, fgs, fss, bss = [], [], [], [], []
+        for b in range(3):
+            boxes, _ = syn.gt_boxes(30 if b < 2 else 2, rng)
+            if b == 1:   # axis-aligned boxes whose faces pass exactly through cell corners
+                boxes[:6, 6] = 0.0
+                boxes[:6, 0] = np.float32(-51.2) + np.float32(0.8) * rng.integers(10, 100, 6).astype(np.float32)
+                boxes[:6, 1] = np.float32(-51.2) + np.float32(0.8) * rng.integers(10, 100, 6).astype(np.float32)
+                boxes[:6, 3] = 1.6; boxes[:6, 4] = 3.2
+                boxes[6, :] = boxes[0, :]          # duplicate box (first-hit tie)
+            bx = boxes.copy()
+            bx[:, 2] = 0; bx[:, 5] = 1
+            mask = bnp.points_in_rbbox(points, bx[:, :7])
+            fg = mask.any(axis=-1).astype(float)
+            pi, bi = np.nonzero(mask)
+            pi, ui = np.unique(pi, return_index=True)
+            bi = bi[ui]
+            fs = np.zeros(H * W, dtype=float)
+            fs[pi] = torch.sqrt((voxel_size[0] * voxel_size[1] * osf * osf) / (bx[bi][:, 3] * bx[bi][:, 4]))
+            bs = np.zeros(H * W, dtype=float)
+            bs[:] = 1.0 / (H * W - np.sum(fg != 0))
+            boxes_all.append(boxes)
+            masks.append(mask)
+            fgs.append(torch.tensor(fg.reshape(W, H).transpose().reshape(1, 1, H, W)))
+            fss.append(torch.tensor(fs.reshape(W, H).transpose().reshape(1, 1, H, W)).float())
+            bss.append(torch.tensor(bs.reshape(W, H).transpose().reshape(1, 1, H, W)).float())
+        _save(f"fgmask_{H}.npz", points=points, xs=np.array([float(v) for v in xs], np.float32),
+              boxes0=boxes_all[0], boxes1=boxes_all[1], boxes2=boxes_all[2],
+              mask0=np.packbits(masks[0], axis=None), mask1=np.packbits(masks[1], axis=None),
+              fg=torch.cat(fgs).float().numpy(), fg_scale=torch.cat(fss).numpy(),
+              bg_scale=torch.cat(bss).numpy())
+        print(H, "fg cells per sample", [int(f.sum()) for f in fgs])
+
+
+SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)
