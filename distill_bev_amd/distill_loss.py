@@ -73,15 +73,19 @@ class ForegroundMaskRasterizer:
             b[:, 2] = 0      # :785-786 unify z: bottom 0, height 1
             b[:, 5] = 1
             planes.append(box_face_planes(b).reshape(-1, 4))
-            # torch.sqrt(area / (w * l)) as float32 tensor ops (:805-806)
-            scales.append(torch.sqrt(area / torch.from_numpy(b[:, 3] * b[:, 4])).numpy())
+            # sqrt(area / (w * l)) in float32 (:805-806).  The reference calls torch.sqrt on the
+            # CPU, whose vectorised kernel is NOT correctly rounded and differs by 1 ulp between
+            # hosts; the correctly rounded numpy sqrt is used here (<= 1 ulp from any of them).
+            scales.append(np.sqrt((np.float32(area.item()) / (b[:, 3] * b[:, 4])).astype(np.float32)))
             offs.append(offs[-1] + b.shape[0])
         B = len(gt_boxes)
         pl = np.concatenate(planes) if offs[-1] else np.zeros((1, 4), np.float32)
         sc = np.concatenate(scales) if offs[-1] else np.zeros((1,), np.float32)
-        pl_d = torch.from_numpy(np.ascontiguousarray(pl)).to(device, non_blocking=True)
-        sc_d = torch.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)).to(device, non_blocking=True)
-        of_d = torch.tensor(offs, dtype=torch.int32).to(device, non_blocking=True)
+        # blocking copies: the sources are pageable temporaries (an async H2D from pageable
+        # memory may still be reading them after they are freed)
+        pl_d = torch.from_numpy(np.ascontiguousarray(pl)).to(device)
+        sc_d = torch.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)).to(device)
+        of_d = torch.tensor(offs, dtype=torch.int32).to(device)
         fg = torch.empty((B, 1, H, W), dtype=torch.float32, device=device)
         fs = torch.empty_like(fg)
         bs = torch.empty_like(fg)

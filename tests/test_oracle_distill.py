@@ -14,7 +14,8 @@ def test_foreground_scale_mask_bit_exact(H):
     assert np.array_equal(OD.cell_coords(H, 0.1, 1024 // H, -51.2), g["xs"])
     fg, fs, bs = OD.foreground_scale_mask(H, H, boxes)
     assert np.array_equal(fg, g["fg"])
-    assert np.array_equal(fs, g["fg_scale"])
+    # reference fg_scale = torch.sqrt (CPU kernel, not correctly rounded, host dependent): 1 ulp
+    assert np.allclose(fs, g["fg_scale"], rtol=2.5e-7, atol=0)
     assert np.array_equal(bs, g["bg_scale"])
 
 
