@@ -1,0 +1,329 @@
+"""CenterHead -- registry mirror of ``mmdet3d/models/dense_heads/centerpoint_head.py``
+(SeparateHead :17-130, CenterHead :246-686) with the mmdet==2.24.0 losses it is configured with
+(GaussianFocalLoss, L1Loss, MSELoss; un-vendored, standard definitions) and the target
+assignment of ``get_targets_single`` :447-611 / ``core/utils/gaussian.py`` :6-88.
+
+The dense head stays PyTorch (MIOpen convs).  Target assignment is host work in the reference too
+(a python loop over the GT boxes issuing hundreds of tiny device ops per sample, plus ``.item()``
+syncs); here it is plain numpy on the host boxes (the GT boxes are host data) followed by ONE
+upload of the stacked targets per step.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .registry import BBOX_CODERS, MODELS, ConvModule, build_conv_layer, build_head, build_loss
+
+
+class LiDARBoxes:
+    """The two members of ``LiDARInstance3DBoxes`` the hot path touches
+    (``core/bbox/structures/lidar_box3d.py:41-47``): ``tensor`` f32[M, 9] =
+    (x, y, z_bottom, w, l, h, yaw, vx, vy) on the host, and ``gravity_center``."""
+
+    def __init__(self, tensor):
+        t = torch.as_tensor(tensor, dtype=torch.float32)
+        self.tensor = t.reshape(-1, t.shape[-1] if t.numel() else 9)
+
+    @property
+    def gravity_center(self):
+        gc = self.tensor[:, :3].clone()
+        gc[:, 2] = gc[:, 2] + self.tensor[:, 5] * 0.5
+        return gc
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+
+def clip_sigmoid(x, eps=1e-4):
+    """models/utils/clip_sigmoid.py:5-19 (in-place sigmoid, as the reference)."""
+    return torch.clamp(x.sigmoid_(), min=eps, max=1 - eps)
+
+
+# ---- losses (mmdet 2.24 semantics) -------------------------------------------------------
+def _weight_reduce(loss, weight, reduction, avg_factor):
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        return loss.mean() if reduction == "mean" else loss.sum() if reduction == "sum" else loss
+    if reduction == "mean":
+        return loss.sum() / avg_factor
+    if reduction == "none":
+        return loss
+    raise ValueError("avg_factor can not be used with reduction='sum'")
+
+
+@MODELS.register_module()
+class GaussianFocalLoss(nn.Module):
+    def __init__(self, alpha=2.0, gamma=4.0, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.alpha, self.gamma, self.reduction, self.loss_weight = alpha, gamma, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        eps = 1e-12
+        pos_w = target.eq(1)
+        neg_w = (1 - target).pow(self.gamma)
+        pos = -(pred + eps).log() * (1 - pred).pow(self.alpha) * pos_w
+        neg = -(1 - pred + eps).log() * pred.pow(self.alpha) * neg_w
+        return self.loss_weight * _weight_reduce(pos + neg, weight, reduction_override or self.reduction, avg_factor)
+
+
+@MODELS.register_module()
+class L1Loss(nn.Module):
+    def __init__(self, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        if target.numel() == 0:
+            return pred.sum() * 0
+        return self.loss_weight * _weight_reduce(torch.abs(pred - target), weight,
+                                                 reduction_override or self.reduction, avg_factor)
+
+
+@MODELS.register_module()
+class MSELoss(nn.Module):
+    def __init__(self, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        return self.loss_weight * _weight_reduce((pred - target) ** 2, weight,
+                                                 reduction_override or self.reduction, avg_factor)
+
+
+@MODELS.register_module()
+class SmoothL1Loss(nn.Module):
+    def __init__(self, beta=1.0, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.beta, self.reduction, self.loss_weight = beta, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        d = torch.abs(pred - target)
+        loss = torch.where(d < self.beta, 0.5 * d * d / self.beta, d - 0.5 * self.beta)
+        return self.loss_weight * _weight_reduce(loss, weight, reduction_override or self.reduction, avg_factor)
+
+
+@BBOX_CODERS.register_module()
+class CenterPointBBoxCoder:
+    """core/bbox/coders/centerpoint_bbox_coders.py -- only the config surface is needed for
+    training (decode belongs to inference post-processing, out of scope)."""
+
+    def __init__(self, pc_range, out_size_factor, voxel_size, post_center_range=None, max_num=100,
+                 score_threshold=None, code_size=9):
+        self.pc_range, self.out_size_factor, self.voxel_size = pc_range, out_size_factor, voxel_size
+        self.post_center_range, self.max_num, self.score_threshold, self.code_size = \
+            post_center_range, max_num, score_threshold, code_size
+
+
+# ---- heads ----------------------------------------------------------------------------
+@MODELS.register_module()
+class SeparateHead(nn.Module):
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, init_bias=-2.19,
+                 conv_cfg=dict(type="Conv2d"), norm_cfg=dict(type="BN2d"), bias="auto", init_cfg=None,
+                 act_cfg=dict(type="ReLU"), **kwargs):
+        super().__init__()
+        self.heads = heads
+        self.init_bias = init_bias
+        for head, (classes, num_conv) in heads.items():
+            layers = []
+            c_in = in_channels
+            for _ in range(num_conv - 1):
+                layers.append(ConvModule(c_in, head_conv, kernel_size=final_kernel, stride=1,
+                                         padding=final_kernel // 2, bias=bias, conv_cfg=conv_cfg,
+                                         norm_cfg=norm_cfg, act_cfg=act_cfg))
+                c_in = head_conv
+            layers.append(build_conv_layer(conv_cfg, head_conv, classes, kernel_size=final_kernel, stride=1,
+                                           padding=final_kernel // 2, bias=True))
+            self.add_module(head, nn.Sequential(*layers))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        if "heatmap" in heads:
+            getattr(self, "heatmap")[-1].bias.data.fill_(init_bias)
+
+    def forward(self, x):
+        return {head: getattr(self, head)(x) for head in self.heads}
+
+
+def gaussian_radius(det_size, min_overlap=0.5):
+    """core/utils/gaussian.py:58-88 in float32 (the reference evaluates it on 0-dim float32 tensors)."""
+    f = np.float32
+    height, width = f(det_size[0]), f(det_size[1])
+    mo = f(min_overlap)
+    b1 = height + width
+    c1 = width * height * (f(1) - mo) / (f(1) + mo)
+    r1 = (b1 + np.sqrt(b1 * b1 - f(4) * c1)) / f(2)
+    b2 = f(2) * (height + width)
+    c2 = (f(1) - mo) * width * height
+    r2 = (b2 + np.sqrt(b2 * b2 - f(16) * c2)) / f(2)
+    a3 = f(4) * mo
+    b3 = f(-2) * mo * (height + width)
+    c3 = (mo - f(1)) * width * height
+    r3 = (b3 + np.sqrt(b3 * b3 - f(4) * a3 * c3)) / f(2)
+    return min(r1, r2, r3)
+
+
+def gaussian_2d(shape, sigma=1.0):
+    """gaussian.py:6-22."""
+    m, n = [(ss - 1.0) / 2.0 for ss in shape]
+    y, x = np.ogrid[-m:m + 1, -n:n + 1]
+    h = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    return h
+
+
+def draw_heatmap_gaussian(heatmap, center, radius, k=1):
+    """gaussian.py:25-55 on a numpy heatmap [H, W] (in place)."""
+    diameter = 2 * radius + 1
+    g = gaussian_2d((diameter, diameter), sigma=diameter / 6)
+    x, y = int(center[0]), int(center[1])
+    height, width = heatmap.shape[:2]
+    left, right = min(x, radius), min(width - x, radius + 1)
+    top, bottom = min(y, radius), min(height - y, radius + 1)
+    mh = heatmap[y - top:y + bottom, x - left:x + right]
+    mg = g[radius - top:radius + bottom, radius - left:radius + right].astype(np.float32)
+    if min(mg.shape) > 0 and min(mh.shape) > 0:
+        np.maximum(mh, mg * k, out=mh)
+    return heatmap
+
+
+@MODELS.register_module()
+class CenterHead(nn.Module):
+    def __init__(self, in_channels=[128], tasks=None, train_cfg=None, test_cfg=None, bbox_coder=None,
+                 common_heads=dict(), loss_cls=dict(type="GaussianFocalLoss", reduction="mean"),
+                 loss_bbox=dict(type="L1Loss", reduction="none", loss_weight=0.25),
+                 separate_head=dict(type="SeparateHead", init_bias=-2.19, final_kernel=3),
+                 share_conv_channel=64, num_heatmap_convs=2, conv_cfg=dict(type="Conv2d"),
+                 norm_cfg=dict(type="BN2d"), bias="auto", norm_bbox=True, init_cfg=None, task_specific=True,
+                 loss_prefix="", act_cfg=dict(type="ReLU")):
+        super().__init__()
+        num_classes = [len(t["class_names"]) for t in tasks]
+        self.class_names = [t["class_names"] for t in tasks]
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.in_channels, self.num_classes, self.norm_bbox = in_channels, num_classes, norm_bbox
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.bbox_coder = BBOX_CODERS.build(bbox_coder) if bbox_coder is not None else None
+        self.shared_conv = ConvModule(in_channels, share_conv_channel, kernel_size=3, padding=1,
+                                      conv_cfg=conv_cfg, norm_cfg=norm_cfg, bias=bias, act_cfg=act_cfg)
+        self.task_heads = nn.ModuleList()
+        for num_cls in num_classes:
+            heads = copy.deepcopy(dict(common_heads))
+            heads.update(dict(heatmap=(num_cls, num_heatmap_convs)))
+            sh = dict(separate_head)
+            sh.update(in_channels=share_conv_channel, heads=heads, num_cls=num_cls)
+            self.task_heads.append(build_head(sh))
+        self.task_specific, self.loss_prefix = task_specific, loss_prefix
+
+    def forward_single(self, x):
+        x = self.shared_conv(x)
+        return [task(x) for task in self.task_heads]
+
+    def forward(self, feats):
+        """-> tuple over tasks of [dict] (multi_apply transposition, centerpoint_head.py:352-363)."""
+        per_level = [self.forward_single(f) for f in feats]
+        return tuple([lvl[t] for lvl in per_level] for t in range(len(self.task_heads)))
+
+    # ---- targets (host, numpy) ------------------------------------------------------------
+    def get_targets_single_np(self, boxes9, labels):
+        """centerpoint_head.py:447-611 for one sample.  boxes9 f32[M, 9] with GRAVITY centre
+        (x, y, z_c, w, l, h, yaw, vx, vy); labels int[M]."""
+        cfg = self.train_cfg
+        f = np.float32
+        max_objs = cfg["max_objs"] * cfg["dense_reg"]
+        osf = cfg["out_size_factor"]
+        grid = np.asarray(cfg["grid_size"])
+        pc = np.asarray(cfg["point_cloud_range"], dtype=f)
+        vs = np.asarray(cfg["voxel_size"], dtype=f)
+        fm = grid[:2] // osf            # (W, H)
+        heatmaps, anno_boxes, inds, masks = [], [], [], []
+        flag = 0
+        for names in self.class_names:
+            ncls = len(names)
+            sel = [np.flatnonzero(labels == (j + flag)) for j in range(ncls)]
+            order = np.concatenate(sel) if sel else np.zeros((0,), np.int64)
+            tb = boxes9[order]
+            tc = (labels[order] + 1 - flag).astype(np.int64)
+            flag += ncls
+            hm = np.zeros((ncls, int(fm[1]), int(fm[0])), dtype=f)
+            ab = np.zeros((max_objs, 10), dtype=f)
+            ind = np.zeros((max_objs,), dtype=np.int64)
+            mk = np.zeros((max_objs,), dtype=np.uint8)
+            for k in range(min(tb.shape[0], max_objs)):
+                cls_id = int(tc[k]) - 1
+                width = f(tb[k, 3] / vs[0] / f(osf))
+                length = f(tb[k, 4] / vs[1] / f(osf))
+                if not (width > 0 and length > 0):
+                    continue
+                radius = gaussian_radius((length, width), min_overlap=cfg["gaussian_overlap"])
+                radius = max(cfg["min_radius"], int(radius))
+                cx = f(f(tb[k, 0] - pc[0]) / vs[0] / f(osf))
+                cy = f(f(tb[k, 1] - pc[1]) / vs[1] / f(osf))
+                ix, iy = int(np.trunc(cx)), int(np.trunc(cy))
+                if not (0 <= ix < fm[0] and 0 <= iy < fm[1]):
+                    continue
+                draw_heatmap_gaussian(hm[cls_id], (ix, iy), radius)
+                ind[k] = iy * int(fm[0]) + ix
+                mk[k] = 1
+                dim = np.log(tb[k, 3:6]) if self.norm_bbox else tb[k, 3:6]
+                ab[k] = np.concatenate([[cx - f(ix), cy - f(iy)], [tb[k, 2]], dim,
+                                        [np.sin(tb[k, 6]), np.cos(tb[k, 6])], tb[k, 7:9]]).astype(f)
+            heatmaps.append(hm); anno_boxes.append(ab); inds.append(ind); masks.append(mk)
+        return heatmaps, anno_boxes, inds, masks
+
+    def get_targets(self, gt_bboxes_3d, gt_labels_3d, device):
+        """:366-413 -> per task stacked tensors on `device` (one upload per tensor kind)."""
+        per_sample = []
+        for boxes, labels in zip(gt_bboxes_3d, gt_labels_3d):
+            b9 = torch.cat((boxes.gravity_center, boxes.tensor[:, 3:]), dim=1).numpy().astype(np.float32)
+            lab = labels.cpu().numpy() if torch.is_tensor(labels) else np.asarray(labels)
+            per_sample.append(self.get_targets_single_np(b9, lab))
+        nt = len(self.task_heads)
+        out = []
+        for kind in range(4):
+            out.append([torch.from_numpy(np.stack([s[kind][t] for s in per_sample])).to(device)
+                        for t in range(nt)])
+        return tuple(out)
+
+    @staticmethod
+    def _gather_feat(feat, ind):
+        dim = feat.size(2)
+        return feat.gather(1, ind.unsqueeze(2).expand(ind.size(0), ind.size(1), dim))
+
+    def loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, get_targets=False, **kwargs):
+        """:615-686 (clip_sigmoid is applied IN PLACE to the predicted heatmaps, as the reference)."""
+        device = preds_dicts[0][0]["heatmap"].device
+        heatmaps, anno_boxes, inds, masks = self.get_targets(gt_bboxes_3d, gt_labels_3d, device)
+        loss_dict = dict()
+        code_weights = self.train_cfg.get("code_weights", None)
+        for task_id, preds_dict in enumerate(preds_dicts):
+            p = preds_dict[0]
+            p["heatmap"] = clip_sigmoid(p["heatmap"])
+            num_pos = heatmaps[task_id].eq(1).float().sum()
+            loss_heatmap = self.loss_cls(p["heatmap"], heatmaps[task_id], avg_factor=torch.clamp(num_pos, min=1))
+            target_box = anno_boxes[task_id]
+            p["anno_box"] = torch.cat((p["reg"], p["height"], p["dim"], p["rot"], p["vel"]), dim=1)
+            ind = inds[task_id]
+            num = masks[task_id].float().sum()
+            pred = p["anno_box"].permute(0, 2, 3, 1).contiguous()
+            pred = self._gather_feat(pred.view(pred.size(0), -1, pred.size(3)), ind)
+            mask = masks[task_id].unsqueeze(2).expand_as(target_box).float()
+            mask = mask * (~torch.isnan(target_box)).float()
+            bbox_weights = mask * mask.new_tensor(code_weights)
+            if self.task_specific:
+                names, clip = ["xy", "z", "whl", "yaw", "vel"], [0, 2, 3, 6, 8, 10]
+                for r, nm in enumerate(names):
+                    sl = slice(clip[r], clip[r + 1])
+                    loss_dict[f"{self.loss_prefix}task{task_id}.loss_{nm}"] = self.loss_bbox(
+                        pred[..., sl], target_box[..., sl], bbox_weights[..., sl], avg_factor=(num + 1e-4))
+            else:
+                loss_dict[f"task{task_id}.loss_bbox"] = self.loss_bbox(pred, target_box, bbox_weights,
+                                                                       avg_factor=(num + 1e-4))
+            loss_dict[f"{self.loss_prefix}task{task_id}.loss_heatmap"] = loss_heatmap
+        if get_targets:
+            return loss_dict, heatmaps, anno_boxes, inds, masks
+        return loss_dict

@@ -1,0 +1,182 @@
+"""Pillar voxel encoders -- registry mirror of
+``mmdet3d/models/voxel_encoders/pillar_encoder.py`` (PillarFeatureNet :14-162,
+DynamicPillarFeatureNet :166-338) and ``voxel_encoders/utils.py`` (PFNLayer :107-181,
+get_paddings_indicator :9-29) on top of the gfx950 dynamic-scatter kernels.
+
+DynamicPillarFeatureNet: the reference runs DynamicScatter twice over the SAME coordinates
+(cluster mean :304, PFN max :331), each a per-sample python loop of unique_dim + float atomics,
+and broadcasts voxel means back to the points through a dense [C, 512*512*B] canvas (:243-280).
+Here the point->voxel grouping is computed ONCE for the whole batch (batch folded into the z
+axis of the voxel grid, which keeps the reference's (b, z, y, x) output order) and reused by
+both reductions; the broadcast is a gather through coors_map.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .registry import MODELS, build_activation_layer, build_norm_layer
+from .voxel import dynamic_scatter, dynamic_scatter_prepare
+
+
+def get_paddings_indicator(actual_num, max_num, axis=0):
+    """voxel_encoders/utils.py:9-29."""
+    actual_num = torch.unsqueeze(actual_num, axis + 1)
+    shape = [1] * len(actual_num.shape)
+    shape[axis + 1] = -1
+    max_num = torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(shape)
+    return actual_num.int() > max_num
+
+
+class PFNLayer(nn.Module):
+    """voxel_encoders/utils.py:107-181."""
+
+    def __init__(self, in_channels, out_channels, norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01),
+                 last_layer=False, mode="max"):
+        super().__init__()
+        self.last_vfe = last_layer
+        if not self.last_vfe:
+            out_channels = out_channels // 2
+        self.units = out_channels
+        self.norm = build_norm_layer(norm_cfg, self.units)[1]
+        self.linear = nn.Linear(in_channels, self.units, bias=False)
+        assert mode in ("max", "avg")
+        self.mode = mode
+
+    def forward(self, inputs, num_voxels=None, aligned_distance=None):
+        x = self.linear(inputs)
+        x = self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        x = F.relu(x)
+        if aligned_distance is not None:
+            x = x.mul(aligned_distance.unsqueeze(-1))
+        if self.mode == "max":
+            x_max = torch.max(x, dim=1, keepdim=True)[0]
+        else:
+            x_max = x.sum(dim=1, keepdim=True) / num_voxels.type_as(inputs).view(-1, 1, 1)
+        if self.last_vfe:
+            return x_max
+        return torch.cat([x, x_max.repeat(1, inputs.shape[1], 1)], dim=2)
+
+
+@MODELS.register_module()
+class PillarFeatureNet(nn.Module):
+    """pillar_encoder.py:14-162 (hard-voxel input [M, max_points, C])."""
+
+    def __init__(self, in_channels=4, feat_channels=(64,), with_distance=False, with_cluster_center=True,
+                 with_voxel_center=True, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), mode="max", legacy=True, virtual=False):
+        super().__init__()
+        assert len(feat_channels) > 0
+        self.legacy = legacy
+        if with_cluster_center:
+            in_channels += 3
+        if with_voxel_center:
+            in_channels += 2
+        if with_distance:
+            in_channels += 1
+        self._with_distance, self._with_cluster_center, self._with_voxel_center = \
+            with_distance, with_cluster_center, with_voxel_center
+        self.in_channels = in_channels
+        chans = [in_channels] + list(feat_channels)
+        self.pfn_layers = nn.ModuleList([
+            PFNLayer(chans[i], chans[i + 1], norm_cfg=norm_cfg, last_layer=(i == len(chans) - 2), mode=mode)
+            for i in range(len(chans) - 1)])
+        self.vx, self.vy = voxel_size[0], voxel_size[1]
+        self.x_offset = self.vx / 2 + point_cloud_range[0]
+        self.y_offset = self.vy / 2 + point_cloud_range[1]
+        self.point_cloud_range = point_cloud_range
+        self.virtual = virtual
+
+    def forward(self, features, num_points, coors):
+        features_ls = [features]
+        if self._with_cluster_center:
+            points_mean = features[:, :, :3].sum(dim=1, keepdim=True) / num_points.type_as(features).view(-1, 1, 1)
+            features_ls.append(features[:, :, :3] - points_mean)
+        dtype = features.dtype
+        if self._with_voxel_center:
+            if not self.legacy:
+                f_center = torch.zeros_like(features[:, :, :2])
+                f_center[:, :, 0] = features[:, :, 0] - (coors[:, 3].to(dtype).unsqueeze(1) * self.vx + self.x_offset)
+                f_center[:, :, 1] = features[:, :, 1] - (coors[:, 2].to(dtype).unsqueeze(1) * self.vy + self.y_offset)
+            else:
+                f_center = features[:, :, :2].clone()
+                f_center[:, :, 0] = f_center[:, :, 0] - (coors[:, 3].type_as(features).unsqueeze(1) * self.vx + self.x_offset)
+                f_center[:, :, 1] = f_center[:, :, 1] - (coors[:, 2].type_as(features).unsqueeze(1) * self.vy + self.y_offset)
+            features_ls.append(f_center)
+        if self._with_distance:
+            features_ls.append(torch.norm(features[:, :, :3], 2, 2, keepdim=True))
+        features = torch.cat(features_ls, dim=-1)
+        mask = get_paddings_indicator(num_points, features.shape[1], axis=0)
+        features = features * torch.unsqueeze(mask, -1).type_as(features)
+        for pfn in self.pfn_layers:
+            features = pfn(features, num_points)
+        return features.squeeze(1)
+
+
+@MODELS.register_module()
+class DynamicPillarFeatureNet(PillarFeatureNet):
+    """pillar_encoder.py:166-338 (dynamic voxelization: points [N, C] + coors [N, 4] = (b,z,y,x))."""
+
+    def __init__(self, in_channels=4, feat_channels=(64,), with_distance=False, with_cluster_center=True,
+                 with_voxel_center=True, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), mode="max", virtual=False,
+                 act_cfg=dict(type="ReLU", inplace=True), use_checkpoint=False):
+        super().__init__(in_channels, feat_channels, with_distance, with_cluster_center=with_cluster_center,
+                         with_voxel_center=with_voxel_center, voxel_size=voxel_size,
+                         point_cloud_range=point_cloud_range, norm_cfg=norm_cfg, mode=mode, virtual=virtual)
+        chans = [self.in_channels] + list(feat_channels)
+        layers = []
+        for i in range(len(chans) - 1):
+            cin = chans[i] * (2 if i > 0 else 1)
+            layers.append(nn.Sequential(nn.Linear(cin, chans[i + 1], bias=False),
+                                        build_norm_layer(norm_cfg, chans[i + 1])[1],
+                                        build_activation_layer(act_cfg)))
+        self.num_pfn = len(layers)
+        self.pfn_layers = nn.ModuleList(layers)
+        self.mode = mode
+        pcr, vs = point_cloud_range, voxel_size
+        self.grid = (max(int(round((pcr[5] - pcr[2]) / vs[2])), 1), int(round((pcr[4] - pcr[1]) / vs[1])),
+                     int(round((pcr[3] - pcr[0]) / vs[0])))  # (gz, gy, gx)
+
+    def _prepare(self, coors, batch_size):
+        """One point->voxel grouping for the whole batch: fold b into z (cell z' = b*gz + z)."""
+        gz, gy, gx = self.grid
+        c = coors.int()
+        invalid = (c[:, 1:] < 0).any(dim=1)
+        zf = torch.where(invalid, torch.full_like(c[:, 0], -1), c[:, 0] * gz + c[:, 1])
+        folded = torch.stack([zf, c[:, 2], c[:, 3]], dim=1).contiguous()
+        prep = dynamic_scatter_prepare(folded, grid=(gz * batch_size, gy, gx))
+        oc = prep["out_coors"]
+        voxel_coors = torch.stack([oc[:, 0] // gz, oc[:, 0] % gz, oc[:, 1], oc[:, 2]], dim=1).int()
+        return folded, prep, voxel_coors
+
+    def forward(self, features, coors, batch_size=None):
+        if self.virtual:
+            vmask = features[..., -2] == -1
+            vpts = features[vmask]
+            vpts[..., -2] = 1
+            features[..., -2] = 0
+            features[vmask] = vpts
+        if batch_size is None:
+            batch_size = int(coors[-1, 0]) + 1
+        folded, prep, voxel_coors = self._prepare(coors, batch_size)
+        cmap = prep["coors_map"].long().clamp(min=0)
+        features_ls = [features]
+        if self._with_cluster_center:
+            voxel_mean, _ = dynamic_scatter(features, folded, "mean", None, prep)
+            points_mean = voxel_mean[cmap]              # map_voxel_center_to_point (:243-280)
+            features_ls.append(features[:, :3] - points_mean[:, :3])
+        if self._with_voxel_center:
+            f_center = features.new_zeros(size=(features.size(0), 2))
+            f_center[:, 0] = features[:, 0] - (coors[:, 3].type_as(features) * self.vx + self.x_offset)
+            f_center[:, 1] = features[:, 1] - (coors[:, 2].type_as(features) * self.vy + self.y_offset)
+            features_ls.append(f_center)
+        if self._with_distance:
+            features_ls.append(torch.norm(features[:, :3], 2, 1, keepdim=True))
+        features = torch.cat(features_ls, dim=-1)
+        voxel_feats = None
+        for i, pfn in enumerate(self.pfn_layers):
+            point_feats = pfn(features)
+            voxel_feats, _ = dynamic_scatter(point_feats, folded, "max" if self.mode == "max" else "mean", None, prep)
+            if i != len(self.pfn_layers) - 1:
+                features = torch.cat([point_feats, voxel_feats[cmap]], dim=1)
+        return voxel_feats, voxel_coors

@@ -1,0 +1,114 @@
+"""Training-step driver for the distillation hot path: synthetic nuScenes-shaped batches, model
+construction from a config, AdamW + grad-clip step, data-parallel over RCCL.
+
+Replaces, for measurement purposes, the orchestration the reference delegates to mmcv/mmdet
+(``tools/train.py`` -> ``mmdet.apis.train_detector`` -> ``EpochBasedRunner.run_iter`` ->
+``MMDistributedDataParallel.train_step`` -> ``OptimizerHook``): one process per GPU,
+samples sharded across ranks, the only collective is the bucketed gradient all-reduce that
+``torch.nn.parallel.DistributedDataParallel`` overlaps with backward (backend "nccl" = RCCL over
+xGMI).  The teacher is not a registered submodule, so DDP neither broadcasts nor reduces it
+(bevdet_distill.py:1599-1610).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import synthetic as syn
+from .center_head import LiDARBoxes
+from .config import Config
+from . import detectors  # noqa: F401  (registers every model component)
+from .registry import build_detector
+
+DEFAULT_CONFIG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs",
+                              "distillbev_centerpoint2bevdepth4d_r50.py")
+
+
+def make_batch(B, rng, device, n_points=240000, n_boxes=30, n_cams=6, input_size=(256, 704), downsample=16):
+    """One synthetic batch in the reference's input contract:
+    img_inputs = (imgs f32[B, 2*N, 3, H, W] interleaved cur/adj per camera,
+                  rots[B,2N,3,3], trans[B,2N,3], intrins[B,2N,3,3], post_rots[B,2N,3,3], post_trans[B,2N,3]
+                  (first N = current frame, last N = adjacent frame), depth_gt f32[B, 2N, fH, fW]);
+    points: list of f32[n_points, 5]; gt_bboxes_3d: list of LiDARBoxes (host); gt_labels_3d: list of int64."""
+    H, W = input_size
+    fH, fW = H // downsample, W // downsample
+    cur = syn.camera_rig(B, rng, n_cams=n_cams, input_size=input_size)
+    adj = {k: v.copy() for k, v in cur.items()}
+    adj["trans"] = adj["trans"] + np.concatenate(
+        [rng.uniform(0.0, 2.0, (B, 1, 1)), rng.uniform(-0.2, 0.2, (B, 1, 1)), np.zeros((B, 1, 1))], 2).astype(np.float32)
+    mats = {k: torch.from_numpy(np.concatenate([cur[k], adj[k]], 1)).to(device) for k in cur}
+    g = torch.Generator(device="cpu").manual_seed(int(rng.integers(0, 2 ** 31)))
+    imgs = torch.randn((B, 2 * n_cams, 3, H, W), generator=g).to(device)
+    dgt = torch.from_numpy(syn.depth_gt(B, 2 * n_cams, fH, fW, rng)).to(device)
+    points, boxes, labels = [], [], []
+    for _ in range(B):
+        points.append(torch.from_numpy(syn.lidar_points(n_points, rng)).to(device))
+        b, l = syn.gt_boxes(n_boxes, rng)
+        boxes.append(LiDARBoxes(b))
+        labels.append(torch.from_numpy(l))
+    img_inputs = (imgs, mats["rots"], mats["trans"], mats["intrins"], mats["post_rots"], mats["post_trans"], dgt)
+    return dict(points=points, img_inputs=img_inputs, gt_bboxes_3d=boxes, gt_labels_3d=labels)
+
+
+def build_model(config=None, cfg_options=None, seed=0):
+    cfg = Config.fromfile(config or DEFAULT_CONFIG) if not isinstance(config, Config) else config
+    if cfg_options:
+        cfg.merge_from_args(cfg_options) if isinstance(cfg_options, (list, tuple)) else cfg.merge_from_dict(cfg_options)
+    torch.manual_seed(seed)
+    model = build_detector(cfg.model)
+    model.init_weights()
+    return model, cfg
+
+
+class _TrainWrapper(nn.Module):
+    """DDP needs the loss computation inside forward()."""
+
+    def __init__(self, detector):
+        super().__init__()
+        self.detector = detector
+
+    def forward(self, **batch):
+        return self.detector.forward_train(**batch)
+
+
+def parse_losses(losses):
+    """mmdet BaseDetector._parse_losses: total = sum of every entry whose key contains 'loss'."""
+    return sum(v for k, v in losses.items() if "loss" in k)
+
+
+class Trainer:
+    def __init__(self, model, cfg, device, world_size=1, channels_last=False):
+        self.device = device
+        self.detector = model.to(device)
+        self.detector.train()
+        if channels_last:
+            self.detector = self.detector.to(memory_format=torch.channels_last)
+        self.wrapper = _TrainWrapper(self.detector)
+        self.world_size = world_size
+        if world_size > 1:
+            self.module = nn.parallel.DistributedDataParallel(
+                self.wrapper, device_ids=[device.index], broadcast_buffers=False,
+                find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
+        else:
+            self.module = self.wrapper
+        opt = dict(cfg.get("optimizer", dict(type="AdamW", lr=2e-4, weight_decay=0.01)))
+        assert opt.pop("type") == "AdamW"
+        params = [p for p in self.detector.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.AdamW(params, **opt, fused=True)
+        oc = cfg.get("optimizer_config", {}) or {}
+        gc = oc.get("grad_clip", None)
+        self.grad_clip = dict(gc) if gc else None
+        self.params = params
+
+    def step(self, batch):
+        losses = self.module(**batch)
+        loss = parse_losses(losses)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.grad_clip:
+            nn.utils.clip_grad_norm_(self.params, **self.grad_clip)
+        self.optimizer.step()
+        return loss.detach(), losses
