@@ -16,13 +16,20 @@ ap.add_argument("--bs", type=int, default=2)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--points", type=int, default=240000)
 ap.add_argument("--channels-last", action="store_true")
+ap.add_argument("--benchmark", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = args.benchmark
 t0 = time.time()
 model, cfg = build_model()
 tr = Trainer(model, cfg, dev, channels_last=args.channels_last)
 print("build+to(device) %.1fs" % (time.time() - t0), flush=True)
 batch = make_batch(args.bs, np.random.default_rng(0), dev, n_points=args.points)
+if args.channels_last:
+    ii = list(batch["img_inputs"])
+    B_, N_, C_, H_, W_ = ii[0].shape
+    ii[0] = ii[0].view(B_ * N_, C_, H_, W_).contiguous(memory_format=torch.channels_last).view(B_, N_, C_, H_, W_)
+    batch["img_inputs"] = tuple(ii)
 torch.cuda.synchronize()
 for i in range(args.steps):
     t = time.time()
