@@ -12,9 +12,11 @@ product sends to the HIP library is replaced by the reference's CPU op sequence:
   FGD losses        (S-T)^2 materialised and reduced once per loss term, exactly the unfused
                     expression of bevdet_distill.py:1253-1262,1282-1287
 
-Used by (a) bench.py's cpu_baseline leg ("port"), (b) the end-to-end parity test that compares
-every loss value of the HIP path against this path on identical weights and inputs.  The
-product package never imports this module.
+Used by (a) bench.py's cpu_baseline leg ("port", everything on the CPU), (b) the end-to-end
+parity test that compares every loss value of the HIP path against this path on identical
+weights and inputs.  The op replacements are device agnostic: with the model on a GPU the
+dense modules run there (same MIOpen kernels as the product, so only the hot ops differ) while
+the numpy/C oracle ops still run on the host.  The product package never imports this module.
 """
 import numpy as np
 import torch
@@ -34,6 +36,7 @@ class CpuDynamicCenterPoint(D.DynamicCenterPoint):
     def extract_pts_feat(self, pts, img_feats=None, img_metas=None, return_canvas=False, return_backbone_feature=False):
         vl = self.pts_voxel_layer
         enc = self.pts_voxel_encoder
+        dev = pts[0].device          # host ops below; tensors return to `dev` for the dense modules
         feats_all, coors_all = [], []
         for b, p in enumerate(pts):
             pn = p.detach().cpu().numpy().astype(np.float32)
@@ -51,7 +54,7 @@ class CpuDynamicCenterPoint(D.DynamicCenterPoint):
             feats_all.append(x)
             coors_all.append(co)
         x = torch.cat(feats_all, 0)
-        point_feats = enc.pfn_layers[0](x)                                               # Linear+BN1d+ReLU
+        point_feats = enc.pfn_layers[0](x.to(dev)).cpu()                                 # Linear+BN1d+ReLU
         off = 0
         vf, vc = [], []
         for b, co in enumerate(coors_all):
@@ -63,7 +66,7 @@ class CpuDynamicCenterPoint(D.DynamicCenterPoint):
         voxel_features = torch.cat(vf, 0)
         coors = np.concatenate(vc, 0)
         canvas = torch.from_numpy(OV.pillars_scatter(voxel_features.numpy(), coors, len(pts),
-                                                     self.pts_middle_encoder.ny, self.pts_middle_encoder.nx))
+                                                     self.pts_middle_encoder.ny, self.pts_middle_encoder.nx)).to(dev)
         return self._backbone_neck(canvas, [], return_canvas, return_backbone_feature)
 
 
@@ -90,7 +93,8 @@ class CpuBEVDepth4DDistill(D.BEVDepth4DDistill):
         tc = self.pts_bbox_head.train_cfg
         fg, fgs, bgs = OD.foreground_scale_mask(H, W, [b.tensor.numpy() for b in gt_bboxes_3d], tc["grid_size"],
                                                 tc["point_cloud_range"], tc["voxel_size"])
-        fg, fg_scale, bg_scale = torch.from_numpy(fg), torch.from_numpy(fgs), torch.from_numpy(bgs)
+        dev = student_feat.device
+        fg, fg_scale, bg_scale = torch.from_numpy(fg).to(dev), torch.from_numpy(fgs).to(dev), torch.from_numpy(bgs).to(dev)
         S_T, C_T, s_ratio = dp["spatial_t"], dp["channel_t"], dp["spatial_student_ratio"]
         t_att = torch.softmax(torch.mean(torch.abs(teacher_feat), [1]).view(B, -1) / S_T, dim=1) * H * W
         s_att = torch.softmax(torch.mean(torch.abs(student_feat), [1]).view(B, -1) / S_T, dim=1) * H * W
