@@ -315,9 +315,13 @@ class BEVDepth4DDistill(CenterPoint):
         feat2bev[2, 2] = 1
         feat2bev = feat2bev.view(1, 3, 3)
         tf = torch.inverse(feat2bev).matmul(l02l1).matmul(feat2bev)
-        grid = tf.matmul(grid)
+        # tf [n,1,1,3,3] @ grid [n,h,w,3,1]: written as broadcast multiply-adds (a broadcast matmul
+        # becomes n*h*w tiny GEMMs -- see lss._apply3x3)
+        g = grid[..., 0]
+        grid = torch.stack([tf[..., i, 0] * g[..., 0] + tf[..., i, 1] * g[..., 1] + tf[..., i, 2] * g[..., 2]
+                            for i in range(2)], -1)
         norm = torch.tensor([w - 1.0, h - 1.0], dtype=dt, device=dev)
-        grid = grid[:, :, :, :2, 0] / norm.view(1, 1, 1, 2) * 2.0 - 1.0
+        grid = grid / norm.view(1, 1, 1, 2) * 2.0 - 1.0
         return F.grid_sample(input, grid.to(dt), align_corners=True, mode=self.interpolation_mode)
 
     def bev_encoder(self, x, return_backbone_feature=False):

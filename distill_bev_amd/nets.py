@@ -380,11 +380,10 @@ def modulated_deform_conv2d(x, offset, mask, weight, bias, stride=1, padding=1, 
     grid = torch.stack((gx, gy), -1).view(N, K * Ho, Wo, 2)
     cols = F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
     cols = cols.view(N, C, K, Ho, Wo) * mask.view(N, 1, K, Ho, Wo)
-    out = torch.einsum("ok,nkp->nop", weight.view(Co, C * K), cols.view(N, C * K, Ho * Wo))
-    out = out.view(N, Co, Ho, Wo)
-    if bias is not None:
-        out = out + bias.view(1, -1, 1, 1)
-    return out
+    # the contraction over (c, k) is a 1x1 convolution of the sampled columns: MIOpen's 1x1 conv
+    # kernels run it ~40x faster than the skinny hipBLASLt GEMM torch.einsum lowers to (measured:
+    # 21 ms -> 0.5 ms per call at N=48, C*K=2304, Ho*Wo=704)
+    return F.conv2d(cols.reshape(N, C * K, Ho, Wo), weight.reshape(Co, C * K, 1, 1), bias)
 
 
 class ModulatedDeformConv2dPack(nn.Module):
