@@ -132,6 +132,9 @@ class Config:
     def __getitem__(self, name):
         return self._cfg[name]
 
+    def __contains__(self, name):
+        return name in self._cfg
+
     def get(self, k, default=None):
         return self._cfg.get(k, default)
 

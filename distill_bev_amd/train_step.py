@@ -90,14 +90,14 @@ class Trainer:
         self.world_size = world_size
         if world_size > 1:
             self.module = nn.parallel.DistributedDataParallel(
-                self.wrapper, device_ids=[device.index], broadcast_buffers=False,
+                self.wrapper, device_ids=[device.index] if device.type == "cuda" else None, broadcast_buffers=False,
                 find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
         else:
             self.module = self.wrapper
         opt = dict(cfg.get("optimizer", dict(type="AdamW", lr=2e-4, weight_decay=0.01)))
         assert opt.pop("type") == "AdamW"
         params = [p for p in self.detector.parameters() if p.requires_grad]
-        self.optimizer = torch.optim.AdamW(params, **opt, fused=True)
+        self.optimizer = torch.optim.AdamW(params, **opt, fused=(device.type == "cuda"))
         oc = cfg.get("optimizer_config", {}) or {}
         gc = oc.get("grad_clip", None)
         self.grad_clip = dict(gc) if gc else None

@@ -1,0 +1,194 @@
+"""CPU: config loader, registry/model construction, host-side target assignment and the dense
+DCNv2 restatement (no GPU, no HIP calls)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from distill_bev_amd.config import Config
+
+REF = "/root/reference"
+CFG_D = ("configs/lidar2camera_bev_distillation/centerpoint_pillar_to_bevdepth4d_r50/"
+         "centerpoint_02pillar_second_secfpn_circlenms_8x4_cyclic_20e_nus_to_bevdepth4d_r50.py")
+CFG_T = "configs/dynamic_centerpoint/dynamic_centerpoint_02pillar_second_secfpn_4x8_cyclic_20e_nus.py"
+RUN_D_OPTIONS = [  # scripts/teacher_to_bevdepth4d/centerpoint2bevdepth.sh:23-47 (model / optimizer part)
+    "model.inherit_head=True", "model.img_bev_encoder_neck.extra_norm_act=True",
+    "model.distill_params.spatial_attentions=['teacher_student',]",
+    "model.distill_params.foreground_mask='gt'", "model.distill_params.background_mask='logical_not'",
+    "model.distill_params.scale_mask='combine_gt'",
+    "model.distill_params.adaptation_type=['upsample_3layer','upsample_3layer','1x1conv']",
+    "model.distill_params.student_adaptation_params.kernel_size=1",
+    "model.distill_params.student_adaptation_params.stride=1",
+    "model.distill_params.student_adaptation_params.upsample_factor=4",
+    "model.distill_params.student_channels=[256,512,256]", "model.distill_params.teacher_channels=[128,256,384]",
+    "model.distill_params.student_feat_pos=['backbone1','backbone2','head']",
+    "model.distill_params.teacher_feat_pos=['backbone1','backbone2','head']",
+    "model.distill_params.fp_as_foreground=['none','none','teacher']", "model.distill_params.output_threshold=0.1",
+    "model.distill_params.fp_weight=6e-2", "model.distill_params.fp_scale_mode='average'",
+    "model.distill_params.fg_feat_loss_weights=[6e-3,]", "model.distill_params.bg_feat_loss_weights=[4e-2,]",
+    "model.distill_params.channel_mask=False",
+    "optimizer_config._delete_=True", "optimizer_config.grad_clip.max_norm=5",
+    "optimizer_config.grad_clip.norm_type=2", "optimizer.lr=2e-4",
+]
+
+
+def _norm(x):
+    if isinstance(x, dict):
+        return {k: _norm(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_norm(v) for v in x]
+    return x
+
+
+def test_config_inheritance_delete_and_overrides(tmp_path):
+    (tmp_path / "base.py").write_text("model = dict(type='A', enc=dict(type='E', c=1, d=2), head=dict(k=[1, 2]))\nlr = 0.1\n")
+    (tmp_path / "child.py").write_text("_base_ = ['./base.py']\nmodel = dict(enc=dict(_delete_=True, type='F', z=3), head=dict(k=[9]))\n")
+    c = Config.fromfile(str(tmp_path / "child.py"))
+    assert c.model.type == "A" and dict(c.model.enc) == {"type": "F", "z": 3} and c.model.head.k == [9] and c.lr == 0.1
+    c.merge_from_args(["model.head.k=[3,4,]", "model.enc.z=7", "lr=2e-4", "model.flag=True", "name='x'"])
+    assert c.model.head.k == [3, 4] and c.model.enc.z == 7 and c.lr == 2e-4 and c.model.flag is True and c.name == "x"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference configs only exist in the build container")
+def test_reference_configs_load_unchanged_and_match_shipped_recipe():
+    """The reference's own config files load through distill_bev_amd.config, and -- with the run
+    script's --cfg-options applied -- give the model the shipped effective config describes."""
+    ref = Config.fromfile(os.path.join(REF, CFG_D))
+    ref.merge_from_args(RUN_D_OPTIONS)
+    teacher = Config.fromfile(os.path.join(REF, CFG_T))
+    mine = Config.fromfile(os.path.join(ROOT, "configs", "distillbev_centerpoint2bevdepth4d_r50.py"))
+    rm, mm = _norm(ref.to_dict()["model"]), _norm(mine.to_dict()["model"])
+    # data_config also carries augmentation ranges of the (out-of-scope) data pipeline
+    dc = rm["img_view_transformer"]["data_config"]
+    rm["img_view_transformer"]["data_config"] = {k: dc[k] for k in mm["img_view_transformer"]["data_config"]}
+    for key in ("type", "distill_type", "aligned", "detach", "before", "inherit_head", "img_neck",
+                "img_view_transformer", "img_bev_encoder_backbone", "img_bev_encoder_neck", "pre_process",
+                "pts_bbox_head", "train_cfg", "test_cfg"):
+        assert rm[key] == mm[key], key
+    assert rm["distill_params"] == mm["distill_params"]
+    for k, v in rm["img_backbone"].items():
+        if k not in ("pretrained", "with_cp"):        # deliberate: no checkpoints, no recompute (see config header)
+            assert mm["img_backbone"][k] == v, k
+    tm = _norm(teacher.to_dict()["model"])
+    assert tm == _norm(mine.to_dict()["teacher"]["model"])
+    assert _norm(ref.to_dict()["optimizer"]) == _norm(mine.to_dict()["optimizer"])
+    assert _norm(ref.to_dict()["optimizer_config"]) == _norm(mine.to_dict()["optimizer_config"])
+    assert ref.data.samples_per_gpu == mine.data.samples_per_gpu == 8
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference configs only exist in the build container")
+def test_reference_config_builds_the_detector():
+    from distill_bev_amd import detectors  # noqa: F401
+    from distill_bev_amd.registry import build_detector
+    ref = Config.fromfile(os.path.join(REF, CFG_D))
+    ref.merge_from_args(RUN_D_OPTIONS + [
+        "model.teacher_config='" + os.path.join(REF, CFG_T) + "'", "model.teacher_ckpt=None",
+        "model.img_backbone.pretrained=None"])
+    m = build_detector(ref.model)
+    assert type(m).__name__ == "BEVDepth4DDistill" and type(m.teacher_model).__name__ == "DynamicCenterPoint"
+
+
+def test_model_builds_with_reference_state_dict_keys_and_hidden_teacher():
+    from distill_bev_amd.train_step import build_model
+    m, cfg = build_model()
+    keys = set(m.state_dict())
+    for k in ("img_backbone.layer3.5.conv3.weight", "img_backbone.layer1.0.downsample.1.running_var",
+              "img_neck.lateral_convs.1.conv.bias", "img_neck.fpn_convs.0.conv.weight",
+              "img_view_transformer.frustum", "img_view_transformer.dx", "img_view_transformer.featnet.weight",
+              "img_view_transformer.se.fc.1.weight", "img_view_transformer.extra_depthnet.layers.0.2.conv2.weight",
+              "img_view_transformer.dcn.0.conv_offset.bias", "img_view_transformer.dcn.1.running_mean",
+              "img_view_transformer.depthnet.bias", "pre_process_net.layers.0.1.bn2.weight",
+              "img_bev_encoder_backbone.layers.2.0.downsample.weight", "img_bev_encoder_neck.up2.4.bias",
+              "pts_bbox_head.shared_conv.bn.weight", "pts_bbox_head.task_heads.5.heatmap.1.bias",
+              "pts_bbox_head.task_heads.0.reg.0.conv.weight", "channel_wise_adaptations.0.1.conv3.weight",
+              "channel_wise_adaptations.2.weight", "spatial_wise_adaptations.1.weight"):
+        assert k in keys, k
+    assert not any("teacher" in k for k in keys)          # bevdet_distill.py:1599-1610
+    assert m.img_view_transformer.frustum.shape == (59, 16, 44, 3)
+    n = sum(p.numel() for p in m.parameters())
+    assert 50e6 < n < 60e6
+    tkeys = set(m.teacher_model.state_dict())
+    for k in ("pts_voxel_encoder.pfn_layers.0.0.weight", "pts_backbone.blocks.2.15.weight",
+              "pts_neck.deblocks.0.0.weight", "pts_bbox_head.task_heads.1.dim.1.weight"):
+        assert k in tkeys, k
+    m.train()
+    assert not m.teacher_model.training and all(not p.requires_grad for p in m.teacher_model.parameters())
+    # inherit_head: the student's task heads start from the teacher's
+    a = m.pts_bbox_head.task_heads[0].reg[0].conv.weight
+    b = m.teacher_model.pts_bbox_head.task_heads[0].reg[0].conv.weight
+    assert torch.equal(a, b)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="imports the reference's gaussian.py")
+def test_center_head_targets_match_reference_gaussian_utils():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import _ref_import as R
+    from distill_bev_amd import center_head as CH
+    from distill_bev_amd import synthetic as syn
+    G = R.gaussian()
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        l, w = rng.uniform(0.3, 15, 2)
+        r_ref = float(G.gaussian_radius((torch.tensor(l, dtype=torch.float32), torch.tensor(w, dtype=torch.float32)), 0.1))
+        assert abs(float(CH.gaussian_radius((l, w), 0.1)) - r_ref) < 1e-4 * max(1.0, r_ref)
+    hm_ref = torch.zeros((128, 128))
+    hm = np.zeros((128, 128), np.float32)
+    for (x, y, r) in [(5, 7, 2), (0, 0, 4), (127, 126, 6), (64, 64, 3), (65, 64, 2)]:
+        G.draw_heatmap_gaussian(hm_ref, torch.tensor([x, y]), r)
+        CH.draw_heatmap_gaussian(hm, (x, y), r)
+    assert np.array_equal(hm, hm_ref.numpy())
+    # full target assignment: shapes, one-hot peaks, indices
+    from distill_bev_amd.train_step import build_model
+    m, _ = build_model()
+    b, lab = syn.gt_boxes(30, rng)
+    boxes = CH.LiDARBoxes(b)
+    hms, abox, inds, masks = m.pts_bbox_head.get_targets([boxes], [torch.from_numpy(lab)], torch.device("cpu"))
+    assert [h.shape for h in hms] == [(1, 1, 128, 128), (1, 2, 128, 128), (1, 2, 128, 128), (1, 1, 128, 128),
+                                      (1, 2, 128, 128), (1, 2, 128, 128)]
+    assert sum(int(mk.sum()) for mk in masks) == 30
+    for t in range(6):
+        k = int(masks[t].sum())
+        if k:
+            iy, ix = (inds[t][0, :k] // 128), (inds[t][0, :k] % 128)
+            assert float(hms[t][0].max(0)[0][iy, ix].min()) == 1.0
+            assert torch.all(abox[t][0, :k, :2] >= 0) and torch.all(abox[t][0, :k, :2] < 1)
+
+
+def test_dcnv2_restatement_against_naive_loops():
+    from distill_bev_amd.nets import modulated_deform_conv2d
+    torch.manual_seed(0)
+    N, C, H, W, Co = 2, 3, 5, 6, 4
+    x = torch.randn(N, C, H, W, dtype=torch.float64)
+    off = torch.randn(N, 18, H, W, dtype=torch.float64) * 1.5
+    mask = torch.rand(N, 9, H, W, dtype=torch.float64)
+    wgt = torch.randn(Co, C, 3, 3, dtype=torch.float64)
+    bias = torch.randn(Co, dtype=torch.float64)
+    out = modulated_deform_conv2d(x, off, mask, wgt, bias, 1, 1, 1)
+
+    def bil(img, y, xx):
+        y0, x0 = int(np.floor(y)), int(np.floor(xx))
+        v = 0.0
+        for dy in (0, 1):
+            for dx in (0, 1):
+                yy, xc = y0 + dy, x0 + dx
+                if 0 <= yy < H and 0 <= xc < W:
+                    v += float(img[yy, xc]) * (1 - abs(y - yy)) * (1 - abs(xx - xc))
+        return v
+    ref = torch.zeros_like(out)
+    for n in range(N):
+        for h in range(H):
+            for w in range(W):
+                for k in range(9):
+                    py = h - 1 + k // 3 + float(off[n, 2 * k, h, w])
+                    px = w - 1 + k % 3 + float(off[n, 2 * k + 1, h, w])
+                    for c in range(C):
+                        s = bil(x[n, c], py, px) * float(mask[n, k, h, w])
+                        ref[n, :, h, w] += wgt[:, c, k // 3, k % 3] * s
+    ref += bias.view(1, -1, 1, 1)
+    assert torch.allclose(out, ref, atol=1e-10)
+    # zero offsets + mask 1 == ordinary convolution
+    out0 = modulated_deform_conv2d(x, torch.zeros_like(off), torch.ones_like(mask), wgt, bias, 1, 1, 1)
+    assert torch.allclose(out0, torch.nn.functional.conv2d(x, wgt, bias, padding=1), atol=1e-10)

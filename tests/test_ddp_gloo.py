@@ -1,0 +1,79 @@
+"""CPU, world_size 2, gloo: the data-parallel path of the training step (Trainer + DDP wrapper):
+samples are sharded across ranks, the only collective is the gradient all-reduce, the hidden
+teacher is neither broadcast nor reduced, and N ranks x B samples == one process x N*B samples."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from distill_bev_amd.config import Config
+from distill_bev_amd.train_step import Trainer, parse_losses
+
+
+class ToyDetector(nn.Module):
+    """Pure-torch stand-in with the detector contract: forward_train(**batch) -> dict of losses,
+    teacher hidden from parameters() exactly like BEVDepth4DDistill does it."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.net = nn.Sequential(nn.Linear(6, 16), nn.ReLU(), nn.Linear(16, 3))
+        object.__setattr__(self, "teacher_model", nn.Linear(6, 3))
+        for p in self.teacher_model.parameters():
+            p.requires_grad_(False)
+
+    def forward_train(self, x=None, y=None):
+        out = self.net(x)
+        with torch.no_grad():
+            t = self.teacher_model(x)
+        return {"loss_task": ((out - y) ** 2).mean(), "kd_loss": 0.1 * ((out - t) ** 2).mean(), "aux_metric": out.mean()}
+
+
+CFG = Config(dict(optimizer=dict(type="AdamW", lr=1e-2, weight_decay=0.01),
+                  optimizer_config=dict(grad_clip=dict(max_norm=5, norm_type=2))))
+
+
+def _data(n):
+    g = torch.Generator().manual_seed(5)
+    return torch.randn((n, 6), generator=g), torch.randn((n, 3), generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, y = _data(8 * world)
+    tr = Trainer(ToyDetector(), CFG, torch.device("cpu"), world_size=world)
+    shard = slice(rank * 8, (rank + 1) * 8)            # contiguous per-rank slices (samplers/distributed_sampler.py:35-39)
+    for _ in range(3):
+        loss, losses = tr.step(dict(x=x[shard], y=y[shard]))
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save({"params": gathered, "nparams": len(tr.params)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_step_equals_single_process_big_batch(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "ddp.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["params"][0], res["params"][1])          # ranks stay in lock step
+    assert res["nparams"] == 4                                       # teacher parameters are not trained / reduced
+    x, y = _data(16)
+    tr = Trainer(ToyDetector(), CFG, torch.device("cpu"), world_size=1)
+    for _ in range(3):
+        tr.step(dict(x=x, y=y))
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
+    assert torch.allclose(flat, res["params"][0], atol=1e-6)
+
+
+def test_parse_losses_sums_only_loss_keys():
+    d = {"loss_a": torch.tensor(1.0), "kd_fg_feat_loss_head_head": torch.tensor(2.0), "acc": torch.tensor(100.0)}
+    assert float(parse_losses(d)) == 3.0
