@@ -37,10 +37,10 @@ _SIGNATURES = {
     "dbev_pillars_scatter": [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p],
     "dbev_pillars_scatter_backward": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "dbev_lift_splat_workspace_bytes": [_i, _i],
-    "dbev_lift_splat_prepare": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
-    "dbev_lift_splat_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "dbev_lift_splat_prepare": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "dbev_lift_splat_forward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dbev_lift_splat_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "dbev_splat_forward": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "dbev_splat_forward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "dbev_splat_backward": [_p, _p, _p, _i, _i, _p],
     "dbev_fg_scale_mask": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
     "dbev_abs_mean_maps_workspace_bytes": [_i, _i, _i],

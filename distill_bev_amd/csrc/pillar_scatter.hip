@@ -48,6 +48,47 @@ __global__ __launch_bounds__(256) void ps_canvas_nchw(const float* __restrict__ 
   }
 }
 
+// Wide-tile variant (nx % 256 == 0): 256 consecutive x cells x all C channels per 512-thread
+// workgroup.  The LDS tile is channel-major ([C][256 + 4] floats) so that the output side is
+// ds_read_b128 + one 16-byte global store per lane: every channel row leaves as a contiguous 1 KiB
+// run (4x the 64-cell tile) and 4x fewer store instructions.  Tiles without any pillar skip LDS.
+constexpr int WIDE_X = 256;
+constexpr int WIDE_LD = WIDE_X + 4;
+
+__global__ __launch_bounds__(512) void ps_canvas_nchw_wide(const float* __restrict__ feats,
+                                                           const int* __restrict__ cellmap,
+                                                           float* __restrict__ canvas, int C, int ny, int nx) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][WIDE_LD]
+  __shared__ int vids[WIDE_X];
+  const int x0 = blockIdx.x * WIDE_X, y = blockIdx.y, b = blockIdx.z;
+  const int t = threadIdx.x;
+  int v = -1;
+  if (t < WIDE_X) { v = cellmap[(b * ny + y) * nx + x0 + t]; vids[t] = v; }
+  const int any = __syncthreads_or(v >= 0);
+  const int nq = C * (WIDE_X / 4);                 // float4 stores of this tile
+  float4* out4 = reinterpret_cast<float4*>(canvas);
+  const size_t row4 = static_cast<size_t>(nx) / 4;
+  if (!any) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = t; i < nq; i += 512) {
+      const int ch = i / (WIDE_X / 4), xq = i - ch * (WIDE_X / 4);
+      out4[((static_cast<size_t>(b) * C + ch) * ny + y) * row4 + x0 / 4 + xq] = z;
+    }
+    return;
+  }
+  for (int i = t; i < WIDE_X * C; i += 512) {
+    const int cx = i / C, ch = i - cx * C;
+    const int vv = vids[cx];
+    tile[ch * WIDE_LD + cx] = vv >= 0 ? feats[static_cast<size_t>(vv) * C + ch] : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < nq; i += 512) {
+    const int ch = i / (WIDE_X / 4), xq = i - ch * (WIDE_X / 4);
+    const float4 val = *reinterpret_cast<const float4*>(&tile[ch * WIDE_LD + 4 * xq]);
+    out4[((static_cast<size_t>(b) * C + ch) * ny + y) * row4 + x0 / 4 + xq] = val;
+  }
+}
+
 __global__ __launch_bounds__(256) void ps_canvas_nhwc(const float* __restrict__ feats,
                                                       const int* __restrict__ cellmap,
                                                       float* __restrict__ canvas, int C, long long ncell) {
@@ -100,6 +141,9 @@ extern "C" int dbev_pillars_scatter(const float* voxel_features, const int32_t* 
     if (blocks > DBEV_MAX_GRID * 8) blocks = DBEV_MAX_GRID * 8;
     hipLaunchKernelGGL(ps_canvas_nhwc, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, voxel_features,
                        cellmap, canvas, C, ncell);
+  } else if (nx % WIDE_X == 0 && sizeof(float) * C * WIDE_LD <= 72 * 1024) {
+    hipLaunchKernelGGL(ps_canvas_nchw_wide, dim3(nx / WIDE_X, ny, B), dim3(512), sizeof(float) * C * WIDE_LD, s,
+                       voxel_features, cellmap, canvas, C, ny, nx);
   } else {
     const size_t lds = sizeof(float) * TILE_X * (C + 1);
     if (lds > 160 * 1024) return DBEV_EINVAL;

@@ -99,10 +99,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep(const int* __rest
   }
 }
 
-// one wave per segment
+// one wave per segment.  Segments of <= 64 values are sorted in registers (bitonic network over
+// the 64 lanes, __shfl_xor); longer ones (dense BEV cells next to the cameras, 2 % of the cells /
+// 12 % of the points of a 6-camera frame) are staged into a wave-private LDS slab and ranked by
+// counting against 4 broadcast LDS values per read.  Values are distinct -> ranks are a permutation.
+constexpr int SORT_LDS_PER_WAVE = 2048;   // values per wave slab (8 KiB); 4 waves -> 32 KiB per block
+
 __global__ __launch_bounds__(256) void segment_sort_kernel(const int* __restrict__ starts,
                                                            const unsigned* __restrict__ src,
                                                            unsigned* __restrict__ dst, int n_seg) {
+  __shared__ __attribute__((aligned(16))) unsigned slab[4][SORT_LDS_PER_WAVE];
   const int seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (seg >= n_seg) return;
@@ -124,10 +130,27 @@ __global__ __launch_bounds__(256) void segment_sort_kernel(const int* __restrict
       }
     }
     if (lane < L) dst[st + lane] = v;
+    return;
+  }
+  const unsigned* p = src + st;
+  if (L <= SORT_LDS_PER_WAVE) {
+    unsigned* my = slab[threadIdx.x >> 6];
+    const int Lp = (L + 3) & ~3;
+    for (int i = lane; i < Lp; i += 64) my[i] = i < L ? p[i] : 0xFFFFFFFFu;   // pad: never < v
+    // wave-private slab: the wave's own LDS writes are visible to its later reads (in-order DS queue)
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    const uint4* my4 = reinterpret_cast<const uint4*>(my);
+    for (int i = lane; i < L; i += 64) {
+      const unsigned v = my[i];
+      int rank = 0;
+      for (int j = 0; j < (Lp >> 2); ++j) {
+        const uint4 q = my4[j];
+        rank += (q.x < v) + (q.y < v) + (q.z < v) + (q.w < v);
+      }
+      dst[st + rank] = v;
+    }
   } else {
-    // long segment (rare: dense BEV cells next to the cameras): rank by counting.
-    // values are distinct, so ranks are a permutation.
-    const unsigned* p = src + st;
+    // degenerate geometry (thousands of points in one cell): same ranking straight from L2
     for (int i = lane; i < L; i += 64) {
       const unsigned v = p[i];
       int rank = 0;

@@ -19,8 +19,8 @@ from . import _lib as L
 class LiftSplatPrep:
     """Per-geometry state shared by forward and backward (and by the two BEVDepth4D frames'
     own calls): voxel index per frustum point and the cell -> points CSR."""
-    __slots__ = ("point_cell", "cell_start", "cell_points", "n_kept", "B", "X", "Y", "Z",
-                 "n_points", "n_cells")
+    __slots__ = ("point_cell", "cell_start", "cell_points", "n_kept", "hot_cells", "n_hot", "B", "X", "Y",
+                 "Z", "n_points", "n_cells")
 
     def voxel_indices(self):
         """Decoded (x, y, z, b) int32[n_points, 4] with -1 rows for dropped points --
@@ -52,13 +52,15 @@ def lift_splat_prepare(geom, dx, bx, nx):
     p.cell_start = torch.empty((n_cells + 1,), dtype=torch.int32, device=dev)
     p.cell_points = torch.empty((max(n_points, 1),), dtype=torch.int32, device=dev)
     p.n_kept = torch.empty((1,), dtype=torch.int32, device=dev)
+    p.hot_cells = torch.empty((n_cells,), dtype=torch.int32, device=dev)
+    p.n_hot = torch.empty((1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         nbytes = L.call("dbev_lift_splat_workspace_bytes", n_points, n_cells)
         ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
         L.call("dbev_lift_splat_prepare", L.ptr(geom), n_points, B,
                L.host_floats([float(v) for v in dx]), L.host_floats([float(v) for v in bx]),
                L.host_ints([X, Y, Z]), L.ptr(p.point_cell), L.ptr(p.cell_start), L.ptr(p.cell_points),
-               L.ptr(p.n_kept), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+               L.ptr(p.n_kept), L.ptr(p.hot_cells), L.ptr(p.n_hot), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
     return p
 
 
@@ -83,7 +85,8 @@ class _LiftSplat(Function):
         out = torch.empty((prep.n_cells, C), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             L.call("dbev_lift_splat_forward", L.ptr(depth), L.ptr(feat_cl), L.ptr(prep.cell_start),
-                   L.ptr(prep.cell_points), L.ptr(out), BN, D, H, W, C, prep.n_cells, L.stream_ptr(dev))
+                   L.ptr(prep.cell_points), L.ptr(prep.hot_cells), L.ptr(prep.n_hot), L.ptr(out), BN, D, H, W, C,
+                   prep.n_cells, L.stream_ptr(dev))
         ctx.save_for_backward(depth, feat_cl)
         ctx.prep = prep
         return _as_logical(out, prep, C)
@@ -121,7 +124,8 @@ class _VoxelPooling(Function):
         out = torch.empty((prep.n_cells, C), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             L.call("dbev_splat_forward", L.ptr(xf), L.ptr(prep.cell_start), L.ptr(prep.cell_points),
-                   L.ptr(out), prep.n_points, C, prep.n_cells, L.stream_ptr(dev))
+                   L.ptr(prep.hot_cells), L.ptr(prep.n_hot), L.ptr(out), prep.n_points, C, prep.n_cells,
+                   L.stream_ptr(dev))
         ctx.prep = prep
         ctx.xshape = tuple(x.shape)
         return _as_logical(out, prep, C)

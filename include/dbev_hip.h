@@ -171,19 +171,23 @@ size_t dbev_lift_splat_workspace_bytes(int n_points, int n_cells);
  *                              index = ((geom - (bx - dx/2)) / dx) truncated TOWARD ZERO, fp32
  *   cell_start i32[n_cells+1], cell_points i32[n_points]   CSR: ascending point ids per cell
  *   n_kept_out DEVICE int: number of points inside the grid
+ *   hot_cells  i32[n_cells] (capacity), n_hot_out DEVICE int: the cells holding more than 128
+ *              points (dense cells next to the cameras); the forward gives each a whole workgroup
  * n_cells = batch*X*Y*Z. */
 int dbev_lift_splat_prepare(const float* geom, int n_points, int batch, const float* dx_host,
                             const float* bx_host, const int32_t* nx_host, int32_t* point_cell,
                             int32_t* cell_start, int32_t* cell_points, int32_t* n_kept_out,
-                            void* workspace, size_t workspace_bytes, dbevStream_t stream);
+                            int32_t* hot_cells, int32_t* n_hot_out, void* workspace,
+                            size_t workspace_bytes, dbevStream_t stream);
 
 /* depth f32[BN, D, H, W] (softmaxed depth distribution); feat_nhwc f32[BN, H, W, C]
  * (channels-last image features); out f32[n_cells, C], every cell written:
  *   out[cell, :] = sum over the cell's points p of depth[p] * feat[bn(p), h(p), w(p), :].
  * C must be a multiple of 4 and <= 256. */
 int dbev_lift_splat_forward(const float* depth, const float* feat_nhwc, const int32_t* cell_start,
-                            const int32_t* cell_points, float* out, int BN, int D, int H, int W, int C,
-                            int n_cells, dbevStream_t stream);
+                            const int32_t* cell_points, const int32_t* hot_cells, const int32_t* n_hot,
+                            float* out, int BN, int D, int H, int W, int C, int n_cells,
+                            dbevStream_t stream);
 
 /* grad_out f32[n_cells, C] -> grad_depth f32[BN, D, H, W], grad_feat_nhwc f32[BN, H, W, C];
  * every element of both written (0 for points outside the grid). */
@@ -193,8 +197,9 @@ int dbev_lift_splat_backward(const float* grad_out, const float* depth, const fl
 
 /* voxel_pooling(geom, x) for a caller that holds the volume x f32[n_points, C]:
  * out[cell, :] = sum of x[p, :] over the cell's points; backward = gather (0 if dropped). */
-int dbev_splat_forward(const float* x, const int32_t* cell_start, const int32_t* cell_points, float* out,
-                       int n_points, int C, int n_cells, dbevStream_t stream);
+int dbev_splat_forward(const float* x, const int32_t* cell_start, const int32_t* cell_points,
+                       const int32_t* hot_cells, const int32_t* n_hot, float* out, int n_points, int C,
+                       int n_cells, dbevStream_t stream);
 int dbev_splat_backward(const float* grad_out, const int32_t* point_cell, float* grad_x, int n_points,
                         int C, dbevStream_t stream);
 
