@@ -92,27 +92,63 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// grid (ceil(HW/256), B); dynamic LDS 4*C floats
+// grid (ceil(HW/1024), ceil(C/64), B); 256 threads x 4 consecutive pixels (float4 when HW % 4 == 0).
+// A block covers 1024 pixels x 64 channels: per-channel sums over its pixels (one wave reduction
+// per channel per 256 pixels) and per-pixel partial sums over its channels; two tiny fixed-order
+// kernels finish both means.  dynamic LDS 4*64 floats.
+constexpr int AM_PX = 1024;
+constexpr int AM_CH = 64;
+
 __global__ __launch_bounds__(256) void abs_mean_kernel(const float* __restrict__ x, int C, int HW,
-                                                       float* __restrict__ pix,
+                                                       float* __restrict__ pixpart,
                                                        float* __restrict__ chpart) {
-  extern __shared__ __attribute__((aligned(16))) float chs[];   // [4][C]
-  const int b = blockIdx.y, tile = blockIdx.x, ntile = gridDim.x;
-  const int p = tile * 256 + threadIdx.x;
-  const bool valid = p < HW;
+  __shared__ float chs[4][AM_CH];
+  const int b = blockIdx.z, tile = blockIdx.x, ntile = gridDim.x, chunk = blockIdx.y, nchunk = gridDim.y;
+  const int c0 = chunk * AM_CH, c1 = min(C, c0 + AM_CH);
+  const int p0 = tile * AM_PX + threadIdx.x * 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float* xb = x + static_cast<size_t>(b) * C * HW + p;
-  float acc = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float v = valid ? fabsf(xb[static_cast<size_t>(c) * HW]) : 0.f;
-    acc += v;
-    const float s = wave_sum(v);
-    if (lane == 0) chs[w * C + c] = s;
+  const bool vec = (HW & 3) == 0 && p0 + 3 < HW;
+  const float* xb = x + static_cast<size_t>(b) * C * HW + p0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = c0; c < c1; ++c) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xc = xb + static_cast<size_t>(c) * HW;
+    if (vec) {
+      v = *reinterpret_cast<const float4*>(xc);
+    } else {
+      if (p0 < HW) v.x = xc[0];
+      if (p0 + 1 < HW) v.y = xc[1];
+      if (p0 + 2 < HW) v.z = xc[2];
+      if (p0 + 3 < HW) v.w = xc[3];
+    }
+    v.x = fabsf(v.x); v.y = fabsf(v.y); v.z = fabsf(v.z); v.w = fabsf(v.w);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const float s = wave_sum((v.x + v.y) + (v.z + v.w));
+    if (lane == 0) chs[w][c - c0] = s;
   }
-  if (valid) pix[static_cast<size_t>(b) * HW + p] = acc / static_cast<float>(C);
+  float* po = pixpart + (static_cast<size_t>(b) * nchunk + chunk) * HW + p0;
+  if (vec) {
+    *reinterpret_cast<float4*>(po) = acc;
+  } else {
+    if (p0 < HW) po[0] = acc.x;
+    if (p0 + 1 < HW) po[1] = acc.y;
+    if (p0 + 2 < HW) po[2] = acc.z;
+    if (p0 + 3 < HW) po[3] = acc.w;
+  }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256)
-    chpart[(static_cast<size_t>(b) * ntile + tile) * C + c] = (chs[c] + chs[C + c]) + (chs[2 * C + c] + chs[3 * C + c]);
+  if (threadIdx.x < c1 - c0)
+    chpart[(static_cast<size_t>(b) * ntile + tile) * C + c0 + threadIdx.x] =
+        (chs[0][threadIdx.x] + chs[1][threadIdx.x]) + (chs[2][threadIdx.x] + chs[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void abs_mean_pix_final(const float* __restrict__ pixpart, int C, int HW,
+                                                          int nchunk, float* __restrict__ pix) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += pixpart[(static_cast<size_t>(b) * nchunk + k) * HW + p];
+  pix[static_cast<size_t>(b) * HW + p] = s / static_cast<float>(C);
 }
 
 __global__ __launch_bounds__(256) void abs_mean_ch_final(const float* __restrict__ chpart, int C, int HW,
@@ -243,19 +279,22 @@ extern "C" int dbev_fg_scale_mask(const float* planes, const float* box_scale, c
 
 extern "C" size_t dbev_abs_mean_maps_workspace_bytes(int B, int C, int HW) {
   if (B <= 0 || C <= 0 || HW <= 0) return 0;
-  return sizeof(float) * static_cast<size_t>(B) * dbev_ceil_div(HW, 256) * C;
+  const size_t chpart = static_cast<size_t>(B) * dbev_ceil_div(HW, AM_PX) * C;
+  const size_t pixpart = static_cast<size_t>(B) * dbev_ceil_div(C, AM_CH) * HW;
+  return sizeof(float) * (chpart + pixpart) + 256;
 }
 
 extern "C" int dbev_abs_mean_maps(const float* x, int B, int C, int HW, float* pix_mean, float* ch_mean,
                                   void* workspace, size_t workspace_bytes, dbevStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return DBEV_EINVAL;
   if (workspace == nullptr || workspace_bytes < dbev_abs_mean_maps_workspace_bytes(B, C, HW)) return DBEV_EINVAL;
-  if (sizeof(float) * 4 * C > 64 * 1024) return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
-  const int ntile = dbev_ceil_div(HW, 256);
+  const int ntile = dbev_ceil_div(HW, AM_PX), nchunk = dbev_ceil_div(C, AM_CH);
   float* chpart = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(abs_mean_kernel, dim3(ntile, B), dim3(256), sizeof(float) * 4 * C, s, x, C, HW, pix_mean,
-                     chpart);
+  float* pixpart = chpart + ((static_cast<size_t>(B) * ntile * C + 63) & ~static_cast<size_t>(63));
+  hipLaunchKernelGGL(abs_mean_kernel, dim3(ntile, nchunk, B), dim3(256), 0, s, x, C, HW, pixpart, chpart);
+  hipLaunchKernelGGL(abs_mean_pix_final, dim3(dbev_ceil_div(HW, 256), B), dim3(256), 0, s, pixpart, C, HW, nchunk,
+                     pix_mean);
   hipLaunchKernelGGL(abs_mean_ch_final, dim3(dbev_ceil_div(C, 256), B), dim3(256), 0, s, chpart, C, HW, ntile,
                      ch_mean);
   DBEV_LAUNCH_CHECK();

@@ -109,38 +109,35 @@ __global__ __launch_bounds__(256) void ls_forward(const float* __restrict__ dept
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (sub < rpw && L > 0) {
     const unsigned* pl = cell_points + st;
-    int j = sub;
-    for (; j + (UNROLL - 1) * rpw < L; j += UNROLL * rpw) {
+    // every batch issues UNROLL predicated (index -> depth, row) gathers back to back: a cell of
+    // <= UNROLL*rpw points (78 % of the occupied cells at UNROLL=4) is ONE round trip deep instead
+    // of a serial tail of dependent loads
+    for (int j = sub; j < L; j += UNROLL * rpw) {
       float4 v[UNROLL];
       float s[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const unsigned p = pl[j + u * rpw];
-        if (LIFT) {
-          const unsigned bn = p / DHW;
-          const unsigned hw = p % HW;
-          s[u] = depth[p];
-          v[u] = rows[(static_cast<size_t>(bn) * HW + hw) * c4 + q];
-        } else {
-          s[u] = 1.f;
-          v[u] = rows[static_cast<size_t>(p) * c4 + q];
+        const int jj = j + u * rpw;
+        const bool ok = jj < L;
+        const unsigned p = ok ? pl[jj] : pl[0];
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s[u] = 0.f;
+        if (ok) {
+          if (LIFT) {
+            const unsigned bn = p / DHW;
+            const unsigned hw = p % HW;
+            s[u] = depth[p];
+            v[u] = rows[(static_cast<size_t>(bn) * HW + hw) * c4 + q];
+          } else {
+            s[u] = 1.f;
+            v[u] = rows[static_cast<size_t>(p) * c4 + q];
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
         if (LIFT) fma4(acc, s[u], v[u]);
-        else { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-      }
-    }
-    for (; j < L; j += rpw) {
-      const unsigned p = pl[j];
-      if (LIFT) {
-        const unsigned bn = p / DHW;
-        const unsigned hw = p % HW;
-        fma4(acc, depth[p], rows[(static_cast<size_t>(bn) * HW + hw) * c4 + q]);
-      } else {
-        const float4 v = rows[static_cast<size_t>(p) * c4 + q];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        else { acc.x += s[u] * v[u].x; acc.y += s[u] * v[u].y; acc.z += s[u] * v[u].z; acc.w += s[u] * v[u].w; }
       }
     }
   }
@@ -248,24 +245,35 @@ __global__ __launch_bounds__(256) void ls_backward(const float4* __restrict__ gr
   const float4 f = active ? feat[static_cast<size_t>(pix) * c4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 gf = make_float4(0.f, 0.f, 0.f, 0.f);
   const size_t pbase = static_cast<size_t>(bn) * D * HW + hw;
-  for (int d = 0; d < D; ++d) {
-    const size_t p = pbase + static_cast<size_t>(d) * HW;
-    const int cell = active ? point_cell[p] : -1;
-    float part = 0.f;
-    if (cell >= 0) {
-      const float4 g = grad_out[static_cast<size_t>(cell) * c4 + q];
-      fma4(gf, depth[p], g);
-      part = fmaf(g.x, f.x, fmaf(g.y, f.y, fmaf(g.z, f.z, g.w * f.w)));
+  constexpr int DU = 4;   // depth bins in flight per lane group (cell id -> grad row gathers are dependent)
+  for (int d0 = 0; d0 < D; d0 += DU) {
+    int cell[DU];
+    float dp[DU];
+    float4 g[DU];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int d = d0 + u;
+      const size_t p = pbase + static_cast<size_t>(d) * HW;
+      cell[u] = (active && d < D) ? point_cell[p] : -1;
+      dp[u] = cell[u] >= 0 ? depth[p] : 0.f;
     }
-    // reduce `part` over the c4 lanes of this pixel (all lanes execute the shuffles)
-    float sum = part;
-    if (pow2) {
-      for (int o = c4 >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    } else {
-      sum = 0.f;
-      for (int k = 0; k < c4; ++k) sum += __shfl(part, sub * c4 + k);
+#pragma unroll
+    for (int u = 0; u < DU; ++u)
+      g[u] = cell[u] >= 0 ? grad_out[static_cast<size_t>(cell[u]) * c4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int d = d0 + u;
+      fma4(gf, dp[u], g[u]);
+      const float part = fmaf(g[u].x, f.x, fmaf(g[u].y, f.y, fmaf(g[u].z, f.z, g[u].w * f.w)));
+      float sum = part;
+      if (pow2) {
+        for (int o = c4 >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      } else {
+        sum = 0.f;
+        for (int k = 0; k < c4; ++k) sum += __shfl(part, sub * c4 + k);
+      }
+      if (active && q == 0 && d < D) grad_depth[pbase + static_cast<size_t>(d) * HW] = sum;   // 0 for a dropped point
     }
-    if (active && q == 0) grad_depth[p] = sum;   // 0 for a dropped point
   }
   if (active) grad_feat[static_cast<size_t>(pix) * c4 + q] = gf;
 }
@@ -390,7 +398,7 @@ extern "C" int dbev_splat_forward(const float* x, const int32_t* cell_start, con
   if (n_points < 0 || n_cells <= 0 || !vec_ok(C)) return DBEV_EINVAL;
   const int c4 = C >> 2, rpw = 64 / c4;
   hipStream_t s = dbev_stream(stream);
-  hipLaunchKernelGGL((ls_forward<false, 8, true>), dim3(dbev_ceil_div(n_cells, 4)), dim3(256), 0, s, nullptr,
+  hipLaunchKernelGGL((ls_forward<false, 4, true>), dim3(dbev_ceil_div(n_cells, 4)), dim3(256), 0, s, nullptr,
                      reinterpret_cast<const float4*>(x), cell_start,
                      reinterpret_cast<const unsigned*>(cell_points), reinterpret_cast<float4*>(out),
                      n_cells, c4, rpw, 1, 1);

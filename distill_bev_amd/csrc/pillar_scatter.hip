@@ -48,44 +48,66 @@ __global__ __launch_bounds__(256) void ps_canvas_nchw(const float* __restrict__ 
   }
 }
 
-// Wide-tile variant (nx % 256 == 0): 256 consecutive x cells x all C channels per 512-thread
-// workgroup.  The LDS tile is channel-major ([C][256 + 4] floats) so that the output side is
-// ds_read_b128 + one 16-byte global store per lane: every channel row leaves as a contiguous 1 KiB
-// run (4x the 64-cell tile) and 4x fewer store instructions.  Tiles without any pillar skip LDS.
+// Wide-tile variant (C == 64, nx % 256 == 0): 256 consecutive x cells x 64 channels per 512-thread
+// workgroup.  The LDS tile is channel-major ([64][256 + 4] floats): it is zero-filled with 16-byte
+// LDS stores, only the OCCUPIED cells' rows are fetched (16 lanes x float4 = one coalesced 256 B
+// row per lane group; pillar rows of one BEV row are consecutive in memory because dynamic scatter
+// emits them in (b, y, x) order) and the output side is ds_read_b128 + one 16-byte global store per
+// lane -- every channel row leaves as a contiguous 1 KiB run.  All index arithmetic is shifts
+// (C and the tile width are compile-time).  Tiles without any pillar skip LDS entirely.
 constexpr int WIDE_X = 256;
 constexpr int WIDE_LD = WIDE_X + 4;
+constexpr int WIDE_C = 64;
 
 __global__ __launch_bounds__(512) void ps_canvas_nchw_wide(const float* __restrict__ feats,
                                                            const int* __restrict__ cellmap,
-                                                           float* __restrict__ canvas, int C, int ny, int nx) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][WIDE_LD]
+                                                           float* __restrict__ canvas, int ny, int nx) {
+  __shared__ __attribute__((aligned(16))) float tile[WIDE_C * WIDE_LD];   // 66,560 B
   __shared__ int vids[WIDE_X];
+  __shared__ int occ[WIDE_X];
+  __shared__ int nocc;
   const int x0 = blockIdx.x * WIDE_X, y = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x;
+  if (t == 0) nocc = 0;
   int v = -1;
   if (t < WIDE_X) { v = cellmap[(b * ny + y) * nx + x0 + t]; vids[t] = v; }
-  const int any = __syncthreads_or(v >= 0);
-  const int nq = C * (WIDE_X / 4);                 // float4 stores of this tile
+  __syncthreads();
+  if (v >= 0) occ[atomicAdd(&nocc, 1)] = t;          // order irrelevant: each cell owns its column
   float4* out4 = reinterpret_cast<float4*>(canvas);
-  const size_t row4 = static_cast<size_t>(nx) / 4;
-  if (!any) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = t; i < nq; i += 512) {
-      const int ch = i / (WIDE_X / 4), xq = i - ch * (WIDE_X / 4);
-      out4[((static_cast<size_t>(b) * C + ch) * ny + y) * row4 + x0 / 4 + xq] = z;
+  const size_t row4 = static_cast<size_t>(nx) >> 2;
+  const size_t obase = (static_cast<size_t>(b) * WIDE_C * ny + y) * row4 + (x0 >> 2);
+  const size_t ch_stride4 = static_cast<size_t>(ny) * row4;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  // zero the tile (16,640 floats = 4160 float4; 512 threads)
+  float4* tile4 = reinterpret_cast<float4*>(tile);
+  for (int i = t; i < WIDE_C * WIDE_LD / 4; i += 512) tile4[i] = z;
+  __syncthreads();
+  const int n = nocc;
+  if (n == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = t + 512 * k;                       // 4096 float4 = 64 ch x 64 quads
+      out4[obase + static_cast<size_t>(i >> 6) * ch_stride4 + (i & 63)] = z;
     }
     return;
   }
-  for (int i = t; i < WIDE_X * C; i += 512) {
-    const int cx = i / C, ch = i - cx * C;
-    const int vv = vids[cx];
-    tile[ch * WIDE_LD + cx] = vv >= 0 ? feats[static_cast<size_t>(vv) * C + ch] : 0.f;
+  // fetch occupied rows: 16 lanes per row (float4 each), 32 rows per pass
+  const int q = t & 15;
+  for (int r = t >> 4; r < n; r += 32) {
+    const int cx = occ[r];
+    const float4 f = reinterpret_cast<const float4*>(feats)[static_cast<size_t>(vids[cx]) * (WIDE_C / 4) + q];
+    tile[(4 * q + 0) * WIDE_LD + cx] = f.x;
+    tile[(4 * q + 1) * WIDE_LD + cx] = f.y;
+    tile[(4 * q + 2) * WIDE_LD + cx] = f.z;
+    tile[(4 * q + 3) * WIDE_LD + cx] = f.w;
   }
   __syncthreads();
-  for (int i = t; i < nq; i += 512) {
-    const int ch = i / (WIDE_X / 4), xq = i - ch * (WIDE_X / 4);
-    const float4 val = *reinterpret_cast<const float4*>(&tile[ch * WIDE_LD + 4 * xq]);
-    out4[((static_cast<size_t>(b) * C + ch) * ny + y) * row4 + x0 / 4 + xq] = val;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = t + 512 * k;
+    const int ch = i >> 6, xq = i & 63;
+    out4[obase + static_cast<size_t>(ch) * ch_stride4 + xq] =
+        *reinterpret_cast<const float4*>(&tile[ch * WIDE_LD + 4 * xq]);
   }
 }
 
@@ -141,9 +163,9 @@ extern "C" int dbev_pillars_scatter(const float* voxel_features, const int32_t* 
     if (blocks > DBEV_MAX_GRID * 8) blocks = DBEV_MAX_GRID * 8;
     hipLaunchKernelGGL(ps_canvas_nhwc, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, voxel_features,
                        cellmap, canvas, C, ncell);
-  } else if (nx % WIDE_X == 0 && sizeof(float) * C * WIDE_LD <= 72 * 1024) {
-    hipLaunchKernelGGL(ps_canvas_nchw_wide, dim3(nx / WIDE_X, ny, B), dim3(512), sizeof(float) * C * WIDE_LD, s,
-                       voxel_features, cellmap, canvas, C, ny, nx);
+  } else if (nx % WIDE_X == 0 && C == WIDE_C) {
+    hipLaunchKernelGGL(ps_canvas_nchw_wide, dim3(nx / WIDE_X, ny, B), dim3(512), 0, s, voxel_features, cellmap,
+                       canvas, ny, nx);
   } else {
     const size_t lds = sizeof(float) * TILE_X * (C + 1);
     if (lds > 160 * 1024) return DBEV_EINVAL;

@@ -27,6 +27,12 @@ def timeit(fn, n=20, warm=3):
     return s.elapsed_time(e) / n * 1e3  # us
 
 
+buf = torch.empty((64 * 512 * 512 * 8,), device=dev); src = torch.randn_like(buf)
+t = timeit(lambda: buf.zero_())
+print(f"[probe] torch zero_ 537 MB: {t:8.1f} us  {buf.numel()*4/t/1e3:7.1f} GB/s written")
+t = timeit(lambda: buf.copy_(src))
+print(f"[probe] torch copy_ 537 MB: {t:8.1f} us  {2*buf.numel()*4/t/1e3:7.1f} GB/s read+written")
+del buf, src
 B = 8
 rig = {k: torch.from_numpy(v).to(dev) for k, v in syn.camera_rig(B, rng).items()}
 dx, bx, nx = LSS.gen_dx_bx([-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8], [-10.0, 10.0, 20.0])
