@@ -137,7 +137,7 @@ class DistillStep(_Base):
         self.B = int(os.environ.get("DBEV_BENCH_BS", self.B))
         self.units_per_step = self.B
         model, cfg = build_model(seed=0)            # same init on every rank (DDP broadcasts anyway)
-        self.trainer = Trainer(model, cfg, dev, world_size=world)
+        self.trainer = Trainer(model, cfg, dev, world_size=world, channels_last=True)
         self.batch = make_batch(self.B, np.random.default_rng(1234 + rank), dev, n_points=self.N_POINTS)
         self.n_params = sum(p.numel() for p in self.trainer.params)
         # occupied teacher pillars of this rank's batch (for the scatter kernel's algorithmic bytes)
@@ -227,7 +227,7 @@ class DistillStep(_Base):
                             + ("+DDP all-reduce" if world > 1 else ""),
                 "global_batch": self.B * world, "per_gpu_batch": self.B, "images_per_sample": 12,
                 "image_size": [256, 704], "lidar_points_per_sample": self.N_POINTS, "gt_boxes_per_sample": 30,
-                "student_params": self.n_params, "parallelism": f"dp{world}",
+                "student_params": self.n_params, "parallelism": f"dp{world}", "memory_format": "channels_last",
                 "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py"}
 
 

@@ -285,7 +285,10 @@ class BEVDepth4DDistill(CenterPoint):
     # ---- student ----------------------------------------------------------------------------
     def image_encoder(self, img):
         B, N, C, imH, imW = img.shape
-        x = self.img_backbone(img.view(B * N, C, imH, imW))
+        x = img.reshape(B * N, C, imH, imW)
+        if getattr(self, "channels_last", False):
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = self.img_backbone(x)
         if self.with_img_neck:
             x = self.img_neck(x)
             if isinstance(x, (list, tuple)):

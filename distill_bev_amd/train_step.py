@@ -86,9 +86,11 @@ class Trainer:
         self.detector.train()
         if channels_last:
             self.detector = self.detector.to(memory_format=torch.channels_last)
+            self.detector.teacher_model.to(memory_format=torch.channels_last)
+            self.detector.channels_last = True
         self.wrapper = _TrainWrapper(self.detector)
         self.world_size = world_size
-        if world_size > 1:
+        if world_size > 1 or os.environ.get("DBEV_FORCE_DDP") == "1":
             self.module = nn.parallel.DistributedDataParallel(
                 self.wrapper, device_ids=[device.index] if device.type == "cuda" else None, broadcast_buffers=False,
                 find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=64)

@@ -25,11 +25,7 @@ model, cfg = build_model()
 tr = Trainer(model, cfg, dev, channels_last=args.channels_last)
 print("build+to(device) %.1fs" % (time.time() - t0), flush=True)
 batch = make_batch(args.bs, np.random.default_rng(0), dev, n_points=args.points)
-if args.channels_last:
-    ii = list(batch["img_inputs"])
-    B_, N_, C_, H_, W_ = ii[0].shape
-    ii[0] = ii[0].view(B_ * N_, C_, H_, W_).contiguous(memory_format=torch.channels_last).view(B_, N_, C_, H_, W_)
-    batch["img_inputs"] = tuple(ii)
+
 torch.cuda.synchronize()
 for i in range(args.steps):
     t = time.time()
