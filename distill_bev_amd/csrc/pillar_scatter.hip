@@ -9,6 +9,7 @@
 // channels_last output ([B, ny, nx, C] physical) is a straight row copy.
 // HBM roofline: M(4C+16) + 4 C ny nx B bytes; write dominated.
 #include "common.h"
+#include "pillar_scatter.h"
 
 namespace {
 
@@ -148,16 +149,11 @@ __global__ __launch_bounds__(256) void ps_backward(const float* __restrict__ gra
 
 }  // namespace
 
-extern "C" int dbev_pillars_scatter(const float* voxel_features, const int32_t* coors, int num_voxels,
-                                    int C, int B, int ny, int nx, float* canvas, int channels_last,
-                                    int32_t* cellmap, dbevStream_t stream) {
-  if (num_voxels < 0 || C <= 0 || B <= 0 || ny <= 0 || nx <= 0 || cellmap == nullptr) return DBEV_EINVAL;
-  hipStream_t s = dbev_stream(stream);
+namespace dbev {
+// canvas[b, c, y, x] (or NHWC) = feats[cellmap[b, y, x], c] or 0 -- every element written once
+int launch_canvas(const float* voxel_features, const int* cellmap, float* canvas, int C, int B, int ny, int nx,
+                  int channels_last, hipStream_t s) {
   const long long ncell = static_cast<long long>(B) * ny * nx;
-  DBEV_HIP_TRY(hipMemsetAsync(cellmap, 0xff, sizeof(int) * ncell, s));  // -1
-  if (num_voxels > 0)
-    hipLaunchKernelGGL(ps_cellmap, dim3(dbev_ceil_div(num_voxels, 256)), dim3(256), 0, s, coors, num_voxels,
-                       B, ny, nx, cellmap);
   if (channels_last) {
     long long blocks = (ncell * C + 255) / 256;
     if (blocks > DBEV_MAX_GRID * 8) blocks = DBEV_MAX_GRID * 8;
@@ -174,6 +170,20 @@ extern "C" int dbev_pillars_scatter(const float* voxel_features, const int32_t* 
   }
   DBEV_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace dbev
+
+extern "C" int dbev_pillars_scatter(const float* voxel_features, const int32_t* coors, int num_voxels,
+                                    int C, int B, int ny, int nx, float* canvas, int channels_last,
+                                    int32_t* cellmap, dbevStream_t stream) {
+  if (num_voxels < 0 || C <= 0 || B <= 0 || ny <= 0 || nx <= 0 || cellmap == nullptr) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const long long ncell = static_cast<long long>(B) * ny * nx;
+  DBEV_HIP_TRY(hipMemsetAsync(cellmap, 0xff, sizeof(int) * ncell, s));  // -1
+  if (num_voxels > 0)
+    hipLaunchKernelGGL(ps_cellmap, dim3(dbev_ceil_div(num_voxels, 256)), dim3(256), 0, s, coors, num_voxels,
+                       B, ny, nx, cellmap);
+  return dbev::launch_canvas(voxel_features, cellmap, canvas, C, B, ny, nx, channels_last, s);
 }
 
 extern "C" int dbev_pillars_scatter_backward(const float* grad_canvas, const int32_t* coors,

@@ -1,0 +1,240 @@
+// Fused teacher pillar path for gfx950:  points -> voxelize -> pillar feature net -> BEV canvas.
+//
+// Replaces, for the frozen (eval, no_grad) CenterPoint-pillar teacher, the whole sequence
+//   DynamicCenterPoint.voxelize          (dynamic_centerpoint.py:71-93, per-sample launches + pad + cat)
+//   DynamicPillarFeatureNet.forward      (pillar_encoder.py:283-338: cluster_scatter(mean) -> canvas gather
+//                                         -> decorate to 10 ch -> Linear(10,64,no bias)+BN1d+ReLU -> pfn_scatter(max))
+//   PointPillarsScatter.forward_batch    (pillar_scatter.py:62-102)
+// which in the reference is two sorted-unique passes, float atomics, a [C, 512*512*B] broadcast
+// canvas, a python loop per sample and (in any op-level implementation) a device->host read of
+// the data-dependent pillar count M.  Here nothing leaves the device and nothing is M-shaped on
+// the host: buffers are sized by the point count, M lives in a device int.
+//
+//   vfe_cell_count : cell of every point (same fp32 floor((p-min)/vs) as dbev_dynamic_voxelize), int histogram
+//   scan           : occupied cells -> pillar ids in (b, y, x) order  (== sorted-unique order)
+//   vfe_emit       : cellmap[b,y,x] = pillar id / -1, per-pillar counts
+//   scan, fill, segment sort : CSR pillar -> points, ascending point id
+//   vfe_reduce     : ONE wavefront per pillar, lane = output channel: sequential xyz mean, decorate,
+//                    10 FMAs against the lane's weight column, folded BN, ReLU, running max
+//   launch_canvas  : output-stationary canvas write (pillar_scatter.hip)
+#include <math.h>
+
+#include "pillar_scatter.h"
+#include "prims.h"
+
+namespace {
+
+constexpr int MAX_B = 64;
+constexpr int MAX_K = 16;   // F + 5 decorated input channels
+
+struct VfeParams {
+  float vs[3], rmin[3];
+  int grid[3];
+  float vx, vy, x_offset, y_offset;   // pillar_encoder.py:86-90
+  int sample_start[MAX_B + 1];
+  int B;
+};
+
+size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+struct VfeLayout { size_t cell, count, vid, vcount, cursor, vstart, tmp, list, vcell, scanws, total; };
+
+VfeLayout vfe_layout(long long n, long long ncell) {
+  VfeLayout L;
+  size_t o = 0;
+  L.cell = o;   o += align_up(sizeof(int) * n);
+  L.count = o;  o += align_up(sizeof(int) * ncell);
+  L.vid = o;    o += align_up(sizeof(int) * (ncell + 1));
+  L.vcount = o; o += align_up(sizeof(int) * n);
+  L.cursor = o; o += align_up(sizeof(int) * n);
+  L.vstart = o; o += align_up(sizeof(int) * (n + 1));
+  L.tmp = o;    o += align_up(sizeof(int) * n);
+  L.list = o;   o += align_up(sizeof(int) * n);
+  L.vcell = o;  o += align_up(sizeof(int) * n);
+  L.scanws = o; o += align_up(sizeof(int) * dbev::scan_workspace_ints(ncell > n ? ncell : n));
+  L.total = o;
+  return L;
+}
+
+__global__ __launch_bounds__(256) void vfe_cell_count(const float* __restrict__ points, int n, int nf,
+                                                      VfeParams P, int* __restrict__ cell,
+                                                      int* __restrict__ count) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = points + static_cast<size_t>(i) * nf;
+  int c[3];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float fl = floorf((p[j] - P.rmin[j]) / P.vs[j]);   // voxelization_cpu.cpp:22-32
+    ok = ok && (fl >= 0.f) && (fl < static_cast<float>(P.grid[j]));
+    c[j] = static_cast<int>(fl);
+  }
+  int lin = -1;
+  if (ok) {
+    int b = 0;
+    while (b + 1 < P.B && i >= P.sample_start[b + 1]) ++b;
+    lin = (b * P.grid[1] + c[1]) * P.grid[0] + c[0];
+    atomicAdd(&count[lin], 1);
+  }
+  cell[i] = lin;
+}
+
+__global__ __launch_bounds__(256) void vfe_emit(const int* __restrict__ count, const int* __restrict__ vid,
+                                                int ncell, int* __restrict__ cellmap,
+                                                int* __restrict__ vcount, int* __restrict__ cursor,
+                                                int* __restrict__ vcell) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int k = count[c];
+  if (k > 0) {
+    const int v = vid[c];
+    vcount[v] = k;
+    cursor[v] = k;
+    vcell[v] = c;
+    cellmap[c] = v;
+  } else {
+    cellmap[c] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void vfe_fill(const int* __restrict__ cell, int n, const int* __restrict__ vid,
+                                                const int* __restrict__ vstart, int* __restrict__ cursor,
+                                                unsigned* __restrict__ tmp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell[i];
+  if (c < 0) return;
+  const int v = vid[c];
+  const int pos = atomicSub(&cursor[v], 1) - 1;
+  tmp[vstart[v] + pos] = static_cast<unsigned>(i);
+}
+
+// one wave per pillar; lane = output channel (Cout <= 64)
+__global__ __launch_bounds__(256) void vfe_reduce(const float* __restrict__ points, int nf,
+                                                  const int* __restrict__ vstart,
+                                                  const unsigned* __restrict__ vlist,
+                                                  const int* __restrict__ vcell,
+                                                  const int* __restrict__ num_voxels,
+                                                  const float* __restrict__ W,        // [Cout, K] row-major
+                                                  const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                  const float* __restrict__ bn_mean, const float* __restrict__ bn_var,
+                                                  float bn_eps, int Cout, int K, VfeParams P,
+                                                  float* __restrict__ voxel_feats) {
+  const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (v >= *num_voxels) return;
+  const int st = vstart[v];
+  const int L = vstart[v + 1] - st;
+  const int c = vcell[v];
+  const int cx = c % P.grid[0];
+  const int cy = (c / P.grid[0]) % P.grid[1];
+  // pillar centre: coors.type_as(features) * vx + x_offset (pillar_encoder.py:318-321), fp32
+  const float pcx = static_cast<float>(cx) * P.vx + P.x_offset;
+  const float pcy = static_cast<float>(cy) * P.vy + P.y_offset;
+  // cluster mean of xyz: sequential fp32 sum in point order / count (DynamicScatter mean)
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const float* p = points + static_cast<size_t>(vlist[st + j]) * nf;
+    sx += p[0]; sy += p[1]; sz += p[2];
+  }
+  const float fl = static_cast<float>(L);
+  const float mx = sx / fl, my = sy / fl, mz = sz / fl;
+  float w[MAX_K];
+  const bool act = lane < Cout;
+#pragma unroll
+  for (int k = 0; k < MAX_K; ++k) w[k] = (act && k < K) ? W[lane * K + k] : 0.f;
+  // BatchNorm1d (eval): (y - mean) / sqrt(var + eps) * weight + bias
+  const float inv_std = act ? 1.f / sqrtf(bn_var[lane] + bn_eps) : 0.f;
+  const float mu = act ? bn_mean[lane] : 0.f, ga = act ? bn_w[lane] : 0.f, be = act ? bn_b[lane] : 0.f;
+  float acc = -INFINITY;
+  for (int j = 0; j < L; ++j) {
+    const float* p = points + static_cast<size_t>(vlist[st + j]) * nf;
+    float y = 0.f;
+    for (int k = 0; k < nf; ++k) y = fmaf(w[k], p[k], y);
+    y = fmaf(w[nf + 0], p[0] - mx, y);
+    y = fmaf(w[nf + 1], p[1] - my, y);
+    y = fmaf(w[nf + 2], p[2] - mz, y);
+    y = fmaf(w[nf + 3], p[0] - pcx, y);
+    y = fmaf(w[nf + 4], p[1] - pcy, y);
+    y = (y - mu) * inv_std * ga + be;
+    y = fmaxf(y, 0.f);
+    acc = fmaxf(acc, y);
+  }
+  if (act) voxel_feats[static_cast<size_t>(v) * Cout + lane] = acc;
+}
+
+}  // namespace
+
+extern "C" size_t dbev_pillar_vfe_workspace_bytes(int n_points, int B, int ny, int nx) {
+  if (n_points < 0 || B <= 0 || ny <= 0 || nx <= 0) return 0;
+  return vfe_layout(n_points, static_cast<long long>(B) * ny * nx).total;
+}
+
+extern "C" int dbev_pillar_vfe_canvas(const float* points, int n_points, int num_features,
+                                      const int32_t* sample_start_host, int B, const float* voxel_size_host,
+                                      const float* coors_range_host, const float* pfn_weight,
+                                      const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                                      const float* bn_var, float bn_eps, int out_channels, float* voxel_feats,
+                                      int32_t* cellmap, int32_t* num_voxels_out, float* canvas,
+                                      int channels_last, void* workspace, size_t workspace_bytes,
+                                      dbevStream_t stream) {
+  if (n_points < 0 || num_features < 3 || num_features + 5 > MAX_K || B <= 0 || B > MAX_B ||
+      out_channels <= 0 || out_channels > 64)
+    return DBEV_EINVAL;
+  VfeParams P;
+  for (int i = 0; i < 3; ++i) {
+    if (!(voxel_size_host[i] > 0.f)) return DBEV_EINVAL;
+    P.vs[i] = voxel_size_host[i];
+    P.rmin[i] = coors_range_host[i];
+    P.grid[i] = static_cast<int>(round((coors_range_host[3 + i] - coors_range_host[i]) / voxel_size_host[i]));
+    if (P.grid[i] <= 0) return DBEV_EINVAL;
+  }
+  if (P.grid[2] != 1) return DBEV_EINVAL;   // pillars: one cell along z
+  P.vx = voxel_size_host[0];
+  P.vy = voxel_size_host[1];
+  P.x_offset = static_cast<float>(static_cast<double>(voxel_size_host[0]) / 2 + coors_range_host[0]);
+  P.y_offset = static_cast<float>(static_cast<double>(voxel_size_host[1]) / 2 + coors_range_host[1]);
+  P.B = B;
+  for (int b = 0; b <= B; ++b) P.sample_start[b] = sample_start_host[b];
+  if (P.sample_start[0] != 0 || P.sample_start[B] != n_points) return DBEV_EINVAL;
+  const int nx = P.grid[0], ny = P.grid[1];
+  const long long ncell = static_cast<long long>(B) * ny * nx;
+  if (ncell > 0x7fffffffLL) return DBEV_EINVAL;
+  const VfeLayout L = vfe_layout(n_points, ncell);
+  if (workspace == nullptr || workspace_bytes < L.total) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  char* ws = static_cast<char*>(workspace);
+  int* cell = reinterpret_cast<int*>(ws + L.cell);
+  int* count = reinterpret_cast<int*>(ws + L.count);
+  int* vid = reinterpret_cast<int*>(ws + L.vid);
+  int* vcount = reinterpret_cast<int*>(ws + L.vcount);
+  int* cursor = reinterpret_cast<int*>(ws + L.cursor);
+  int* vstart = reinterpret_cast<int*>(ws + L.vstart);
+  unsigned* tmp = reinterpret_cast<unsigned*>(ws + L.tmp);
+  unsigned* list = reinterpret_cast<unsigned*>(ws + L.list);
+  int* vcell = reinterpret_cast<int*>(ws + L.vcell);
+  int* scanws = reinterpret_cast<int*>(ws + L.scanws);
+
+  DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * ncell, s));
+  DBEV_HIP_TRY(hipMemsetAsync(vcount, 0, sizeof(int) * static_cast<size_t>(n_points > 0 ? n_points : 1), s));
+  const int nb = dbev_ceil_div(n_points > 0 ? n_points : 1, 256);
+  if (n_points > 0)
+    hipLaunchKernelGGL(vfe_cell_count, dim3(nb), dim3(256), 0, s, points, n_points, num_features, P, cell, count);
+  int rc = dbev::exclusive_scan_i32(count, vid, ncell, true, num_voxels_out, scanws, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(vfe_emit, dim3(dbev_ceil_div(ncell, 256)), dim3(256), 0, s, count, vid,
+                     static_cast<int>(ncell), cellmap, vcount, cursor, vcell);
+  if (n_points > 0) {
+    rc = dbev::exclusive_scan_i32(vcount, vstart, n_points, false, nullptr, scanws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vfe_fill, dim3(nb), dim3(256), 0, s, cell, n_points, vid, vstart, cursor, tmp);
+    rc = dbev::segment_sort_u32(vstart, tmp, list, n_points, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vfe_reduce, dim3(dbev_ceil_div(n_points, 4)), dim3(256), 0, s, points, num_features,
+                       vstart, list, vcell, num_voxels_out, pfn_weight, bn_weight, bn_bias, bn_mean, bn_var,
+                       bn_eps, out_channels, num_features + 5, P, voxel_feats);
+  }
+  return dbev::launch_canvas(voxel_feats, cellmap, canvas, out_channels, B, ny, nx, channels_last, s);
+}

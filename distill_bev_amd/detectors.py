@@ -120,6 +120,12 @@ class DynamicCenterPoint(CenterPoint):
         if not self.with_pts_bbox:
             return None
         outputs = []
+        if getattr(self, "use_fused_pillar_path", True) and pillar_encoder.fused_pillar_canvas_eligible(
+                self.pts_voxel_layer, self.pts_voxel_encoder, self.pts_middle_encoder):
+            # frozen teacher: voxelize -> PFN -> max -> canvas in one asynchronous library call
+            x = pillar_encoder.fused_pillar_canvas(pts, self.pts_voxel_layer, self.pts_voxel_encoder,
+                                                   self.pts_middle_encoder)
+            return self._backbone_neck(x, outputs, return_canvas, return_backbone_feature)
         voxels, coors = self.voxelize(pts)
         coors = coors.type(torch.int32)
         batch_size = len(pts)

@@ -14,8 +14,56 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as L
 from .registry import MODELS, build_activation_layer, build_norm_layer
 from .voxel import dynamic_scatter, dynamic_scatter_prepare
+
+
+def fused_pillar_canvas_eligible(voxel_layer, encoder, middle_encoder):
+    """The fused teacher kernel covers the shipped teacher recipe (CFG_T / CFG_TB): dynamic voxelization,
+    one PFN layer (Linear no-bias + BN1d + ReLU), cluster + voxel centre decoration, max pooling, eval BN."""
+    if not isinstance(encoder, DynamicPillarFeatureNet) or encoder.training:
+        return False
+    if encoder.num_pfn != 1 or encoder.mode != "max" or encoder._with_distance or encoder.virtual:
+        return False
+    if not (encoder._with_cluster_center and encoder._with_voxel_center):
+        return False
+    lin, bn, act = encoder.pfn_layers[0][0], encoder.pfn_layers[0][1], encoder.pfn_layers[0][2]
+    if lin.bias is not None or not isinstance(bn, nn.BatchNorm1d) or not isinstance(act, nn.ReLU):
+        return False
+    if lin.out_features > 64 or voxel_layer.max_num_points != -1:
+        return False
+    return encoder.grid[0] == 1 and (middle_encoder.ny, middle_encoder.nx) == (encoder.grid[1], encoder.grid[2])
+
+
+@torch.no_grad()
+def fused_pillar_canvas(points, voxel_layer, encoder, middle_encoder):
+    """points: list of f32[N_i, F] -> canvas f32[B, C, ny, nx]  (dbev_pillar_vfe_canvas)."""
+    dev = L.require_cuda(*points)
+    B = len(points)
+    pts = torch.cat(points, dim=0).contiguous() if B > 1 else points[0].contiguous()
+    starts = [0]
+    for p in points:
+        starts.append(starts[-1] + p.shape[0])
+    n, F_ = pts.shape
+    lin, bn = encoder.pfn_layers[0][0], encoder.pfn_layers[0][1]
+    C = lin.out_features
+    ny, nx = middle_encoder.ny, middle_encoder.nx
+    cl = bool(getattr(middle_encoder, "channels_last", False))
+    canvas = torch.empty((B, C, ny, nx), dtype=torch.float32, device=dev,
+                         memory_format=torch.channels_last if cl else torch.contiguous_format)
+    vf = torch.empty((max(n, 1), C), dtype=torch.float32, device=dev)
+    cellmap = torch.empty((B * ny * nx,), dtype=torch.int32, device=dev)
+    m = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = L.call("dbev_pillar_vfe_workspace_bytes", n, B, ny, nx)
+        ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+        L.call("dbev_pillar_vfe_canvas", L.ptr(pts), n, F_, L.host_ints(starts), B,
+               L.host_floats(voxel_layer.voxel_size), L.host_floats(voxel_layer.point_cloud_range),
+               L.ptr(lin.weight.contiguous()), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
+               L.ptr(bn.running_var), float(bn.eps), C, L.ptr(vf), L.ptr(cellmap), L.ptr(m), L.ptr(canvas),
+               1 if cl else 0, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    return canvas
 
 
 def get_paddings_indicator(actual_num, max_num, axis=0):

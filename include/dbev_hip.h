@@ -244,6 +244,26 @@ int dbev_fgd_masked_mse_backward(const float* S, const float* T, const float* Wf
                                  const float* Wfp, const float* Cc, const float* grad_scale3, int B,
                                  int C, int HW, float* dS, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused teacher pillar path (frozen CenterPoint-pillar teacher, eval / no_grad):
+ *   DynamicCenterPoint.voxelize (dynamic_centerpoint.py:71-93) ->
+ *   DynamicPillarFeatureNet.forward with ONE PFN layer, cluster + voxel centre decoration, max
+ *   pooling (pillar_encoder.py:283-338) -> PointPillarsScatter.forward_batch (pillar_scatter.py:62-102)
+ * in one asynchronous call; the data-dependent pillar count never reaches the host.
+ *   points f32[n_points, F] = the B samples' clouds concatenated; sample_start_host i32[B+1] (HOST)
+ *   pfn_weight f32[Cout, F+5] (nn.Linear weight, no bias); bn_* f32[Cout] BatchNorm1d eval statistics
+ *   voxel_feats f32[n_points, Cout] (capacity; rows >= M untouched), cellmap i32[B*ny*nx],
+ *   num_voxels_out DEVICE int, canvas f32[B, Cout, ny, nx] (or channels-last), all caller-allocated.
+ * Pillar rows come out in (b, y, x) order -- the order of the reference's sorted-unique scatter. */
+size_t dbev_pillar_vfe_workspace_bytes(int n_points, int B, int ny, int nx);
+int dbev_pillar_vfe_canvas(const float* points, int n_points, int num_features,
+                           const int32_t* sample_start_host, int B, const float* voxel_size_host,
+                           const float* coors_range_host, const float* pfn_weight, const float* bn_weight,
+                           const float* bn_bias, const float* bn_mean, const float* bn_var, float bn_eps,
+                           int out_channels, float* voxel_feats, int32_t* cellmap, int32_t* num_voxels_out,
+                           float* canvas, int channels_last, void* workspace, size_t workspace_bytes,
+                           dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,3 +184,36 @@ def test_pillars_scatter_full_size_vs_oracle():
     for cl in (False, True):
         out = pillars_scatter(torch.from_numpy(f).to(dev), torch.from_numpy(co).to(dev), 2, 512, 512, cl)
         assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_fused_teacher_pillar_path_vs_op_level_and_oracle():
+    """dbev_pillar_vfe_canvas (voxelize -> PFN -> max -> canvas, no host sync) against (a) the op-level
+    HIP path (DynamicPillarFeatureNet + PointPillarsScatter mirrors) and (b) the reference op sequence on
+    the CPU oracle (oracle/cpu_step.CpuDynamicCenterPoint).  Ragged batch, 10 % points out of range."""
+    from distill_bev_amd import detectors as D
+    from distill_bev_amd.config import Config
+    from distill_bev_amd.registry import build_detector
+    from distill_bev_amd.train_step import DEFAULT_CONFIG
+    from oracle.cpu_step import CpuDynamicCenterPoint
+    dev = _dev()
+    cfg = Config.fromfile(DEFAULT_CONFIG)
+    torch.manual_seed(1)
+    teacher = build_detector(cfg.teacher["model"]).to(dev).eval()
+    bn = teacher.pts_voxel_encoder.pfn_layers[0][1]
+    with torch.no_grad():                              # non-trivial BN statistics
+        bn.running_mean.uniform_(-0.5, 0.5); bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2)
+    rng = np.random.default_rng(11)
+    pts = [torch.from_numpy(syn.lidar_points(n, rng)).to(dev) for n in (30000, 1000, 45000)]
+    pts[1][:400, :3] = pts[1][0, :3]                    # 400 points in one pillar (long segment)
+    with torch.no_grad():
+        teacher.use_fused_pillar_path = True
+        fused = teacher.extract_pts_feat(pts, return_canvas=True, return_backbone_feature=True)[1]
+        teacher.use_fused_pillar_path = False
+        oplevel = teacher.extract_pts_feat(pts, return_canvas=True, return_backbone_feature=True)[1]
+        teacher.__class__ = CpuDynamicCenterPoint
+        ref = teacher.extract_pts_feat(pts, return_canvas=True, return_backbone_feature=True)[1]
+    assert fused.shape == (3, 64, 512, 512)
+    assert torch.equal(fused == 0, ref == 0)            # same occupied pillars
+    assert float((fused - oplevel).abs().max()) < 1e-5
+    assert float((fused - ref).abs().max()) < 1e-5

@@ -30,9 +30,10 @@ torch.cuda.synchronize()
 for i in range(args.steps):
     t = time.time()
     loss, losses = tr.step(batch)
+    host = time.time() - t
     torch.cuda.synchronize()
     dt = time.time() - t
-    print(f"step {i}: loss {float(loss):.4f}  {dt*1e3:.1f} ms  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    print(f"step {i}: loss {float(loss):.4f}  {dt*1e3:.1f} ms (host issue {host*1e3:.1f} ms)  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
     if i == 0:
         for k, v in losses.items():
             print(f"   {k}: {float(v):.5f}")
