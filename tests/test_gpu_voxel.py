@@ -215,5 +215,6 @@ def test_fused_teacher_pillar_path_vs_op_level_and_oracle():
         ref = teacher.extract_pts_feat(pts, return_canvas=True, return_backbone_feature=True)[1]
     assert fused.shape == (3, 64, 512, 512)
     assert torch.equal(fused == 0, ref == 0)            # same occupied pillars
-    assert float((fused - oplevel).abs().max()) < 1e-5
-    assert float((fused - ref).abs().max()) < 1e-5
+    scale = float(ref.abs().max())                      # features reach ~1e2 (intensity up to 255)
+    assert float((fused - oplevel).abs().max()) < 2e-6 * scale
+    assert float((fused - ref).abs().max()) < 2e-6 * scale
