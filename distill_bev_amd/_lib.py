@@ -50,6 +50,8 @@ _SIGNATURES = {
     "dbev_fgd_masked_mse_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dbev_pillar_vfe_workspace_bytes": [_i, _i, _i, _i],
     "dbev_pillar_vfe_canvas": [_p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _i, _p, _sz, _p],
+    "dbev_upsample_bilinear_ac_forward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "dbev_upsample_bilinear_ac_backward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_pillar_vfe_workspace_bytes": ctypes.c_size_t,

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from .center_head import LiDARBoxes, clip_sigmoid  # noqa: F401
 from .config import Config
-from .distill_loss import ForegroundMaskRasterizer, fgd_feature_losses
+from .distill_loss import ForegroundMaskRasterizer, UpsampleBilinearAC, fgd_feature_losses
 from .registry import MODELS, build_backbone, build_detector, build_head, build_loss, build_neck
 from .voxel import Voxelization
 
@@ -237,11 +237,11 @@ class BEVDepth4DDistill(CenterPoint):
             elif at in ("upsample_2layer", "upsample_3layer"):
                 cls = TwoLayer if at == "upsample_2layer" else ThreeLayer
                 cwa.append(nn.Sequential(
-                    nn.Upsample(scale_factor=sap["upsample_factor"], mode="bilinear", align_corners=True),
+                    UpsampleBilinearAC(sap["upsample_factor"]),     # == nn.Upsample(bilinear, align_corners=True)
                     cls(in_features=s_c, out_features=t_c, kernel_size=sap["kernel_size"], stride=sap["stride"])))
             elif at == "upsample_1x1conv":
                 cwa.append(nn.Sequential(
-                    nn.Upsample(scale_factor=sap["upsample_factor"], mode="bilinear", align_corners=True),
+                    UpsampleBilinearAC(sap["upsample_factor"]),
                     nn.Conv2d(s_c, t_c, kernel_size=1, stride=1, padding=0)))
             else:
                 raise NotImplementedError(at)

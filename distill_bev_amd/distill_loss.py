@@ -201,3 +201,47 @@ def fgd_feature_losses(student_feat, teacher_feat, fg, fg_scale, bg_scale, *, w_
     if fp is not None:
         out["kd_fp_bg_feat_loss"] = sums[2] * (w_fp / B)
     return out, att, c_att
+
+
+class _UpsampleBilinearAC(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        dev = L.require_cuda(x)
+        B, C, IH, IW = x.shape
+        OH, OW = int(IH * scale), int(IW * scale)
+        cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() and C % 4 == 0
+        x = x.contiguous(memory_format=torch.channels_last) if cl else x.contiguous()
+        y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=dev,
+                        memory_format=torch.channels_last if cl else torch.contiguous_format)
+        with torch.cuda.device(dev):
+            L.call("dbev_upsample_bilinear_ac_forward", L.ptr(x), L.ptr(y), B, C, IH, IW, OH, OW, 1 if cl else 0,
+                   L.stream_ptr(dev))
+        ctx.dims = (B, C, IH, IW, OH, OW, cl)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, IH, IW, OH, OW, cl = ctx.dims
+        dev = gy.device
+        gy = gy.contiguous(memory_format=torch.channels_last) if cl else gy.contiguous()
+        gx = torch.empty((B, C, IH, IW), dtype=torch.float32, device=dev,
+                         memory_format=torch.channels_last if cl else torch.contiguous_format)
+        with torch.cuda.device(dev):
+            L.call("dbev_upsample_bilinear_ac_backward", L.ptr(gy), L.ptr(gx), B, C, IH, IW, OH, OW, 1 if cl else 0,
+                   L.stream_ptr(dev))
+        return gx, None
+
+
+class UpsampleBilinearAC(torch.nn.Module):
+    """nn.Upsample(scale_factor=s, mode='bilinear', align_corners=True) on the gfx950 kernel
+    (parameter-free, so checkpoints are unaffected)."""
+
+    def __init__(self, scale_factor):
+        super().__init__()
+        self.scale_factor = scale_factor
+
+    def forward(self, x):
+        return _UpsampleBilinearAC.apply(x, self.scale_factor)
+
+    def extra_repr(self):
+        return f"scale_factor={self.scale_factor}, mode=bilinear, align_corners=True"

@@ -264,6 +264,15 @@ int dbev_pillar_vfe_canvas(const float* points, int n_points, int num_features,
                            float* canvas, int channels_last, void* workspace, size_t workspace_bytes,
                            dbevStream_t stream);
 
+/* Bilinear upsampling with align_corners=True (nn.Upsample in the student adaptation layers of the
+ * FGD loss, bevdet_distill.py:275-288; ATen upsample_bilinear2d index rule).  x f32[B,C,IH,IW] ->
+ * y f32[B,C,OH,OW]; channels_last=1: both tensors are physically [B,H,W,C].  backward: every element
+ * of grad_x written (gather formulation, no atomics). */
+int dbev_upsample_bilinear_ac_forward(const float* x, float* y, int B, int C, int IH, int IW, int OH, int OW,
+                                      int channels_last, dbevStream_t stream);
+int dbev_upsample_bilinear_ac_backward(const float* grad_y, float* grad_x, int B, int C, int IH, int IW, int OH,
+                                       int OW, int channels_last, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,5 +138,8 @@ class CpuBEVDepth4DDistill(D.BEVDepth4DDistill):
 def to_cpu_reference(model):
     """Re-class a built (CPU) BEVDepth4DDistill into the reference-sequence CPU variant, in place."""
     model.__class__ = CpuBEVDepth4DDistill
+    for seq in model.channel_wise_adaptations:         # the reference's own nn.Upsample
+        if isinstance(seq, torch.nn.Sequential) and type(seq[0]).__name__ == "UpsampleBilinearAC":
+            seq[0] = torch.nn.Upsample(scale_factor=seq[0].scale_factor, mode="bilinear", align_corners=True)
     model._cpu_teacher()
     return model

@@ -104,3 +104,29 @@ def test_masked_mse_determinism_and_small_odd_channels():
     sq = (S - T).double() ** 2
     assert abs(float(a[0]) - float((sq * wf.double()).sum())) < 1e-3
     assert abs(float(a[1]) - float((sq * wb.double()).sum())) < 1e-3
+
+
+@pytest.mark.parametrize("shape,scale", [((2, 256, 32, 32), 4), ((1, 6, 5, 7), 4), ((2, 3, 1, 9), 2), ((1, 8, 16, 16), 3)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_upsample_bilinear_align_corners_vs_torch(shape, scale, channels_last):
+    """vs torch's own upsample_bilinear2d (the op the reference calls) on the CPU, forward and backward."""
+    from distill_bev_amd.distill_loss import UpsampleBilinearAC
+    dev = _dev()
+    torch.manual_seed(0)
+    x_cpu = torch.randn(shape, requires_grad=True)
+    ref = torch.nn.functional.interpolate(x_cpu, scale_factor=scale, mode="bilinear", align_corners=True)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    x = x_cpu.detach().to(dev)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    y = UpsampleBilinearAC(scale)(x)
+    assert y.shape == ref.shape
+    # the source coordinate r*o carries 1 ulp (1.9e-6 at o~127) of rounding freedom -> 1e-5 on O(1) data
+    assert float((y.detach().cpu() - ref.detach()).abs().max()) < 2e-5
+    gg = g.to(dev)
+    if channels_last:
+        gg = gg.contiguous(memory_format=torch.channels_last)
+    y.backward(gg)
+    assert float((x.grad.cpu() - x_cpu.grad).abs().max()) < 1e-4

@@ -90,3 +90,17 @@ print(f"masked_mse bwd head B={B}: {t:8.1f} us   {alg / t / 1e3:7.1f} GB/s algor
 t = timeit(lambda: abs_mean_maps(T))
 alg = B * 4 * 128 * 128 * 384
 print(f"abs_mean_maps head  B={B}: {t:8.1f} us   {alg / t / 1e3:7.1f} GB/s algorithmic")
+
+from distill_bev_amd.distill_loss import UpsampleBilinearAC
+for cl in (False, True):
+    x = torch.randn((B, 256, 32, 32), device=dev)
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    up_t = torch.nn.Upsample(scale_factor=4, mode="bilinear", align_corners=True)
+    up_m = UpsampleBilinearAC(4)
+    yt = up_t(x); ym = up_m(x); g = torch.randn_like(ym)
+    t1 = timeit(lambda: up_t(x)); t2 = timeit(lambda: up_m(x))
+    t3 = timeit(lambda: torch.autograd.grad(yt, x, g, retain_graph=True)); t4 = timeit(lambda: torch.autograd.grad(ym, x, g, retain_graph=True))
+    mb = B * 256 * 128 * 128 * 4 / 1e6
+    print(f"upsample x4 8x256x32x32 cl={cl}: fwd torch {t1:7.1f} us | hip {t2:7.1f} us ({mb/t2*1e3:6.0f} GB/s)   bwd torch {t3:7.1f} us | hip {t4:7.1f} us")
