@@ -38,6 +38,7 @@ _SIGNATURES = {
     "dbev_pillars_scatter_backward": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "dbev_lift_splat_workspace_bytes": [_i, _i],
     "dbev_lift_splat_prepare": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "dbev_lift_splat_prepare_cam": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "dbev_lift_splat_forward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dbev_lift_splat_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_splat_forward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],

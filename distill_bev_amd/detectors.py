@@ -356,8 +356,8 @@ class BEVDepth4DDistill(CenterPoint):
             Bx, Nx, C, fH, fW = x.shape
             img_feat, depth_digit = vt.depth_and_feat(x.view(Bx * Nx, C, fH, fW), rot, tran, intrin, post_rot, post_tran)
             depth = vt.get_depth_dist(depth_digit)
-            geom = vt.get_geometry(rot, tran, intrin, post_rot, post_tran)
-            bev_feat_list.append(vt.lift_splat(geom, depth, img_feat))    # fused lift x splat
+            # get_geometry + lift + voxel_pooling (:411-421) in three library calls, no volume, no geom tensor
+            bev_feat_list.append(vt.lift_splat_cameras(rot, tran, intrin, post_rot, post_tran, depth, img_feat))
             depth_digit_list.append(depth_digit)
         if self.before and self.pre_process:
             bev_feat_list = [self.pre_process_net(b)[0] for b in bev_feat_list]

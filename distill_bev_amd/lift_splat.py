@@ -64,6 +64,43 @@ def lift_splat_prepare(geom, dx, bx, nx):
     return p
 
 
+def camera_params(rots, trans, intrins, post_rots, post_trans):
+    """f32[B*N, 24] per camera: inverse(post_rots) (9), post_trans (3), rots @ inverse(intrins) (9), trans (3)
+    -- the matrices of get_geometry (vt_mine.py:121-136), a few hundred bytes of torch work per step."""
+    B, N = trans.shape[:2]
+    a = torch.inverse(post_rots).reshape(B * N, 9)
+    c = rots.matmul(torch.inverse(intrins)).reshape(B * N, 9)
+    return torch.cat([a, post_trans.reshape(B * N, 3), c, trans.reshape(B * N, 3)], dim=1).contiguous()
+
+
+def lift_splat_prepare_cam(frustum, rots, trans, intrins, post_rots, post_trans, dx, bx, nx):
+    """lift_splat_prepare with get_geometry fused into the index kernel (no [B,N,D,H,W,3] tensor)."""
+    dev = L.require_cuda(frustum, rots)
+    B, N = trans.shape[:2]
+    D, H, W = frustum.shape[:3]
+    cam = camera_params(rots, trans, intrins, post_rots, post_trans)
+    fr = frustum.contiguous()
+    n_points = B * N * D * H * W
+    X, Y, Z = (int(v) for v in nx)
+    n_cells = B * X * Y * Z
+    p = LiftSplatPrep()
+    p.B, p.X, p.Y, p.Z, p.n_points, p.n_cells = B, X, Y, Z, n_points, n_cells
+    p.point_cell = torch.empty((n_points,), dtype=torch.int32, device=dev)
+    p.cell_start = torch.empty((n_cells + 1,), dtype=torch.int32, device=dev)
+    p.cell_points = torch.empty((max(n_points, 1),), dtype=torch.int32, device=dev)
+    p.n_kept = torch.empty((1,), dtype=torch.int32, device=dev)
+    p.hot_cells = torch.empty((n_cells,), dtype=torch.int32, device=dev)
+    p.n_hot = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = L.call("dbev_lift_splat_workspace_bytes", n_points, n_cells)
+        ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+        L.call("dbev_lift_splat_prepare_cam", L.ptr(cam), L.ptr(fr), B * N, D, H, W, B,
+               L.host_floats([float(v) for v in dx]), L.host_floats([float(v) for v in bx]),
+               L.host_ints([X, Y, Z]), L.ptr(p.point_cell), L.ptr(p.cell_start), L.ptr(p.cell_points),
+               L.ptr(p.n_kept), L.ptr(p.hot_cells), L.ptr(p.n_hot), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    return p
+
+
 def _as_logical(out, prep, C):
     # physical [B, Y, X, Z, C] -> logical [B, Z*C, Y, X] with channels-last strides
     return out.view(prep.B, prep.Y, prep.X, prep.Z * C).permute(0, 3, 1, 2)

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import lss as LSS
-from .lift_splat import lift_splat, lift_splat_prepare, voxel_pooling as _voxel_pooling
+from .lift_splat import lift_splat, lift_splat_prepare, lift_splat_prepare_cam, voxel_pooling as _voxel_pooling
 from .nets import SELikeModule
 from .registry import MODELS, build_backbone, build_conv_layer
 
@@ -67,14 +67,20 @@ class ViewTransformerLiftSplatShoot(nn.Module):
         """fused: == voxel_pooling(geom, depth_prob[:,None] * img_feat[:,:,None] permuted)."""
         return lift_splat(depth_prob, img_feat, self.prepare(geom))
 
+    def lift_splat_cameras(self, rots, trans, intrins, post_rots, post_trans, depth_prob, img_feat):
+        """get_geometry + lift + splat in the library: the ego-frame geometry is evaluated inside the voxel
+        index kernel (same arithmetic as get_geometry, bit-identical indices), never materialised."""
+        prep = lift_splat_prepare_cam(self.frustum, rots, trans, intrins, post_rots, post_trans,
+                                      self._dx_host, self._bx_host, self._nx_host)
+        return lift_splat(depth_prob, img_feat, prep)
+
     def forward(self, input):
         x, rots, trans, intrins, post_rots, post_trans = input[:6]
         B, N, C, H, W = x.shape
         x = self.depthnet(x.view(B * N, C, H, W))
         depth = self.get_depth_dist(x[:, :self.D])
-        geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)
         img_feat = x[:, self.D:(self.D + self.numC_Trans)]
-        return self.lift_splat(geom, depth, img_feat)
+        return self.lift_splat_cameras(rots, trans, intrins, post_rots, post_trans, depth, img_feat)
 
 
 @MODELS.register_module()
@@ -107,8 +113,7 @@ class ViewTransformerLSSBEVDepth(ViewTransformerLiftSplatShoot):
         B, N, C, H, W = x.shape
         img_feat, depth_digit = self.depth_and_feat(x.view(B * N, C, H, W), rots, trans, intrins, post_rots, post_trans)
         depth_prob = self.get_depth_dist(depth_digit)
-        geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)
-        return self.lift_splat(geom, depth_prob, img_feat), depth_digit
+        return self.lift_splat_cameras(rots, trans, intrins, post_rots, post_trans, depth_prob, img_feat), depth_digit
 
 
 # bev_pool-based twins of view_transformer.py resolve to the same implementation

@@ -180,6 +180,19 @@ int dbev_lift_splat_prepare(const float* geom, int n_points, int batch, const fl
                             int32_t* hot_cells, int32_t* n_hot_out, void* workspace,
                             size_t workspace_bytes, dbevStream_t stream);
 
+/* Same, with get_geometry (view_transformer_mine.py:111-139) fused in: no geometry tensor is read.
+ *   cam_params f32[BN, 24] per camera = inverse(post_rots) row-major (9), post_trans (3),
+ *              rots @ inverse(intrins) row-major (9), trans (3)   -- tiny host/torch-side matrix work
+ *   frustum    f32[D, H, W, 3] (create_frustum, vt_mine.py:98-109)
+ * The ego-frame point is evaluated as separate fp32 multiplies and adds in the order
+ * ((m0*x + m1*y) + m2*z) (no FMA), i.e. bit-identical to distill_bev_amd.lss.get_geometry. */
+int dbev_lift_splat_prepare_cam(const float* cam_params, const float* frustum, int BN, int D, int H, int W,
+                                int batch, const float* dx_host, const float* bx_host,
+                                const int32_t* nx_host, int32_t* point_cell, int32_t* cell_start,
+                                int32_t* cell_points, int32_t* n_kept_out, int32_t* hot_cells,
+                                int32_t* n_hot_out, void* workspace, size_t workspace_bytes,
+                                dbevStream_t stream);
+
 /* depth f32[BN, D, H, W] (softmaxed depth distribution); feat_nhwc f32[BN, H, W, C]
  * (channels-last image features); out f32[n_cells, C], every cell written:
  *   out[cell, :] = sum over the cell's points p of depth[p] * feat[bn(p), h(p), w(p), :].

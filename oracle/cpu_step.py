@@ -80,8 +80,10 @@ class CpuBEVDepth4DDistill(D.BEVDepth4DDistill):
     def extract_img_feat(self, img, img_metas=None, return_lss_feature=False, return_backbone_feature=False):
         vt = self.img_view_transformer
         # the reference sequence: materialise the volume, then argsort + cumsum voxel_pooling
-        vt.lift_splat = lambda geom, depth, feat: OT.voxel_pooling_cumsum(
-            geom, OT.lift(depth, feat, geom.shape[0], geom.shape[1]), vt.dx, vt.bx, vt.nx)
+        def ref_lift_splat(rot, tran, intrin, post_rot, post_tran, depth, feat):
+            geom = vt.get_geometry(rot, tran, intrin, post_rot, post_tran)
+            return OT.voxel_pooling_cumsum(geom, OT.lift(depth, feat, geom.shape[0], geom.shape[1]), vt.dx, vt.bx, vt.nx)
+        vt.lift_splat_cameras = ref_lift_splat
         return super().extract_img_feat(img, img_metas, return_lss_feature, return_backbone_feature)
 
     def fgd_distill_loss(self, teacher_feat, student_feat, gt_bboxes_3d, gt_labels_3d, canvas_feat, heatmaps,

@@ -128,3 +128,32 @@ def test_lift_splat_degenerate_geometries():
     assert int((bev != 0).sum()) == C
     cs = prep.cell_points[:800]
     assert torch.equal(cs, torch.arange(800, device=dev, dtype=torch.int32))
+
+
+def test_fused_geometry_prepare_bit_identical_to_geometry_tensor_path():
+    """dbev_lift_splat_prepare_cam (get_geometry evaluated inside the index kernel) must produce exactly the
+    voxel indices and CSR of dbev_lift_splat_prepare fed with lss.get_geometry computed by torch on the GPU."""
+    from distill_bev_amd import lss as LSS
+    from distill_bev_amd.lift_splat import lift_splat_prepare, lift_splat_prepare_cam
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    B = 4
+    rig = {k: torch.from_numpy(v).to(dev) for k, v in syn.camera_rig(B, rng).items()}
+    # non-trivial image augmentation: rotated / flipped post_rots
+    th = torch.tensor(0.07)
+    rig["post_rots"][1, :, :2, :2] = 0.44 * torch.tensor([[torch.cos(th), -torch.sin(th)], [torch.sin(th), torch.cos(th)]])
+    rig["post_rots"][2, :, 0, 0] *= -1
+    rig["post_trans"][2, :, 0] = 704.0
+    dx, bx, nx = LSS.gen_dx_bx([-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8], [-10.0, 10.0, 20.0])
+    fr = LSS.create_frustum().to(dev)
+    geom = LSS.get_geometry(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"])
+    a = lift_splat_prepare(geom, dx.tolist(), bx.tolist(), [128, 128, 1])
+    b = lift_splat_prepare_cam(fr, rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"],
+                               dx.tolist(), bx.tolist(), [128, 128, 1])
+    assert torch.equal(a.point_cell, b.point_cell)
+    assert torch.equal(a.cell_start, b.cell_start)
+    n = int(a.n_kept)
+    assert n == int(b.n_kept) and n > 0.8 * 0.8 * a.n_points
+    assert torch.equal(a.cell_points[:n], b.cell_points[:n])
+    assert int(a.n_hot) == int(b.n_hot)
+    assert torch.equal(torch.sort(a.hot_cells[:int(a.n_hot)])[0], torch.sort(b.hot_cells[:int(b.n_hot)])[0])
