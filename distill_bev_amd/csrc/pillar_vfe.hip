@@ -122,47 +122,58 @@ __global__ __launch_bounds__(256) void vfe_reduce(const float* __restrict__ poin
                                                   const float* __restrict__ bn_mean, const float* __restrict__ bn_var,
                                                   float bn_eps, int Cout, int K, VfeParams P,
                                                   float* __restrict__ voxel_feats) {
-  const int v = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (v >= *num_voxels) return;
-  const int st = vstart[v];
-  const int L = vstart[v + 1] - st;
-  const int c = vcell[v];
-  const int cx = c % P.grid[0];
-  const int cy = (c / P.grid[0]) % P.grid[1];
-  // pillar centre: coors.type_as(features) * vx + x_offset (pillar_encoder.py:318-321), fp32
-  const float pcx = static_cast<float>(cx) * P.vx + P.x_offset;
-  const float pcy = static_cast<float>(cy) * P.vy + P.y_offset;
-  // cluster mean of xyz: sequential fp32 sum in point order / count (DynamicScatter mean)
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int j = 0; j < L; ++j) {
-    const float* p = points + static_cast<size_t>(vlist[st + j]) * nf;
-    sx += p[0]; sy += p[1]; sz += p[2];
-  }
-  const float fl = static_cast<float>(L);
-  const float mx = sx / fl, my = sy / fl, mz = sz / fl;
-  float w[MAX_K];
+  const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int M = *num_voxels;
+  // per-lane constants, loaded ONCE per wave (the wave then walks ~M/nwaves pillars): weight column of
+  // output channel `lane` and its folded BatchNorm1d (eval): (y - mean) / sqrt(var + eps) * weight + bias
+  // (static register indices only: a runtime-indexed array would live in scratch)
+  constexpr int MAX_F = MAX_K - 5;
+  float wf[MAX_F];
   const bool act = lane < Cout;
 #pragma unroll
-  for (int k = 0; k < MAX_K; ++k) w[k] = (act && k < K) ? W[lane * K + k] : 0.f;
-  // BatchNorm1d (eval): (y - mean) / sqrt(var + eps) * weight + bias
+  for (int k = 0; k < MAX_F; ++k) wf[k] = (act && k < nf) ? W[lane * K + k] : 0.f;
+  const float wd0 = act ? W[lane * K + nf + 0] : 0.f, wd1 = act ? W[lane * K + nf + 1] : 0.f;
+  const float wd2 = act ? W[lane * K + nf + 2] : 0.f, wd3 = act ? W[lane * K + nf + 3] : 0.f;
+  const float wd4 = act ? W[lane * K + nf + 4] : 0.f;
   const float inv_std = act ? 1.f / sqrtf(bn_var[lane] + bn_eps) : 0.f;
   const float mu = act ? bn_mean[lane] : 0.f, ga = act ? bn_w[lane] : 0.f, be = act ? bn_b[lane] : 0.f;
-  float acc = -INFINITY;
-  for (int j = 0; j < L; ++j) {
-    const float* p = points + static_cast<size_t>(vlist[st + j]) * nf;
-    float y = 0.f;
-    for (int k = 0; k < nf; ++k) y = fmaf(w[k], p[k], y);
-    y = fmaf(w[nf + 0], p[0] - mx, y);
-    y = fmaf(w[nf + 1], p[1] - my, y);
-    y = fmaf(w[nf + 2], p[2] - mz, y);
-    y = fmaf(w[nf + 3], p[0] - pcx, y);
-    y = fmaf(w[nf + 4], p[1] - pcy, y);
-    y = (y - mu) * inv_std * ga + be;
-    y = fmaxf(y, 0.f);
-    acc = fmaxf(acc, y);
+  for (int v = wave0; v < M; v += nwaves) {
+    const int st = vstart[v];
+    const int L = vstart[v + 1] - st;
+    const int c = vcell[v];
+    const int cx = c % P.grid[0];
+    const int cy = (c / P.grid[0]) % P.grid[1];
+    // pillar centre: coors.type_as(features) * vx + x_offset (pillar_encoder.py:318-321), fp32
+    const float pcx = static_cast<float>(cx) * P.vx + P.x_offset;
+    const float pcy = static_cast<float>(cy) * P.vy + P.y_offset;
+    // cluster mean of xyz: sequential fp32 sum in point order / count (DynamicScatter mean)
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float* p = points + static_cast<size_t>(vlist[st + j]) * nf;
+      sx += p[0]; sy += p[1]; sz += p[2];
+    }
+    const float fl = static_cast<float>(L);
+    const float mx = sx / fl, my = sy / fl, mz = sz / fl;
+    float acc = -INFINITY;
+    for (int j = 0; j < L; ++j) {
+      const float* p = points + static_cast<size_t>(vlist[st + j]) * nf;
+      float y = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAX_F; ++k)
+        if (k < nf) y = fmaf(wf[k], p[k], y);
+      y = fmaf(wd0, p[0] - mx, y);
+      y = fmaf(wd1, p[1] - my, y);
+      y = fmaf(wd2, p[2] - mz, y);
+      y = fmaf(wd3, p[0] - pcx, y);
+      y = fmaf(wd4, p[1] - pcy, y);
+      y = (y - mu) * inv_std * ga + be;
+      y = fmaxf(y, 0.f);
+      acc = fmaxf(acc, y);
+    }
+    if (act) voxel_feats[static_cast<size_t>(v) * Cout + lane] = acc;
   }
-  if (act) voxel_feats[static_cast<size_t>(v) * Cout + lane] = acc;
 }
 
 }  // namespace
@@ -232,7 +243,7 @@ extern "C" int dbev_pillar_vfe_canvas(const float* points, int n_points, int num
     hipLaunchKernelGGL(vfe_fill, dim3(nb), dim3(256), 0, s, cell, n_points, vid, vstart, cursor, tmp);
     rc = dbev::segment_sort_u32(vstart, tmp, list, n_points, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(vfe_reduce, dim3(dbev_ceil_div(n_points, 4)), dim3(256), 0, s, points, num_features,
+    hipLaunchKernelGGL(vfe_reduce, dim3(DBEV_MAX_GRID), dim3(256), 0, s, points, num_features,
                        vstart, list, vcell, num_voxels_out, pfn_weight, bn_weight, bn_bias, bn_mean, bn_var,
                        bn_eps, out_channels, num_features + 5, P, voxel_feats);
   }

@@ -104,3 +104,13 @@ for cl in (False, True):
     t3 = timeit(lambda: torch.autograd.grad(yt, x, g, retain_graph=True)); t4 = timeit(lambda: torch.autograd.grad(ym, x, g, retain_graph=True))
     mb = B * 256 * 128 * 128 * 4 / 1e6
     print(f"upsample x4 8x256x32x32 cl={cl}: fwd torch {t1:7.1f} us | hip {t2:7.1f} us ({mb/t2*1e3:6.0f} GB/s)   bwd torch {t3:7.1f} us | hip {t4:7.1f} us")
+
+# fused teacher pillar path (dbev_pillar_vfe_canvas) at the step shapes
+from distill_bev_amd.config import Config
+from distill_bev_amd.registry import build_detector
+from distill_bev_amd.train_step import DEFAULT_CONFIG
+import distill_bev_amd.detectors  # noqa
+from distill_bev_amd import pillar_encoder as PE
+teacher = build_detector(Config.fromfile(DEFAULT_CONFIG).teacher["model"]).to(dev).eval()
+t = timeit(lambda: PE.fused_pillar_canvas(pts, teacher.pts_voxel_layer, teacher.pts_voxel_encoder, teacher.pts_middle_encoder), n=10)
+print(f"fused teacher pillar path (8 x 240k pts -> canvas): {t:8.1f} us")
