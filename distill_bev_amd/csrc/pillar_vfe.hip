@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void vfe_reduce(const float* __restrict__ poin
                                                   float bn_eps, int Cout, int K, VfeParams P,
                                                   float* __restrict__ voxel_feats) {
   const int lane = threadIdx.x & 63;
-  const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // wave-uniform by construction; readfirstlane lets the compiler keep the pillar bookkeeping (list bounds,
+  // point ids, point coordinates: identical for all 64 lanes) in SGPRs / scalar loads
+  const int wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int M = *num_voxels;
   // per-lane constants, loaded ONCE per wave (the wave then walks ~M/nwaves pillars): weight column of
@@ -139,10 +141,14 @@ __global__ __launch_bounds__(256) void vfe_reduce(const float* __restrict__ poin
   const float wd4 = act ? W[lane * K + nf + 4] : 0.f;
   const float inv_std = act ? 1.f / sqrtf(bn_var[lane] + bn_eps) : 0.f;
   const float mu = act ? bn_mean[lane] : 0.f, ga = act ? bn_w[lane] : 0.f, be = act ? bn_b[lane] : 0.f;
+  // next pillar's bookkeeping is fetched while the current one is reduced
+  int st_n = 0, en_n = 0, c_n = 0;
+  if (wave0 < M) { st_n = vstart[wave0]; en_n = vstart[wave0 + 1]; c_n = vcell[wave0]; }
   for (int v = wave0; v < M; v += nwaves) {
-    const int st = vstart[v];
-    const int L = vstart[v + 1] - st;
-    const int c = vcell[v];
+    const int st = st_n;
+    const int L = en_n - st_n;
+    const int c = c_n;
+    if (v + nwaves < M) { st_n = vstart[v + nwaves]; en_n = vstart[v + nwaves + 1]; c_n = vcell[v + nwaves]; }
     const int cx = c % P.grid[0];
     const int cy = (c / P.grid[0]) % P.grid[1];
     // pillar centre: coors.type_as(features) * vx + x_offset (pillar_encoder.py:318-321), fp32
