@@ -129,7 +129,11 @@ class DistillStep(_Base):
     default_warmup = 5
     N_POINTS = 240000
     # dominant hand-written kernel timed for the roofline: teacher pillars scatter (write-bound)
-    ROOF_KERNEL = "dbev_pillars_scatter"
+    ROOF_KERNEL = "dbev_pillars_canvas"
+    TIMED = ("dbev_pillars_canvas", "dbev_pillar_vfe_canvas", "dbev_lift_splat_prepare_cam", "dbev_lift_splat_forward",
+             "dbev_lift_splat_backward", "dbev_abs_mean_maps", "dbev_fgd_masked_mse_forward",
+             "dbev_fgd_masked_mse_backward", "dbev_fg_scale_mask", "dbev_upsample_bilinear_ac_forward",
+             "dbev_upsample_bilinear_ac_backward")
 
     def __init__(self, dev, rank, world):
         from distill_bev_amd.train_step import Trainer, build_model, make_batch
@@ -151,14 +155,11 @@ class DistillStep(_Base):
         self.trainer.step(self.batch)
 
     def begin_timed(self):
-        for k in ("dbev_pillars_scatter", "dbev_lift_splat_forward", "dbev_lift_splat_backward",
-                  "dbev_fgd_masked_mse_forward", "dbev_fgd_masked_mse_backward", "dbev_lift_splat_prepare"):
+        for k in self.TIMED:
             L.enable_timing(k)
 
     def roofline(self):
-        t = {k: L.timing_ms(k) for k in ("dbev_pillars_scatter", "dbev_lift_splat_forward",
-                                           "dbev_lift_splat_backward", "dbev_fgd_masked_mse_forward",
-                                           "dbev_fgd_masked_mse_backward", "dbev_lift_splat_prepare")}
+        t = {k: L.timing_ms(k) for k in self.TIMED}
         L.disable_timing()
         ms = t[self.ROOF_KERNEL]
         if not ms:
@@ -170,9 +171,14 @@ class DistillStep(_Base):
         avg_s = float(np.mean(ms)) * 1e-3
         ach = alg / avg_s / 1e9
         other = {k: {"avg_us": float(np.mean(v)) * 1e3, "launches": len(v)} for k, v in t.items() if v}
-        return {"bound": "hbm", "kernel": "ps_canvas_nchw_wide (teacher PointPillarsScatter, 64x512x512 canvas per sample), timed per "
-                "dbev_pillars_scatter call = cellmap memset + ps_cellmap + ps_canvas_nchw_wide",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        return {"bound": "hbm", "kernel": "ps_canvas_nchw_wide (teacher PointPillarsScatter, 64x512x512 canvas per sample; the largest "
+                "HBM mover among the hand-written kernels), one launch per dbev_pillars_canvas call",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                # PMC pass of the same kernel at the same shapes (profiles/r01_pmc_*.txt, tools/pmc_target.py):
+                # FETCH_SIZE 140046 KB x2 (gfx950 wide-read correction, calibrated on a 512 MiB copy) +
+                # WRITE_SIZE 524288 KB (calibrated factor 1 on a 512 MiB fill) = bytes per launch
+                "traffic": (140046.0 * 2 + 524288.0) * 1024, "traffic_source": "profiles/r01_pmc_FETCH_SIZE.txt + "
+                "profiles/r01_pmc_WRITE_SIZE.txt (separate --pmc passes, not collected live)",
                 "avg_launch_us": avg_s * 1e6, "launches": len(ms), "algorithmic_bytes_per_launch": alg,
                 "pillars_per_launch": M,
                 "other_hot_kernels": other}

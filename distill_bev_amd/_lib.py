@@ -50,6 +50,7 @@ _SIGNATURES = {
     "dbev_fgd_masked_mse_forward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "dbev_fgd_masked_mse_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dbev_pillar_vfe_workspace_bytes": [_i, _i, _i, _i],
+    "dbev_pillars_canvas": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_pillar_vfe_canvas": [_p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _i, _p, _sz, _p],
     "dbev_upsample_bilinear_ac_forward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_upsample_bilinear_ac_backward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -253,5 +253,13 @@ extern "C" int dbev_pillar_vfe_canvas(const float* points, int n_points, int num
                        vstart, list, vcell, num_voxels_out, pfn_weight, bn_weight, bn_bias, bn_mean, bn_var,
                        bn_eps, out_channels, num_features + 5, P, voxel_feats);
   }
+  if (canvas == nullptr) return 0;     // caller writes the canvas itself (dbev_pillars_canvas)
   return dbev::launch_canvas(voxel_feats, cellmap, canvas, out_channels, B, ny, nx, channels_last, s);
+}
+
+extern "C" int dbev_pillars_canvas(const float* voxel_feats, const int32_t* cellmap, float* canvas, int C, int B,
+                                   int ny, int nx, int channels_last, dbevStream_t stream) {
+  if (C <= 0 || B <= 0 || ny <= 0 || nx <= 0 || voxel_feats == nullptr || cellmap == nullptr || canvas == nullptr)
+    return DBEV_EINVAL;
+  return dbev::launch_canvas(voxel_feats, cellmap, canvas, C, B, ny, nx, channels_last, dbev_stream(stream));
 }

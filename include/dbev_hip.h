@@ -267,8 +267,12 @@ int dbev_fgd_masked_mse_backward(const float* S, const float* T, const float* Wf
  *   pfn_weight f32[Cout, F+5] (nn.Linear weight, no bias); bn_* f32[Cout] BatchNorm1d eval statistics
  *   voxel_feats f32[n_points, Cout] (capacity; rows >= M untouched), cellmap i32[B*ny*nx],
  *   num_voxels_out DEVICE int, canvas f32[B, Cout, ny, nx] (or channels-last), all caller-allocated.
- * Pillar rows come out in (b, y, x) order -- the order of the reference's sorted-unique scatter. */
+ * Pillar rows come out in (b, y, x) order -- the order of the reference's sorted-unique scatter.
+ * canvas may be NULL: then only voxel_feats / cellmap / num_voxels are produced and the canvas is written by
+ * dbev_pillars_canvas (one launch: canvas[b, :, y, x] = voxel_feats[cellmap[b, y, x], :] or 0). */
 size_t dbev_pillar_vfe_workspace_bytes(int n_points, int B, int ny, int nx);
+int dbev_pillars_canvas(const float* voxel_feats, const int32_t* cellmap, float* canvas, int C, int B, int ny,
+                        int nx, int channels_last, dbevStream_t stream);
 int dbev_pillar_vfe_canvas(const float* points, int n_points, int num_features,
                            const int32_t* sample_start_host, int B, const float* voxel_size_host,
                            const float* coors_range_host, const float* pfn_weight, const float* bn_weight,
