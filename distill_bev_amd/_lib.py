@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdbev_hip.so")
+LIB_PATH = os.environ.get("DBEV_HIP_LIB") or os.path.join(_HERE, "libdbev_hip.so")   # override: A/B builds
 _lib = None
 
 _p = ctypes.c_void_p

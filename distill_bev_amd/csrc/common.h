@@ -26,3 +26,14 @@ static constexpr int DBEV_NUM_CU = 256;
 static constexpr int DBEV_MAX_GRID = DBEV_NUM_CU * 8;
 
 static inline hipStream_t dbev_stream(dbevStream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// XCD-aware block order.  The dispatcher deals workgroups round-robin over the 8 XCDs (block i runs
+// on XCD i % 8) and every XCD has a private 4 MB L2.  Launch a grid that is a multiple of 8 and use
+// logical block xcd_block(): XCD k then walks the k-th contiguous eighth of the index space, so data
+// that is shared between neighbouring blocks (one sample-frame's feature map) lives in ONE L2 instead
+// of being replicated in all eight.
+static constexpr int DBEV_NUM_XCD = 8;
+static inline int dbev_round_xcd(int blocks) { return (blocks + DBEV_NUM_XCD - 1) / DBEV_NUM_XCD * DBEV_NUM_XCD; }
+__device__ __forceinline__ int xcd_block() {
+  return (blockIdx.x % DBEV_NUM_XCD) * (gridDim.x / DBEV_NUM_XCD) + blockIdx.x / DBEV_NUM_XCD;
+}

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void ls_forward(const float* __restrict__ dept
                                                   const unsigned* __restrict__ cell_points,
                                                   float4* __restrict__ out, int n_cells, int c4, int rpw,
                                                   int HW, int DHW) {
-  const int cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int cell = (xcd_block() * blockDim.x + threadIdx.x) >> 6;   // grid is a multiple of 8 blocks
   const int lane = threadIdx.x & 63;
   if (cell >= n_cells) return;
   const int st = cell_start[cell];
@@ -258,6 +258,63 @@ __global__ __launch_bounds__(256) void ls_forward(const float* __restrict__ dept
     tot.w += __shfl(acc.w, src);
   }
   if (sub == 0) out[static_cast<size_t>(cell) * c4 + q] = tot;  // zeros for an empty cell
+}
+
+// C/4 == 16 (C = 64): one 16-lane group per cell, 4 consecutive cells per wave.  The group pulls 16
+// point ids per (prefetched) coalesced load, the owning lane fetches the point's depth and computes its
+// row offset once, and the rows are gathered 8 at a time.  Compared with ls_forward this quarters the
+// number of waves (the kernel is bound by dependent-load round trips x wave generations, not by
+// bytes) and takes the id -> depth -> row chain off the per-row critical path.  Each lane adds its
+// cell's points in list order (ascending point id) with one fma chain: the sequential sum of the
+// reference's bev_pool kernel (bev_pool_cuda.cu:33-40), run-to-run bit identical.
+template <bool LIFT>
+__global__ __launch_bounds__(256) void ls_forward_c64(const float* __restrict__ depth,
+                                                      const float4* __restrict__ rows,
+                                                      const int* __restrict__ cell_start,
+                                                      const unsigned* __restrict__ cell_points,
+                                                      float4* __restrict__ out, int n_cells, int HW,
+                                                      int DHW) {
+  constexpr int C4 = 16, DU = 8;
+  const int wave = (xcd_block() * blockDim.x + threadIdx.x) >> 6;   // grid is a multiple of 8 blocks
+  const int lane = threadIdx.x & 63;
+  const int sub = lane >> 4, q = lane & 15, g0 = lane & 48;
+  const int cell = wave * 4 + sub;
+  if (cell >= n_cells) return;                       // whole groups leave together
+  const int st = cell_start[cell];
+  const int L = cell_start[cell + 1] - st;
+  if (L > HOT_CELL_POINTS) return;                   // written by ls_forward_hot
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned* pl = cell_points + st;
+  unsigned idx = q < L ? pl[q] : 0u;
+  for (int j0 = 0; j0 < L; j0 += 16) {
+    const int nb = min(16, L - j0);
+    float myd = 0.f;
+    unsigned myrow = 0u;
+    if (q < nb) {
+      if (LIFT) {
+        myd = depth[idx];
+        myrow = (idx / static_cast<unsigned>(DHW)) * HW + idx % static_cast<unsigned>(HW);
+      } else {
+        myd = 1.f;
+        myrow = idx;
+      }
+    }
+    if (j0 + 16 + q < L) idx = pl[j0 + 16 + q];      // next id block is in flight during the gathers
+#pragma unroll
+    for (int h = 0; h < 16; h += DU) {
+      if (h < nb) {                                  // uniform inside the group
+        float4 v[DU];
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+          const unsigned r = __shfl(myrow, g0 | (h + u));
+          v[u] = (h + u) < nb ? rows[static_cast<size_t>(r) * C4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) fma4(acc, __shfl(myd, g0 | (h + u)), v[u]);   // padding: 0 * 0
+      }
+    }
+  }
+  out[static_cast<size_t>(cell) * C4 + q] = acc;     // zeros for an empty cell
 }
 
 // cells whose list is longer than HOT_CELL_POINTS (0.6 % of the cells, 6 % of the points of a
@@ -342,7 +399,7 @@ __global__ __launch_bounds__(256) void ls_backward(const float4* __restrict__ gr
                                                    float* __restrict__ grad_depth,
                                                    float4* __restrict__ grad_feat, int n_pix, int c4,
                                                    int rpw, int D, int HW, bool pow2) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int wave = (xcd_block() * blockDim.x + threadIdx.x) >> 6;   // grid is a multiple of 8 blocks
   const int lane = threadIdx.x & 63;
   const int sub = lane / c4;
   const int q = lane - sub * c4;
@@ -384,6 +441,74 @@ __global__ __launch_bounds__(256) void ls_backward(const float4* __restrict__ gr
     }
   }
   if (active) grad_feat[static_cast<size_t>(pix) * c4 + q] = gf;
+}
+
+// C/4 == 16 (C = 64) and D <= 64: same pixel-stationary walk, but the lane group first fetches the
+// cell id + depth of ALL depth bins in one round trip (lane q owns bins q, q+16, q+32, q+48), then
+// streams the grad rows 8 bins per batch: ~1 + D/8 dependent round trips per pixel instead of 2*D/4.
+// Accumulation order (bins ascending, xor tree over the 16 lanes) is the one of ls_backward ->
+// bit-identical results.
+__global__ __launch_bounds__(256) void ls_backward_c64(const float4* __restrict__ grad_out,
+                                                       const float* __restrict__ depth,
+                                                       const float4* __restrict__ feat,
+                                                       const int* __restrict__ point_cell,
+                                                       float* __restrict__ grad_depth,
+                                                       float4* __restrict__ grad_feat, int n_pix, int D,
+                                                       int HW) {
+  constexpr int C4 = 16, RPW = 4, DU = 8;
+  const int wave = (xcd_block() * blockDim.x + threadIdx.x) >> 6;   // grid is a multiple of 8 blocks
+  const int lane = threadIdx.x & 63;
+  const int sub = lane >> 4;
+  const int q = lane & 15;
+  const int pix = wave * RPW + sub;           // = bn*HW + hw
+  const bool active = pix < n_pix;
+  const int bn = active ? pix / HW : 0;
+  const int hw = active ? pix - bn * HW : 0;
+  const size_t pbase = static_cast<size_t>(bn) * D * HW + hw;
+  int mycell[4];
+  float mydp[4], mysum[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = q + k * C4;
+    const bool ok = active && d < D;
+    const size_t p = pbase + static_cast<size_t>(d) * HW;
+    mycell[k] = ok ? point_cell[p] : -1;
+    mydp[k] = ok ? depth[p] : 0.f;
+    mysum[k] = 0.f;
+  }
+  const float4 f = active ? feat[static_cast<size_t>(pix) * C4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gf = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int d0 = 0; d0 < 64; d0 += DU) {
+    if (d0 < D) {                              // wave-uniform
+      float4 g[DU];
+      float dp[DU];
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const int d = d0 + u, k = d >> 4, src = (sub << 4) | (d & 15);
+        const int cell = __shfl(mycell[k], src);
+        dp[u] = cell >= 0 ? __shfl(mydp[k], src) : 0.f;
+        g[u] = cell >= 0 ? grad_out[static_cast<size_t>(cell) * C4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const int d = d0 + u, k = d >> 4;
+        fma4(gf, dp[u], g[u]);
+        float sum = fmaf(g[u].x, f.x, fmaf(g[u].y, f.y, fmaf(g[u].z, f.z, g[u].w * f.w)));
+        sum += __shfl_xor(sum, 8);
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 1);
+        if (q == (d & 15)) mysum[k] = sum;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = q + k * C4;
+    if (active && d < D) grad_depth[pbase + static_cast<size_t>(d) * HW] = mysum[k];   // 0 for a dropped point
+  }
+  if (active) grad_feat[static_cast<size_t>(pix) * C4 + q] = gf;
 }
 
 // backward of splat-from-volume: grad_x[p, :] = grad_out[cell(p), :] or 0
@@ -500,7 +625,13 @@ extern "C" int dbev_lift_splat_forward(const float* depth, const float* feat_nhw
   if (BN <= 0 || D <= 0 || H <= 0 || W <= 0 || n_cells <= 0 || !vec_ok(C)) return DBEV_EINVAL;
   const int c4 = C >> 2, rpw = 64 / c4;
   hipStream_t s = dbev_stream(stream);
-  hipLaunchKernelGGL((ls_forward<true, 4, true>), dim3(dbev_ceil_div(n_cells, 4)), dim3(256), 0, s, depth,
+  if (c4 == 16)
+    hipLaunchKernelGGL((ls_forward_c64<true>), dim3(dbev_round_xcd(dbev_ceil_div(n_cells, 16))), dim3(256), 0, s,
+                       depth, reinterpret_cast<const float4*>(feat_nhwc), cell_start,
+                       reinterpret_cast<const unsigned*>(cell_points), reinterpret_cast<float4*>(out), n_cells,
+                       H * W, D * H * W);
+  else
+  hipLaunchKernelGGL((ls_forward<true, 4, true>), dim3(dbev_round_xcd(dbev_ceil_div(n_cells, 4))), dim3(256), 0, s, depth,
                      reinterpret_cast<const float4*>(feat_nhwc), cell_start,
                      reinterpret_cast<const unsigned*>(cell_points), reinterpret_cast<float4*>(out),
                      n_cells, c4, rpw, H * W, D * H * W);
@@ -520,7 +651,15 @@ extern "C" int dbev_lift_splat_backward(const float* grad_out, const float* dept
   const int c4 = C >> 2, rpw = 64 / c4;
   const int n_pix = BN * H * W;
   const int waves = dbev_ceil_div(n_pix, rpw);
-  hipLaunchKernelGGL(ls_backward, dim3(dbev_ceil_div(waves, 4)), dim3(256), 0, dbev_stream(stream),
+  if (c4 == 16 && D <= 64) {
+    hipLaunchKernelGGL(ls_backward_c64, dim3(dbev_round_xcd(dbev_ceil_div(waves, 4))), dim3(256), 0,
+                       dbev_stream(stream), reinterpret_cast<const float4*>(grad_out), depth,
+                       reinterpret_cast<const float4*>(feat_nhwc), point_cell, grad_depth,
+                       reinterpret_cast<float4*>(grad_feat_nhwc), n_pix, D, H * W);
+    DBEV_LAUNCH_CHECK();
+    return 0;
+  }
+  hipLaunchKernelGGL(ls_backward, dim3(dbev_round_xcd(dbev_ceil_div(waves, 4))), dim3(256), 0, dbev_stream(stream),
                      reinterpret_cast<const float4*>(grad_out), depth,
                      reinterpret_cast<const float4*>(feat_nhwc), point_cell, grad_depth,
                      reinterpret_cast<float4*>(grad_feat_nhwc), n_pix, c4, rpw, D, H * W,
@@ -535,7 +674,13 @@ extern "C" int dbev_splat_forward(const float* x, const int32_t* cell_start, con
   if (n_points < 0 || n_cells <= 0 || !vec_ok(C)) return DBEV_EINVAL;
   const int c4 = C >> 2, rpw = 64 / c4;
   hipStream_t s = dbev_stream(stream);
-  hipLaunchKernelGGL((ls_forward<false, 4, true>), dim3(dbev_ceil_div(n_cells, 4)), dim3(256), 0, s, nullptr,
+  if (c4 == 16)
+    hipLaunchKernelGGL((ls_forward_c64<false>), dim3(dbev_round_xcd(dbev_ceil_div(n_cells, 16))), dim3(256), 0, s,
+                       nullptr, reinterpret_cast<const float4*>(x), cell_start,
+                       reinterpret_cast<const unsigned*>(cell_points), reinterpret_cast<float4*>(out), n_cells,
+                       1, 1);
+  else
+  hipLaunchKernelGGL((ls_forward<false, 4, true>), dim3(dbev_round_xcd(dbev_ceil_div(n_cells, 4))), dim3(256), 0, s, nullptr,
                      reinterpret_cast<const float4*>(x), cell_start,
                      reinterpret_cast<const unsigned*>(cell_points), reinterpret_cast<float4*>(out),
                      n_cells, c4, rpw, 1, 1);
