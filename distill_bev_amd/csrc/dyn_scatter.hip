@@ -19,7 +19,7 @@ namespace {
 
 size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-struct DsLayout { size_t cell, count, vid, cursor, tmp, scanws, total; };
+struct DsLayout { size_t cell, count, vid, cursor, tmp, scanws, sortws, total; };
 
 DsLayout ds_layout(long long n, long long ncell) {
   DsLayout L;
@@ -30,6 +30,7 @@ DsLayout ds_layout(long long n, long long ncell) {
   L.cursor = o; o += align_up(sizeof(int) * n);
   L.tmp = o;    o += align_up(sizeof(int) * n);
   L.scanws = o; o += align_up(sizeof(int) * dbev::scan_workspace_ints(ncell > n ? ncell : n));
+  L.sortws = o; o += align_up(sizeof(int) * dbev::segment_sort_workspace_ints(n));
   L.total = o;
   return L;
 }
@@ -191,6 +192,7 @@ extern "C" int dbev_dynamic_scatter_prepare(const int32_t* coors, int num_points
   int* cursor = reinterpret_cast<int*>(ws + L.cursor);
   unsigned* tmp = reinterpret_cast<unsigned*>(ws + L.tmp);
   int* scanws = reinterpret_cast<int*>(ws + L.scanws);
+  int* sortws = reinterpret_cast<int*>(ws + L.sortws);
   DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * ncell, s));
   DBEV_HIP_TRY(hipMemsetAsync(reduce_count, 0, sizeof(int) * static_cast<size_t>(num_points), s));
   const int nb = dbev_ceil_div(num_points, 256);
@@ -204,7 +206,7 @@ extern "C" int dbev_dynamic_scatter_prepare(const int32_t* coors, int num_points
   if (rc) return rc;
   hipLaunchKernelGGL(ds_fill, dim3(nb), dim3(256), 0, s, coors_map, num_points, voxel_point_start, cursor, tmp);
   rc = dbev::segment_sort_u32(voxel_point_start, tmp, reinterpret_cast<unsigned*>(voxel_point_list),
-                              num_points, s);
+                              num_points, sortws, s);
   if (rc) return rc;
   DBEV_LAUNCH_CHECK();
   return 0;

@@ -33,7 +33,7 @@ struct GridParams {
 
 size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-struct LsLayout { size_t count, list, scanws, total; };
+struct LsLayout { size_t count, list, scanws, sortws, total; };
 
 LsLayout ls_layout(long long np, long long ncell) {
   LsLayout L;
@@ -41,6 +41,7 @@ LsLayout ls_layout(long long np, long long ncell) {
   L.count = o;  o += align_up(sizeof(int) * ncell);
   L.list = o;   o += align_up(sizeof(int) * np);
   L.scanws = o; o += align_up(sizeof(int) * dbev::scan_workspace_ints(ncell));
+  L.sortws = o; o += align_up(sizeof(int) * dbev::segment_sort_workspace_ints(np));
   L.total = o;
   return L;
 }
@@ -582,7 +583,7 @@ static int prepare_impl(const float* geom, const float* cam, const float* frustu
   if (n_points > 0) {
     hipLaunchKernelGGL(ls_fill_agg, dim3(nblk), dim3(256), 0, s, point_cell, n_points, cell_start, count, list);
     rc = dbev::segment_sort_u32(cell_start, list, reinterpret_cast<unsigned*>(cell_points),
-                                static_cast<int>(ncell), s);
+                                static_cast<int>(ncell), reinterpret_cast<int*>(ws + L.sortws), s);
     if (rc) return rc;
     hipLaunchKernelGGL(ls_hot_cells, dim3(dbev_ceil_div(ncell, 256)), dim3(256), 0, s, cell_start,
                        static_cast<int>(ncell), hot_cells, n_hot_out);

@@ -37,7 +37,7 @@ struct VfeParams {
 
 size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-struct VfeLayout { size_t cell, count, vid, vcount, cursor, vstart, tmp, list, vcell, scanws, total; };
+struct VfeLayout { size_t cell, count, vid, vcount, cursor, vstart, tmp, list, vcell, scanws, sortws, total; };
 
 VfeLayout vfe_layout(long long n, long long ncell) {
   VfeLayout L;
@@ -52,6 +52,7 @@ VfeLayout vfe_layout(long long n, long long ncell) {
   L.list = o;   o += align_up(sizeof(int) * n);
   L.vcell = o;  o += align_up(sizeof(int) * n);
   L.scanws = o; o += align_up(sizeof(int) * dbev::scan_workspace_ints(ncell > n ? ncell : n));
+  L.sortws = o; o += align_up(sizeof(int) * dbev::segment_sort_workspace_ints(n));
   L.total = o;
   return L;
 }
@@ -233,6 +234,7 @@ extern "C" int dbev_pillar_vfe_canvas(const float* points, int n_points, int num
   unsigned* list = reinterpret_cast<unsigned*>(ws + L.list);
   int* vcell = reinterpret_cast<int*>(ws + L.vcell);
   int* scanws = reinterpret_cast<int*>(ws + L.scanws);
+  int* sortws = reinterpret_cast<int*>(ws + L.sortws);
 
   DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * ncell, s));
   DBEV_HIP_TRY(hipMemsetAsync(vcount, 0, sizeof(int) * static_cast<size_t>(n_points > 0 ? n_points : 1), s));
@@ -247,7 +249,7 @@ extern "C" int dbev_pillar_vfe_canvas(const float* points, int n_points, int num
     rc = dbev::exclusive_scan_i32(vcount, vstart, n_points, false, nullptr, scanws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vfe_fill, dim3(nb), dim3(256), 0, s, cell, n_points, vid, vstart, cursor, tmp);
-    rc = dbev::segment_sort_u32(vstart, tmp, list, n_points, s);
+    rc = dbev::segment_sort_u32(vstart, tmp, list, n_points, sortws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vfe_reduce, dim3(DBEV_MAX_GRID), dim3(256), 0, s, points, num_features,
                        vstart, list, vcell, num_voxels_out, pfn_weight, bn_weight, bn_bias, bn_mean, bn_var,

@@ -22,7 +22,10 @@ int exclusive_scan_i32(const int* in, int* out, long long n, bool as_flags, int*
 
 // For every segment g in [0, n_seg): dst[starts[g] .. starts[g+1]) = ascending sort of
 // src[starts[g] .. starts[g+1]).  Values inside one segment must be distinct (point ids).
-int segment_sort_u32(const int* starts, const unsigned* src, unsigned* dst, int n_seg,
+// `ws` (work list of the segments longer than a wave) must hold
+// segment_sort_workspace_ints(total number of values) ints.
+size_t segment_sort_workspace_ints(long long n_values);
+int segment_sort_u32(const int* starts, const unsigned* src, unsigned* dst, int n_seg, int* ws,
                      hipStream_t s);
 
 }  // namespace dbev

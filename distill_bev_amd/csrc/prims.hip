@@ -99,66 +99,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep(const int* __rest
   }
 }
 
-// one wave per segment.  Segments of <= 64 values are sorted in registers (bitonic network over
-// the 64 lanes, __shfl_xor); longer ones (dense BEV cells next to the cameras, 2 % of the cells /
-// 12 % of the points of a 6-camera frame) are staged into a wave-private LDS slab and ranked by
-// counting against 4 broadcast LDS values per read.  Values are distinct -> ranks are a permutation.
-constexpr int SORT_LDS_PER_WAVE = 2048;   // values per wave slab (8 KiB); 4 waves -> 32 KiB per block
+// Segment sort (values distinct).  Three size classes:
+//   <= 16 values : 16-lane bitonic network, four consecutive segments per wave (78 % of the occupied BEV
+//                  cells and virtually every LiDAR pillar);
+//   17..64       : 64-lane bitonic network in registers, the wave visits those segments one by one;
+//   > 64         : (dense BEV cells next to the cameras: 2 % of the cells, 12 % of the points of a
+//                  6-camera frame, and adjacent to each other) are queued on a device work list and
+//                  sorted by a second kernel, a whole workgroup per segment: LDS slab + counting rank against 4 broadcast LDS values per read.  Leaving
+//                  them to the wave that owns them made 4 x 600-value segments in a row the critical path
+//                  of the launch (105 of 130 us).
+constexpr int SORT_LDS_VALUES = 2048;   // slab of the long-segment kernel (8 KiB)
 
-// full-wave paths for one segment of L > 16 values (see above)
-__device__ __forceinline__ void sort_segment_wave(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
-                                                  int st, int L, int lane, unsigned* my /* LDS slab */) {
-  if (L <= 64) {
-    unsigned v = lane < L ? src[st + lane] : 0xFFFFFFFFu;
+__device__ __forceinline__ void sort_segment_wave64(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
+                                                    int st, int L, int lane) {
+  unsigned v = lane < L ? src[st + lane] : 0xFFFFFFFFu;
 #pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
+  for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        const unsigned o = __shfl_xor(v, j);
-        const bool up = (lane & k) == 0;
-        const bool lower = (lane & j) == 0;
-        v = (lower == up) ? (v < o ? v : o) : (v > o ? v : o);
-      }
-    }
-    if (lane < L) dst[st + lane] = v;
-    return;
-  }
-  const unsigned* p = src + st;
-  if (L <= SORT_LDS_PER_WAVE) {
-    const int Lp = (L + 3) & ~3;
-    for (int i = lane; i < Lp; i += 64) my[i] = i < L ? p[i] : 0xFFFFFFFFu;   // pad: never < v
-    // wave-private slab: the wave's own LDS writes are visible to its later reads (in-order DS queue)
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    const uint4* my4 = reinterpret_cast<const uint4*>(my);
-    for (int i = lane; i < L; i += 64) {
-      const unsigned v = my[i];
-      int rank = 0;
-      for (int j = 0; j < (Lp >> 2); ++j) {
-        const uint4 q = my4[j];
-        rank += (q.x < v) + (q.y < v) + (q.z < v) + (q.w < v);
-      }
-      dst[st + rank] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-  } else {
-    // degenerate geometry (thousands of points in one cell): same ranking straight from L2
-    for (int i = lane; i < L; i += 64) {
-      const unsigned v = p[i];
-      int rank = 0;
-      for (int j = 0; j < L; ++j) rank += p[j] < v ? 1 : 0;
-      dst[st + rank] = v;
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const unsigned o = __shfl_xor(v, j);
+      const bool up = (lane & k) == 0;
+      const bool lower = (lane & j) == 0;
+      v = (lower == up) ? (v < o ? v : o) : (v > o ? v : o);
     }
   }
+  if (lane < L) dst[st + lane] = v;
 }
 
-// One wave handles FOUR consecutive segments: each 16-lane group sorts a segment of <= 16 values with a
-// 16-wide bitonic network (xor distances <= 8 stay inside the group) -- that is 78 % of the occupied BEV
-// cells and virtually every LiDAR pillar -- then the wave visits its segments of > 16 values one by one.
 __global__ __launch_bounds__(256) void segment_sort_kernel(const int* __restrict__ starts,
                                                            const unsigned* __restrict__ src,
-                                                           unsigned* __restrict__ dst, int n_seg) {
-  __shared__ __attribute__((aligned(16))) unsigned slab[4][SORT_LDS_PER_WAVE];
+                                                           unsigned* __restrict__ dst, int n_seg,
+                                                           int* __restrict__ long_list /* [0] = count */) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int grp = lane >> 4, lig = lane & 15;
@@ -166,6 +137,7 @@ __global__ __launch_bounds__(256) void segment_sort_kernel(const int* __restrict
   int st = 0, L = 0;
   if (seg < n_seg) { st = starts[seg]; L = starts[seg + 1] - st; }
   const bool small = L <= 16;
+  if (L > 64 && lig == 0) long_list[1 + atomicAdd(long_list, 1)] = seg;   // order irrelevant
   if (__any(small && L > 0)) {
     unsigned v = (small && lig < L) ? src[st + lig] : 0xFFFFFFFFu;
     if (__any(small && L > 1)) {
@@ -182,12 +154,52 @@ __global__ __launch_bounds__(256) void segment_sort_kernel(const int* __restrict
     }
     if (small && lig < L) dst[st + lig] = v;
   }
-  if (__any(!small)) {
+  if (__any(!small && L <= 64)) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int Lg = __shfl(L, g * 16);
       const int sg = __shfl(st, g * 16);
-      if (Lg > 16) sort_segment_wave(src, dst, sg, Lg, lane, slab[threadIdx.x >> 6]);
+      if (Lg > 16 && Lg <= 64) sort_segment_wave64(src, dst, sg, Lg, lane);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void segment_sort_long_kernel(const int* __restrict__ starts,
+                                                                const unsigned* __restrict__ src,
+                                                                unsigned* __restrict__ dst,
+                                                                const int* __restrict__ long_list) {
+  __shared__ __attribute__((aligned(16))) unsigned slab[SORT_LDS_VALUES];
+  const int tid = threadIdx.x;
+  const int nl = long_list[0];
+  for (int k = blockIdx.x; k < nl; k += gridDim.x) {
+    const int seg = long_list[1 + k];
+    const int st = starts[seg];
+    const int L = starts[seg + 1] - st;
+    const unsigned* p = src + st;
+    if (L <= SORT_LDS_VALUES) {
+      const int Lp = (L + 3) & ~3;
+      for (int i = tid; i < Lp; i += 256) slab[i] = i < L ? p[i] : 0xFFFFFFFFu;   // pad: never < v
+      __syncthreads();
+      const uint4* s4 = reinterpret_cast<const uint4*>(slab);
+      for (int i = tid; i < L; i += 256) {
+        const unsigned v = slab[i];
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < (Lp >> 2); ++j) {
+          const uint4 q = s4[j];                                                   // same address in every lane
+          rank += (q.x < v) + (q.y < v) + (q.z < v) + (q.w < v);
+        }
+        dst[st + rank] = v;
+      }
+      __syncthreads();
+    } else {
+      // degenerate geometry (thousands of points in one cell): same ranking straight from L2
+      for (int i = tid; i < L; i += 256) {
+        const unsigned v = p[i];
+        int rank = 0;
+        for (int j = 0; j < L; ++j) rank += p[j] < v ? 1 : 0;
+        dst[st + rank] = v;
+      }
     }
   }
 }
@@ -213,10 +225,15 @@ int exclusive_scan_i32(const int* in, int* out, long long n, bool as_flags, int*
   return 0;
 }
 
-int segment_sort_u32(const int* starts, const unsigned* src, unsigned* dst, int n_seg, hipStream_t s) {
+size_t segment_sort_workspace_ints(long long n_values) { return static_cast<size_t>(n_values / 65) + 2; }
+
+int segment_sort_u32(const int* starts, const unsigned* src, unsigned* dst, int n_seg, int* ws, hipStream_t s) {
   if (n_seg <= 0) return 0;
+  if (ws == nullptr) return DBEV_EINVAL;
+  DBEV_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int), s));
   hipLaunchKernelGGL(segment_sort_kernel, dim3(dbev_ceil_div(n_seg, 16)), dim3(256), 0, s, starts, src,
-                     dst, n_seg);
+                     dst, n_seg, ws);
+  hipLaunchKernelGGL(segment_sort_long_kernel, dim3(DBEV_NUM_CU * 4), dim3(256), 0, s, starts, src, dst, ws);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -142,7 +142,7 @@ bool make_params(const float* voxel_size, const float* coors_range, VoxParams* P
 size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
 struct HvLayout {
-  size_t cell, count, start, list, sorted, flag, vidscan, scanws, nheads, total;
+  size_t cell, count, start, list, sorted, flag, vidscan, scanws, sortws, nheads, total;
 };
 
 HvLayout hv_layout(long long n, long long ncell) {
@@ -157,6 +157,7 @@ HvLayout hv_layout(long long n, long long ncell) {
   L.vidscan = o; o += align_up(sizeof(int) * (n + 1));
   const size_t sw = dbev::scan_workspace_ints(ncell > n ? ncell : n);
   L.scanws = o;  o += align_up(sizeof(int) * sw);
+  L.sortws = o;  o += align_up(sizeof(int) * dbev::segment_sort_workspace_ints(n));
   L.nheads = o;  o += align_up(sizeof(int) * 4);
   L.total = o;
   return L;
@@ -209,6 +210,7 @@ extern "C" int dbev_hard_voxelize(const float* points, float* voxels, int32_t* c
   int* flag = reinterpret_cast<int*>(ws + L.flag);
   int* vidscan = reinterpret_cast<int*>(ws + L.vidscan);
   int* scanws = reinterpret_cast<int*>(ws + L.scanws);
+  int* sortws = reinterpret_cast<int*>(ws + L.sortws);
   int* nheads = reinterpret_cast<int*>(ws + L.nheads);
 
   // outputs: the reference's caller hands in zeros (voxelize.py:57-62); do not rely on it
@@ -223,7 +225,7 @@ extern "C" int dbev_hard_voxelize(const float* points, float* voxels, int32_t* c
   int rc = dbev::exclusive_scan_i32(count, start, ncell, false, nheads + 1 /* n_valid */, scanws, s);
   if (rc) return rc;
   hipLaunchKernelGGL(hv_fill, dim3(nb), dim3(256), 0, s, cell, num_points, start, count, list);
-  rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(ncell), s);
+  rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(ncell), sortws, s);
   if (rc) return rc;
   hipLaunchKernelGGL(hv_head_flags, dim3(nb), dim3(256), 0, s, cell, num_points, start, sorted, flag);
   rc = dbev::exclusive_scan_i32(flag, vidscan, num_points, false, nheads, scanws, s);
