@@ -54,6 +54,8 @@ _SIGNATURES = {
     "dbev_pillar_vfe_canvas": [_p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _i, _p, _sz, _p],
     "dbev_upsample_bilinear_ac_forward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_upsample_bilinear_ac_backward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "dbev_dcnv2_im2col": [_p, _p, _p] + [_i] * 11 + [_p],
+    "dbev_dcnv2_col2im": [_p, _p, _p, _p, _p] + [_i] * 11 + [_p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_pillar_vfe_workspace_bytes": ctypes.c_size_t,

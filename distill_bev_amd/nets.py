@@ -12,8 +12,7 @@ names, constructor kwargs and attribute (= checkpoint key) names follow the refe
   FPN_LSS           mmdet3d/models/necks/lss_fpn.py:10-72
   SECOND            mmdet3d/models/backbones/second.py:11-93
   SECONDFPN         mmdet3d/models/necks/second_fpn.py:12-93
-  DCNv2             mmcv-full==1.6.0 mmcv/ops/modulated_deform_conv.py ModulatedDeformConv2dPack
-                    (un-vendored CUDA op; restated with grid_sample -- "parity unpinned")
+  (DCNv2 lives in dcn.py on the gfx950 sampling kernels)
 """
 import numpy as np
 import torch
@@ -354,65 +353,6 @@ class SECONDFPN(nn.Module):
         assert len(x) == len(self.in_channels)
         ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
         return [torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]]
-
-
-# --------------------------------------------------------------------------------------
-def modulated_deform_conv2d(x, offset, mask, weight, bias, stride=1, padding=1, dilation=1):
-    """DCNv2 forward (deform_groups=1, groups=1) restated with one grid_sample:
-    out[n,o,h,w] = sum_{c,k} W[o,c,k] * mask[n,k,h,w] * bilinear(x[n,c], p_k + offset_k), zero padding.
-    offset channels: (dy_0, dx_0, dy_1, dx_1, ...) for the kh*kw taps in row-major order (mmcv
-    modulated_deform_conv CUDA kernel convention)."""
-    N, C, H, W = x.shape
-    Co, _, kh, kw = weight.shape
-    K = kh * kw
-    Ho = (H + 2 * padding - dilation * (kh - 1) - 1) // stride + 1
-    Wo = (W + 2 * padding - dilation * (kw - 1) - 1) // stride + 1
-    dev, dt = x.device, x.dtype
-    ys = torch.arange(Ho, device=dev, dtype=dt) * stride - padding
-    xs = torch.arange(Wo, device=dev, dtype=dt) * stride - padding
-    ky = (torch.arange(kh, device=dev, dtype=dt) * dilation).repeat_interleave(kw)
-    kx = (torch.arange(kw, device=dev, dtype=dt) * dilation).repeat(kh)
-    off = offset.view(N, K, 2, Ho, Wo)
-    py = ys.view(1, 1, Ho, 1) + ky.view(1, K, 1, 1) + off[:, :, 0]
-    px = xs.view(1, 1, 1, Wo) + kx.view(1, K, 1, 1) + off[:, :, 1]
-    gx = 2.0 * px / max(W - 1, 1) - 1.0
-    gy = 2.0 * py / max(H - 1, 1) - 1.0
-    grid = torch.stack((gx, gy), -1).view(N, K * Ho, Wo, 2)
-    cols = F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
-    cols = cols.view(N, C, K, Ho, Wo) * mask.view(N, 1, K, Ho, Wo)
-    # the contraction over (c, k) is a 1x1 convolution of the sampled columns: MIOpen's 1x1 conv
-    # kernels run it ~40x faster than the skinny hipBLASLt GEMM torch.einsum lowers to (measured:
-    # 21 ms -> 0.5 ms per call at N=48, C*K=2304, Ho*Wo=704)
-    return F.conv2d(cols.reshape(N, C * K, Ho, Wo), weight.reshape(Co, C * K, 1, 1), bias)
-
-
-class ModulatedDeformConv2dPack(nn.Module):
-    """mmcv ModulatedDeformConv2dPack ('DCNv2'): conv_offset predicts 2K offsets + K masks."""
-
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
-                 deform_groups=1, bias=True):
-        super().__init__()
-        assert groups == 1 and deform_groups == 1
-        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
-        self.stride, self.padding, self.dilation, self.k = stride, padding, dilation, k
-        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k))
-        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
-        self.conv_offset = nn.Conv2d(in_channels, 3 * k * k, kernel_size=k, stride=stride, padding=padding,
-                                     dilation=dilation, bias=True)
-        n = in_channels * k * k
-        stdv = 1.0 / n ** 0.5
-        nn.init.uniform_(self.weight, -stdv, stdv)
-        nn.init.zeros_(self.conv_offset.weight); nn.init.zeros_(self.conv_offset.bias)
-
-    def forward(self, x):
-        out = self.conv_offset(x)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        return modulated_deform_conv2d(x, offset, torch.sigmoid(mask), self.weight, self.bias,
-                                       self.stride, self.padding, self.dilation)
-
-
-register_conv("DCNv2", ModulatedDeformConv2dPack)
 
 
 class SELikeModule(nn.Module):

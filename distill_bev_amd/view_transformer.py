@@ -10,6 +10,7 @@ unique+scatter_sum, bev_pool extension) are the same segmented sum; all route to
 import torch
 import torch.nn as nn
 
+from . import dcn  # noqa: F401  (registers conv type 'DCNv2')
 from . import lss as LSS
 from .lift_splat import lift_splat, lift_splat_prepare, lift_splat_prepare_cam, voxel_pooling as _voxel_pooling
 from .nets import SELikeModule

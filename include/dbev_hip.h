@@ -290,6 +290,24 @@ int dbev_upsample_bilinear_ac_forward(const float* x, float* y, int B, int C, in
 int dbev_upsample_bilinear_ac_backward(const float* grad_y, float* grad_x, int B, int C, int IH, int IW, int OH,
                                        int OW, int channels_last, dbevStream_t stream);
 
+/* Modulated deformable convolution (DCNv2) sampling stage, channels-last.  Replaces mmcv-full 1.6.0
+ * `modulated_deform_conv` (un-vendored dependency; reference call site
+ * mmdet3d/models/necks/view_transformer_mine.py:298-306,325-329; algorithm: mmcv
+ * modulated_deform_conv_cuda_kernel.cuh im2col / col2im / col2im_coord).  deform_groups = groups = 1.
+ *   x_nhwc            f32[N,H,W,C]            input feature (C % 4 == 0; C/4 a power of two or a multiple of 64)
+ *   offset_mask_nhwc  f32[N,Ho,Wo,3*kh*kw]    RAW conv_offset output: channels 2k,2k+1 = (dy,dx) of tap k,
+ *                                             channels 2K+k = mask logits (sigmoid fused in the kernel)
+ *   cols              f32[N*Ho*Wo, kh*kw*C]   sigmoid(logit_k) * bilinear(x, p_k), k-major: the NHWC image of
+ *                                             [N, K*C, Ho, Wo]; contract with weight[Co, kh, kw, C] (1x1 conv / GEMM)
+ * col2im: grad_x_nhwc is zero-filled by the callee and accumulated with float atomics (as in mmcv);
+ * grad_offset_mask_nhwc has the layout of offset_mask_nhwc (d/d logit includes the sigmoid derivative).
+ * Returns DBEV_EINVAL if Ho/Wo do not match the convolution arithmetic. */
+int dbev_dcnv2_im2col(const float* x_nhwc, const float* offset_mask_nhwc, float* cols, int N, int C, int H, int W,
+                      int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, dbevStream_t stream);
+int dbev_dcnv2_col2im(const float* grad_cols, const float* x_nhwc, const float* offset_mask_nhwc,
+                      float* grad_x_nhwc, float* grad_offset_mask_nhwc, int N, int C, int H, int W, int Ho, int Wo,
+                      int kh, int kw, int stride, int pad, int dil, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

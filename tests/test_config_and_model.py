@@ -158,7 +158,7 @@ def test_center_head_targets_match_reference_gaussian_utils():
 
 
 def test_dcnv2_restatement_against_naive_loops():
-    from distill_bev_amd.nets import modulated_deform_conv2d
+    from oracle.dcn import modulated_deform_conv2d
     torch.manual_seed(0)
     N, C, H, W, Co = 2, 3, 5, 6, 4
     x = torch.randn(N, C, H, W, dtype=torch.float64)

@@ -1,0 +1,108 @@
+"""gfx950 DCNv2 sampling kernels (csrc/dcn.hip) through the C ABI vs the torch restatement in oracle/dcn.py
+(itself pinned against naive loops in test_config_and_model.py).  fp32, tolerances stated per check."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(N, C, H, W, Co, k, stride, pad, dil, seed, off_scale, channels_last):
+    g = torch.Generator().manual_seed(seed)
+    K = k * k
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    x = torch.randn((N, C, H, W), generator=g)
+    om = torch.randn((N, 3 * K, Ho, Wo), generator=g)
+    om[:, :2 * K] *= off_scale                          # offsets up to several pixels: samples leave the image
+    w = torch.randn((Co, C, k, k), generator=g) / (C * K) ** 0.5
+    b = torch.randn((Co,), generator=g)
+    return x, om, w, b, (Ho, Wo)
+
+
+def _oracle(x, om, w, b, stride, pad, dil, K, dtype):
+    from oracle.dcn import modulated_deform_conv2d
+    x = x.detach().to(dtype).requires_grad_(True)
+    om = om.detach().to(dtype).requires_grad_(True)
+    w = w.detach().to(dtype).requires_grad_(True)
+    b = b.detach().to(dtype).requires_grad_(True)
+    out = modulated_deform_conv2d(x, om[:, :2 * K], torch.sigmoid(om[:, 2 * K:]), w, b, stride, pad, dil)
+    return out, (x, om, w, b)
+
+
+@pytest.mark.parametrize("N,C,H,W,Co,k,stride,pad,dil,off_scale,cl", [
+    (2, 8, 5, 6, 4, 3, 1, 1, 1, 1.5, False),        # C/4 = 2 lanes per pixel, several pixels per wave
+    (2, 64, 9, 7, 16, 3, 1, 1, 1, 3.0, True),       # offsets far outside the image
+    (3, 256, 16, 44, 256, 3, 1, 1, 1, 0.7, True),   # the depth-head shape of the recipe (vt_mine.py:298-306)
+    (1, 512, 6, 5, 8, 3, 2, 1, 1, 1.0, True),       # C/4 = 128: lane loops over two float4 columns; stride 2
+    (2, 16, 8, 8, 8, 3, 1, 2, 2, 1.0, False),       # dilation 2
+    (1, 32, 7, 9, 4, 1, 1, 0, 1, 2.0, True),        # 1x1 kernel
+])
+def test_dcnv2_forward_backward_vs_oracle(N, C, H, W, Co, k, stride, pad, dil, off_scale, cl):
+    from distill_bev_amd.dcn import modulated_deform_conv2d_raw
+    dev = torch.device("cuda:0")
+    x, om, w, b, (Ho, Wo) = _case(N, C, H, W, Co, k, stride, pad, dil, 7, off_scale, cl)
+    ref, (rx, rom, rw, rb) = _oracle(x, om, w, b, stride, pad, dil, k * k, torch.float64)
+    gout = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    ref.backward(gout)
+
+    xd = x.to(dev); omd = om.to(dev)
+    if cl:
+        xd = xd.contiguous(memory_format=torch.channels_last); omd = omd.contiguous(memory_format=torch.channels_last)
+    xd.requires_grad_(True); omd.requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True); bd = b.to(dev).requires_grad_(True)
+    out = modulated_deform_conv2d_raw(xd, omd, wd, bd, stride, pad, dil)
+    assert out.shape == ref.shape
+    out.backward(gout.float().to(dev))
+
+    def close(a, r, tol, what):
+        a = a.detach().double().cpu(); r = r.detach()
+        scale = float(r.abs().max()) + 1e-12
+        err = float((a - r).abs().max()) / scale
+        assert err < tol, f"{what}: max err {err:.3e} of scale {scale:.3e}"
+    # fp32 kernels + fp32 GEMM vs fp64 oracle: a few ulp of the largest term times sqrt(K*C) accumulation
+    close(out, ref, 2e-5, "out")
+    close(xd.grad, rx.grad, 2e-5, "grad_x")
+    close(omd.grad, rom.grad, 5e-5, "grad_offset_mask")
+    close(wd.grad, rw.grad, 2e-5, "grad_weight")
+    close(bd.grad, rb.grad, 2e-5, "grad_bias")
+
+
+def test_dcnv2_zero_offset_unit_mask_is_a_convolution():
+    from distill_bev_amd.dcn import modulated_deform_conv2d
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 32, 10, 12), generator=g).to(dev)
+    w = torch.randn((8, 32, 3, 3), generator=g).to(dev) / 17.0
+    b = torch.randn((8,), generator=g).to(dev)
+    off = torch.zeros((2, 18, 10, 12), device=dev)
+    out = modulated_deform_conv2d(x, off, torch.ones((2, 9, 10, 12), device=dev), w, b, 1, 1, 1)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert float((out.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+def test_dcnv2_pack_matches_oracle_pack_and_rejects_cpu():
+    from distill_bev_amd.dcn import ModulatedDeformConv2dPack
+    from distill_bev_amd._lib import DbevHipError
+    from oracle.dcn import pack_forward
+    torch.manual_seed(1)
+    m = ModulatedDeformConv2dPack(16, 16, 3, stride=1, padding=1)
+    torch.nn.init.normal_(m.conv_offset.weight, std=0.05)      # mmcv zero-inits it; exercise real offsets
+    x = torch.randn(2, 16, 6, 7)
+    ref = pack_forward(m.double(), x.double()).float()
+    m = m.float()
+    with pytest.raises(DbevHipError):
+        m(x)                                                   # no CPU fallback in the product
+    out = m.to("cuda:0")(x.to("cuda:0"))
+    assert float((out.cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_dcnv2_rejects_bad_geometry():
+    from distill_bev_amd import _lib as L
+    dev = torch.device("cuda:0")
+    x = torch.zeros((1, 6, 4, 4), device=dev)                  # C % 4 != 0
+    with pytest.raises(L.DbevHipError):
+        L.call("dbev_dcnv2_im2col", L.ptr(x), L.ptr(x), L.ptr(x), 1, 6, 4, 4, 4, 4, 3, 3, 1, 1, 1, L.stream_ptr(dev))
+    x = torch.zeros((1, 8, 4, 4), device=dev)                  # Ho does not match the conv arithmetic
+    with pytest.raises(L.DbevHipError):
+        L.call("dbev_dcnv2_im2col", L.ptr(x), L.ptr(x), L.ptr(x), 1, 8, 4, 4, 5, 4, 3, 3, 1, 1, 1, L.stream_ptr(dev))
