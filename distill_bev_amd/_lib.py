@@ -19,6 +19,7 @@ _p = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
+_ll = ctypes.c_longlong
 
 # name -> argtypes (restype is int unless listed in _RESTYPES).  Must list EVERY symbol
 # include/dbev_hip.h declares (tests/test_abi.py cross-checks against the header).
@@ -56,6 +57,10 @@ _SIGNATURES = {
     "dbev_upsample_bilinear_ac_backward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_dcnv2_im2col": [_p, _p, _p] + [_i] * 11 + [_p],
     "dbev_dcnv2_col2im": [_p, _p, _p, _p, _p] + [_i] * 11 + [_p],
+    "dbev_bn_act_workspace_bytes": [_ll, _i],
+    "dbev_bn_act_train_forward": [_p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_act_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_pillar_vfe_workspace_bytes": ctypes.c_size_t,
@@ -63,7 +68,8 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_fgd_masked_mse_workspace_bytes": ctypes.c_size_t,
              "dbev_lift_splat_workspace_bytes": ctypes.c_size_t,
              "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
-             "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t}
+             "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t,
+             "dbev_bn_act_workspace_bytes": ctypes.c_size_t}
 _NO_CHECK = set(_RESTYPES)
 
 

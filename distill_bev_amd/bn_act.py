@@ -1,0 +1,167 @@
+"""BatchNorm2d fused with the residual add and ReLU that follow it, on the gfx950 kernels of csrc/bn_act.hip.
+
+The reference chains `norm -> (+ identity) -> relu` as separate modules (mmdet ResNet Bottleneck, mmdet3d
+bricks/res_block.py:11-100, mmcv ConvModule, the nn.Sequential stacks of second.py:60-78 / lss_fpn.py:30-60);
+on MI355X those are 20 % of the training step in HBM-bound full-tensor passes.  `bn_act()` computes exactly
+`relu(batch_norm(x) + residual)` (training: batch statistics + running-stat update; eval under no_grad: running
+statistics) in 3 passes forward / 5 backward instead of 5-7 / 8.  `fuse_bn_relu_modules()` rewires a built model
+WITHOUT touching parameter names: a BatchNorm2d followed by nn.ReLU becomes a `BatchNormAct2d` (same
+parameters/buffers, same state-dict keys) and the ReLU becomes nn.Identity.
+
+Anything the kernels do not cover (CPU tensors, NCHW-contiguous activations, channel counts that are not
+4 * 2^k, eval mode with autograd, SyncBN, momentum=None) takes the unfused torch ops -- still the GPU path of
+the reference's own op sequence, not a CPU fallback.
+"""
+import contextlib
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib as L
+
+_state = {"enabled": os.environ.get("DBEV_FUSED_BN", "1") != "0"}
+
+
+@contextlib.contextmanager
+def disabled():
+    """Run the enclosed code with the unfused torch op sequence (used by the parity tests)."""
+    old = _state["enabled"]
+    _state["enabled"] = False
+    try:
+        yield
+    finally:
+        _state["enabled"] = old
+
+
+def _channels_ok(C):
+    if C % 4:
+        return False
+    c4 = C // 4
+    return (c4 & (c4 - 1)) == 0 if c4 <= 256 else c4 % 256 == 0
+
+
+def _nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def eligible(x, bn, residual=None):
+    if not (_state["enabled"] and x.is_cuda and x.dtype == torch.float32 and _nhwc(x) and type(bn) in _BN_TYPES
+            and bn.affine and _channels_ok(x.shape[1]) and x.numel() > 0):
+        return False
+    if residual is not None and not (residual.shape == x.shape and residual.dtype == x.dtype and _nhwc(residual)):
+        return False
+    use_batch_stats = bn.training or bn.running_mean is None
+    if use_batch_stats:
+        return bn.momentum is not None or bn.running_mean is None
+    return not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad
+                                             or (residual is not None and residual.requires_grad)))
+
+
+class _BNActTrain(Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
+        dev = x.device
+        N, C, H, W = x.shape
+        M = N * H * W
+        y = torch.empty_like(x)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        coef = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+        nbytes = L.lib().dbev_bn_act_workspace_bytes(M, C)
+        ws = torch.empty((nbytes + 12 * C,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.call("dbev_bn_act_train_forward", L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
+                   L.ptr(running_mean), L.ptr(running_var), float(momentum or 0.0), float(eps), int(relu), L.ptr(y),
+                   L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+        need_y = relu and residual is not None
+        ctx.save_for_backward(x, y if need_y else None, weight, save_mean, save_invstd, coef)
+        ctx.cfg = (M, C, bool(relu), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, save_mean, save_invstd, coef = ctx.saved_tensors
+        M, C, relu, has_res = ctx.cfg
+        dev = dy.device
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        # without ReLU the residual branch receives dy itself: nothing to write
+        dres = torch.empty_like(x) if (has_res and relu) else None
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        nbytes = L.lib().dbev_bn_act_workspace_bytes(M, C)
+        ws = torch.empty((nbytes + 12 * C,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.call("dbev_bn_act_backward", L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(weight), L.ptr(save_mean),
+                   L.ptr(save_invstd), L.ptr(coef), int(relu), L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), M, C,
+                   L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+        return dx, (dres if relu else dy) if has_res else None, dgamma, dbeta, None, None, None, None, None
+
+
+def _infer(x, residual, bn, relu):
+    dev = x.device
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty((8 * C,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dbev_bn_act_infer", L.ptr(x), L.ptr(residual), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
+               L.ptr(bn.running_var), float(bn.eps), int(relu), L.ptr(y), N * H * W, C, L.ptr(ws), ws.numel(),
+               L.stream_ptr(dev))
+    return y
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    """relu(bn(x) + residual) with the module `bn`'s parameters, statistics and mode."""
+    if eligible(x, bn, residual):
+        if bn.training or bn.running_mean is None:
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            return _BNActTrain.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
+                                     bn.eps, relu)
+        return _infer(x, residual, bn, relu)
+    out = nn.BatchNorm2d.forward(bn, x) if isinstance(bn, BatchNormAct2d) else bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out) if relu else out
+
+
+class BatchNormAct2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d that also applies the ReLU which followed it in the reference's module list
+    (parameters, buffers and state-dict keys are those of the BatchNorm2d it replaces)."""
+
+    def forward(self, x):
+        return bn_act(x, self, None, True)
+
+    def extra_repr(self):
+        return super().extra_repr() + ", fused_act=ReLU"
+
+
+_BN_TYPES = (nn.BatchNorm2d, BatchNormAct2d)
+
+
+def _is_plain_relu(m):
+    return type(m) is nn.ReLU
+
+
+def fuse_bn_relu_modules(model):
+    """Rewire every `BatchNorm2d -> ReLU` module pair of nn.Sequential stacks and mmcv-style ConvModules.
+    Returns the number of fused pairs.  Idempotent."""
+    from .registry import ConvModule
+    n = 0
+    for mod in model.modules():
+        if isinstance(mod, nn.Sequential):
+            kids = list(mod._modules.items())
+            for (ka, a), (kb, b) in zip(kids, kids[1:]):
+                if type(a) is nn.BatchNorm2d and _is_plain_relu(b):
+                    a.__class__ = BatchNormAct2d
+                    mod._modules[kb] = nn.Identity()
+                    n += 1
+        elif isinstance(mod, ConvModule) and mod.with_norm and mod.with_activation:
+            if type(mod.norm) is nn.BatchNorm2d and _is_plain_relu(mod.activate):
+                mod.norm.__class__ = BatchNormAct2d
+                mod.activate = nn.Identity()
+                n += 1
+    return n

@@ -1,0 +1,460 @@
+// Training-mode BatchNorm2d fused with the residual add and ReLU that follow it, channels-last fp32.
+//
+// The dense stack of the training step (ResNet-50 image encoder mmdet ResNet `Bottleneck`, the BEV
+// encoder mmdet3d/models/bricks/res_block.py:11-100, mmcv ConvModule conv-norm-act triples) spends 20 % of
+// the step in HBM-bound BN / ReLU / add passes over activations of up to 1.1 GB (96 x 256 x 64 x 176 fp32).
+// Unfused (MIOpen BN + ATen clamp / add / threshold_backward) a conv-BN-ReLU costs 5 full-tensor passes
+// forward and 8 backward; here 3 and 5:
+//   forward :  bn_stats (read x)                 -> per-workgroup partial (sum, sum of squares) per channel
+//              bn_finalize (tiny)                 -> mean, invstd, scale/shift, running-stat update (fp64 merge)
+//              bn_apply (read x [,res], write y)  -> y = relu(x * scale + shift [+ res])
+//   backward:  bn_bwd_reduce (read dy, x [,y])    -> partial (sum dz, sum dz * xhat),  dz = dy * [y > 0]
+//              bn_bwd_finalize (tiny)             -> dgamma, dbeta, per-channel (A, B, C)
+//              bn_bwd_dx (read dy, x [,y], write dx [,dres])   dx = A * dz + B * x + C,  dres = dz
+// Semantics = torch.nn.functional.batch_norm(training=True) + add + relu: biased variance for the
+// normalisation, unbiased for running_var, running = (1 - momentum) * running + momentum * batch.
+// Every reduction has a fixed order (no float atomics): bit-reproducible run to run.
+//
+// Mapping: the tensor is M rows x C channels, C4 = C / 4 float4 columns.  A workgroup of 256 threads covers
+// CH = min(C4, 256) consecutive columns x RP = 256 / CH row phases, so a thread keeps ONE column and its
+// per-channel accumulators / coefficients in registers while it strides over rows, and a wave always
+// touches >= 1 KB of contiguous memory.  gridDim.y walks column chunks when C4 > 256.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_MAX_BLOCKS_X = 2048;   // partial sums per channel merged by the finalize kernels
+constexpr int BN_ROWS_UNROLL = 4;
+constexpr int BN_FIN_CH = 8, BN_FIN_PH = 32;   // finalize kernels: channels x partial phases per workgroup of 256
+
+struct BnGeom {
+  int M, C, C4, CH, RP, GY, NBX;
+};
+
+bool bn_geom(long long M, int C, BnGeom* g) {
+  if (M <= 0 || M > 0x3fffffffLL || C <= 0 || (C & 3)) return false;   // row indices stay clear of int overflow
+  const int C4 = C >> 2;
+  int CH;
+  if (C4 <= 256) {
+    if (C4 & (C4 - 1)) return false;
+    CH = C4;
+  } else {
+    if (C4 & 255) return false;
+    CH = 256;
+  }
+  g->M = static_cast<int>(M);
+  g->C = C;
+  g->C4 = C4;
+  g->CH = CH;
+  g->RP = 256 / CH;
+  g->GY = C4 / CH;
+  const long long tiles = (M + static_cast<long long>(g->RP) * 16 - 1) / (static_cast<long long>(g->RP) * 16);
+  long long nbx = BN_MAX_BLOCKS_X / g->GY;
+  if (nbx < 1) nbx = 1;
+  g->NBX = static_cast<int>(tiles < nbx ? tiles : nbx);
+  return true;
+}
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ void fma4v(float4& a, const float4& b, const float4& c) {
+  a.x = fmaf(b.x, c.x, a.x); a.y = fmaf(b.y, c.y, a.y); a.z = fmaf(b.z, c.z, a.z); a.w = fmaf(b.w, c.w, a.w);
+}
+
+// every workgroup streams ONE contiguous range of rows (HBM pages / TLB entries are walked once, in order):
+// returns the first row, *r_end = one past the last
+__device__ __forceinline__ int block_rows(const BnGeom& g, int* r_end) {
+  int per = (g.M + gridDim.x - 1) / gridDim.x;
+  per = (per + g.RP - 1) / g.RP * g.RP;
+  const long long b = static_cast<long long>(blockIdx.x) * per;
+  const long long e = b + per;
+  *r_end = static_cast<int>(e < g.M ? e : g.M);
+  return static_cast<int>(b < g.M ? b : g.M);
+}
+
+// block-level merge of two float4 accumulators over the row phases, result written by phase 0:
+// partial[(blockIdx.x * 2 + which) * C + 4*q .. +4]
+__device__ __forceinline__ void block_merge_store(float4 a, float4 b, float* __restrict__ partial, int C, int CH, int RP,
+                                                  int q, int ql, int rp) {
+  __shared__ float4 sa[256], sb[256];
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int st = RP >> 1; st > 0; st >>= 1) {
+    if (rp < st) {
+      add4(sa[threadIdx.x], sa[threadIdx.x + st * CH]);
+      add4(sb[threadIdx.x], sb[threadIdx.x + st * CH]);
+    }
+    __syncthreads();
+  }
+  if (rp == 0) {
+    reinterpret_cast<float4*>(partial + (static_cast<size_t>(blockIdx.x) * 2 + 0) * C)[q] = sa[ql];
+    reinterpret_cast<float4*>(partial + (static_cast<size_t>(blockIdx.x) * 2 + 1) * C)[q] = sb[ql];
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats(const float4* __restrict__ x, float* __restrict__ partial, BnGeom g) {
+  const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
+  const int q = blockIdx.y * g.CH + ql;
+  float4 s = f4(0.f), ss = f4(0.f);
+  const int stride = g.RP;
+  int r_end;
+  int r = block_rows(g, &r_end) + rp;
+  for (; r + (BN_ROWS_UNROLL - 1) * stride < r_end; r += BN_ROWS_UNROLL * stride) {
+    float4 v[BN_ROWS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) v[u] = x[static_cast<size_t>(r + u * stride) * g.C4 + q];
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) { add4(s, v[u]); fma4v(ss, v[u], v[u]); }
+  }
+  for (; r < r_end; r += stride) {
+    const float4 v = x[static_cast<size_t>(r) * g.C4 + q];
+    add4(s, v);
+    fma4v(ss, v, v);
+  }
+  block_merge_store(s, ss, partial, g.C, g.CH, g.RP, q, ql, rp);
+}
+
+// 8 channels x 32 partial phases per workgroup; fp64 merge.  coef: [0] scale, [1] shift (forward) -- saved for backward.
+__global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ partial, int nbx, int M, int C,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                   float momentum, float eps, float* __restrict__ save_mean,
+                                                   float* __restrict__ save_invstd, float* __restrict__ coef) {
+  __shared__ double ls[BN_FIN_PH][BN_FIN_CH], lq[BN_FIN_PH][BN_FIN_CH];
+  const int cl = threadIdx.x % BN_FIN_CH, ph = threadIdx.x / BN_FIN_CH;
+  const int c = blockIdx.x * BN_FIN_CH + cl;
+  double s = 0.0, sq = 0.0;
+  if (c < C)
+    for (int b = ph; b < nbx; b += BN_FIN_PH) {
+      s += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 0) * C + c]);
+      sq += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 1) * C + c]);
+    }
+  ls[ph][cl] = s;
+  lq[ph][cl] = sq;
+  __syncthreads();
+  if (ph == 0 && c < C) {
+    for (int p = 1; p < BN_FIN_PH; ++p) { s += ls[p][cl]; sq += lq[p][cl]; }
+    const double mean = s / M;
+    double var = sq / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    const float mf = static_cast<float>(mean);
+    save_mean[c] = mf;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    coef[c] = sc;
+    coef[C + c] = fmaf(-mf, sc, beta[c]);
+    if (running_mean != nullptr) {
+      const double unbiased = M > 1 ? var * (static_cast<double>(M) / (M - 1)) : var;
+      running_mean[c] = static_cast<float>((1.0 - momentum) * running_mean[c] + momentum * mean);
+      running_var[c] = static_cast<float>((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+}
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, const float4* __restrict__ res,
+                                                const float* __restrict__ coef, float4* __restrict__ y, BnGeom g) {
+  const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
+  const int q = blockIdx.y * g.CH + ql;
+  const float4 sc = reinterpret_cast<const float4*>(coef)[q];
+  const float4 sh = reinterpret_cast<const float4*>(coef + g.C)[q];
+  const int stride = g.RP;
+  int r_end;
+  for (int r0 = block_rows(g, &r_end) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
+    float4 v[BN_ROWS_UNROLL], w[BN_ROWS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      if (r < r_end) {
+        v[u] = x[static_cast<size_t>(r) * g.C4 + q];
+        if (RES) w[u] = res[static_cast<size_t>(r) * g.C4 + q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      if (r < r_end) {
+        float4 o;
+        o.x = fmaf(v[u].x, sc.x, sh.x); o.y = fmaf(v[u].y, sc.y, sh.y);
+        o.z = fmaf(v[u].z, sc.z, sh.z); o.w = fmaf(v[u].w, sc.w, sh.w);
+        if (RES) add4(o, w[u]);
+        if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        y[static_cast<size_t>(r) * g.C4 + q] = o;
+      }
+    }
+  }
+}
+
+// dz = dy gated by the ReLU: MASK 0 = no activation, 1 = recompute the pre-activation sign from x
+// (no residual: z = x * scale + shift), 2 = read the saved output y (residual variant).
+template <int MASK>
+__device__ __forceinline__ float4 gate(const float4& dy, const float4& x, const float4& y, const float4& sc,
+                                       const float4& sh) {
+  if (MASK == 0) return dy;
+  float4 o;
+  if (MASK == 1) {
+    o.x = fmaf(x.x, sc.x, sh.x) > 0.f ? dy.x : 0.f;
+    o.y = fmaf(x.y, sc.y, sh.y) > 0.f ? dy.y : 0.f;
+    o.z = fmaf(x.z, sc.z, sh.z) > 0.f ? dy.z : 0.f;
+    o.w = fmaf(x.w, sc.w, sh.w) > 0.f ? dy.w : 0.f;
+  } else {
+    o.x = y.x > 0.f ? dy.x : 0.f;
+    o.y = y.y > 0.f ? dy.y : 0.f;
+    o.z = y.z > 0.f ? dy.z : 0.f;
+    o.w = y.w > 0.f ? dy.w : 0.f;
+  }
+  return o;
+}
+
+template <int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_reduce(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                     const float4* __restrict__ y, const float* __restrict__ coef,
+                                                     const float* __restrict__ save_mean,
+                                                     const float* __restrict__ save_invstd,
+                                                     float* __restrict__ partial, BnGeom g) {
+  const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
+  const int q = blockIdx.y * g.CH + ql;
+  const float4 sc = reinterpret_cast<const float4*>(coef)[q];
+  const float4 sh = reinterpret_cast<const float4*>(coef + g.C)[q];
+  const float4 mu = reinterpret_cast<const float4*>(save_mean)[q];
+  const float4 is = reinterpret_cast<const float4*>(save_invstd)[q];
+  float4 db = f4(0.f), dg = f4(0.f);
+  const int stride = g.RP;
+  int r_end;
+  for (int r0 = block_rows(g, &r_end) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
+    float4 a[BN_ROWS_UNROLL], v[BN_ROWS_UNROLL], o[BN_ROWS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      a[u] = f4(0.f); v[u] = f4(0.f); o[u] = f4(0.f);
+      if (r < r_end) {
+        a[u] = dy[static_cast<size_t>(r) * g.C4 + q];
+        v[u] = x[static_cast<size_t>(r) * g.C4 + q];
+        if (MASK == 2) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+      const float4 dz = gate<MASK>(a[u], v[u], o[u], sc, sh);      // rows past M: dy = 0 -> no contribution
+      float4 xh;
+      xh.x = (v[u].x - mu.x) * is.x; xh.y = (v[u].y - mu.y) * is.y;
+      xh.z = (v[u].z - mu.z) * is.z; xh.w = (v[u].w - mu.w) * is.w;
+      add4(db, dz);
+      fma4v(dg, dz, xh);
+    }
+  }
+  block_merge_store(db, dg, partial, g.C, g.CH, g.RP, q, ql, rp);
+}
+
+// dgamma, dbeta and the per-channel coefficients of dx = A * dz + B * x + Cc  (bcoef: [0] A, [1] B, [2] Cc)
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ partial, int nbx, int M, int C,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_invstd,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       float* __restrict__ bcoef) {
+  __shared__ double ls[BN_FIN_PH][BN_FIN_CH], lq[BN_FIN_PH][BN_FIN_CH];
+  const int cl = threadIdx.x % BN_FIN_CH, ph = threadIdx.x / BN_FIN_CH;
+  const int c = blockIdx.x * BN_FIN_CH + cl;
+  double s = 0.0, sq = 0.0;
+  if (c < C)
+    for (int b = ph; b < nbx; b += BN_FIN_PH) {
+      s += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 0) * C + c]);
+      sq += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 1) * C + c]);
+    }
+  ls[ph][cl] = s;
+  lq[ph][cl] = sq;
+  __syncthreads();
+  if (ph == 0 && c < C) {
+    for (int p = 1; p < BN_FIN_PH; ++p) { s += ls[p][cl]; sq += lq[p][cl]; }
+    dbeta[c] = static_cast<float>(s);
+    dgamma[c] = static_cast<float>(sq);
+    const double is = save_invstd[c], mu = save_mean[c];
+    const double A = static_cast<double>(gamma[c]) * is;
+    bcoef[c] = static_cast<float>(A);
+    bcoef[C + c] = static_cast<float>(-A * is * sq / M);
+    bcoef[2 * C + c] = static_cast<float>(A * (mu * is * sq - s) / M);
+  }
+}
+
+template <int MASK, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                 const float4* __restrict__ y, const float* __restrict__ coef,
+                                                 const float* __restrict__ bcoef, float4* __restrict__ dx,
+                                                 float4* __restrict__ dres, BnGeom g) {
+  const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
+  const int q = blockIdx.y * g.CH + ql;
+  const float4 sc = reinterpret_cast<const float4*>(coef)[q];
+  const float4 sh = reinterpret_cast<const float4*>(coef + g.C)[q];
+  const float4 A = reinterpret_cast<const float4*>(bcoef)[q];
+  const float4 Bc = reinterpret_cast<const float4*>(bcoef + g.C)[q];
+  const float4 Cc = reinterpret_cast<const float4*>(bcoef + 2 * g.C)[q];
+  const int stride = g.RP;
+  int r_end;
+  for (int r0 = block_rows(g, &r_end) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
+    float4 a[BN_ROWS_UNROLL], v[BN_ROWS_UNROLL], o[BN_ROWS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      a[u] = f4(0.f); v[u] = f4(0.f); o[u] = f4(0.f);
+      if (r < r_end) {
+        a[u] = dy[static_cast<size_t>(r) * g.C4 + q];
+        v[u] = x[static_cast<size_t>(r) * g.C4 + q];
+        if (MASK == 2) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      if (r < r_end) {
+        const float4 dz = gate<MASK>(a[u], v[u], o[u], sc, sh);
+        float4 d;
+        d.x = fmaf(A.x, dz.x, fmaf(Bc.x, v[u].x, Cc.x));
+        d.y = fmaf(A.y, dz.y, fmaf(Bc.y, v[u].y, Cc.y));
+        d.z = fmaf(A.z, dz.z, fmaf(Bc.z, v[u].z, Cc.z));
+        d.w = fmaf(A.w, dz.w, fmaf(Bc.w, v[u].w, Cc.w));
+        dx[static_cast<size_t>(r) * g.C4 + q] = d;
+        if (DRES) dres[static_cast<size_t>(r) * g.C4 + q] = dz;
+      }
+    }
+  }
+}
+
+// eval mode: scale/shift from the running statistics (torch batch_norm(training=False))
+__global__ __launch_bounds__(256) void bn_infer_coef(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mean, const float* __restrict__ var,
+                                                     float eps, int C, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = static_cast<float>(1.0 / sqrt(static_cast<double>(var[c]) + static_cast<double>(eps)));
+  const float sc = gamma[c] * invstd;
+  coef[c] = sc;
+  coef[C + c] = fmaf(-mean[c], sc, beta[c]);
+}
+
+struct BnWs { size_t partial, total; };
+BnWs bn_ws(const BnGeom& g) {
+  BnWs w;
+  w.partial = 0;
+  w.total = sizeof(float) * static_cast<size_t>(g.NBX) * 2 * g.C;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t dbev_bn_act_workspace_bytes(long long M, int C) {
+  BnGeom g;
+  if (!bn_geom(M, C, &g)) return 0;
+  return bn_ws(g).total;
+}
+
+extern "C" int dbev_bn_act_train_forward(const float* x, const float* residual, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                         float* y, float* save_mean, float* save_invstd, float* save_scale_shift,
+                                         long long M, int C, void* workspace, size_t workspace_bytes,
+                                         dbevStream_t stream) {
+  BnGeom g;
+  if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
+  if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || save_mean == nullptr ||
+      save_invstd == nullptr || save_scale_shift == nullptr || workspace == nullptr ||
+      workspace_bytes < bn_ws(g).total || (running_mean == nullptr) != (running_var == nullptr))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  float* partial = static_cast<float*>(workspace);
+  const dim3 grid(g.NBX, g.GY);
+  hipLaunchKernelGGL(bn_stats, grid, dim3(256), 0, s, reinterpret_cast<const float4*>(x), partial, g);
+  hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma, beta,
+                     running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* r4 = reinterpret_cast<const float4*>(residual);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  // the apply pass has no reduction: use enough workgroups for latency hiding on its own
+  const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
+  const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
+  const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
+  if (residual != nullptr) {
+    if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+    else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+  } else {
+    if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+    else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+  }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_bn_act_infer(const float* x, const float* residual, const float* gamma, const float* beta,
+                                 const float* running_mean, const float* running_var, float eps, int relu, float* y,
+                                 long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  BnGeom g;
+  if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
+  if (x == nullptr || gamma == nullptr || beta == nullptr || running_mean == nullptr || running_var == nullptr ||
+      y == nullptr || workspace == nullptr || workspace_bytes < sizeof(float) * 2 * static_cast<size_t>(C))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  float* coef = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(bn_infer_coef, dim3(dbev_ceil_div(C, 256)), dim3(256), 0, s, gamma, beta, running_mean,
+                     running_var, eps, C, coef);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* r4 = reinterpret_cast<const float4*>(residual);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
+  const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
+  const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
+  if (residual != nullptr) {
+    if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g);
+    else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g);
+  } else {
+    if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g);
+    else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g);
+  }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
+                                    const float* save_mean, const float* save_invstd, const float* save_scale_shift,
+                                    int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                                    long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  BnGeom g;
+  if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
+  const size_t need = bn_ws(g).total + sizeof(float) * 3 * static_cast<size_t>(C);
+  if (grad_y == nullptr || x == nullptr || gamma == nullptr || save_mean == nullptr || save_invstd == nullptr ||
+      save_scale_shift == nullptr || grad_x == nullptr || grad_gamma == nullptr || grad_beta == nullptr ||
+      workspace == nullptr || workspace_bytes < need)
+    return DBEV_EINVAL;
+  // the ReLU gate of the residual variant needs the saved output; without residual it is recomputed from x
+  const int mask = !relu ? 0 : (grad_residual != nullptr ? 2 : 1);
+  if (mask == 2 && y == nullptr) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  float* partial = static_cast<float*>(workspace);
+  float* bcoef = reinterpret_cast<float*>(static_cast<char*>(workspace) + bn_ws(g).total);
+  const dim3 grid(g.NBX, g.GY);
+  const float4* dy4 = reinterpret_cast<const float4*>(grad_y);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* y4 = reinterpret_cast<const float4*>(y);
+  if (mask == 0)
+    hipLaunchKernelGGL((bn_bwd_reduce<0>), grid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, g);
+  else if (mask == 1)
+    hipLaunchKernelGGL((bn_bwd_reduce<1>), grid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, g);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce<2>), grid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, g);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma,
+                     save_mean, save_invstd, grad_gamma, grad_beta, bcoef);
+  const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
+  const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
+  const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
+  float4* dx4 = reinterpret_cast<float4*>(grad_x);
+  float4* dr4 = reinterpret_cast<float4*>(grad_residual);
+  if (grad_residual != nullptr) {
+    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
+    else hipLaunchKernelGGL((bn_bwd_dx<0, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
+  } else {
+    if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx<1, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
+    else hipLaunchKernelGGL((bn_bwd_dx<0, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
+  }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}

@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 
+from .bn_act import bn_act
 from .registry import (MODELS, ConvModule, build_activation_layer, build_conv_layer, build_norm_layer,
                        build_upsample_layer, register_conv)
 
@@ -53,10 +54,18 @@ class BasicBlock(nn.Module):
             identity = self.downsample(x)
         return out + identity
 
+    def _fused(self, x):
+        """same op sequence with norm -> (+identity) -> relu on the fused kernels (bn_act falls back by itself)"""
+        out = bn_act(self.conv1(x), getattr(self, self.norm1_name), None, True)
+        identity = x if self.downsample is None else self.downsample(x)
+        return bn_act(self.conv2(out), getattr(self, self.norm2_name), identity, True)
+
     def forward(self, x):
-        out = cp.checkpoint(self._inner, x, use_reentrant=False) if (self.with_cp and x.requires_grad) \
-            else self._inner(x)
-        return self.act2(out)
+        if self.with_cp and x.requires_grad:
+            return self.act2(cp.checkpoint(self._inner, x, use_reentrant=False))
+        if type(self.act1) is nn.ReLU and type(self.act2) is nn.ReLU:
+            return self._fused(x)
+        return self.act2(self._inner(x))
 
 
 class Bottleneck(nn.Module):
@@ -93,10 +102,19 @@ class Bottleneck(nn.Module):
             identity = self.downsample(x)
         return out + identity
 
+    def _fused(self, x):
+        """same op sequence with norm -> (+identity) -> relu on the fused kernels (bn_act falls back by itself)"""
+        out = bn_act(self.conv1(x), getattr(self, self.norm1_name), None, True)
+        out = bn_act(self.conv2(out), getattr(self, self.norm2_name), None, True)
+        identity = x if self.downsample is None else self.downsample(x)
+        return bn_act(self.conv3(out), getattr(self, self.norm3_name), identity, True)
+
     def forward(self, x):
-        out = cp.checkpoint(self._inner, x, use_reentrant=False) if (self.with_cp and x.requires_grad) \
-            else self._inner(x)
-        return self.act3(out)
+        if self.with_cp and x.requires_grad:
+            return self.act3(cp.checkpoint(self._inner, x, use_reentrant=False))
+        if type(self.act1) is nn.ReLU and type(self.act2) is nn.ReLU and type(self.act3) is nn.ReLU:
+            return self._fused(x)
+        return self.act3(self._inner(x))
 
 
 @MODELS.register_module()
@@ -160,7 +178,7 @@ class ResNet(nn.Module):
         return getattr(self, self.norm1_name)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.norm1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.conv1(x), self.norm1, None, True))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

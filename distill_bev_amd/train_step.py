@@ -88,6 +88,9 @@ class Trainer:
             self.detector = self.detector.to(memory_format=torch.channels_last)
             self.detector.teacher_model.to(memory_format=torch.channels_last)
             self.detector.channels_last = True
+            # norm -> relu module pairs onto the fused NHWC kernels (parameter names unchanged)
+            from .bn_act import fuse_bn_relu_modules
+            self.fused_bn_relu = fuse_bn_relu_modules(self.detector) + fuse_bn_relu_modules(self.detector.teacher_model)
         self.wrapper = _TrainWrapper(self.detector)
         self.world_size = world_size
         if world_size > 1 or os.environ.get("DBEV_FORCE_DDP") == "1":

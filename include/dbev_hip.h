@@ -308,6 +308,31 @@ int dbev_dcnv2_col2im(const float* grad_cols, const float* x_nhwc, const float* 
                       float* grad_x_nhwc, float* grad_offset_mask_nhwc, int N, int C, int H, int W, int Ho, int Wo,
                       int kh, int kw, int stride, int pad, int dil, dbevStream_t stream);
 
+/* Training-mode BatchNorm2d fused with the residual add and ReLU that follow it (channels-last fp32):
+ *   y = relu( (x - mean_batch) / sqrt(var_batch + eps) * gamma + beta  [+ residual] )
+ * = torch.nn.functional.batch_norm(training=True) [+ add] [+ relu] as the reference's dense blocks chain them
+ * (mmdet ResNet Bottleneck conv-bn-relu / conv-bn-add-relu; mmdet3d/models/bricks/res_block.py:11-100; mmcv
+ * ConvModule).  x, residual, y, grad_*: f32[M, C] with M = N*H*W rows (NHWC); C % 4 == 0 and C/4 a power of two
+ * (<= 256) or a multiple of 256.  running_mean/var (may both be NULL) are updated in place with `momentum`,
+ * running_var with the unbiased variance.  save_mean, save_invstd f32[C] and save_scale_shift f32[2*C] are
+ * outputs of forward / inputs of backward.  backward: y is only read when relu != 0 and grad_residual != NULL
+ * (otherwise the gate is recomputed from x); grad_residual (NULL if there was no residual) receives
+ * dy * [y > 0].  All reductions have a fixed order (no float atomics).
+ * workspace: dbev_bn_act_workspace_bytes(M, C) for forward, + 12*C bytes for backward. */
+size_t dbev_bn_act_workspace_bytes(long long M, int C);
+int dbev_bn_act_train_forward(const float* x, const float* residual, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int relu,
+                              float* y, float* save_mean, float* save_invstd, float* save_scale_shift,
+                              long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+/* eval mode (running statistics, no gradient): y = relu(x * scale + shift [+ residual]); workspace >= 8*C bytes */
+int dbev_bn_act_infer(const float* x, const float* residual, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, float eps, int relu, float* y,
+                      long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_bn_act_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
+                         const float* save_mean, const float* save_invstd, const float* save_scale_shift,
+                         int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                         long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

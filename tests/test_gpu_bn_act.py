@@ -1,0 +1,145 @@
+"""Fused BatchNorm2d(+residual)(+ReLU) kernels (csrc/bn_act.hip) through the C ABI vs the torch op sequence
+F.batch_norm -> add -> relu evaluated in fp64 on the host.  fp32 kernels: tolerances are a few ulp of the
+tensor scale (stated per check)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(x, res, bn, relu, training):
+    x = x.detach().double().requires_grad_(True)
+    r = None if res is None else res.detach().double().requires_grad_(True)
+    w = bn.weight.detach().double().requires_grad_(True)
+    b = bn.bias.detach().double().requires_grad_(True)
+    rm, rv = bn.running_mean.detach().double().clone(), bn.running_var.detach().double().clone()
+    out = F.batch_norm(x, rm, rv, w, b, training, bn.momentum, bn.eps)
+    if r is not None:
+        out = out + r
+    if relu:
+        out = F.relu(out)
+    return out, (x, r, w, b), (rm, rv)
+
+
+def _close(a, r, tol, what):
+    a = a.detach().double().cpu(); r = r.detach().double().cpu()
+    scale = float(r.abs().max()) + 1e-12
+    err = float((a - r).abs().max()) / scale
+    assert err < tol, f"{what}: max err {err:.3e} x scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("N,C,H,W,res,relu", [
+    (3, 64, 9, 7, False, True),      # C/4 = 16 columns, 16 row phases per workgroup
+    (2, 256, 16, 11, True, True),    # bottleneck tail: bn -> +identity -> relu
+    (2, 8, 5, 5, True, False),       # tiny C, no activation
+    (1, 2048, 4, 3, False, True),    # C/4 = 512 -> two column chunks (gridDim.y = 2)
+    (4, 128, 33, 17, False, False),  # plain BN
+    (2, 1024, 6, 5, True, True),     # C/4 = 256
+    (5, 4, 3, 2, False, True),       # C/4 = 1
+])
+def test_train_forward_backward_and_running_stats(N, C, H, W, res, relu):
+    from distill_bev_amd.bn_act import bn_act, eligible
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn((N, C, H, W), generator=g) * 2.0 + 0.7)
+    r = torch.randn((N, C, H, W), generator=g) if res else None
+    bn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g)); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    ref, (rx, rr, rw, rb), (rm, rv) = _ref(x, r, bn, relu, True)
+    gout = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(gout)
+
+    bn = bn.to(DEV).train()
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rd = None if r is None else r.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert eligible(xd, bn, rd)
+    out = bn_act(xd, bn, rd, relu)
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    out.backward(gout.float().to(DEV).contiguous(memory_format=torch.channels_last))
+    _close(out, ref, 5e-6, "y")
+    _close(bn.running_mean, rm, 1e-6, "running_mean")
+    _close(bn.running_var, rv, 2e-6, "running_var")
+    assert int(bn.num_batches_tracked) == 1
+    M = N * H * W
+    _close(xd.grad, rx.grad, 2e-5, "grad_x")
+    _close(bn.weight.grad, rw.grad, 1e-5 * max(1.0, M ** 0.5 / 8), "grad_gamma")
+    _close(bn.bias.grad, rb.grad, 1e-5 * max(1.0, M ** 0.5 / 8), "grad_beta")
+    if res:
+        _close(rd.grad, rr.grad, 1e-6, "grad_residual")
+
+
+def test_train_is_bit_reproducible_and_large_shape():
+    from distill_bev_amd.bn_act import bn_act
+    torch.manual_seed(0)
+    bn = nn.BatchNorm2d(256).to(DEV).train()
+    x = torch.randn((12, 256, 64, 176), device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    res = torch.randn_like(x)
+    outs = []
+    for _ in range(2):
+        x.grad = None; bn.zero_grad()
+        y = bn_act(x, bn, res, True)
+        y.backward(torch.ones_like(y))
+        outs.append((y.detach().clone(), x.grad.clone(), bn.weight.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # against torch on the same device (fp32 both sides)
+    bn2 = nn.BatchNorm2d(256).to(DEV).train()
+    ref = F.relu(bn2(x.detach()) + res)
+    assert float((outs[0][0] - ref).abs().max()) < 1e-5
+
+
+def test_eval_mode_uses_running_stats_and_fallback_paths():
+    from distill_bev_amd import bn_act as BA
+    torch.manual_seed(1)
+    bn = nn.BatchNorm2d(64, eps=1e-3).to(DEV)
+    with torch.no_grad():
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+    bn.eval()
+    x = torch.randn((2, 64, 8, 8), device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert BA.eligible(x, bn)
+        y = BA.bn_act(x, bn, None, True)
+        ref = F.relu(bn(x))
+    assert float((y - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    # eval + autograd, NCHW input, odd channel count, disabled(): all take the torch ops and agree with them
+    xg = x.clone().requires_grad_(True)
+    assert not BA.eligible(xg, bn)
+    assert not BA.eligible(x.contiguous(), bn)
+    assert not BA.eligible(torch.zeros((1, 6, 2, 2), device=DEV).contiguous(memory_format=torch.channels_last),
+                           nn.BatchNorm2d(6).to(DEV))
+    with BA.disabled():
+        assert not BA.eligible(x, bn)
+        assert torch.equal(BA.bn_act(x, bn, None, True), ref)
+
+
+def test_module_surgery_keeps_state_dict_and_matches_unfused_model():
+    from distill_bev_amd import bn_act as BA
+    from distill_bev_amd.nets import ResNet
+    torch.manual_seed(2)
+    net = ResNet(depth=50, out_indices=(2, 3), norm_eval=False).to(DEV).to(memory_format=torch.channels_last).train()
+    keys = list(net.state_dict().keys())
+    seq = nn.Sequential(nn.Conv2d(3, 16, 3, padding=1), nn.BatchNorm2d(16), nn.ReLU(inplace=True)).to(DEV)
+    assert BA.fuse_bn_relu_modules(seq) == 1 and isinstance(seq[1], BA.BatchNormAct2d) and isinstance(seq[2], nn.Identity)
+    assert BA.fuse_bn_relu_modules(seq) == 0
+    assert list(seq.state_dict().keys()) == ["0.weight", "0.bias", "1.weight", "1.bias", "1.running_mean",
+                                             "1.running_var", "1.num_batches_tracked"]
+    x = torch.randn((2, 3, 64, 96), device=DEV).contiguous(memory_format=torch.channels_last)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    outs_f = net(x)
+    loss = sum(o.square().mean() for o in outs_f); loss.backward()
+    gf = net.conv1.weight.grad.clone(); rm_f = net.bn1.running_mean.clone() if hasattr(net, "bn1") else None
+    net.load_state_dict(sd); net.zero_grad()
+    with BA.disabled():
+        outs_u = net(x)
+        loss_u = sum(o.square().mean() for o in outs_u); loss_u.backward()
+    assert list(net.state_dict().keys()) == keys
+    for a, b in zip(outs_f, outs_u):
+        assert float((a - b).abs().max()) < 2e-4 * float(b.abs().max())
+    assert abs(float(loss) - float(loss_u)) < 1e-4 * abs(float(loss_u))
+    gu = net.conv1.weight.grad
+    assert float((gf - gu).norm() / gu.norm()) < 5e-3      # 53 BN layers of fp32 round-off, random init
