@@ -131,9 +131,11 @@ class DistillStep(_Base):
     # dominant hand-written kernel timed for the roofline: teacher pillars scatter (write-bound)
     ROOF_KERNEL = "dbev_pillars_canvas"
     TIMED = ("dbev_pillars_canvas", "dbev_pillar_vfe_canvas", "dbev_lift_splat_prepare_cam", "dbev_lift_splat_forward",
-             "dbev_lift_splat_backward", "dbev_abs_mean_maps", "dbev_fgd_masked_mse_forward",
-             "dbev_fgd_masked_mse_backward", "dbev_fg_scale_mask", "dbev_upsample_bilinear_ac_forward",
-             "dbev_upsample_bilinear_ac_backward")
+             "dbev_lift_splat_backward", "dbev_abs_mean_maps", "dbev_abs_mean_maps_nhwc", "dbev_fgd_masked_mse_forward",
+             "dbev_fgd_masked_mse_forward_nhwc", "dbev_fgd_masked_mse_backward", "dbev_fgd_masked_mse_backward_nhwc",
+             "dbev_fg_scale_mask", "dbev_upsample_bilinear_ac_forward", "dbev_upsample_bilinear_ac_backward",
+             "dbev_dcnv2_im2col", "dbev_dcnv2_col2im", "dbev_bn_act_train_forward", "dbev_bn_act_backward",
+             "dbev_bn_act_infer")
 
     def __init__(self, dev, rank, world):
         from distill_bev_amd.train_step import Trainer, build_model, make_batch
@@ -153,13 +155,16 @@ class DistillStep(_Base):
 
     def step(self):
         self.trainer.step(self.batch)
+        self.steps_timed = getattr(self, "steps_timed", 0) + 1
 
     def begin_timed(self):
+        self.steps_timed = 0
         for k in self.TIMED:
             L.enable_timing(k)
 
     def roofline(self):
         t = {k: L.timing_ms(k) for k in self.TIMED}
+        nbytes = {k: L.timing_bytes(k) for k in self.TIMED}
         L.disable_timing()
         ms = t[self.ROOF_KERNEL]
         if not ms:
@@ -170,14 +175,21 @@ class DistillStep(_Base):
         alg = M * (4 * C + 16) + 4 * C * 512 * 512 * B    # pillar rows + coords read, canvas written
         avg_s = float(np.mean(ms)) * 1e-3
         ach = alg / avg_s / 1e9
-        other = {k: {"avg_us": float(np.mean(v)) * 1e3, "launches": len(v)} for k, v in t.items() if v}
-        return {"bound": "hbm", "kernel": "ps_canvas_nchw_wide (teacher PointPillarsScatter, 64x512x512 canvas per sample; the largest "
-                "HBM mover among the hand-written kernels), one launch per dbev_pillars_canvas call",
+        other = {}
+        for k, v in t.items():
+            if v:
+                other[k] = {"avg_us": float(np.mean(v)) * 1e3, "launches": len(v), "ms_per_step": float(np.sum(v)) / self.steps_timed}
+                if sum(nbytes[k]) > 0:      # entries whose callers attach algorithmic bytes (multi-kernel entry points)
+                    other[k]["achieved_GBps"] = float(sum(nbytes[k])) / (float(np.sum(v)) * 1e-3) / 1e9
+        nhwc = bool(getattr(self.trainer.detector.teacher_model.pts_middle_encoder, "channels_last", False))
+        kname = "ps_canvas_nhwc_vec" if nhwc else "ps_canvas_nchw_wide"
+        return {"bound": "hbm", "kernel": kname + " (teacher PointPillarsScatter, 64x512x512 canvas per sample: the largest "
+                "single-launch HBM mover among the hand-written kernels), one launch per dbev_pillars_canvas call",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 # PMC pass of the same kernel at the same shapes (profiles/r01_pmc_*.txt, tools/pmc_target.py):
-                # FETCH_SIZE 140046 KB x2 (gfx950 wide-read correction, calibrated on a 512 MiB copy) +
-                # WRITE_SIZE 524288 KB (calibrated factor 1 on a 512 MiB fill) = bytes per launch
-                "traffic": (140046.0 * 2 + 524288.0) * 1024, "traffic_source": "profiles/r01_pmc_FETCH_SIZE.txt + "
+                # FETCH_SIZE 144187 KB (nhwc_vec) / 140048 KB (nchw_wide) x2 (gfx950 wide-read correction,
+                # calibrated on a 512 MiB copy) + WRITE_SIZE 524288 KB (factor 1, calibrated on a fill) per launch
+                "traffic": ((144186.7 if nhwc else 140047.6) * 2 + 524288.0) * 1024, "traffic_source": "profiles/r01_pmc_FETCH_SIZE.txt + "
                 "profiles/r01_pmc_WRITE_SIZE.txt (separate --pmc passes, not collected live)",
                 "avg_launch_us": avg_s * 1e6, "launches": len(ms), "algorithmic_bytes_per_launch": alg,
                 "pillars_per_launch": M,

@@ -57,8 +57,13 @@ _SIGNATURES = {
     "dbev_upsample_bilinear_ac_backward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_dcnv2_im2col": [_p, _p, _p] + [_i] * 11 + [_p],
     "dbev_dcnv2_col2im": [_p, _p, _p, _p, _p] + [_i] * 11 + [_p],
+    "dbev_abs_mean_maps_nhwc_workspace_bytes": [_i, _i, _i],
+    "dbev_abs_mean_maps_nhwc": [_p, _i, _i, _i, _p, _p, _p, _sz, _p],
+    "dbev_fgd_masked_mse_nhwc_workspace_bytes": [_i, _i, _i],
+    "dbev_fgd_masked_mse_forward_nhwc": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p],
+    "dbev_fgd_masked_mse_backward_nhwc": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dbev_bn_act_workspace_bytes": [_ll, _i],
-    "dbev_bn_act_train_forward": [_p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_act_train_forward": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
 }
@@ -69,7 +74,9 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_lift_splat_workspace_bytes": ctypes.c_size_t,
              "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
              "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t,
-             "dbev_bn_act_workspace_bytes": ctypes.c_size_t}
+             "dbev_bn_act_workspace_bytes": ctypes.c_size_t,
+             "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
+             "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
 _NO_CHECK = set(_RESTYPES)
 
 
@@ -115,11 +122,21 @@ def disable_timing(name=None):
 def timing_ms(name):
     """Per-call durations in ms of the recorded calls (synchronises)."""
     torch.cuda.synchronize()
-    return [s.elapsed_time(e) for s, e in _timers.get(name, [])]
+    return [r[0].elapsed_time(r[1]) for r in _timers.get(name, [])]
 
 
-def call(name, *args):
-    """Invoke ABI entry `name`, raising on a non-zero return code."""
+def timing_bytes(name):
+    """Algorithmic bytes the callers attached to the recorded calls (0 where none was given)."""
+    return [r[2] for r in _timers.get(name, [])]
+
+
+def timing_enabled(name):
+    return name in _timers
+
+
+def call(name, *args, alg_bytes=0):
+    """Invoke ABI entry `name`, raising on a non-zero return code.  `alg_bytes`: the call's algorithmic
+    HBM bytes, kept next to its event pair when timing is enabled (bench roofline bookkeeping)."""
     fn = getattr(lib(), name)
     rec = _timers.get(name)
     if rec is not None:
@@ -128,7 +145,7 @@ def call(name, *args):
         s.record()
         rc = fn(*args)
         e.record()
-        rec.append((s, e))
+        rec.append((s, e, alg_bytes))
     else:
         rc = fn(*args)
     if name in _NO_CHECK:

@@ -62,7 +62,7 @@ def eligible(x, bn, residual=None):
 
 class _BNActTrain(Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu):
         dev = x.device
         N, C, H, W = x.shape
         M = N * H * W
@@ -74,8 +74,9 @@ class _BNActTrain(Function):
         ws = torch.empty((nbytes + 12 * C,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             L.call("dbev_bn_act_train_forward", L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
-                   L.ptr(running_mean), L.ptr(running_var), float(momentum or 0.0), float(eps), int(relu), L.ptr(y),
-                   L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+                   L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), float(momentum or 0.0), float(eps), int(relu), L.ptr(y),
+                   L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+                   alg_bytes=4 * M * C * (3 + (residual is not None)))     # x twice (stats, apply) [+ res] + y
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, weight, save_mean, save_invstd, coef)
         ctx.cfg = (M, C, bool(relu), residual is not None)
@@ -97,8 +98,9 @@ class _BNActTrain(Function):
         with torch.cuda.device(dev):
             L.call("dbev_bn_act_backward", L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(weight), L.ptr(save_mean),
                    L.ptr(save_invstd), L.ptr(coef), int(relu), L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), M, C,
-                   L.ptr(ws), ws.numel(), L.stream_ptr(dev))
-        return dx, (dres if relu else dy) if has_res else None, dgamma, dbeta, None, None, None, None, None
+                   L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+                   alg_bytes=4 * M * C * (5 + 3 * (dres is not None)))     # dy, x twice each + dx [+ y twice + dres]
+        return dx, (dres if relu else dy) if has_res else None, dgamma, dbeta, None, None, None, None, None, None
 
 
 def _infer(x, residual, bn, relu):
@@ -117,10 +119,9 @@ def bn_act(x, bn, residual=None, relu=True):
     """relu(bn(x) + residual) with the module `bn`'s parameters, statistics and mode."""
     if eligible(x, bn, residual):
         if bn.training or bn.running_mean is None:
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
-            return _BNActTrain.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
-                                     bn.eps, relu)
+            # num_batches_tracked += 1 happens inside the finalize kernel (no extra launch)
+            return _BNActTrain.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     bn.num_batches_tracked, bn.momentum, bn.eps, relu)
         return _infer(x, residual, bn, relu)
     out = nn.BatchNorm2d.forward(bn, x) if isinstance(bn, BatchNormAct2d) else bn(x)
     if residual is not None:

@@ -25,7 +25,7 @@ namespace {
 
 constexpr int BN_MAX_BLOCKS_X = 2048;   // partial sums per channel merged by the finalize kernels
 constexpr int BN_ROWS_UNROLL = 4;
-constexpr int BN_FIN_CH = 8, BN_FIN_PH = 32;   // finalize kernels: channels x partial phases per workgroup of 256
+constexpr int BN_FIN_CH = 4, BN_FIN_PH = 64;   // finalize kernels: channels x partial phases per workgroup of 256
 
 struct BnGeom {
   int M, C, C4, CH, RP, GY, NBX;
@@ -115,21 +115,35 @@ __global__ __launch_bounds__(256) void bn_stats(const float4* __restrict__ x, fl
   block_merge_store(s, ss, partial, g.C, g.CH, g.RP, q, ql, rp);
 }
 
-// 8 channels x 32 partial phases per workgroup; fp64 merge.  coef: [0] scale, [1] shift (forward) -- saved for backward.
+// 4 channels x 64 partial phases per workgroup; fp64 merge in a fixed order.  coef: [0] scale, [1] shift (forward) -- saved for backward.
 __global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ partial, int nbx, int M, int C,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                                    float momentum, float eps, float* __restrict__ save_mean,
-                                                   float* __restrict__ save_invstd, float* __restrict__ coef) {
+                                                   float* __restrict__ save_invstd, float* __restrict__ coef,
+                                                   long long* __restrict__ num_batches_tracked) {
+  if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   __shared__ double ls[BN_FIN_PH][BN_FIN_CH], lq[BN_FIN_PH][BN_FIN_CH];
   const int cl = threadIdx.x % BN_FIN_CH, ph = threadIdx.x / BN_FIN_CH;
   const int c = blockIdx.x * BN_FIN_CH + cl;
   double s = 0.0, sq = 0.0;
-  if (c < C)
-    for (int b = ph; b < nbx; b += BN_FIN_PH) {
+  if (c < C) {
+    int b = ph;
+    for (; b + 3 * BN_FIN_PH < nbx; b += 4 * BN_FIN_PH) {      // 8 independent loads in flight
+      float a[4], q2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 0) * C + c];
+        q2[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s += static_cast<double>(a[u]); sq += static_cast<double>(q2[u]); }
+    }
+    for (; b < nbx; b += BN_FIN_PH) {
       s += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 0) * C + c]);
       sq += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 1) * C + c]);
     }
+  }
   ls[ph][cl] = s;
   lq[ph][cl] = sq;
   __syncthreads();
@@ -259,11 +273,23 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__
   const int cl = threadIdx.x % BN_FIN_CH, ph = threadIdx.x / BN_FIN_CH;
   const int c = blockIdx.x * BN_FIN_CH + cl;
   double s = 0.0, sq = 0.0;
-  if (c < C)
-    for (int b = ph; b < nbx; b += BN_FIN_PH) {
+  if (c < C) {
+    int b = ph;
+    for (; b + 3 * BN_FIN_PH < nbx; b += 4 * BN_FIN_PH) {      // 8 independent loads in flight
+      float a[4], q2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 0) * C + c];
+        q2[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s += static_cast<double>(a[u]); sq += static_cast<double>(q2[u]); }
+    }
+    for (; b < nbx; b += BN_FIN_PH) {
       s += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 0) * C + c]);
       sq += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 1) * C + c]);
     }
+  }
   ls[ph][cl] = s;
   lq[ph][cl] = sq;
   __syncthreads();
@@ -351,10 +377,10 @@ extern "C" size_t dbev_bn_act_workspace_bytes(long long M, int C) {
 }
 
 extern "C" int dbev_bn_act_train_forward(const float* x, const float* residual, const float* gamma, const float* beta,
-                                         float* running_mean, float* running_var, float momentum, float eps, int relu,
-                                         float* y, float* save_mean, float* save_invstd, float* save_scale_shift,
-                                         long long M, int C, void* workspace, size_t workspace_bytes,
-                                         dbevStream_t stream) {
+                                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                                         float momentum, float eps, int relu, float* y, float* save_mean,
+                                         float* save_invstd, float* save_scale_shift, long long M, int C,
+                                         void* workspace, size_t workspace_bytes, dbevStream_t stream) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
   if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || save_mean == nullptr ||
@@ -366,7 +392,8 @@ extern "C" int dbev_bn_act_train_forward(const float* x, const float* residual, 
   const dim3 grid(g.NBX, g.GY);
   hipLaunchKernelGGL(bn_stats, grid, dim3(256), 0, s, reinterpret_cast<const float4*>(x), partial, g);
   hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma, beta,
-                     running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift);
+                     running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
+                     num_batches_tracked);
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* r4 = reinterpret_cast<const float4*>(residual);
   float4* y4 = reinterpret_cast<float4*>(y);

@@ -163,7 +163,6 @@ __global__ __launch_bounds__(256) void abs_mean_ch_final(const float* __restrict
 
 // ---- masked MSE -------------------------------------------------------------------------
 constexpr int MSE_CCHUNK = 16;   // channels per block
-constexpr int MSE_PX = 1024;     // pixels per block (256 threads x float4)
 
 // grid (HW/1024, ceil(C/16), B)
 __global__ __launch_bounds__(256) void masked_mse_fwd(const float4* __restrict__ S,
@@ -260,6 +259,205 @@ __global__ __launch_bounds__(256) void masked_mse_bwd(const float4* __restrict__
   }
 }
 
+
+// ---- channels-last (NHWC) variants ---------------------------------------------------------
+// x, S, T f32[B, HW, C]: a pixel's C channels are contiguous.  One WAVE per pixel row (lane = float4 column,
+// NQ = ceil(C/256) columns per lane), 4 waves per workgroup walking one contiguous range of rows: the
+// per-pixel weights are wave-uniform scalars, the per-channel factors / channel sums live in registers.
+constexpr int NHWC_ROWS_PER_BLOCK = 64;
+
+template <int NQ>
+__global__ __launch_bounds__(256) void abs_mean_nhwc(const float4* __restrict__ x, int C4, int HW,
+                                                     float* __restrict__ pix, float* __restrict__ chpart) {
+  __shared__ float4 red[4][64 * NQ];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * NHWC_ROWS_PER_BLOCK, r1 = min(HW, r0 + NHWC_ROWS_PER_BLOCK);
+  const float invC = 1.f / static_cast<float>(C4 * 4);
+  float4 acc[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = r0 + w; r < r1; r += 8) {
+    float ps[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rr = r + 4 * u;
+      if (rr < r1) {
+        const float4* row = x + (static_cast<size_t>(b) * HW + rr) * C4;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          const int q = lane + 64 * j;
+          if (q < C4) {
+            float4 v = row[q];
+            v.x = fabsf(v.x); v.y = fabsf(v.y); v.z = fabsf(v.z); v.w = fabsf(v.w);
+            acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
+            ps[u] += (v.x + v.y) + (v.z + v.w);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rr = r + 4 * u;
+      const float t = wave_sum(ps[u]);
+      if (lane == 0 && rr < r1) pix[static_cast<size_t>(b) * HW + rr] = t * invC;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) red[w][lane + 64 * j] = acc[j];
+  __syncthreads();
+  for (int q = threadIdx.x; q < C4; q += 256) {
+    float4 t = red[0][q];
+    for (int k = 1; k < 4; ++k) { t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w; }
+    reinterpret_cast<float4*>(chpart + (static_cast<size_t>(b) * gridDim.x + blockIdx.x) * C4 * 4)[q] = t;
+  }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void masked_mse_fwd_nhwc(const float4* __restrict__ S, const float4* __restrict__ T,
+                                                           const float* __restrict__ Wfg, const float* __restrict__ Wbg,
+                                                           const float* __restrict__ Wfp, const float* __restrict__ Cc,
+                                                           int C4, int HW, float* __restrict__ partial) {
+  __shared__ float red[3][4];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * NHWC_ROWS_PER_BLOCK, r1 = min(HW, r0 + NHWC_ROWS_PER_BLOCK);
+  float4 cc[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int q = lane + 64 * j;
+    cc[j] = (Cc != nullptr && q < C4) ? reinterpret_cast<const float4*>(Cc + static_cast<size_t>(b) * C4 * 4)[q]
+                                      : make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+  float a_fg = 0.f, a_bg = 0.f, a_fp = 0.f;
+  for (int r = r0 + w; r < r1; r += 4) {
+    const size_t pr = static_cast<size_t>(b) * HW + r;
+    const float wf = Wfg[pr], wb = Wbg[pr], wp = Wfp ? Wfp[pr] : 0.f;
+    float qs = 0.f, qp = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int q = lane + 64 * j;
+      if (q < C4) {
+        const float4 s = S[pr * C4 + q], t = T[pr * C4 + q];
+        const float dx = s.x - t.x, dy = s.y - t.y, dz = s.z - t.z, dw = s.w - t.w;
+        const float qx = dx * dx, qy = dy * dy, qz = dz * dz, qw = dw * dw;
+        qs += (qx + qy) + (qz + qw);
+        qp += (qx * cc[j].x + qy * cc[j].y) + (qz * cc[j].z + qw * cc[j].w);
+      }
+    }
+    a_fg = fmaf(qs, wf, a_fg);
+    a_bg = fmaf(qs, wb, a_bg);
+    a_fp = fmaf(qp, wp, a_fp);
+  }
+  a_fg = wave_sum(a_fg); a_bg = wave_sum(a_bg); a_fp = wave_sum(a_fp);
+  if (lane == 0) { red[0][w] = a_fg; red[1][w] = a_bg; red[2][w] = a_fp; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    const size_t blk = static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+    partial[blk * 3 + k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+  }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void masked_mse_bwd_nhwc(const float4* __restrict__ S, const float4* __restrict__ T,
+                                                           const float* __restrict__ Wfg, const float* __restrict__ Wbg,
+                                                           const float* __restrict__ Wfp, const float* __restrict__ Cc,
+                                                           const float* __restrict__ gsc, int C4, int HW,
+                                                           float4* __restrict__ dS) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * NHWC_ROWS_PER_BLOCK, r1 = min(HW, r0 + NHWC_ROWS_PER_BLOCK);
+  const float g0 = gsc[0], g1 = gsc[1], g2 = gsc[2];
+  float4 cc[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int q = lane + 64 * j;
+    cc[j] = (Cc != nullptr && q < C4) ? reinterpret_cast<const float4*>(Cc + static_cast<size_t>(b) * C4 * 4)[q]
+                                      : make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+  for (int r = r0 + w; r < r1; r += 4) {
+    const size_t pr = static_cast<size_t>(b) * HW + r;
+    const float base = g0 * Wfg[pr] + g1 * Wbg[pr];
+    const float kp = Wfp ? g2 * Wfp[pr] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int q = lane + 64 * j;
+      if (q < C4) {
+        const float4 s = S[pr * C4 + q], t = T[pr * C4 + q];
+        float4 o;
+        o.x = 2.f * (s.x - t.x) * (base + kp * cc[j].x);
+        o.y = 2.f * (s.y - t.y) * (base + kp * cc[j].y);
+        o.z = 2.f * (s.z - t.z) * (base + kp * cc[j].z);
+        o.w = 2.f * (s.w - t.w) * (base + kp * cc[j].w);
+        dS[pr * C4 + q] = o;
+      }
+    }
+  }
+}
+
+#define DBEV_NQ_DISPATCH(NQV, KERNEL, ...)                                                     \
+  switch (NQV) {                                                                               \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break;                               \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__); break;                               \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), __VA_ARGS__); break;                               \
+    default: hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__); break;                              \
+  }
+
+bool nhwc_ok(int B, int C, int HW) { return B > 0 && HW > 0 && C > 0 && (C & 3) == 0 && C <= 1024; }
+
+}  // namespace
+
+extern "C" size_t dbev_abs_mean_maps_nhwc_workspace_bytes(int B, int C, int HW) {
+  if (!nhwc_ok(B, C, HW)) return 0;
+  return sizeof(float) * static_cast<size_t>(B) * dbev_ceil_div(HW, NHWC_ROWS_PER_BLOCK) * C + 256;
+}
+
+extern "C" int dbev_abs_mean_maps_nhwc(const float* x_nhwc, int B, int C, int HW, float* pix_mean, float* ch_mean,
+                                       void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  if (!nhwc_ok(B, C, HW)) return DBEV_EINVAL;
+  if (workspace == nullptr || workspace_bytes < dbev_abs_mean_maps_nhwc_workspace_bytes(B, C, HW)) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const int nbx = dbev_ceil_div(HW, NHWC_ROWS_PER_BLOCK), C4 = C >> 2;
+  float* chpart = static_cast<float*>(workspace);
+  DBEV_NQ_DISPATCH((C4 + 63) / 64, abs_mean_nhwc, dim3(nbx, B), dim3(256), 0, s,
+                   reinterpret_cast<const float4*>(x_nhwc), C4, HW, pix_mean, chpart);
+  hipLaunchKernelGGL(abs_mean_ch_final, dim3(dbev_ceil_div(C, 256), B), dim3(256), 0, s, chpart, C, HW, nbx, ch_mean);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t dbev_fgd_masked_mse_nhwc_workspace_bytes(int B, int C, int HW) {
+  if (!nhwc_ok(B, C, HW)) return 0;
+  return sizeof(float) * 3 * static_cast<size_t>(B) * dbev_ceil_div(HW, NHWC_ROWS_PER_BLOCK);
+}
+
+extern "C" int dbev_fgd_masked_mse_forward_nhwc(const float* S, const float* T, const float* Wfg, const float* Wbg,
+                                                const float* Wfp, const float* Cc, int B, int C, int HW, float* out3,
+                                                void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  if (!nhwc_ok(B, C, HW)) return DBEV_EINVAL;
+  if (workspace == nullptr || workspace_bytes < dbev_fgd_masked_mse_nhwc_workspace_bytes(B, C, HW)) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const int nbx = dbev_ceil_div(HW, NHWC_ROWS_PER_BLOCK), C4 = C >> 2;
+  float* partial = static_cast<float*>(workspace);
+  DBEV_NQ_DISPATCH((C4 + 63) / 64, masked_mse_fwd_nhwc, dim3(nbx, B), dim3(256), 0, s,
+                   reinterpret_cast<const float4*>(S), reinterpret_cast<const float4*>(T), Wfg, Wbg, Wfp, Cc, C4, HW,
+                   partial);
+  hipLaunchKernelGGL(masked_mse_final, dim3(1), dim3(256), 0, s, partial, nbx * B, out3);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_fgd_masked_mse_backward_nhwc(const float* S, const float* T, const float* Wfg, const float* Wbg,
+                                                 const float* Wfp, const float* Cc, const float* grad_scale3, int B,
+                                                 int C, int HW, float* dS, dbevStream_t stream) {
+  if (!nhwc_ok(B, C, HW)) return DBEV_EINVAL;
+  const int nbx = dbev_ceil_div(HW, NHWC_ROWS_PER_BLOCK), C4 = C >> 2;
+  DBEV_NQ_DISPATCH((C4 + 63) / 64, masked_mse_bwd_nhwc, dim3(nbx, B), dim3(256), 0, dbev_stream(stream),
+                   reinterpret_cast<const float4*>(S), reinterpret_cast<const float4*>(T), Wfg, Wbg, Wfp, Cc,
+                   grad_scale3, C4, HW, reinterpret_cast<float4*>(dS));
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
 }  // namespace
 
 extern "C" int dbev_fg_scale_mask(const float* planes, const float* box_scale, const int32_t* box_offsets,

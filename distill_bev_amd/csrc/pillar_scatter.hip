@@ -125,6 +125,41 @@ __global__ __launch_bounds__(256) void ps_canvas_nhwc(const float* __restrict__ 
   }
 }
 
+// C % 4 == 0: one float4 (4 channels of one cell) per lane, 4 independent cells-rows in flight per lane.
+// The canvas is one contiguous stream of ncell * C floats written exactly once; a wave covers 1 KB of it
+// (64 / (C/4) consecutive cells), the cell ids are read once per lane group, the occupied rows are
+// contiguous C*4-byte gathers.
+__global__ __launch_bounds__(256) void ps_canvas_nhwc_vec(const float4* __restrict__ feats,
+                                                          const int* __restrict__ cellmap,
+                                                          float4* __restrict__ canvas, int C4, long long total4) {
+  constexpr int U = 4;
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i0 = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i0 < total4; i0 += U * stride) {
+    int v[U];
+    int q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = i0 + u * stride;
+      v[u] = -1;
+      q[u] = 0;
+      if (i < total4) {
+        const long long cell = i / C4;
+        q[u] = static_cast<int>(i - cell * C4);
+        v[u] = cellmap[cell];
+      }
+    }
+    float4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      r[u] = v[u] >= 0 ? feats[static_cast<size_t>(v[u]) * C4 + q[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = i0 + u * stride;
+      if (i < total4) canvas[i] = r[u];
+    }
+  }
+}
+
 // backward: grad_feats[v, c] = grad_canvas[b, c, y, x] (rows that lost a duplicate race get 0)
 __global__ __launch_bounds__(256) void ps_backward(const float* __restrict__ grad_canvas,
                                                    const int* __restrict__ coors,
@@ -154,7 +189,14 @@ namespace dbev {
 int launch_canvas(const float* voxel_features, const int* cellmap, float* canvas, int C, int B, int ny, int nx,
                   int channels_last, hipStream_t s) {
   const long long ncell = static_cast<long long>(B) * ny * nx;
-  if (channels_last) {
+  if (channels_last && (C & 3) == 0) {
+    const long long total4 = ncell * (C >> 2);
+    long long blocks = (total4 + 256 * 4 - 1) / (256 * 4);
+    if (blocks > DBEV_MAX_GRID * 8) blocks = DBEV_MAX_GRID * 8;
+    hipLaunchKernelGGL(ps_canvas_nhwc_vec, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(voxel_features), cellmap, reinterpret_cast<float4*>(canvas),
+                       C >> 2, total4);
+  } else if (channels_last) {
     long long blocks = (ncell * C + 255) / 256;
     if (blocks > DBEV_MAX_GRID * 8) blocks = DBEV_MAX_GRID * 8;
     hipLaunchKernelGGL(ps_canvas_nhwc, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, voxel_features,

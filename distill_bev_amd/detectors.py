@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 from .center_head import LiDARBoxes, clip_sigmoid  # noqa: F401
 from .config import Config
+from .bn_act import bn_act
 from .distill_loss import ForegroundMaskRasterizer, UpsampleBilinearAC, fgd_feature_losses
 from .registry import MODELS, build_backbone, build_detector, build_head, build_loss, build_neck
 from .voxel import Voxelization
@@ -150,9 +151,9 @@ class ThreeLayer(nn.Module):
         self.norm3 = nn.BatchNorm2d(out_features); self.act3 = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        x = self.act1(self.norm1(self.conv1(x)))
-        x = self.act2(self.norm2(self.conv2(x)))
-        return self.act3(self.norm3(self.conv3(x)))
+        x = bn_act(self.conv1(x), self.norm1, None, True)      # norm -> relu on the fused kernel when eligible
+        x = bn_act(self.conv2(x), self.norm2, None, True)
+        return bn_act(self.conv3(x), self.norm3, None, True)
 
 
 class TwoLayer(nn.Module):
@@ -168,7 +169,7 @@ class TwoLayer(nn.Module):
         self.norm2 = nn.BatchNorm2d(out_features); self.act2 = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.act2(self.norm2(self.conv2(self.act1(self.norm1(self.conv1(x))))))
+        return bn_act(self.conv2(bn_act(self.conv1(x), self.norm1, None, True)), self.norm2, None, True)
 
 
 def _as_list(v, n):

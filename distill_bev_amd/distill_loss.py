@@ -96,13 +96,26 @@ class ForegroundMaskRasterizer:
         return fg, fs, bs
 
 
+def _is_nhwc(t):
+    """physically [B, H, W, C] (and not also NCHW-contiguous), fp32, channel count the NHWC kernels take"""
+    return (t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous(memory_format=torch.channels_last)
+            and not t.is_contiguous() and t.shape[1] % 4 == 0 and t.shape[1] <= 1024)
+
+
 def abs_mean_maps(x):
     """x f32[B, C, H, W] -> (mean_c |x| f32[B,1,H,W], mean_hw |x| f32[B,C,1,1]) in one pass."""
     dev = L.require_cuda(x)
-    x = x.contiguous()
     B, C, H, W = x.shape
     pix = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
     ch = torch.empty((B, C, 1, 1), dtype=torch.float32, device=dev)
+    if _is_nhwc(x):                       # channels-last activations are consumed as they are
+        with torch.cuda.device(dev):
+            nbytes = L.call("dbev_abs_mean_maps_nhwc_workspace_bytes", B, C, H * W)
+            ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+            L.call("dbev_abs_mean_maps_nhwc", L.ptr(x), B, C, H * W, L.ptr(pix), L.ptr(ch), L.ptr(ws), ws.numel(),
+                   L.stream_ptr(dev))
+        return pix, ch
+    x = x.contiguous()
     with torch.cuda.device(dev):
         nbytes = L.call("dbev_abs_mean_maps_workspace_bytes", B, C, H * W)
         ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
@@ -115,14 +128,24 @@ class _MaskedMSE(Function):
     @staticmethod
     def forward(ctx, S, T, Wfg, Wbg, Wfp, Cc):
         dev = L.require_cuda(S, T, Wfg, Wbg)
-        S = S.contiguous()
-        T = T.contiguous()
         B, C, H, W = S.shape
         assert T.shape == S.shape
         Wfg = Wfg.contiguous(); Wbg = Wbg.contiguous()
         Wfp = Wfp.contiguous() if Wfp is not None else None
         Cc = Cc.contiguous() if Cc is not None else None
         out = torch.empty((3,), dtype=torch.float32, device=dev)
+        ctx.nhwc = _is_nhwc(S)
+        if ctx.nhwc:
+            T = T.contiguous(memory_format=torch.channels_last)
+            with torch.cuda.device(dev):
+                nbytes = L.call("dbev_fgd_masked_mse_nhwc_workspace_bytes", B, C, H * W)
+                ws = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=dev)
+                L.call("dbev_fgd_masked_mse_forward_nhwc", L.ptr(S), L.ptr(T), L.ptr(Wfg), L.ptr(Wbg), L.ptr(Wfp),
+                       L.ptr(Cc), B, C, H * W, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+            ctx.save_for_backward(S, T, Wfg, Wbg, Wfp, Cc)
+            return out
+        S = S.contiguous()
+        T = T.contiguous()
         with torch.cuda.device(dev):
             nbytes = L.call("dbev_fgd_masked_mse_workspace_bytes", B, C, H * W)
             if nbytes == 0:
@@ -139,9 +162,9 @@ class _MaskedMSE(Function):
         B, C, H, W = S.shape
         dev = S.device
         g = grad_out.contiguous().float()
-        dS = torch.empty_like(S)
+        dS = torch.empty_like(S)          # keeps S's memory format
         with torch.cuda.device(dev):
-            L.call("dbev_fgd_masked_mse_backward", L.ptr(S), L.ptr(T), L.ptr(Wfg), L.ptr(Wbg), L.ptr(Wfp),
+            L.call("dbev_fgd_masked_mse_backward_nhwc" if ctx.nhwc else "dbev_fgd_masked_mse_backward", L.ptr(S), L.ptr(T), L.ptr(Wfg), L.ptr(Wbg), L.ptr(Wfp),
                    L.ptr(Cc), L.ptr(g), B, C, H * W, L.ptr(dS), L.stream_ptr(dev))
         return dS, None, None, None, None, None
 

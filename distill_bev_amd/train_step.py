@@ -79,6 +79,28 @@ def parse_losses(losses):
     return sum(v for k, v in losses.items() if "loss" in k)
 
 
+def accelerate_modules(detector):
+    """Rewire parameter-free / parameter-preserving module pairs of a built, channels-last, on-GPU detector
+    (student + hidden teacher) onto the gfx950 kernels: BatchNorm2d->ReLU pairs (bn_act.fuse_bn_relu_modules),
+    bilinear align_corners nn.Upsample (UpsampleBilinearAC), NHWC teacher canvas.  State-dict keys are unchanged."""
+    from .bn_act import fuse_bn_relu_modules
+    from .distill_loss import UpsampleBilinearAC
+    roots = [detector] + ([detector.teacher_model] if getattr(detector, "teacher_model", None) is not None else [])
+    n_bn = sum(fuse_bn_relu_modules(r) for r in roots)
+    n_up = 0
+    for r in roots:
+        for mod in r.modules():
+            for name, child in list(mod._modules.items()):
+                if type(child) is nn.Upsample and child.mode == "bilinear" and child.align_corners \
+                        and child.size is None and isinstance(child.scale_factor, (int, float)):
+                    mod._modules[name] = UpsampleBilinearAC(child.scale_factor)
+                    n_up += 1
+        me = getattr(r, "pts_middle_encoder", None)
+        if me is not None:
+            me.channels_last = True            # canvas written NHWC: no NCHW->NHWC copy in front of SECOND
+    return n_bn, n_up
+
+
 class Trainer:
     def __init__(self, model, cfg, device, world_size=1, channels_last=False):
         self.device = device
@@ -88,9 +110,7 @@ class Trainer:
             self.detector = self.detector.to(memory_format=torch.channels_last)
             self.detector.teacher_model.to(memory_format=torch.channels_last)
             self.detector.channels_last = True
-            # norm -> relu module pairs onto the fused NHWC kernels (parameter names unchanged)
-            from .bn_act import fuse_bn_relu_modules
-            self.fused_bn_relu = fuse_bn_relu_modules(self.detector) + fuse_bn_relu_modules(self.detector.teacher_model)
+            self.fused_bn_relu, self.swapped_upsample = accelerate_modules(self.detector)
         self.wrapper = _TrainWrapper(self.detector)
         self.world_size = world_size
         if world_size > 1 or os.environ.get("DBEV_FORCE_DDP") == "1":

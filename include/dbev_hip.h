@@ -281,6 +281,20 @@ int dbev_pillar_vfe_canvas(const float* points, int n_points, int num_features,
                            float* canvas, int channels_last, void* workspace, size_t workspace_bytes,
                            dbevStream_t stream);
 
+/* Channels-last variants of the two loss kernels above: x, S, T are f32[B, HW, C] (the NHWC image of
+ * [B, C, H, W]), so the channels-last activations of the dense stack are consumed / dS is produced without a
+ * layout copy.  Same arguments and results otherwise; C % 4 == 0, C <= 1024, any HW. */
+size_t dbev_abs_mean_maps_nhwc_workspace_bytes(int B, int C, int HW);
+int dbev_abs_mean_maps_nhwc(const float* x_nhwc, int B, int C, int HW, float* pix_mean, float* ch_mean,
+                            void* workspace, size_t workspace_bytes, dbevStream_t stream);
+size_t dbev_fgd_masked_mse_nhwc_workspace_bytes(int B, int C, int HW);
+int dbev_fgd_masked_mse_forward_nhwc(const float* S, const float* T, const float* Wfg, const float* Wbg,
+                                     const float* Wfp, const float* Cc, int B, int C, int HW, float* out3,
+                                     void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_fgd_masked_mse_backward_nhwc(const float* S, const float* T, const float* Wfg, const float* Wbg,
+                                      const float* Wfp, const float* Cc, const float* grad_scale3, int B, int C,
+                                      int HW, float* dS, dbevStream_t stream);
+
 /* Bilinear upsampling with align_corners=True (nn.Upsample in the student adaptation layers of the
  * FGD loss, bevdet_distill.py:275-288; ATen upsample_bilinear2d index rule).  x f32[B,C,IH,IW] ->
  * y f32[B,C,OH,OW]; channels_last=1: both tensors are physically [B,H,W,C].  backward: every element
@@ -314,16 +328,17 @@ int dbev_dcnv2_col2im(const float* grad_cols, const float* x_nhwc, const float* 
  * (mmdet ResNet Bottleneck conv-bn-relu / conv-bn-add-relu; mmdet3d/models/bricks/res_block.py:11-100; mmcv
  * ConvModule).  x, residual, y, grad_*: f32[M, C] with M = N*H*W rows (NHWC); C % 4 == 0 and C/4 a power of two
  * (<= 256) or a multiple of 256.  running_mean/var (may both be NULL) are updated in place with `momentum`,
- * running_var with the unbiased variance.  save_mean, save_invstd f32[C] and save_scale_shift f32[2*C] are
+ * running_var with the unbiased variance; num_batches_tracked (i64 scalar, may be NULL) is incremented.  save_mean, save_invstd f32[C] and save_scale_shift f32[2*C] are
  * outputs of forward / inputs of backward.  backward: y is only read when relu != 0 and grad_residual != NULL
  * (otherwise the gate is recomputed from x); grad_residual (NULL if there was no residual) receives
  * dy * [y > 0].  All reductions have a fixed order (no float atomics).
  * workspace: dbev_bn_act_workspace_bytes(M, C) for forward, + 12*C bytes for backward. */
 size_t dbev_bn_act_workspace_bytes(long long M, int C);
 int dbev_bn_act_train_forward(const float* x, const float* residual, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float momentum, float eps, int relu,
-                              float* y, float* save_mean, float* save_invstd, float* save_scale_shift,
-                              long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                              float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd,
+                              float* save_scale_shift, long long M, int C, void* workspace, size_t workspace_bytes,
+                              dbevStream_t stream);
 /* eval mode (running statistics, no gradient): y = relu(x * scale + shift [+ residual]); workspace >= 8*C bytes */
 int dbev_bn_act_infer(const float* x, const float* residual, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, float eps, int relu, float* y,

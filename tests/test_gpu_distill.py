@@ -92,6 +92,52 @@ def test_fgd_losses_vs_fp64_oracle_and_autograd():
     assert float(gerr) < 1e-4
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 384, 128, 128), (3, 128, 17, 9), (1, 8, 5, 3), (2, 1024, 8, 8), (2, 260, 6, 7)])
+def test_channels_last_loss_kernels_match_nchw_kernels_and_fp64(B, C, H, W):
+    """NHWC variants (dbev_abs_mean_maps_nhwc, dbev_fgd_masked_mse_*_nhwc): same numbers as the NCHW kernels
+    (summation order differs: 1e-6 relative) and as the fp64 torch expression; dS comes back channels-last."""
+    from distill_bev_amd.distill_loss import _is_nhwc, abs_mean_maps, masked_mse_sums
+    dev = _dev()
+    g = torch.Generator().manual_seed(C + H)
+    S = torch.randn((B, C, H, W), generator=g).to(dev); T = torch.randn((B, C, H, W), generator=g).to(dev)
+    wf = torch.rand((B, 1, H, W), generator=g).to(dev); wb = torch.rand((B, 1, H, W), generator=g).to(dev)
+    wp = torch.rand((B, 1, H, W), generator=g).to(dev); cc = torch.rand((B, C), generator=g).to(dev)
+    Scl = S.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    Tcl = T.contiguous(memory_format=torch.channels_last)
+    assert _is_nhwc(Scl) and not _is_nhwc(S)
+    if (H * W) % 4:                       # the NCHW masked-MSE kernels need HW % 4 == 0; the NHWC ones do not
+        out_c = masked_mse_sums(Scl, Tcl, wf, wb, wp, cc)
+        sq = (S - T).double() ** 2
+        ref = torch.stack([(sq * wf.double()).sum(), (sq * wb.double()).sum(),
+                           (sq * wp.double() * cc.double().view(B, C, 1, 1)).sum()])
+        assert float(((out_c.double() - ref).abs() / ref.abs()).max()) < 2e-6
+        pix_c, ch_c = abs_mean_maps(Tcl)
+        assert torch.allclose(pix_c, T.abs().mean(1, keepdim=True), atol=1e-6, rtol=1e-5)
+        assert torch.allclose(ch_c, T.abs().mean((2, 3), keepdim=True), atol=1e-6, rtol=1e-5)
+        return
+    pix_n, ch_n = abs_mean_maps(T)
+    pix_c, ch_c = abs_mean_maps(Tcl)
+    assert torch.allclose(pix_c, T.abs().mean(1, keepdim=True), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(ch_c, T.abs().mean((2, 3), keepdim=True), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(pix_c, pix_n, atol=1e-6, rtol=1e-5) and torch.allclose(ch_c, ch_n, atol=1e-6, rtol=1e-5)
+    Sn = S.clone().requires_grad_(True)
+    out_n = masked_mse_sums(Sn, T, wf, wb, wp, cc)
+    out_c = masked_mse_sums(Scl, Tcl, wf, wb, wp, cc)
+    assert torch.equal(out_c, masked_mse_sums(Scl, Tcl, wf, wb, wp, cc))          # fixed summation order
+    sq = (S - T).double() ** 2
+    ref = torch.stack([(sq * wf.double()).sum(), (sq * wb.double()).sum(),
+                       (sq * wp.double() * cc.double().view(B, C, 1, 1)).sum()])
+    assert float(((out_c.double() - ref).abs() / ref.abs()).max()) < 2e-6
+    assert float(((out_c - out_n).abs() / out_n.abs()).max()) < 2e-6
+    wts = torch.tensor([0.3, 1.7, -0.9], device=dev)
+    (out_n * wts).sum().backward(); (out_c * wts).sum().backward()
+    assert Scl.grad.is_contiguous(memory_format=torch.channels_last)
+    assert float((Scl.grad - Sn.grad).abs().max()) <= 1e-6 * float(Sn.grad.abs().max())
+    # without the third term / channel factors
+    o2 = masked_mse_sums(Scl, Tcl, wf, wb)
+    assert float(o2[2]) == 0.0 and abs(float(o2[0]) - float(ref[0])) < 2e-6 * float(ref[0])
+
+
 def test_masked_mse_determinism_and_small_odd_channels():
     from distill_bev_amd.distill_loss import masked_mse_sums
     dev = _dev()

@@ -24,6 +24,18 @@ vf = torch.randn((pr["M"], 64), device=dev)
 print("pillars M =", pr["M"], "algorithmic bytes per launch =", pr["M"] * (4 * 64 + 16) + 4 * 64 * 512 * 512 * B)
 for _ in range(5):
     pillars_scatter(vf, vc, B, 512, 512)
+for _ in range(5):
+    pillars_scatter(vf, vc, B, 512, 512, True)          # NHWC canvas (the bench configuration)
+# fused BN(+add)+ReLU at the ResNet-50 layer1 tail shape of the step (48 x 256 x 64 x 176, 554 MB per tensor)
+import torch.nn as nn
+from distill_bev_amd.bn_act import bn_act
+bn = nn.BatchNorm2d(256).to(dev).train()
+xb = torch.randn((48, 256, 64, 176), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+rb = torch.randn_like(xb).requires_grad_(True)
+for _ in range(3):
+    yb = bn_act(xb, bn, rb, True)
+    yb.backward(torch.ones_like(yb))
+    xb.grad = None; rb.grad = None; bn.zero_grad(set_to_none=True)
 S = torch.randn((B, 384, 128, 128), device=dev); T = torch.randn((B, 384, 128, 128), device=dev)
 w = torch.rand((B, 1, 128, 128), device=dev)
 for _ in range(5):
