@@ -130,6 +130,7 @@ class DistillStep(_Base):
     N_POINTS = 240000
     # dominant hand-written kernel timed for the roofline: teacher pillars scatter (write-bound)
     ROOF_KERNEL = "dbev_pillars_canvas"
+    EXTRA_INSTRUMENTED_STEPS = 3
     TIMED = ("dbev_pillars_canvas", "dbev_pillar_vfe_canvas", "dbev_lift_splat_prepare_cam", "dbev_lift_splat_forward",
              "dbev_lift_splat_backward", "dbev_abs_mean_maps", "dbev_abs_mean_maps_nhwc", "dbev_fgd_masked_mse_forward",
              "dbev_fgd_masked_mse_forward_nhwc", "dbev_fgd_masked_mse_backward", "dbev_fgd_masked_mse_backward_nhwc",
@@ -158,17 +159,23 @@ class DistillStep(_Base):
         self.steps_timed = getattr(self, "steps_timed", 0) + 1
 
     def begin_timed(self):
-        self.steps_timed = 0
-        for k in self.TIMED:
-            L.enable_timing(k)
+        # inside the timed region only the roofline kernel carries an event pair per launch; the other entry
+        # points (7000+ calls per 20 steps) are instrumented in EXTRA steps after it (roofline())
+        L.enable_timing(self.ROOF_KERNEL)
 
     def roofline(self):
+        ms = L.timing_ms(self.ROOF_KERNEL)
+        L.disable_timing()
+        if not ms:
+            return None
+        for k in self.TIMED:                       # every rank runs these (DDP collectives stay matched)
+            L.enable_timing(k)
+        self.steps_timed = 0
+        for _ in range(self.EXTRA_INSTRUMENTED_STEPS):
+            self.step()
         t = {k: L.timing_ms(k) for k in self.TIMED}
         nbytes = {k: L.timing_bytes(k) for k in self.TIMED}
         L.disable_timing()
-        ms = t[self.ROOF_KERNEL]
-        if not ms:
-            return None
         # pillars_scatter = M(4C+16) + 4*C*512^2*B ; M ~ pillars of the batch
         C, B = 64, self.B
         M = self.n_pillars
@@ -193,6 +200,8 @@ class DistillStep(_Base):
                 "profiles/r01_pmc_WRITE_SIZE.txt (separate --pmc passes, not collected live)",
                 "avg_launch_us": avg_s * 1e6, "launches": len(ms), "algorithmic_bytes_per_launch": alg,
                 "pillars_per_launch": M,
+                "other_hot_kernels_note": "HIP-event brackets of every hand-written ABI entry point over %d extra "
+                "steps run AFTER the timed region (an entry point may launch several kernels)" % self.EXTRA_INSTRUMENTED_STEPS,
                 "other_hot_kernels": other}
 
     def cpu_baseline(self):
