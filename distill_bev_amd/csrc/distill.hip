@@ -151,14 +151,23 @@ __global__ __launch_bounds__(256) void abs_mean_pix_final(const float* __restric
   pix[static_cast<size_t>(b) * HW + p] = s / static_cast<float>(C);
 }
 
+// 32 channels x 8 tile phases per workgroup (the NHWC path has 256 row tiles per sample: one thread per channel
+// walking them serially was a 30 us latency chain); fixed summation order.  grid (ceil(C/32), B)
 __global__ __launch_bounds__(256) void abs_mean_ch_final(const float* __restrict__ chpart, int C, int HW,
                                                          int ntile, float* __restrict__ ch) {
+  __shared__ float red[8][32];
   const int b = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int cl = threadIdx.x & 31, ph = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int t = 0; t < ntile; ++t) s += chpart[(static_cast<size_t>(b) * ntile + t) * C + c];
-  ch[b * C + c] = s / static_cast<float>(HW);
+  if (c < C)
+    for (int t = ph; t < ntile; t += 8) s += chpart[(static_cast<size_t>(b) * ntile + t) * C + c];
+  red[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && c < C) {
+    for (int p = 1; p < 8; ++p) s += red[p][cl];
+    ch[b * C + c] = s / static_cast<float>(HW);
+  }
 }
 
 // ---- masked MSE -------------------------------------------------------------------------
@@ -419,7 +428,7 @@ extern "C" int dbev_abs_mean_maps_nhwc(const float* x_nhwc, int B, int C, int HW
   float* chpart = static_cast<float*>(workspace);
   DBEV_NQ_DISPATCH((C4 + 63) / 64, abs_mean_nhwc, dim3(nbx, B), dim3(256), 0, s,
                    reinterpret_cast<const float4*>(x_nhwc), C4, HW, pix_mean, chpart);
-  hipLaunchKernelGGL(abs_mean_ch_final, dim3(dbev_ceil_div(C, 256), B), dim3(256), 0, s, chpart, C, HW, nbx, ch_mean);
+  hipLaunchKernelGGL(abs_mean_ch_final, dim3(dbev_ceil_div(C, 32), B), dim3(256), 0, s, chpart, C, HW, nbx, ch_mean);
   DBEV_LAUNCH_CHECK();
   return 0;
 }
@@ -493,7 +502,7 @@ extern "C" int dbev_abs_mean_maps(const float* x, int B, int C, int HW, float* p
   hipLaunchKernelGGL(abs_mean_kernel, dim3(ntile, nchunk, B), dim3(256), 0, s, x, C, HW, pixpart, chpart);
   hipLaunchKernelGGL(abs_mean_pix_final, dim3(dbev_ceil_div(HW, 256), B), dim3(256), 0, s, pixpart, C, HW, nchunk,
                      pix_mean);
-  hipLaunchKernelGGL(abs_mean_ch_final, dim3(dbev_ceil_div(C, 256), B), dim3(256), 0, s, chpart, C, HW, ntile,
+  hipLaunchKernelGGL(abs_mean_ch_final, dim3(dbev_ceil_div(C, 32), B), dim3(256), 0, s, chpart, C, HW, ntile,
                      ch_mean);
   DBEV_LAUNCH_CHECK();
   return 0;

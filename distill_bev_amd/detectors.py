@@ -25,6 +25,7 @@ from .registry import MODELS, build_backbone, build_detector, build_head, build_
 from .voxel import Voxelization
 
 # make every registered component importable through this module
+from . import lss as LSS  # noqa: E402
 from . import nets, pillar_encoder, pillars, view_transformer  # noqa: F401,E402
 
 MODELS.register_module(name="PointPillarsScatter", module=pillars.PointPillarsScatter)
@@ -315,7 +316,7 @@ class BEVDepth4DDistill(CenterPoint):
         c02l0[:, :, :3, :3] = rots[0]; c02l0[:, :, :3, 3] = trans[0]; c02l0[:, :, 3, 3] = 1
         c12l0 = torch.zeros((n, v, 4, 4), dtype=dt, device=dev)
         c12l0[:, :, :3, :3] = rots[1]; c12l0[:, :, :3, 3] = trans[1]; c12l0[:, :, 3, 3] = 1
-        l02l1 = c02l0.matmul(torch.inverse(c12l0))[:, 0, :, :].view(n, 1, 1, 4, 4)
+        l02l1 = c02l0.matmul(LSS.inverse_nosync(c12l0))[:, 0, :, :].view(n, 1, 1, 4, 4)
         keep = [0, 1, 3]
         l02l1 = l02l1[:, :, :, keep, :][:, :, :, :, keep]
         vt = self.img_view_transformer
@@ -324,7 +325,7 @@ class BEVDepth4DDistill(CenterPoint):
         feat2bev[0, 2] = vt.bx[0] - vt.dx[0] / 2.0; feat2bev[1, 2] = vt.bx[1] - vt.dx[1] / 2.0
         feat2bev[2, 2] = 1
         feat2bev = feat2bev.view(1, 3, 3)
-        tf = torch.inverse(feat2bev).matmul(l02l1).matmul(feat2bev)
+        tf = LSS.inverse_nosync(feat2bev).matmul(l02l1).matmul(feat2bev)
         # tf [n,1,1,3,3] @ grid [n,h,w,3,1]: written as broadcast multiply-adds (a broadcast matmul
         # becomes n*h*w tiny GEMMs -- see lss._apply3x3)
         g = grid[..., 0]

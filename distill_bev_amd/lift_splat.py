@@ -14,6 +14,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from . import lss as LSS
 
 
 class LiftSplatPrep:
@@ -68,8 +69,8 @@ def camera_params(rots, trans, intrins, post_rots, post_trans):
     """f32[B*N, 24] per camera: inverse(post_rots) (9), post_trans (3), rots @ inverse(intrins) (9), trans (3)
     -- the matrices of get_geometry (vt_mine.py:121-136), a few hundred bytes of torch work per step."""
     B, N = trans.shape[:2]
-    a = torch.inverse(post_rots).reshape(B * N, 9)
-    c = rots.matmul(torch.inverse(intrins)).reshape(B * N, 9)
+    a = LSS.inverse_nosync(post_rots).reshape(B * N, 9)
+    c = rots.matmul(LSS.inverse_nosync(intrins)).reshape(B * N, 9)
     return torch.cat([a, post_trans.reshape(B * N, 3), c, trans.reshape(B * N, 3)], dim=1).contiguous()
 
 
