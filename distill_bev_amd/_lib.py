@@ -56,7 +56,8 @@ _SIGNATURES = {
     "dbev_upsample_bilinear_ac_forward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_upsample_bilinear_ac_backward": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_dcnv2_im2col": [_p, _p, _p] + [_i] * 11 + [_p],
-    "dbev_dcnv2_col2im": [_p, _p, _p, _p, _p] + [_i] * 11 + [_p],
+    "dbev_dcnv2_col2im_workspace_bytes": [_i] * 8,
+    "dbev_dcnv2_col2im": [_p, _p, _p, _p, _p] + [_i] * 11 + [_p, _sz, _p],
     "dbev_abs_mean_maps_nhwc_workspace_bytes": [_i, _i, _i],
     "dbev_abs_mean_maps_nhwc": [_p, _i, _i, _i, _p, _p, _p, _sz, _p],
     "dbev_fgd_masked_mse_nhwc_workspace_bytes": [_i, _i, _i],
@@ -75,6 +76,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
              "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t,
              "dbev_bn_act_workspace_bytes": ctypes.c_size_t,
+             "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
 _NO_CHECK = set(_RESTYPES)

@@ -16,7 +16,7 @@
 // and channels 2K+k = mask logits; the sigmoid is fused here), cols f32[N*Ho*Wo, K*C] (k-major), i.e.
 // the NHWC image of a [N, K*C, Ho, Wo] tensor.  One lane owns 4 channels (float4) of one output pixel
 // and walks the K taps: every corner fetch / column store of a lane group is one contiguous C*4-byte row.
-#include "common.h"
+#include "prims.h"
 
 namespace {
 
@@ -217,6 +217,107 @@ __global__ __launch_bounds__(512) void dcn_col2im_gx_lds(const float4* __restric
   }
 }
 
+// ---- grad_x as a deterministic gather (C/4 a power of two in [8, 64]) ------------------------------------
+// Every (output pixel, tap) touches up to 4 input pixels.  Group those "tap corners" by input pixel with the
+// library's CSR primitive (int histogram -> scan -> fill -> per-pixel sort by corner id), then one lane group
+// per input pixel adds  coef * grad_cols[tap, :]  over its list in ascending id order: no float atomics, a fixed
+// summation order (bit-reproducible), and every grad_x element written exactly once.  The coefficient
+// mask * w_corner is recomputed from the offsets by the lane that owns the list entry (one make_tap per entry).
+// corner id e = ((row * K + k) << 2) | corner.
+size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+struct GxLayout { size_t count, start, list, sorted, scanws, sortws, total; };
+GxLayout gx_layout(long long npix, long long nent) {
+  GxLayout L;
+  size_t o = 0;
+  L.count = o;  o += align_up(sizeof(int) * npix);
+  L.start = o;  o += align_up(sizeof(int) * (npix + 1));
+  L.list = o;   o += align_up(sizeof(int) * nent);
+  L.sorted = o; o += align_up(sizeof(int) * nent);
+  L.scanws = o; o += align_up(sizeof(int) * dbev::scan_workspace_ints(npix));
+  L.sortws = o; o += align_up(sizeof(int) * dbev::segment_sort_workspace_ints(nent));
+  L.total = o;
+  return L;
+}
+
+__device__ __forceinline__ Tap tap_of(const float* __restrict__ om, const DcnDims& d, int row, int k) {
+  const int K = d.kh * d.kw;
+  const int wo = row % d.Wo;
+  const int ho = (row / d.Wo) % d.Ho;
+  const int i = k / d.kw, j = k - i * d.kw;
+  const float* omr = om + static_cast<size_t>(row) * 3 * K;
+  return make_tap(static_cast<float>(ho * d.stride - d.pad + i * d.dil) + omr[2 * k],
+                  static_cast<float>(wo * d.stride - d.pad + j * d.dil) + omr[2 * k + 1], d.H, d.W);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void dcn_corner_bin(const float* __restrict__ om, DcnDims d, int ntaps /* rows*K */,
+                                                      const int* __restrict__ start, int* __restrict__ count,
+                                                      unsigned* __restrict__ list) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntaps) return;
+  const int K = d.kh * d.kw;
+  const int row = t / K, k = t - row * K;
+  const int n = row / (d.Ho * d.Wo);
+  const Tap tp = tap_of(om, d, row, k);
+  const int base = n * d.H * d.W;
+  const int offs[4] = {tp.o1, tp.o2, tp.o3, tp.o4};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (offs[c] < 0) continue;
+    const int pix = base + offs[c];
+    if (FILL) list[start[pix] + atomicSub(&count[pix], 1) - 1] = (static_cast<unsigned>(t) << 2) | c;
+    else atomicAdd(&count[pix], 1);
+  }
+}
+
+// G = C4 lanes per input pixel, 64 / G pixels per wave.
+__global__ __launch_bounds__(256) void dcn_gx_gather(const float4* __restrict__ gcols, const float* __restrict__ om,
+                                                     const int* __restrict__ start, const unsigned* __restrict__ ents,
+                                                     float4* __restrict__ gx, DcnDims d, int npix) {
+  constexpr int DU = 8;
+  const int G = d.C4;
+  const int lane = threadIdx.x & 63;
+  const int g0 = lane & ~(G - 1), q = lane & (G - 1);
+  const int pix = static_cast<int>((static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G);
+  if (pix >= npix) return;                                  // whole groups leave together
+  const int K = d.kh * d.kw;
+  const int st = start[pix];
+  const int L = start[pix + 1] - st;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = 0; j0 < L; j0 += G) {
+    const int nb = min(G, L - j0);
+    unsigned mytap = 0u;
+    float mycoef = 0.f;
+    if (q < nb) {
+      const unsigned e = ents[st + j0 + q];
+      mytap = e >> 2;
+      const int row = static_cast<int>(mytap / K), k = static_cast<int>(mytap - static_cast<unsigned>(row) * K);
+      const Tap tp = tap_of(om, d, row, k);
+      const int c = e & 3;
+      const float w = c == 0 ? tp.w1 : (c == 1 ? tp.w2 : (c == 2 ? tp.w3 : tp.w4));
+      mycoef = sigmoidf(om[static_cast<size_t>(row) * 3 * K + 2 * K + k]) * w;
+    }
+    for (int h = 0; h < nb; h += DU) {                      // uniform inside the group
+      float4 v[DU];
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const unsigned t = __shfl(mytap, g0 | ((h + u) & (G - 1)));
+        v[u] = (h + u) < nb ? gcols[static_cast<size_t>(t) * G + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const float c = __shfl(mycoef, g0 | ((h + u) & (G - 1)));
+        if ((h + u) < nb) { acc.x = fmaf(c, v[u].x, acc.x); acc.y = fmaf(c, v[u].y, acc.y);
+                            acc.z = fmaf(c, v[u].z, acc.z); acc.w = fmaf(c, v[u].w, acc.w); }
+      }
+    }
+  }
+  gx[static_cast<size_t>(pix) * G + q] = acc;
+}
+
+bool gather_ok(int C4) { return C4 >= 8 && C4 <= 64 && (C4 & (C4 - 1)) == 0; }
+
 constexpr int DCN_LDS_BYTES = 64 * 1024;   // dynamic LDS budget of the slice kernel (3 workgroups per CU at 45 KB)
 
 bool dims_ok(int N, int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, int* G) {
@@ -253,9 +354,18 @@ extern "C" int dbev_dcnv2_im2col(const float* x_nhwc, const float* offset_mask_n
   return 0;
 }
 
+extern "C" size_t dbev_dcnv2_col2im_workspace_bytes(int N, int C, int H, int W, int Ho, int Wo, int kh, int kw) {
+  if (N <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || kw <= 0) return 0;
+  if (!gather_ok(C >> 2)) return 256;     // LDS-slice / atomic paths need no scratch
+  const long long npix = static_cast<long long>(N) * H * W, nent = static_cast<long long>(N) * Ho * Wo * kh * kw * 4;
+  if (nent > 0x3fffffffLL) return 256;
+  return gx_layout(npix, nent).total;
+}
+
 extern "C" int dbev_dcnv2_col2im(const float* grad_cols, const float* x_nhwc, const float* offset_mask_nhwc,
                                  float* grad_x_nhwc, float* grad_offset_mask_nhwc, int N, int C, int H, int W, int Ho,
-                                 int Wo, int kh, int kw, int stride, int pad, int dil, dbevStream_t stream) {
+                                 int Wo, int kh, int kw, int stride, int pad, int dil, void* workspace,
+                                 size_t workspace_bytes, dbevStream_t stream) {
   int G = 0;
   if (!dims_ok(N, C, H, W, Ho, Wo, kh, kw, stride, pad, dil, &G)) return DBEV_EINVAL;
   if (grad_cols == nullptr || x_nhwc == nullptr || offset_mask_nhwc == nullptr || grad_x_nhwc == nullptr ||
@@ -265,6 +375,34 @@ extern "C" int dbev_dcnv2_col2im(const float* grad_cols, const float* x_nhwc, co
   const int rows = N * Ho * Wo;
   const long long threads = static_cast<long long>(rows) * G;
   hipStream_t s = dbev_stream(stream);
+  const long long npix = static_cast<long long>(N) * H * W, nent = static_cast<long long>(rows) * kh * kw * 4;
+  if (gather_ok(d.C4) && nent <= 0x3fffffffLL) {
+    const GxLayout Lw = gx_layout(npix, nent);
+    if (workspace == nullptr || workspace_bytes < Lw.total) return DBEV_EINVAL;
+    char* ws = static_cast<char*>(workspace);
+    int* count = reinterpret_cast<int*>(ws + Lw.count);
+    int* start = reinterpret_cast<int*>(ws + Lw.start);
+    unsigned* list = reinterpret_cast<unsigned*>(ws + Lw.list);
+    unsigned* sorted = reinterpret_cast<unsigned*>(ws + Lw.sorted);
+    const int ntaps = rows * kh * kw;
+    hipLaunchKernelGGL((dcn_col2im_nhwc<false>), dim3(dbev_ceil_div(threads, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(grad_cols), reinterpret_cast<const float4*>(x_nhwc),
+                       offset_mask_nhwc, reinterpret_cast<float4*>(grad_x_nhwc), grad_offset_mask_nhwc, d, G, rows);
+    DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * npix, s));
+    hipLaunchKernelGGL((dcn_corner_bin<false>), dim3(dbev_ceil_div(ntaps, 256)), dim3(256), 0, s, offset_mask_nhwc, d,
+                       ntaps, start, count, list);
+    int rc = dbev::exclusive_scan_i32(count, start, npix, false, nullptr, reinterpret_cast<int*>(ws + Lw.scanws), s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((dcn_corner_bin<true>), dim3(dbev_ceil_div(ntaps, 256)), dim3(256), 0, s, offset_mask_nhwc, d,
+                       ntaps, start, count, list);
+    rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(npix), reinterpret_cast<int*>(ws + Lw.sortws), s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dcn_gx_gather, dim3(dbev_ceil_div(npix * d.C4, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(grad_cols), offset_mask_nhwc, start, sorted,
+                       reinterpret_cast<float4*>(grad_x_nhwc), d, static_cast<int>(npix));
+    DBEV_LAUNCH_CHECK();
+    return 0;
+  }
   int SC4 = 0;                                   // float4 columns per workgroup slice: largest of 4, 2, 1 that fits
   for (int c = 4; c >= 1; c >>= 1)
     if (d.C4 % c == 0 && static_cast<long long>(H) * W * c * 16 <= DCN_LDS_BYTES) { SC4 = c; break; }

@@ -46,8 +46,10 @@ class _DCNv2Columns(Function):
         gx = torch.empty_like(x)          # channels-last; zero-filled by the library
         gom = torch.empty_like(om)
         with torch.cuda.device(dev):
+            nbytes = L.call("dbev_dcnv2_col2im_workspace_bytes", N, C, H, W, Ho, Wo, kh, kw)
+            ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
             L.call("dbev_dcnv2_col2im", L.ptr(gcols), L.ptr(x), L.ptr(om), L.ptr(gx), L.ptr(gom), N, C, H, W, Ho, Wo,
-                   kh, kw, stride, padding, dilation, L.stream_ptr(dev))
+                   kh, kw, stride, padding, dilation, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
         return gx, gom, None, None, None, None, None
 
 

@@ -313,14 +313,18 @@ int dbev_upsample_bilinear_ac_backward(const float* grad_y, float* grad_x, int B
  *                                             channels 2K+k = mask logits (sigmoid fused in the kernel)
  *   cols              f32[N*Ho*Wo, kh*kw*C]   sigmoid(logit_k) * bilinear(x, p_k), k-major: the NHWC image of
  *                                             [N, K*C, Ho, Wo]; contract with weight[Co, kh, kw, C] (1x1 conv / GEMM)
- * col2im: grad_x_nhwc is zero-filled by the callee and accumulated with float atomics (as in mmcv);
+ * col2im: every grad_x_nhwc element is written by the callee.  C/4 a power of two in [8, 64]: deterministic gather over a
+ * per-input-pixel list of tap corners (no float atomics, fixed summation order; needs the workspace); other channel
+ * counts: per-(image, channel slice) LDS accumulation, or global float atomics (as in mmcv) for images that do not fit.
  * grad_offset_mask_nhwc has the layout of offset_mask_nhwc (d/d logit includes the sigmoid derivative).
  * Returns DBEV_EINVAL if Ho/Wo do not match the convolution arithmetic. */
 int dbev_dcnv2_im2col(const float* x_nhwc, const float* offset_mask_nhwc, float* cols, int N, int C, int H, int W,
                       int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, dbevStream_t stream);
+size_t dbev_dcnv2_col2im_workspace_bytes(int N, int C, int H, int W, int Ho, int Wo, int kh, int kw);
 int dbev_dcnv2_col2im(const float* grad_cols, const float* x_nhwc, const float* offset_mask_nhwc,
                       float* grad_x_nhwc, float* grad_offset_mask_nhwc, int N, int C, int H, int W, int Ho, int Wo,
-                      int kh, int kw, int stride, int pad, int dil, dbevStream_t stream);
+                      int kh, int kw, int stride, int pad, int dil, void* workspace, size_t workspace_bytes,
+                      dbevStream_t stream);
 
 /* Training-mode BatchNorm2d fused with the residual add and ReLU that follow it (channels-last fp32):
  *   y = relu( (x - mean_batch) / sqrt(var_batch + eps) * gamma + beta  [+ residual] )

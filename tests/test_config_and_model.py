@@ -192,3 +192,34 @@ def test_dcnv2_restatement_against_naive_loops():
     # zero offsets + mask 1 == ordinary convolution
     out0 = modulated_deform_conv2d(x, torch.zeros_like(off), torch.ones_like(mask), wgt, bias, 1, 1, 1)
     assert torch.allclose(out0, torch.nn.functional.conv2d(x, wgt, bias, padding=1), atol=1e-10)
+
+
+def test_norm_act_module_surgery_is_parameter_preserving_and_falls_back_on_cpu():
+    """bn_act.fuse_bn_relu_modules / train_step.accelerate_modules: no state-dict key changes, idempotent, and on CPU
+    tensors (no HIP kernels) the rewired modules compute exactly what the original module sequence did."""
+    import torch.nn as nn
+    from distill_bev_amd import bn_act as BA
+    from distill_bev_amd.nets import SECOND, ResNet
+    from distill_bev_amd.registry import ConvModule
+    torch.manual_seed(0)
+    net = nn.ModuleDict({
+        "second": SECOND(in_channels=8, out_channels=[8, 16], layer_nums=[1, 1], layer_strides=[2, 2]),
+        "cm": ConvModule(8, 8, 3, padding=1, norm_cfg=dict(type="BN"), act_cfg=dict(type="ReLU")),
+        "res": ResNet(depth=18, out_indices=(3,), norm_eval=False),
+        "keep": nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4), nn.Sigmoid()),       # BN not followed by ReLU
+    }).train()
+    keys = list(net.state_dict().keys())
+    x8, x3 = torch.randn(2, 8, 16, 16), torch.randn(2, 3, 32, 32)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    ref = (net["second"](x8), net["cm"](x8), net["res"](x3), net["keep"](x3))
+    n = BA.fuse_bn_relu_modules(net)
+    assert n == 2 * 2 + 1                                   # two (conv, BN, ReLU) triples per SECOND stage + ConvModule
+    assert BA.fuse_bn_relu_modules(net) == 0
+    assert list(net.state_dict().keys()) == keys
+    assert type(net["keep"][1]) is nn.BatchNorm2d
+    net.load_state_dict(sd)                                 # reset running statistics
+    out = (net["second"](x8), net["cm"](x8), net["res"](x3), net["keep"](x3))
+    for a, b in zip(ref, out):
+        for u, v in zip(a if isinstance(a, (tuple, list)) else [a], b if isinstance(b, (tuple, list)) else [b]):
+            assert torch.equal(u, v)
+    assert not BA.eligible(x8, net["cm"].norm)              # CPU tensor -> stock torch ops
