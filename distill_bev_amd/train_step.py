@@ -101,6 +101,55 @@ def accelerate_modules(detector):
     return n_bn, n_up
 
 
+class GradReducer:
+    """Data-parallel gradient averaging for the one collective of the step: the student's 54 M fp32
+    gradients (217 MB) in ~64 MB buckets.  Each bucket is packed with ONE concat kernel, pre-divided by the world
+    size, all-reduced asynchronously (RCCL ring over xGMI on the GPU, gloo in the CPU tests) and unpacked with one
+    multi-tensor copy; the buckets' collectives are in flight together.
+
+    Why not torch's DistributedDataParallel (kept behind DBEV_TORCH_DDP=1): on MI355X its reducer costs 10 ms per
+    step at this model size (per-parameter autograd hooks, 330 grad->bucket copies and divisions: measured 188 vs
+    178 ms at one rank) to hide a collective that takes ~1.5-3 ms on 8 GPUs of one node -- the exposed all-reduce
+    is cheaper than the machinery that overlaps it.  Semantics are DDP's: parameters (and buffers, once) are
+    broadcast from rank 0 at construction, every rank ends the step with identical averaged gradients, BatchNorm
+    statistics stay local, and a parameter without a gradient on any rank is an error (find_unused_parameters=False).
+    """
+
+    def __init__(self, params, buffers=(), bucket_mb=64):
+        self.params = list(params)
+        self.world = dist.get_world_size()
+        with torch.no_grad():
+            for t in list(self.params) + list(buffers):
+                dist.broadcast(t.data, 0)
+        cap = int(bucket_mb) * (1 << 20)
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):            # gradients become ready roughly in reverse parameter order
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= cap:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+
+    @torch.no_grad()
+    def all_reduce_grads(self):
+        pending = []
+        for bucket in self.buckets:
+            grads = []
+            for p in bucket:
+                if p.grad is None:
+                    raise RuntimeError("GradReducer: a parameter received no gradient on this rank "
+                                       "(all ranks must reduce the same set; find_unused_parameters is not supported)")
+                grads.append(p.grad)
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            flat.div_(self.world)
+            pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, grads))
+        for work, flat, grads in pending:
+            work.wait()
+            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+
 class Trainer:
     def __init__(self, model, cfg, device, world_size=1, channels_last=False):
         self.device = device
@@ -113,7 +162,14 @@ class Trainer:
             self.fused_bn_relu, self.swapped_upsample = accelerate_modules(self.detector)
         self.wrapper = _TrainWrapper(self.detector)
         self.world_size = world_size
-        if world_size > 1 or os.environ.get("DBEV_FORCE_DDP") == "1":
+        self.reducer = None
+        distributed = world_size > 1 or os.environ.get("DBEV_FORCE_DDP") == "1"
+        if distributed and os.environ.get("DBEV_TORCH_DDP") != "1":
+            # default data-parallel path: bucketed flat gradient all-reduce right after backward (GradReducer)
+            self.module = self.wrapper
+            self.reducer = GradReducer([p for p in self.detector.parameters() if p.requires_grad],
+                                       list(self.detector.buffers()), bucket_mb=64)
+        elif distributed:
             self.module = nn.parallel.DistributedDataParallel(
                 self.wrapper, device_ids=[device.index] if device.type == "cuda" else None, broadcast_buffers=False,
                 find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
@@ -137,6 +193,8 @@ class Trainer:
         loss = parse_losses(losses)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self.reducer is not None:
+            self.reducer.all_reduce_grads()
         if self.grad_clip:
             nn.utils.clip_grad_norm_(self.params, **self.grad_clip)
         self.optimizer.step()

@@ -1,4 +1,5 @@
-"""CPU, world_size 2, gloo: the data-parallel path of the training step (Trainer + DDP wrapper):
+"""CPU, world_size 2, gloo: the data-parallel path of the training step (Trainer + GradReducer, and the
+torch DistributedDataParallel alternative behind DBEV_TORCH_DDP=1):
 samples are sharded across ranks, the only collective is the gradient all-reduce, the hidden
 teacher is neither broadcast nor reduced, and N ranks x B samples == one process x N*B samples."""
 import os
@@ -41,12 +42,19 @@ def _data(n):
     return torch.randn((n, 6), generator=g), torch.randn((n, 3), generator=g)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, torch_ddp=False, desync=False):
+    os.environ["DBEV_TORCH_DDP"] = "1" if torch_ddp else "0"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     x, y = _data(8 * world)
-    tr = Trainer(ToyDetector(), CFG, torch.device("cpu"), world_size=world)
+    det = ToyDetector()
+    if desync and rank == 1:                           # ranks start from different weights: rank 0's must win
+        with torch.no_grad():
+            for p in det.net.parameters():
+                p.add_(1.0)
+    tr = Trainer(det, CFG, torch.device("cpu"), world_size=world)
+    assert (tr.reducer is None) == torch_ddp
     shard = slice(rank * 8, (rank + 1) * 8)            # contiguous per-rank slices (samplers/distributed_sampler.py:35-39)
     for _ in range(3):
         loss, losses = tr.step(dict(x=x[shard], y=y[shard]))
@@ -59,10 +67,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_step_equals_single_process_big_batch(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("torch_ddp,desync", [(False, False), (False, True), (True, False)])
+def test_two_rank_gloo_step_equals_single_process_big_batch(tmp_path, torch_ddp, desync):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "ddp.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, torch_ddp, desync), nprocs=2, join=True)
     res = torch.load(out)
     assert torch.equal(res["params"][0], res["params"][1])          # ranks stay in lock step
     assert res["nparams"] == 4                                       # teacher parameters are not trained / reduced
