@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, co
         o.z = fmaf(v[u].z, sc.z, sh.z); o.w = fmaf(v[u].w, sc.w, sh.w);
         if (RES) add4(o, w[u]);
         if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        y[static_cast<size_t>(r) * g.C4 + q] = o;
+        st_nt(y + static_cast<size_t>(r) * g.C4 + q, o);
       }
     }
   }
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, 
         d.y = fmaf(A.y, dz.y, fmaf(Bc.y, v[u].y, Cc.y));
         d.z = fmaf(A.z, dz.z, fmaf(Bc.z, v[u].z, Cc.z));
         d.w = fmaf(A.w, dz.w, fmaf(Bc.w, v[u].w, Cc.w));
-        dx[static_cast<size_t>(r) * g.C4 + q] = d;
-        if (DRES) dres[static_cast<size_t>(r) * g.C4 + q] = dz;
+        st_nt(dx + static_cast<size_t>(r) * g.C4 + q, d);
+        if (DRES) st_nt(dres + static_cast<size_t>(r) * g.C4 + q, dz);
       }
     }
   }

@@ -37,3 +37,11 @@ static inline int dbev_round_xcd(int blocks) { return (blocks + DBEV_NUM_XCD - 1
 __device__ __forceinline__ int xcd_block() {
   return (blockIdx.x % DBEV_NUM_XCD) * (gridDim.x / DBEV_NUM_XCD) + blockIdx.x / DBEV_NUM_XCD;
 }
+
+// streaming 16-byte store (global_store_dwordx4 ... nt): output that is written once and not re-read by this
+// kernel should not displace the L2 lines the gathers need; measured +7 % on the canvas write.
+__device__ __forceinline__ void st_nt(float4* p, const float4& v) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_nhwc(const float4* __restrict_
       r.y = m * (tp.w1 * v1.y + tp.w2 * v2.y + tp.w3 * v3.y + tp.w4 * v4.y);
       r.z = m * (tp.w1 * v1.z + tp.w2 * v2.z + tp.w3 * v3.z + tp.w4 * v4.z);
       r.w = m * (tp.w1 * v1.w + tp.w2 * v2.w + tp.w3 * v3.w + tp.w4 * v4.w);
-      out[static_cast<size_t>(k) * d.C4 + q] = r;
+      st_nt(out + static_cast<size_t>(k) * d.C4 + q, r);
     }
   }
 }

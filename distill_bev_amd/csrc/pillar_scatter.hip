@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void ps_canvas_nhwc_vec(const float4* __restri
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long i = i0 + u * stride;
-      if (i < total4) canvas[i] = r[u];
+      if (i < total4) st_nt(canvas + i, r[u]);
     }
   }
 }
