@@ -46,44 +46,6 @@ LsLayout ls_layout(long long np, long long ncell) {
   return L;
 }
 
-// vt_mine.py:150-160.  cell = ((b*Y + y)*X + x)*Z + z  (channels-last order of [B, Z*C, Y, X])
-__global__ __launch_bounds__(256) void ls_cell_count(const float* __restrict__ geom, int np,
-                                                     int pts_per_batch, GridParams G,
-                                                     int* __restrict__ point_cell,
-                                                     int* __restrict__ count) {
-#pragma clang fp contract(off)
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= np) return;
-  const float* g = geom + static_cast<size_t>(p) * 3;
-  int idx[3];
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float q = (g[k] - G.lo[k]) / G.dx[k];
-    const float t = truncf(q);                     // .long(): toward zero
-    ok = ok && (t >= 0.f) && (t < static_cast<float>(G.nx[k]));  // NaN -> dropped
-    idx[k] = static_cast<int>(t);
-  }
-  int lin = -1;
-  if (ok) {
-    const int b = p / pts_per_batch;
-    lin = ((b * G.nx[1] + idx[1]) * G.nx[0] + idx[0]) * G.nx[2] + idx[2];
-    atomicAdd(&count[lin], 1);
-  }
-  point_cell[p] = lin;
-}
-
-__global__ __launch_bounds__(256) void ls_fill(const int* __restrict__ point_cell, int np,
-                                               const int* __restrict__ cell_start,
-                                               int* __restrict__ count, unsigned* __restrict__ list) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= np) return;
-  const int c = point_cell[p];
-  if (c < 0) return;
-  const int pos = atomicSub(&count[c], 1) - 1;
-  list[cell_start[c] + pos] = static_cast<unsigned>(p);
-}
-
 // ---- block-aggregated histogram / fill --------------------------------------------------------
 // Neighbouring frustum points (same camera, same depth bin, adjacent pixels) mostly share a BEV cell:
 // 1024 consecutive points of a near depth bin land in ~20-300 distinct cells.  Each workgroup therefore
