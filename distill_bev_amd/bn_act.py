@@ -55,6 +55,8 @@ def eligible(x, bn, residual=None):
         return False
     use_batch_stats = bn.training or bn.running_mean is None
     if use_batch_stats:
+        if x.numel() // x.shape[1] <= 1:      # torch raises "Expected more than 1 value per channel": keep that
+            return False
         return bn.momentum is not None or bn.running_mean is None
     return not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad
                                              or (residual is not None and residual.requires_grad)))

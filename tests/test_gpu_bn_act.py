@@ -143,3 +143,23 @@ def test_module_surgery_keeps_state_dict_and_matches_unfused_model():
     assert abs(float(loss) - float(loss_u)) < 1e-4 * abs(float(loss_u))
     gu = net.conv1.weight.grad
     assert float((gf - gu).norm() / gu.norm()) < 5e-3      # 53 BN layers of fp32 round-off, random init
+
+
+def test_edge_cases_single_value_per_channel_and_tiny_tensors():
+    from distill_bev_amd import bn_act as BA
+    bn = nn.BatchNorm2d(8).to(DEV).train()
+    x1 = torch.randn((1, 8, 1, 1), device=DEV).contiguous(memory_format=torch.channels_last)
+    assert not BA.eligible(x1, bn)
+    with pytest.raises(ValueError):                       # the reference module's own error, not a kernel result
+        BA.bn_act(x1, bn, None, True)
+    # two values per channel: smallest legal training batch; unbiased running_var = 2 * biased
+    x2 = torch.tensor([[1.0], [3.0]], device=DEV).view(2, 1, 1, 1).repeat(1, 8, 1, 1).contiguous(memory_format=torch.channels_last)
+    assert BA.eligible(x2, bn)
+    y = BA.bn_act(x2, bn, None, False)
+    ref = nn.BatchNorm2d(8).to(DEV).train()
+    assert torch.allclose(y, ref(x2), atol=1e-6)
+    assert torch.allclose(bn.running_var, ref.running_var, atol=1e-7) and torch.allclose(bn.running_mean, ref.running_mean)
+    # rows not a multiple of the row phases / unroll, C/4 = 1..512 already covered above; odd M here
+    bn3 = nn.BatchNorm2d(64).to(DEV).train(); ref3 = nn.BatchNorm2d(64).to(DEV).train()
+    x3 = torch.randn((1, 64, 7, 13), device=DEV).contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(BA.bn_act(x3, bn3, None, True), torch.relu(ref3(x3)), atol=2e-6)
