@@ -63,6 +63,7 @@ _SIGNATURES = {
     "dbev_fgd_masked_mse_nhwc_workspace_bytes": [_i, _i, _i],
     "dbev_fgd_masked_mse_forward_nhwc": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "dbev_fgd_masked_mse_backward_nhwc": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "dbev_centerhead_targets": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p, _p, _sz, _p],
     "dbev_bn_act_workspace_bytes": [_ll, _i],
     "dbev_bn_act_train_forward": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],

@@ -3,10 +3,9 @@
 (GaussianFocalLoss, L1Loss, MSELoss; un-vendored, standard definitions) and the target
 assignment of ``get_targets_single`` :447-611 / ``core/utils/gaussian.py`` :6-88.
 
-The dense head stays PyTorch (MIOpen convs).  Target assignment is host work in the reference too
-(a python loop over the GT boxes issuing hundreds of tiny device ops per sample, plus ``.item()``
-syncs); here it is plain numpy on the host boxes (the GT boxes are host data) followed by ONE
-upload of the stacked targets per step.
+The dense head stays PyTorch (MIOpen convs).  Target assignment (in the reference a python loop over the GT
+boxes issuing hundreds of tiny device ops per sample, plus ``.item()`` syncs) is ONE library call for all
+tasks and samples (``dbev_centerhead_targets``, csrc/center_targets.hip) after two uploads (boxes, labels).
 """
 import copy
 
@@ -149,48 +148,6 @@ class SeparateHead(nn.Module):
         return {head: getattr(self, head)(x) for head in self.heads}
 
 
-def gaussian_radius(det_size, min_overlap=0.5):
-    """core/utils/gaussian.py:58-88 in float32 (the reference evaluates it on 0-dim float32 tensors)."""
-    f = np.float32
-    height, width = f(det_size[0]), f(det_size[1])
-    mo = f(min_overlap)
-    b1 = height + width
-    c1 = width * height * (f(1) - mo) / (f(1) + mo)
-    r1 = (b1 + np.sqrt(b1 * b1 - f(4) * c1)) / f(2)
-    b2 = f(2) * (height + width)
-    c2 = (f(1) - mo) * width * height
-    r2 = (b2 + np.sqrt(b2 * b2 - f(16) * c2)) / f(2)
-    a3 = f(4) * mo
-    b3 = f(-2) * mo * (height + width)
-    c3 = (mo - f(1)) * width * height
-    r3 = (b3 + np.sqrt(b3 * b3 - f(4) * a3 * c3)) / f(2)
-    return min(r1, r2, r3)
-
-
-def gaussian_2d(shape, sigma=1.0):
-    """gaussian.py:6-22."""
-    m, n = [(ss - 1.0) / 2.0 for ss in shape]
-    y, x = np.ogrid[-m:m + 1, -n:n + 1]
-    h = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
-    h[h < np.finfo(h.dtype).eps * h.max()] = 0
-    return h
-
-
-def draw_heatmap_gaussian(heatmap, center, radius, k=1):
-    """gaussian.py:25-55 on a numpy heatmap [H, W] (in place)."""
-    diameter = 2 * radius + 1
-    g = gaussian_2d((diameter, diameter), sigma=diameter / 6)
-    x, y = int(center[0]), int(center[1])
-    height, width = heatmap.shape[:2]
-    left, right = min(x, radius), min(width - x, radius + 1)
-    top, bottom = min(y, radius), min(height - y, radius + 1)
-    mh = heatmap[y - top:y + bottom, x - left:x + right]
-    mg = g[radius - top:radius + bottom, radius - left:radius + right].astype(np.float32)
-    if min(mg.shape) > 0 and min(mh.shape) > 0:
-        np.maximum(mh, mg * k, out=mh)
-    return heatmap
-
-
 @MODELS.register_module()
 class CenterHead(nn.Module):
     def __init__(self, in_channels=[128], tasks=None, train_cfg=None, test_cfg=None, bbox_coder=None,
@@ -228,66 +185,47 @@ class CenterHead(nn.Module):
         per_level = [self.forward_single(f) for f in feats]
         return tuple([lvl[t] for lvl in per_level] for t in range(len(self.task_heads)))
 
-    # ---- targets (host, numpy) ------------------------------------------------------------
-    def get_targets_single_np(self, boxes9, labels):
-        """centerpoint_head.py:447-611 for one sample.  boxes9 f32[M, 9] with GRAVITY centre
-        (x, y, z_c, w, l, h, yaw, vx, vy); labels int[M]."""
+    # ---- targets -------------------------------------------------------------------------
+    def get_targets_device(self, gt_bboxes_3d, gt_labels_3d, device):
+        """:366-413 on the GPU: two uploads (boxes, labels), one library call (dbev_centerhead_targets) for all
+        tasks and samples; returns the same per-task lists as the host path (views of the packed outputs)."""
+        from . import _lib as L
         cfg = self.train_cfg
-        f = np.float32
+        B, T = len(gt_bboxes_3d), len(self.task_heads)
+        b9, labs, starts = [], [], [0]
+        for boxes, labels in zip(gt_bboxes_3d, gt_labels_3d):
+            t9 = torch.cat((boxes.gravity_center, boxes.tensor[:, 3:]), dim=1).float()
+            b9.append(t9.cpu()); labs.append(torch.as_tensor(labels).to(torch.int32).cpu())
+            starts.append(starts[-1] + t9.shape[0])
+        boxes_d = torch.cat(b9).contiguous().to(device) if starts[-1] else torch.zeros((1, 9), device=device)
+        labels_d = torch.cat(labs).contiguous().to(device) if starts[-1] else torch.zeros((1,), dtype=torch.int32, device=device)
         max_objs = cfg["max_objs"] * cfg["dense_reg"]
         osf = cfg["out_size_factor"]
-        grid = np.asarray(cfg["grid_size"])
-        pc = np.asarray(cfg["point_cloud_range"], dtype=f)
-        vs = np.asarray(cfg["voxel_size"], dtype=f)
-        fm = grid[:2] // osf            # (W, H)
-        heatmaps, anno_boxes, inds, masks = [], [], [], []
-        flag = 0
-        for names in self.class_names:
-            ncls = len(names)
-            sel = [np.flatnonzero(labels == (j + flag)) for j in range(ncls)]
-            order = np.concatenate(sel) if sel else np.zeros((0,), np.int64)
-            tb = boxes9[order]
-            tc = (labels[order] + 1 - flag).astype(np.int64)
-            flag += ncls
-            hm = np.zeros((ncls, int(fm[1]), int(fm[0])), dtype=f)
-            ab = np.zeros((max_objs, 10), dtype=f)
-            ind = np.zeros((max_objs,), dtype=np.int64)
-            mk = np.zeros((max_objs,), dtype=np.uint8)
-            for k in range(min(tb.shape[0], max_objs)):
-                cls_id = int(tc[k]) - 1
-                width = f(tb[k, 3] / vs[0] / f(osf))
-                length = f(tb[k, 4] / vs[1] / f(osf))
-                if not (width > 0 and length > 0):
-                    continue
-                radius = gaussian_radius((length, width), min_overlap=cfg["gaussian_overlap"])
-                radius = max(cfg["min_radius"], int(radius))
-                cx = f(f(tb[k, 0] - pc[0]) / vs[0] / f(osf))
-                cy = f(f(tb[k, 1] - pc[1]) / vs[1] / f(osf))
-                ix, iy = int(np.trunc(cx)), int(np.trunc(cy))
-                if not (0 <= ix < fm[0] and 0 <= iy < fm[1]):
-                    continue
-                draw_heatmap_gaussian(hm[cls_id], (ix, iy), radius)
-                ind[k] = iy * int(fm[0]) + ix
-                mk[k] = 1
-                dim = np.log(tb[k, 3:6]) if self.norm_bbox else tb[k, 3:6]
-                ab[k] = np.concatenate([[cx - f(ix), cy - f(iy)], [tb[k, 2]], dim,
-                                        [np.sin(tb[k, 6]), np.cos(tb[k, 6])], tb[k, 7:9]]).astype(f)
-            heatmaps.append(hm); anno_boxes.append(ab); inds.append(ind); masks.append(mk)
-        return heatmaps, anno_boxes, inds, masks
+        W, H = int(cfg["grid_size"][0]) // osf, int(cfg["grid_size"][1]) // osf
+        ncls = [len(n) for n in self.class_names]
+        hm = torch.empty((B, sum(ncls), H, W), dtype=torch.float32, device=device)
+        ab = torch.empty((T, B, max_objs, 10), dtype=torch.float32, device=device)
+        ind = torch.empty((T, B, max_objs), dtype=torch.int64, device=device)
+        mk = torch.empty((T, B, max_objs), dtype=torch.uint8, device=device)
+        ws = torch.empty((16 * max(starts[-1], 1),), dtype=torch.uint8, device=device)
+        pc, vs = cfg["point_cloud_range"], cfg["voxel_size"]
+        with torch.cuda.device(device):
+            L.call("dbev_centerhead_targets", L.ptr(boxes_d), L.ptr(labels_d), L.host_ints(starts), B, L.host_ints(ncls), T,
+                   H, W, max_objs, int(cfg["min_radius"]), float(cfg["gaussian_overlap"]), float(pc[0]), float(pc[1]),
+                   float(vs[0]), float(vs[1]), int(osf), 1 if self.norm_bbox else 0, L.ptr(hm), L.ptr(ab), L.ptr(ind),
+                   L.ptr(mk), L.ptr(ws), ws.numel(), L.stream_ptr(device))
+        edges = np.cumsum([0] + ncls)
+        return ([hm[:, edges[t]:edges[t + 1]] for t in range(T)], [ab[t] for t in range(T)],
+                [ind[t] for t in range(T)], [mk[t] for t in range(T)])
 
     def get_targets(self, gt_bboxes_3d, gt_labels_3d, device):
-        """:366-413 -> per task stacked tensors on `device` (one upload per tensor kind)."""
-        per_sample = []
-        for boxes, labels in zip(gt_bboxes_3d, gt_labels_3d):
-            b9 = torch.cat((boxes.gravity_center, boxes.tensor[:, 3:]), dim=1).numpy().astype(np.float32)
-            lab = labels.cpu().numpy() if torch.is_tensor(labels) else np.asarray(labels)
-            per_sample.append(self.get_targets_single_np(b9, lab))
-        nt = len(self.task_heads)
-        out = []
-        for kind in range(4):
-            out.append([torch.from_numpy(np.stack([s[kind][t] for s in per_sample])).to(device)
-                        for t in range(nt)])
-        return tuple(out)
+        """:366-413 -> per task lists (heatmaps, anno_boxes, inds, masks) on `device`.  GPU only: the host restatement
+        the kernels are tested against lives in oracle/center_targets.py (test infrastructure)."""
+        if torch.device(device).type != "cuda":
+            from ._lib import DbevHipError
+            raise DbevHipError("CenterHead.get_targets runs on the HIP kernels (dbev_centerhead_targets) and needs a "
+                               "GPU device; there is no CPU fallback in the product path")
+        return self.get_targets_device(gt_bboxes_3d, gt_labels_3d, device)
 
     @staticmethod
     def _gather_feat(feat, ind):

@@ -326,6 +326,24 @@ int dbev_dcnv2_col2im(const float* grad_cols, const float* x_nhwc, const float* 
                       int kh, int kw, int stride, int pad, int dil, void* workspace, size_t workspace_bytes,
                       dbevStream_t stream);
 
+/* CenterHead training targets for all tasks of a batch in two launches.  Replaces CenterHead.get_targets /
+ * get_targets_single (mmdet3d/models/dense_heads/centerpoint_head.py:366-413,447-611) and draw_heatmap_gaussian /
+ * gaussian_radius (mmdet3d/core/utils/gaussian.py:6-88).
+ *   boxes9 f32[sumM,9] (x, y, z GRAVITY centre, w, l, h, yaw, vx, vy), labels i32[sumM] (global class ids, -1 ignored),
+ *   box_start_host i32[B+1] (HOST; boxes of sample b = [box_start[b], box_start[b+1]), <= 1024 per sample),
+ *   task_num_classes_host i32[num_tasks] (HOST): task t owns the next task_num_classes[t] global class ids.
+ * -> heatmap f32[B, sum(classes), H, W] (task t = channel slice), anno_box f32[T,B,max_objs,10] = (dx, dy, z, log w|l|h
+ *    (dims themselves if !norm_bbox), sin yaw, cos yaw, vx, vy), ind i64[T,B,max_objs] = iy*W+ix, mask u8[T,B,max_objs];
+ *    all four fully written by the callee.  A box takes slot k = its rank among the sample's boxes of the same task in
+ *    (class, index) order; boxes with k >= max_objs, non-positive size or a centre outside the map draw nothing.
+ * workspace >= 16 * max(sumM, 1) bytes. */
+int dbev_centerhead_targets(const float* boxes9, const int32_t* labels, const int32_t* box_start_host, int B,
+                            const int32_t* task_num_classes_host, int num_tasks, int H, int W, int max_objs,
+                            int min_radius, float gaussian_overlap, float pc_x, float pc_y, float voxel_x,
+                            float voxel_y, int out_size_factor, int norm_bbox, float* heatmap, float* anno_box,
+                            long long* ind, unsigned char* mask, void* workspace, size_t workspace_bytes,
+                            dbevStream_t stream);
+
 /* Training-mode BatchNorm2d fused with the residual add and ReLU that follow it (channels-last fp32):
  *   y = relu( (x - mean_batch) / sqrt(var_batch + eps) * gamma + beta  [+ residual] )
  * = torch.nn.functional.batch_norm(training=True) [+ add] [+ relu] as the reference's dense blocks chain them

