@@ -64,6 +64,9 @@ _SIGNATURES = {
     "dbev_fgd_masked_mse_forward_nhwc": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "dbev_fgd_masked_mse_backward_nhwc": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dbev_centerhead_targets": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p, _p, _sz, _p],
+    "dbev_centerhead_loss_workspace_bytes": [_i, _i, _i, _i, _i],
+    "dbev_centerhead_loss_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _sz, _p],
+    "dbev_centerhead_loss_backward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p],
     "dbev_bn_act_workspace_bytes": [_ll, _i],
     "dbev_bn_act_train_forward": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],
@@ -77,6 +80,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
              "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t,
              "dbev_bn_act_workspace_bytes": ctypes.c_size_t,
+             "dbev_centerhead_loss_workspace_bytes": ctypes.c_size_t,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
@@ -155,6 +159,11 @@ def call(name, *args, alg_bytes=0):
         return rc
     check(rc, name)
     return 0
+
+
+def host_ptrs(tensors):
+    """HOST array of device pointers (argument tables of the multi-tensor entry points)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 def host_ints(values):

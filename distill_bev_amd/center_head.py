@@ -148,6 +148,76 @@ class SeparateHead(nn.Module):
         return {head: getattr(self, head)(x) for head in self.heads}
 
 
+
+_HEAD_ORDER = ("reg", "height", "dim", "rot", "vel", "heatmap")
+
+
+def _nhwc_flag(t):
+    """1 if the tensor is physically NHWC (and not also NCHW-contiguous); raises if it is neither."""
+    if t.is_contiguous():
+        return 0
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return 1
+    raise ValueError("head output must be NCHW- or channels-last-contiguous")
+
+
+class _CenterHeadLoss(torch.autograd.Function):
+    """All tasks' heat-map focal losses and task-specific L1 terms on the HIP kernels (csrc/center_loss.hip).
+    forward(targets..., *36 head tensors) -> (losses f32[T, 6], clipped-sigmoid heat map per task)."""
+
+    @staticmethod
+    def forward(ctx, hm, anno, ind, mask, ncls, code_w, lw_bbox, lw_cls, *heads):
+        from . import _lib as L
+        T = len(ncls)
+        dev = heads[0].device
+        heads = [h if (h.is_contiguous() or h.is_contiguous(memory_format=torch.channels_last)) else h.contiguous()
+                 for h in heads]
+        flags = [_nhwc_flag(h) for h in heads]
+        B, _, H, W = heads[5].shape
+        sig = [torch.empty_like(heads[t * 6 + 5]) for t in range(T)]
+        losses = torch.empty((T, 6), dtype=torch.float32, device=dev)
+        avg = torch.empty((2 * T,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nbytes = L.call("dbev_centerhead_loss_workspace_bytes", B, int(sum(ncls)), T, H, W)
+            ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=dev)
+            L.call("dbev_centerhead_loss_forward", L.host_ptrs(heads), L.host_ints(flags), L.host_ptrs(sig),
+                   L.host_ints(ncls), T, B, H, W, anno.shape[2], L.ptr(hm), L.ptr(anno), L.ptr(ind), L.ptr(mask),
+                   L.host_floats(code_w), float(lw_bbox), float(lw_cls), L.ptr(losses), L.ptr(avg), L.ptr(ws),
+                   ws.numel(), L.stream_ptr(dev))
+        ctx.save_for_backward(hm, anno, ind, mask, avg, *heads)
+        ctx.cfg = (tuple(ncls), tuple(code_w), float(lw_bbox), float(lw_cls), tuple(flags), (B, H, W))
+        ctx.mark_non_differentiable(*sig)
+        return (losses, *sig)
+
+    @staticmethod
+    def backward(ctx, g_losses, *_):
+        from . import _lib as L
+        hm, anno, ind, mask, avg, *heads = ctx.saved_tensors
+        ncls, code_w, lw_bbox, lw_cls, flags, (B, H, W) = ctx.cfg
+        T = len(ncls)
+        dev = g_losses.device
+        # one zero-filled slab for the 5 regression-head gradients of every task (only object pixels are written),
+        # heat-map gradients are fully written by the kernel
+        sizes = [h.numel() for h in heads]
+        reg_total = sum(n for i, n in enumerate(sizes) if i % 6 != 5)
+        slab = torch.zeros((reg_total,), dtype=torch.float32, device=dev)
+        grads, o = [], 0
+        for i, h in enumerate(heads):
+            if i % 6 == 5:
+                grads.append(torch.empty_like(h))
+            else:
+                g = slab[o:o + sizes[i]]
+                o += sizes[i]
+                grads.append(g.view(h.shape[0], h.shape[2], h.shape[3], h.shape[1]).permute(0, 3, 1, 2) if flags[i]
+                             else g.view(h.shape))
+        with torch.cuda.device(dev):
+            L.call("dbev_centerhead_loss_backward", L.host_ptrs(heads), L.host_ints(flags), L.host_ptrs(grads),
+                   L.host_ints(ncls), T, B, H, W, anno.shape[2], L.ptr(hm), L.ptr(anno), L.ptr(ind), L.ptr(mask),
+                   L.host_floats(code_w), lw_bbox, lw_cls, L.ptr(avg), L.ptr(g_losses.contiguous().float()),
+                   L.stream_ptr(dev))
+        return (None,) * 8 + tuple(grads)
+
+
 @MODELS.register_module()
 class CenterHead(nn.Module):
     def __init__(self, in_channels=[128], tasks=None, train_cfg=None, test_cfg=None, bbox_coder=None,
@@ -215,6 +285,7 @@ class CenterHead(nn.Module):
                    float(vs[0]), float(vs[1]), int(osf), 1 if self.norm_bbox else 0, L.ptr(hm), L.ptr(ab), L.ptr(ind),
                    L.ptr(mk), L.ptr(ws), ws.numel(), L.stream_ptr(device))
         edges = np.cumsum([0] + ncls)
+        self._packed_targets = (hm, ab, ind, mk)       # the fused loss consumes the packed tensors directly
         return ([hm[:, edges[t]:edges[t + 1]] for t in range(T)], [ab[t] for t in range(T)],
                 [ind[t] for t in range(T)], [mk[t] for t in range(T)])
 
@@ -227,6 +298,40 @@ class CenterHead(nn.Module):
                                "GPU device; there is no CPU fallback in the product path")
         return self.get_targets_device(gt_bboxes_3d, gt_labels_3d, device)
 
+    fused_loss = True      # class-level switch (tests compare against the op-by-op sequence below)
+
+    def _fused_loss_ok(self, preds_dicts, heatmaps):
+        """the HIP loss covers the recipe's configuration: task-specific L1 groups, GaussianFocalLoss(2, 4, mean),
+        L1Loss(mean), packed device targets, fp32 head outputs on the GPU"""
+        p0 = preds_dicts[0][0]
+        pk = getattr(self, "_packed_targets", None)
+        packed = pk is not None and getattr(heatmaps[0], "_base", None) is pk[0]
+        return (self.fused_loss and self.task_specific and p0["heatmap"].is_cuda and p0["heatmap"].dtype == torch.float32
+                and packed and type(self.loss_cls) is GaussianFocalLoss and self.loss_cls.alpha == 2.0
+                and self.loss_cls.gamma == 4.0 and self.loss_cls.reduction == "mean" and type(self.loss_bbox) is L1Loss
+                and self.loss_bbox.reduction == "mean" and self.train_cfg.get("code_weights", None) is not None
+                and all(set(_HEAD_ORDER) <= set(p[0]) for p in preds_dicts))
+
+    def _fused_loss(self, preds_dicts, heatmaps, anno_boxes, inds, masks):
+        """:615-686 for all tasks through dbev_centerhead_loss_* (side effect kept: p['heatmap'] becomes the clipped
+        sigmoid, which add_fp_as_fg reads later)."""
+        T = len(preds_dicts)
+        hm, anno, ind, mask = self._packed_targets
+        ncls = [len(n) for n in self.class_names]
+        heads = [preds_dicts[t][0][k] for t in range(T) for k in _HEAD_ORDER]
+        out = _CenterHeadLoss.apply(hm, anno, ind, mask, ncls, [float(v) for v in self.train_cfg["code_weights"]],
+                                    self.loss_bbox.loss_weight, self.loss_cls.loss_weight, *heads)
+        sig = out[1:]
+        vals = out[0].reshape(-1).unbind(0)          # ONE backward node (a stack) for the 36 scalars
+        loss_dict = dict()
+        names = ["xy", "z", "whl", "yaw", "vel"]
+        for t in range(T):
+            preds_dicts[t][0]["heatmap"] = sig[t]
+            for r, nm in enumerate(names):
+                loss_dict[f"{self.loss_prefix}task{t}.loss_{nm}"] = vals[t * 6 + r]
+            loss_dict[f"{self.loss_prefix}task{t}.loss_heatmap"] = vals[t * 6 + 5]
+        return loss_dict
+
     @staticmethod
     def _gather_feat(feat, ind):
         dim = feat.size(2)
@@ -236,6 +341,9 @@ class CenterHead(nn.Module):
         """:615-686 (clip_sigmoid is applied IN PLACE to the predicted heatmaps, as the reference)."""
         device = preds_dicts[0][0]["heatmap"].device
         heatmaps, anno_boxes, inds, masks = self.get_targets(gt_bboxes_3d, gt_labels_3d, device)
+        if self._fused_loss_ok(preds_dicts, heatmaps):
+            loss_dict = self._fused_loss(preds_dicts, heatmaps, anno_boxes, inds, masks)
+            return (loss_dict, heatmaps, anno_boxes, inds, masks) if get_targets else loss_dict
         loss_dict = dict()
         code_weights = self.train_cfg.get("code_weights", None)
         for task_id, preds_dict in enumerate(preds_dicts):

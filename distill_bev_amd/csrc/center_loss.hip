@@ -1,0 +1,325 @@
+// CenterHead training loss, all tasks in four launches forward / two backward.
+//
+// Replaces the per-task op chain of CenterHead.loss (mmdet3d/models/dense_heads/centerpoint_head.py:615-686):
+// clip_sigmoid -> GaussianFocalLoss (mmdet 2.24 gaussian_focal_loss: alpha 2, gamma 4, mean with avg_factor =
+// max(#positives, 1)) on the heat maps, and cat / permute / gather / isnan-mask / L1Loss (mean with avg_factor =
+// #objects + 1e-4, loss_weight) on the 10 regression channels split into the xy | z | whl | yaw | vel groups of the
+// task-specific variant -- ~250 tiny ATen ops per task forward+backward, 6.5 ms of GPU time per step for the six tasks.
+//
+// Tensors: for task t the six head outputs (reg 2, height 1, dim 3, rot 2, vel 2, heatmap ncls[t] channels), each
+// f32[B, c, H, W] NCHW- or NHWC-contiguous (flag per tensor); targets in the packed layout of dbev_centerhead_targets.
+// All sums are block partials merged in a fixed order (no float atomics); the scatter of the regression gradients
+// resolves objects that share a pixel in ascending slot order (deterministic).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int HL_MAX_TASKS = 8;
+constexpr int HL_HEADS = 6;          // reg, height, dim, rot, vel, heatmap
+constexpr int HL_MAX_OBJS = 1024;
+
+struct HlArgs {
+  const float* head[HL_MAX_TASKS][HL_HEADS];
+  float* sig[HL_MAX_TASKS];                 // forward: clipped sigmoid of the heat maps (layout of head[t][5])
+  float* ghead[HL_MAX_TASKS][HL_HEADS];     // backward: gradients (layouts of head[t][h]); regression ones pre-zeroed
+  int ncls[HL_MAX_TASKS];
+  int cls_start[HL_MAX_TASKS + 1];
+  unsigned nhwc[HL_MAX_TASKS];              // bit h: tensor (t, h) is NHWC
+  int T, B, H, W, max_objs;
+  float loss_weight_bbox, loss_weight_cls;
+  float code_w[10];
+};
+
+__device__ __forceinline__ int head_channels(const HlArgs& A, int t, int h) {
+  return h == 0 ? 2 : (h == 1 ? 1 : (h == 2 ? 3 : (h == 5 ? A.ncls[t] : 2)));
+}
+__device__ __forceinline__ size_t hoff(const HlArgs& A, int t, int h, int b, int ch, int pix) {
+  const int c = head_channels(A, t, h);
+  const size_t HW = static_cast<size_t>(A.H) * A.W;
+  return (A.nhwc[t] >> h) & 1u ? (static_cast<size_t>(b) * HW + pix) * c + ch : (static_cast<size_t>(b) * c + ch) * HW + pix;
+}
+// anno column j -> (head, channel)
+__device__ __forceinline__ void col_head(int j, int* h, int* ch) {
+  if (j < 2) { *h = 0; *ch = j; }
+  else if (j < 3) { *h = 1; *ch = 0; }
+  else if (j < 6) { *h = 2; *ch = j - 3; }
+  else if (j < 8) { *h = 3; *ch = j - 6; }
+  else { *h = 4; *ch = j - 8; }
+}
+__device__ __forceinline__ int col_group(int j) { return j < 2 ? 0 : (j < 3 ? 1 : (j < 6 ? 2 : (j < 8 ? 3 : 4))); }
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr float HL_CLIP = 1e-4f;
+constexpr float HL_EPS = 1e-12f;
+
+// grid (ceil(HW/256), total classes, B): focal loss partials + clipped sigmoid
+__global__ __launch_bounds__(256) void hl_focal_fwd(HlArgs A, const float* __restrict__ hm, int n_cls,
+                                                    float* __restrict__ partial /* [blocks][2] */) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.z, cg = blockIdx.y;
+  int t = 0;
+  while (cg >= A.cls_start[t + 1]) ++t;
+  const int ch = cg - A.cls_start[t];
+  const int HW = A.H * A.W;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  float loss = 0.f, npos = 0.f;
+  if (pix < HW) {
+    const size_t o = hoff(A, t, 5, b, ch, pix);
+    const float x = A.head[t][5][o];
+    const float s = 1.f / (1.f + expf(-x));
+    const float p = fminf(fmaxf(s, HL_CLIP), 1.f - HL_CLIP);
+    A.sig[t][o] = p;
+    const float tg = hm[(static_cast<size_t>(b) * n_cls + cg) * HW + pix];
+    const float q = 1.f - tg;
+    const float negw = (q * q) * (q * q);
+    const float pos = tg == 1.f ? 1.f : 0.f;
+    const float om = 1.f - p;
+    loss = -logf(p + HL_EPS) * (om * om) * pos + -logf(om + HL_EPS) * (p * p) * negw;
+    npos = pos;
+  }
+  loss = wave_sum_f(loss); npos = wave_sum_f(npos);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[0][w] = loss; red[1][w] = npos; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const size_t blk = (static_cast<size_t>(b) * n_cls + cg) * gridDim.x + blockIdx.x;
+    partial[blk * 2 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  }
+}
+
+// one block per task: fixed-order fp64 merge -> out[t*6 + 5] = heat-map loss, npos[t]
+__global__ __launch_bounds__(256) void hl_focal_final(HlArgs A, const float* __restrict__ partial, int n_cls, int tiles,
+                                                      float* __restrict__ out, float* __restrict__ npos_out) {
+  __shared__ double red[2][256];
+  const int t = blockIdx.x;
+  double a = 0.0, n = 0.0;
+  const int ncg = A.ncls[t];
+  const int per_b = ncg * tiles;
+  for (int i = threadIdx.x; i < A.B * per_b; i += 256) {
+    const int b = i / per_b, r = i - b * per_b;
+    const size_t blk = (static_cast<size_t>(b) * n_cls + A.cls_start[t]) * tiles + r;
+    a += partial[blk * 2];
+    n += partial[blk * 2 + 1];
+  }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float np = static_cast<float>(red[1][0]);
+    const float avg = fmaxf(np, 1.f);
+    npos_out[t] = avg;
+    out[t * 6 + 5] = A.loss_weight_cls * static_cast<float>(red[0][0]) / avg;
+  }
+}
+
+// grid (T*B): L1 partial sums of the 5 column groups + object count
+__global__ __launch_bounds__(256) void hl_reg_fwd(HlArgs A, const float* __restrict__ anno, const long long* __restrict__ ind,
+                                                  const unsigned char* __restrict__ mask, float* __restrict__ partial /* [T*B][6] */) {
+  __shared__ float red[6][4];
+  const int t = blockIdx.x / A.B, b = blockIdx.x - t * A.B;
+  float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float cnt = 0.f;
+  for (int k = threadIdx.x; k < A.max_objs; k += blockDim.x) {
+    const size_t row = (static_cast<size_t>(t) * A.B + b) * A.max_objs + k;
+    const float m = mask[row] ? 1.f : 0.f;
+    cnt += m;
+    const int pix = static_cast<int>(ind[row]);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      int h, ch;
+      col_head(j, &h, &ch);
+      const float pred = A.head[t][h][hoff(A, t, h, b, ch, pix)];
+      const float tg = anno[row * 10 + j];
+      const float w = m * (isnan(tg) ? 0.f : 1.f) * A.code_w[j];
+      g[col_group(j)] += fabsf(pred - tg) * w;
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { const float s = wave_sum_f(g[q]); if (lane == 0) red[q][wv] = s; }
+  { const float s = wave_sum_f(cnt); if (lane == 0) red[5][wv] = s; }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    partial[static_cast<size_t>(blockIdx.x) * 6 + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// one thread per (task, group): out[t*6 + g] = loss_weight * sum / (num + 1e-4); num_out[t]
+__global__ void hl_reg_final(HlArgs A, const float* __restrict__ partial, float* __restrict__ out, float* __restrict__ num_out) {
+  const int t = blockIdx.x, q = threadIdx.x;
+  if (q >= 5) return;
+  double s = 0.0, n = 0.0;
+  for (int b = 0; b < A.B; ++b) {
+    s += partial[(static_cast<size_t>(t) * A.B + b) * 6 + q];
+    n += partial[(static_cast<size_t>(t) * A.B + b) * 6 + 5];
+  }
+  const float avg = static_cast<float>(n) + 1e-4f;
+  if (q == 0) num_out[t] = avg;
+  out[t * 6 + q] = A.loss_weight_bbox * static_cast<float>(s) / avg;
+}
+
+// backward of the focal term: d logits.  gout f32[T*6] upstream gradients of the 36 losses.
+__global__ __launch_bounds__(256) void hl_focal_bwd(HlArgs A, const float* __restrict__ hm, int n_cls,
+                                                    const float* __restrict__ npos, const float* __restrict__ gout) {
+  const int b = blockIdx.z, cg = blockIdx.y;
+  int t = 0;
+  while (cg >= A.cls_start[t + 1]) ++t;
+  const int ch = cg - A.cls_start[t];
+  const int HW = A.H * A.W;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= HW) return;
+  const size_t o = hoff(A, t, 5, b, ch, pix);
+  const float x = A.head[t][5][o];
+  const float s = 1.f / (1.f + expf(-x));
+  float d = 0.f;
+  if (s >= HL_CLIP && s <= 1.f - HL_CLIP) {          // clamp passes the gradient inside [min, max]
+    const float p = s;
+    const float tg = hm[(static_cast<size_t>(b) * n_cls + cg) * HW + pix];
+    const float q = 1.f - tg;
+    const float negw = (q * q) * (q * q);
+    const float om = 1.f - p;
+    float dp;
+    if (tg == 1.f) dp = -(om * om) / (p + HL_EPS) + 2.f * om * logf(p + HL_EPS);
+    else dp = negw * ((p * p) / (om + HL_EPS) - 2.f * p * logf(om + HL_EPS));
+    d = gout[t * 6 + 5] * A.loss_weight_cls / npos[t] * dp * (s * (1.f - s));
+  }
+  A.ghead[t][5][o] = d;
+}
+
+// backward of the L1 terms: scatter into the (pre-zeroed) regression-head gradients.  grid (T*B).
+__global__ __launch_bounds__(256) void hl_reg_bwd(HlArgs A, const float* __restrict__ anno, const long long* __restrict__ ind,
+                                                  const unsigned char* __restrict__ mask, const float* __restrict__ num,
+                                                  const float* __restrict__ gout) {
+  __shared__ int s_ind[HL_MAX_OBJS];
+  const int t = blockIdx.x / A.B, b = blockIdx.x - t * A.B;
+  const size_t row0 = (static_cast<size_t>(t) * A.B + b) * A.max_objs;
+  for (int k = threadIdx.x; k < A.max_objs; k += blockDim.x) s_ind[k] = mask[row0 + k] ? static_cast<int>(ind[row0 + k]) : -1;
+  __syncthreads();
+  const float scale = A.loss_weight_bbox / num[t];
+  for (int k = threadIdx.x; k < A.max_objs; k += blockDim.x) {
+    const int pix = s_ind[k];
+    if (pix < 0) continue;
+    bool owner = true;
+    for (int k2 = 0; k2 < k; ++k2) owner = owner && (s_ind[k2] != pix);
+    if (!owner) continue;                       // the lowest slot of a shared pixel accumulates, in slot order
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      int h, ch;
+      col_head(j, &h, &ch);
+      const size_t o = hoff(A, t, h, b, ch, pix);
+      const float pred = A.head[t][h][o];
+      const float go = gout[t * 6 + col_group(j)] * scale;
+      float acc = 0.f;
+      for (int k2 = k; k2 < A.max_objs; ++k2) {
+        if (s_ind[k2] != pix) continue;
+        const float tg = anno[(row0 + k2) * 10 + j];
+        const float w = (isnan(tg) ? 0.f : 1.f) * A.code_w[j];
+        const float df = pred - tg;
+        const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : df);      // sgn, NaN propagates like torch.abs backward
+        acc += sg * w * go;
+      }
+      A.ghead[t][h][o] = acc;
+    }
+  }
+}
+
+bool fill_args(HlArgs* A, const float* const* heads, const int32_t* nhwc_flags, const int32_t* ncls, int T, int B, int H,
+               int W, int max_objs, const float* code_w, float lw_bbox, float lw_cls) {
+  if (T <= 0 || T > HL_MAX_TASKS || B <= 0 || H <= 0 || W <= 0 || max_objs <= 0 || max_objs > HL_MAX_OBJS) return false;
+  A->T = T; A->B = B; A->H = H; A->W = W; A->max_objs = max_objs;
+  A->loss_weight_bbox = lw_bbox; A->loss_weight_cls = lw_cls;
+  A->cls_start[0] = 0;
+  for (int t = 0; t < T; ++t) {
+    if (ncls[t] <= 0) return false;
+    A->ncls[t] = ncls[t];
+    A->cls_start[t + 1] = A->cls_start[t] + ncls[t];
+    A->nhwc[t] = 0;
+    for (int h = 0; h < HL_HEADS; ++h) {
+      if (heads[t * HL_HEADS + h] == nullptr) return false;
+      A->head[t][h] = heads[t * HL_HEADS + h];
+      if (nhwc_flags[t * HL_HEADS + h]) A->nhwc[t] |= 1u << h;
+      A->ghead[t][h] = nullptr;
+    }
+    A->sig[t] = nullptr;
+  }
+  for (int j = 0; j < 10; ++j) A->code_w[j] = code_w[j];
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t dbev_centerhead_loss_workspace_bytes(int B, int num_classes_total, int num_tasks, int H, int W) {
+  if (B <= 0 || num_classes_total <= 0 || num_tasks <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t tiles = static_cast<size_t>(dbev_ceil_div(static_cast<long long>(H) * W, 256));
+  return sizeof(float) * (2 * static_cast<size_t>(B) * num_classes_total * tiles + 6 * static_cast<size_t>(num_tasks) * B) + 256;
+}
+
+extern "C" int dbev_centerhead_loss_forward(const float* const* heads_host, const int32_t* nhwc_flags_host,
+                                            float* const* sig_out_host, const int32_t* task_num_classes_host,
+                                            int num_tasks, int B, int H, int W, int max_objs, const float* heatmap,
+                                            const float* anno_box, const long long* ind, const unsigned char* mask,
+                                            const float* code_weights_host, float loss_weight_bbox, float loss_weight_cls,
+                                            float* losses, float* avg_factors, void* workspace, size_t workspace_bytes,
+                                            dbevStream_t stream) {
+  HlArgs A;
+  if (!fill_args(&A, heads_host, nhwc_flags_host, task_num_classes_host, num_tasks, B, H, W, max_objs, code_weights_host,
+                 loss_weight_bbox, loss_weight_cls))
+    return DBEV_EINVAL;
+  const int n_cls = A.cls_start[num_tasks];
+  if (heatmap == nullptr || anno_box == nullptr || ind == nullptr || mask == nullptr || losses == nullptr ||
+      avg_factors == nullptr || workspace == nullptr ||
+      workspace_bytes < dbev_centerhead_loss_workspace_bytes(B, n_cls, num_tasks, H, W))
+    return DBEV_EINVAL;
+  for (int t = 0; t < num_tasks; ++t) {
+    if (sig_out_host[t] == nullptr) return DBEV_EINVAL;
+    A.sig[t] = sig_out_host[t];
+  }
+  hipStream_t s = dbev_stream(stream);
+  const int tiles = dbev_ceil_div(static_cast<long long>(H) * W, 256);
+  float* p_focal = static_cast<float*>(workspace);
+  float* p_reg = p_focal + 2 * static_cast<size_t>(B) * n_cls * tiles;
+  hipLaunchKernelGGL(hl_focal_fwd, dim3(tiles, n_cls, B), dim3(256), 0, s, A, heatmap, n_cls, p_focal);
+  hipLaunchKernelGGL(hl_focal_final, dim3(num_tasks), dim3(256), 0, s, A, p_focal, n_cls, tiles, losses, avg_factors);
+  hipLaunchKernelGGL(hl_reg_fwd, dim3(num_tasks * B), dim3(256), 0, s, A, anno_box, ind, mask, p_reg);
+  hipLaunchKernelGGL(hl_reg_final, dim3(num_tasks), dim3(64), 0, s, A, p_reg, losses, avg_factors + num_tasks);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_centerhead_loss_backward(const float* const* heads_host, const int32_t* nhwc_flags_host,
+                                             float* const* grad_heads_host, const int32_t* task_num_classes_host,
+                                             int num_tasks, int B, int H, int W, int max_objs, const float* heatmap,
+                                             const float* anno_box, const long long* ind, const unsigned char* mask,
+                                             const float* code_weights_host, float loss_weight_bbox, float loss_weight_cls,
+                                             const float* avg_factors, const float* grad_losses, dbevStream_t stream) {
+  HlArgs A;
+  if (!fill_args(&A, heads_host, nhwc_flags_host, task_num_classes_host, num_tasks, B, H, W, max_objs, code_weights_host,
+                 loss_weight_bbox, loss_weight_cls))
+    return DBEV_EINVAL;
+  if (heatmap == nullptr || anno_box == nullptr || ind == nullptr || mask == nullptr || avg_factors == nullptr ||
+      grad_losses == nullptr)
+    return DBEV_EINVAL;
+  for (int t = 0; t < num_tasks; ++t)
+    for (int h = 0; h < HL_HEADS; ++h) {
+      if (grad_heads_host[t * HL_HEADS + h] == nullptr) return DBEV_EINVAL;
+      A.ghead[t][h] = grad_heads_host[t * HL_HEADS + h];
+    }
+  const int n_cls = A.cls_start[num_tasks];
+  hipStream_t s = dbev_stream(stream);
+  const int tiles = dbev_ceil_div(static_cast<long long>(H) * W, 256);
+  hipLaunchKernelGGL(hl_focal_bwd, dim3(tiles, n_cls, B), dim3(256), 0, s, A, heatmap, n_cls, avg_factors, grad_losses);
+  hipLaunchKernelGGL(hl_reg_bwd, dim3(num_tasks * B), dim3(256), 0, s, A, anno_box, ind, mask, avg_factors + num_tasks,
+                     grad_losses);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}

@@ -344,6 +344,33 @@ int dbev_centerhead_targets(const float* boxes9, const int32_t* labels, const in
                             long long* ind, unsigned char* mask, void* workspace, size_t workspace_bytes,
                             dbevStream_t stream);
 
+/* CenterHead training loss of all tasks: clip_sigmoid + GaussianFocalLoss (alpha 2, gamma 4, avg_factor = max(#pos, 1)) on
+ * the heat maps and the masked L1 terms of the five regression groups xy | z | whl | yaw | vel (avg_factor = #objects +
+ * 1e-4).  Replaces the per-task op chain of CenterHead.loss (mmdet3d/models/dense_heads/centerpoint_head.py:615-686,
+ * task_specific variant; mmdet 2.24 gaussian_focal_loss / l1_loss).
+ *   heads_host        HOST array [num_tasks*6] of DEVICE pointers: per task reg(2) height(1) dim(3) rot(2) vel(2)
+ *                     heatmap(ncls[t]) channels, each f32[B,c,H,W]; nhwc_flags_host[i] != 0: tensor i is NHWC-contiguous
+ *   sig_out_host      HOST array [num_tasks] of device pointers: clipped sigmoid of the heat maps (layout of the logits)
+ *   heatmap/anno_box/ind/mask   targets in the packed layout of dbev_centerhead_targets
+ *   losses            f32[num_tasks*6]: per task (loss_xy, loss_z, loss_whl, loss_yaw, loss_vel, loss_heatmap)
+ *   avg_factors       f32[2*num_tasks]: max(#pos,1) per task, then #objects + 1e-4 per task (input of backward)
+ * backward: grad_heads_host = HOST array [num_tasks*6] of device pointers with the layouts of the inputs; the 5 regression
+ * gradients of every task must be ZERO-FILLED by the caller (only the object pixels are written), the heat-map gradients
+ * are fully written; grad_losses f32[num_tasks*6] (device).  Fixed summation orders, no float atomics. */
+size_t dbev_centerhead_loss_workspace_bytes(int B, int num_classes_total, int num_tasks, int H, int W);
+int dbev_centerhead_loss_forward(const float* const* heads_host, const int32_t* nhwc_flags_host,
+                                 float* const* sig_out_host, const int32_t* task_num_classes_host, int num_tasks, int B,
+                                 int H, int W, int max_objs, const float* heatmap, const float* anno_box,
+                                 const long long* ind, const unsigned char* mask, const float* code_weights_host,
+                                 float loss_weight_bbox, float loss_weight_cls, float* losses, float* avg_factors,
+                                 void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_centerhead_loss_backward(const float* const* heads_host, const int32_t* nhwc_flags_host,
+                                  float* const* grad_heads_host, const int32_t* task_num_classes_host, int num_tasks,
+                                  int B, int H, int W, int max_objs, const float* heatmap, const float* anno_box,
+                                  const long long* ind, const unsigned char* mask, const float* code_weights_host,
+                                  float loss_weight_bbox, float loss_weight_cls, const float* avg_factors,
+                                  const float* grad_losses, dbevStream_t stream);
+
 /* Training-mode BatchNorm2d fused with the residual add and ReLU that follow it (channels-last fp32):
  *   y = relu( (x - mean_batch) / sqrt(var_batch + eps) * gamma + beta  [+ residual] )
  * = torch.nn.functional.batch_norm(training=True) [+ add] [+ relu] as the reference's dense blocks chain them
