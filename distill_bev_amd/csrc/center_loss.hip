@@ -201,12 +201,20 @@ __global__ __launch_bounds__(256) void hl_reg_bwd(HlArgs A, const float* __restr
                                                   const unsigned char* __restrict__ mask, const float* __restrict__ num,
                                                   const float* __restrict__ gout) {
   __shared__ int s_ind[HL_MAX_OBJS];
+  __shared__ int s_last;                      // highest occupied slot + 1: the lists are short (objects of one task in one sample)
   const int t = blockIdx.x / A.B, b = blockIdx.x - t * A.B;
   const size_t row0 = (static_cast<size_t>(t) * A.B + b) * A.max_objs;
-  for (int k = threadIdx.x; k < A.max_objs; k += blockDim.x) s_ind[k] = mask[row0 + k] ? static_cast<int>(ind[row0 + k]) : -1;
+  if (threadIdx.x == 0) s_last = 0;
   __syncthreads();
-  const float scale = A.loss_weight_bbox / num[t];
   for (int k = threadIdx.x; k < A.max_objs; k += blockDim.x) {
+    const int v = mask[row0 + k] ? static_cast<int>(ind[row0 + k]) : -1;
+    s_ind[k] = v;
+    if (v >= 0) atomicMax(&s_last, k + 1);
+  }
+  __syncthreads();
+  const int last = s_last;
+  const float scale = A.loss_weight_bbox / num[t];
+  for (int k = threadIdx.x; k < last; k += blockDim.x) {
     const int pix = s_ind[k];
     if (pix < 0) continue;
     bool owner = true;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256) void hl_reg_bwd(HlArgs A, const float* __restr
       const float pred = A.head[t][h][o];
       const float go = gout[t * 6 + col_group(j)] * scale;
       float acc = 0.f;
-      for (int k2 = k; k2 < A.max_objs; ++k2) {
+      for (int k2 = k; k2 < last; ++k2) {
         if (s_ind[k2] != pix) continue;
         const float tg = anno[(row0 + k2) * 10 + j];
         const float w = (isnan(tg) ? 0.f : 1.f) * A.code_w[j];

@@ -23,6 +23,14 @@ ka = prof.key_averages(group_by_input_shape=True)
 names = ("aten::copy_", "aten::clone", "aten::contiguous", "aten::miopen_batch_norm", "aten::miopen_batch_norm_backward",
          "aten::add", "aten::add_", "aten::upsample_bilinear2d", "aten::upsample_bilinear2d_backward", "aten::native_batch_norm",
          "aten::mul", "aten::sum", "aten::cat", "aten::relu", "aten::relu_", "aten::threshold_backward", "aten::sigmoid")
+allk = sorted(ka, key=lambda e: -e.self_device_time_total)
+agg = {}
+for e in allk:
+    agg.setdefault(e.key, [0, 0])
+    agg[e.key][0] += e.self_device_time_total; agg[e.key][1] += e.count
+print("top ops by self device time (us/step, calls):")
+for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"   {k[:70]:70s} {t:9.0f} us  n={n}")
 rows = [e for e in ka if e.key in names]
 rows.sort(key=lambda e: -e.device_time_total)
 tot = {}
