@@ -59,10 +59,10 @@ _SIGNATURES = {
     "dbev_dcnv2_col2im_workspace_bytes": [_i] * 8,
     "dbev_dcnv2_col2im": [_p, _p, _p, _p, _p] + [_i] * 11 + [_p, _sz, _p],
     "dbev_abs_mean_maps_nhwc_workspace_bytes": [_i, _i, _i],
-    "dbev_abs_mean_maps_nhwc": [_p, _i, _i, _i, _p, _p, _p, _sz, _p],
+    "dbev_abs_mean_maps_nhwc": [_p, _i, _i, _i, _p, _p, _p, _p, _sz, _p],
     "dbev_fgd_masked_mse_nhwc_workspace_bytes": [_i, _i, _i],
     "dbev_fgd_masked_mse_forward_nhwc": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p],
-    "dbev_fgd_masked_mse_backward_nhwc": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "dbev_fgd_masked_mse_backward_nhwc": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dbev_centerhead_targets": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p, _p, _sz, _p],
     "dbev_centerhead_loss_workspace_bytes": [_i, _i, _i, _i, _i],
     "dbev_centerhead_loss_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _sz, _p],

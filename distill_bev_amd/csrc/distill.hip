@@ -277,7 +277,8 @@ constexpr int NHWC_ROWS_PER_BLOCK = 64;
 
 template <int NQ>
 __global__ __launch_bounds__(256) void abs_mean_nhwc(const float4* __restrict__ x, int C4, int HW,
-                                                     float* __restrict__ pix, float* __restrict__ chpart) {
+                                                     float* __restrict__ pix, float* __restrict__ chpart,
+                                                     float* __restrict__ pool /* mean_c x per pixel, may be null */) {
   __shared__ float4 red[4][64 * NQ];
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r0 = blockIdx.x * NHWC_ROWS_PER_BLOCK, r1 = min(HW, r0 + NHWC_ROWS_PER_BLOCK);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void abs_mean_nhwc(const float4* __restrict__ 
 #pragma unroll
   for (int j = 0; j < NQ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int r = r0 + w; r < r1; r += 8) {
-    float ps[2] = {0.f, 0.f};
+    float ps[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int rr = r + 4 * u;
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) void abs_mean_nhwc(const float4* __restrict__ 
           const int q = lane + 64 * j;
           if (q < C4) {
             float4 v = row[q];
+            sg[u] += (v.x + v.y) + (v.z + v.w);
             v.x = fabsf(v.x); v.y = fabsf(v.y); v.z = fabsf(v.z); v.w = fabsf(v.w);
             acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
             ps[u] += (v.x + v.y) + (v.z + v.w);
@@ -309,6 +311,10 @@ __global__ __launch_bounds__(256) void abs_mean_nhwc(const float4* __restrict__ 
       const int rr = r + 4 * u;
       const float t = wave_sum(ps[u]);
       if (lane == 0 && rr < r1) pix[static_cast<size_t>(b) * HW + rr] = t * invC;
+      if (pool != nullptr) {                               // uniform
+        const float t2 = wave_sum(sg[u]);
+        if (lane == 0 && rr < r1) pool[static_cast<size_t>(b) * HW + rr] = t2 * invC;
+      }
     }
   }
 #pragma unroll
@@ -370,9 +376,11 @@ template <int NQ>
 __global__ __launch_bounds__(256) void masked_mse_bwd_nhwc(const float4* __restrict__ S, const float4* __restrict__ T,
                                                            const float* __restrict__ Wfg, const float* __restrict__ Wbg,
                                                            const float* __restrict__ Wfp, const float* __restrict__ Cc,
-                                                           const float* __restrict__ gsc, int C4, int HW,
-                                                           float4* __restrict__ dS) {
+                                                           const float* __restrict__ gsc,
+                                                           const float* __restrict__ gpool /* d/d mean_c S, may be null */,
+                                                           int C4, int HW, float4* __restrict__ dS) {
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float invC = 1.f / static_cast<float>(C4 * 4);
   const int r0 = blockIdx.x * NHWC_ROWS_PER_BLOCK, r1 = min(HW, r0 + NHWC_ROWS_PER_BLOCK);
   const float g0 = gsc[0], g1 = gsc[1], g2 = gsc[2];
   float4 cc[NQ];
@@ -386,16 +394,17 @@ __global__ __launch_bounds__(256) void masked_mse_bwd_nhwc(const float4* __restr
     const size_t pr = static_cast<size_t>(b) * HW + r;
     const float base = g0 * Wfg[pr] + g1 * Wbg[pr];
     const float kp = Wfp ? g2 * Wfp[pr] : 0.f;
+    const float gp = gpool ? gpool[pr] * invC : 0.f;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       const int q = lane + 64 * j;
       if (q < C4) {
         const float4 s = S[pr * C4 + q], t = T[pr * C4 + q];
         float4 o;
-        o.x = 2.f * (s.x - t.x) * (base + kp * cc[j].x);
-        o.y = 2.f * (s.y - t.y) * (base + kp * cc[j].y);
-        o.z = 2.f * (s.z - t.z) * (base + kp * cc[j].z);
-        o.w = 2.f * (s.w - t.w) * (base + kp * cc[j].w);
+        o.x = 2.f * (s.x - t.x) * (base + kp * cc[j].x) + gp;
+        o.y = 2.f * (s.y - t.y) * (base + kp * cc[j].y) + gp;
+        o.z = 2.f * (s.z - t.z) * (base + kp * cc[j].z) + gp;
+        o.w = 2.f * (s.w - t.w) * (base + kp * cc[j].w) + gp;
         dS[pr * C4 + q] = o;
       }
     }
@@ -420,14 +429,15 @@ extern "C" size_t dbev_abs_mean_maps_nhwc_workspace_bytes(int B, int C, int HW) 
 }
 
 extern "C" int dbev_abs_mean_maps_nhwc(const float* x_nhwc, int B, int C, int HW, float* pix_mean, float* ch_mean,
-                                       void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+                                       float* pix_signed_mean, void* workspace, size_t workspace_bytes,
+                                       dbevStream_t stream) {
   if (!nhwc_ok(B, C, HW)) return DBEV_EINVAL;
   if (workspace == nullptr || workspace_bytes < dbev_abs_mean_maps_nhwc_workspace_bytes(B, C, HW)) return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   const int nbx = dbev_ceil_div(HW, NHWC_ROWS_PER_BLOCK), C4 = C >> 2;
   float* chpart = static_cast<float*>(workspace);
   DBEV_NQ_DISPATCH((C4 + 63) / 64, abs_mean_nhwc, dim3(nbx, B), dim3(256), 0, s,
-                   reinterpret_cast<const float4*>(x_nhwc), C4, HW, pix_mean, chpart);
+                   reinterpret_cast<const float4*>(x_nhwc), C4, HW, pix_mean, chpart, pix_signed_mean);
   hipLaunchKernelGGL(abs_mean_ch_final, dim3(dbev_ceil_div(C, 32), B), dim3(256), 0, s, chpart, C, HW, nbx, ch_mean);
   DBEV_LAUNCH_CHECK();
   return 0;
@@ -455,13 +465,14 @@ extern "C" int dbev_fgd_masked_mse_forward_nhwc(const float* S, const float* T, 
 }
 
 extern "C" int dbev_fgd_masked_mse_backward_nhwc(const float* S, const float* T, const float* Wfg, const float* Wbg,
-                                                 const float* Wfp, const float* Cc, const float* grad_scale3, int B,
-                                                 int C, int HW, float* dS, dbevStream_t stream) {
+                                                 const float* Wfp, const float* Cc, const float* grad_scale3,
+                                                 const float* grad_pixel_mean, int B, int C, int HW, float* dS,
+                                                 dbevStream_t stream) {
   if (!nhwc_ok(B, C, HW)) return DBEV_EINVAL;
   const int nbx = dbev_ceil_div(HW, NHWC_ROWS_PER_BLOCK), C4 = C >> 2;
   DBEV_NQ_DISPATCH((C4 + 63) / 64, masked_mse_bwd_nhwc, dim3(nbx, B), dim3(256), 0, dbev_stream(stream),
                    reinterpret_cast<const float4*>(S), reinterpret_cast<const float4*>(T), Wfg, Wbg, Wfp, Cc,
-                   grad_scale3, C4, HW, reinterpret_cast<float4*>(dS));
+                   grad_scale3, grad_pixel_mean, C4, HW, reinterpret_cast<float4*>(dS));
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -435,15 +435,18 @@ class BEVDepth4DDistill(CenterPoint):
         use_fp = dp["fp_as_foreground"][index] != "none" and self._epoch >= dp["fp_epoch"]
         if use_fp:
             fp, fp_scale, n_fp = self.add_fp_as_fg(dp["fp_as_foreground"][index], fg, heatmaps, teacher_preds, student_preds)
-        losses, att, _ = fgd_feature_losses(
+        losses, att, _, pools = fgd_feature_losses(
             student_feat, teacher_feat, fg, fg_scale, bg_scale,
             w_fg=_pick(dp["fg_feat_loss_weights"], index), w_bg=_pick(dp["bg_feat_loss_weights"], index),
             spatial_t=dp["spatial_t"], channel_t=dp["channel_t"], s_ratio=dp["spatial_student_ratio"],
             spatial_att=_pick(dp["spatial_attentions"], index), spatial_mask=dp["spatial_mask"],
             channel_mask=dp["channel_mask"], fp=fp, fp_scale=fp_scale, n_fp=n_fp, w_fp=dp["fp_weight"])
         if dp["spatial_mask"]:
-            t_pool = torch.mean(teacher_feat, [1], keepdim=True)
-            s_pool = torch.mean(student_feat, [1], keepdim=True)
+            if pools is not None:                  # mean over channels fused into the attention / dS kernels
+                t_pool, s_pool = pools
+            else:
+                t_pool = torch.mean(teacher_feat, [1], keepdim=True)
+                s_pool = torch.mean(student_feat, [1], keepdim=True)
             losses["kd_spatial_loss"] = self.spatial_criterion(
                 t_pool, self.spatial_wise_adaptations[index](s_pool)).sum() * (_pick(dp["spatial_loss_weights"], index) / B)
         return losses

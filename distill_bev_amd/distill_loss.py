@@ -102,31 +102,35 @@ def _is_nhwc(t):
             and not t.is_contiguous() and t.shape[1] % 4 == 0 and t.shape[1] <= 1024)
 
 
-def abs_mean_maps(x):
-    """x f32[B, C, H, W] -> (mean_c |x| f32[B,1,H,W], mean_hw |x| f32[B,C,1,1]) in one pass."""
+def abs_mean_maps(x, with_pool=False):
+    """x f32[B, C, H, W] -> (mean_c |x| f32[B,1,H,W], mean_hw |x| f32[B,C,1,1]) in one pass.
+    with_pool=True: also mean_c x f32[B,1,H,W] (no autograd; None when the layout has no fused path)."""
     dev = L.require_cuda(x)
     B, C, H, W = x.shape
     pix = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
     ch = torch.empty((B, C, 1, 1), dtype=torch.float32, device=dev)
     if _is_nhwc(x):                       # channels-last activations are consumed as they are
+        pool = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if with_pool else None
         with torch.cuda.device(dev):
             nbytes = L.call("dbev_abs_mean_maps_nhwc_workspace_bytes", B, C, H * W)
             ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
-            L.call("dbev_abs_mean_maps_nhwc", L.ptr(x), B, C, H * W, L.ptr(pix), L.ptr(ch), L.ptr(ws), ws.numel(),
-                   L.stream_ptr(dev))
-        return pix, ch
+            L.call("dbev_abs_mean_maps_nhwc", L.ptr(x), B, C, H * W, L.ptr(pix), L.ptr(ch), L.ptr(pool), L.ptr(ws),
+                   ws.numel(), L.stream_ptr(dev))
+        return (pix, ch, pool) if with_pool else (pix, ch)
     x = x.contiguous()
     with torch.cuda.device(dev):
         nbytes = L.call("dbev_abs_mean_maps_workspace_bytes", B, C, H * W)
         ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
         L.call("dbev_abs_mean_maps", L.ptr(x), B, C, H * W, L.ptr(pix), L.ptr(ch), L.ptr(ws), ws.numel(),
                L.stream_ptr(dev))
-    return pix, ch
+    return (pix, ch, None) if with_pool else (pix, ch)
 
 
 class _MaskedMSE(Function):
     @staticmethod
-    def forward(ctx, S, T, Wfg, Wbg, Wfp, Cc):
+    def forward(ctx, S, T, Wfg, Wbg, Wfp, Cc, s_pool=None):
+        """s_pool (optional, NHWC path only): mean_c S precomputed by abs_mean_maps(S, with_pool=True); it is returned
+        as a second, differentiable output whose gradient is folded into the dS kernel (+ grad / C per channel)."""
         dev = L.require_cuda(S, T, Wfg, Wbg)
         B, C, H, W = S.shape
         assert T.shape == S.shape
@@ -143,7 +147,10 @@ class _MaskedMSE(Function):
                 L.call("dbev_fgd_masked_mse_forward_nhwc", L.ptr(S), L.ptr(T), L.ptr(Wfg), L.ptr(Wbg), L.ptr(Wfp),
                        L.ptr(Cc), B, C, H * W, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
             ctx.save_for_backward(S, T, Wfg, Wbg, Wfp, Cc)
-            return out
+            ctx.pooled = s_pool is not None
+            return (out, s_pool.view_as(s_pool)) if ctx.pooled else out
+        assert s_pool is None, "the pooled-mean output exists on the channels-last path only"
+        ctx.pooled = False
         S = S.contiguous()
         T = T.contiguous()
         with torch.cuda.device(dev):
@@ -157,22 +164,28 @@ class _MaskedMSE(Function):
         return out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, grad_pool=None):
         S, T, Wfg, Wbg, Wfp, Cc = ctx.saved_tensors
         B, C, H, W = S.shape
         dev = S.device
-        g = grad_out.contiguous().float()
+        g = (grad_out if grad_out is not None else torch.zeros((3,), device=dev)).contiguous().float()
         dS = torch.empty_like(S)          # keeps S's memory format
         with torch.cuda.device(dev):
-            L.call("dbev_fgd_masked_mse_backward_nhwc" if ctx.nhwc else "dbev_fgd_masked_mse_backward", L.ptr(S), L.ptr(T), L.ptr(Wfg), L.ptr(Wbg), L.ptr(Wfp),
-                   L.ptr(Cc), L.ptr(g), B, C, H * W, L.ptr(dS), L.stream_ptr(dev))
-        return dS, None, None, None, None, None
+            if ctx.nhwc:
+                gp = grad_pool.contiguous().float() if (ctx.pooled and grad_pool is not None) else None
+                L.call("dbev_fgd_masked_mse_backward_nhwc", L.ptr(S), L.ptr(T), L.ptr(Wfg), L.ptr(Wbg), L.ptr(Wfp),
+                       L.ptr(Cc), L.ptr(g), L.ptr(gp), B, C, H * W, L.ptr(dS), L.stream_ptr(dev))
+            else:
+                L.call("dbev_fgd_masked_mse_backward", L.ptr(S), L.ptr(T), L.ptr(Wfg), L.ptr(Wbg), L.ptr(Wfp),
+                       L.ptr(Cc), L.ptr(g), B, C, H * W, L.ptr(dS), L.stream_ptr(dev))
+        return dS, None, None, None, None, None, None
 
 
-def masked_mse_sums(S, T, Wfg, Wbg, Wfp=None, Cc=None):
+def masked_mse_sums(S, T, Wfg, Wbg, Wfp=None, Cc=None, s_pool=None):
     """-> f32[3]: sum((S-T)^2 Wfg), sum((S-T)^2 Wbg), sum((S-T)^2 Wfp Cc) (0 if Wfp is None).
-    Differentiable wrt S only (teacher and masks are detached in the reference)."""
-    return _MaskedMSE.apply(S, T, Wfg, Wbg, Wfp, Cc)
+    Differentiable wrt S only (teacher and masks are detached in the reference).
+    s_pool: see _MaskedMSE.forward -> returns (sums, differentiable mean_c S)."""
+    return _MaskedMSE.apply(S, T, Wfg, Wbg, Wfp, Cc, s_pool)
 
 
 def fgd_feature_losses(student_feat, teacher_feat, fg, fg_scale, bg_scale, *, w_fg, w_bg,
@@ -184,12 +197,13 @@ def fgd_feature_losses(student_feat, teacher_feat, fg, fg_scale, bg_scale, *, w_
     student_feat: adapted student features (requires grad); teacher_feat: no grad."""
     B, C, H, W = student_feat.shape
     teacher_feat = teacher_feat.detach()
-    t_pix, t_ch = abs_mean_maps(teacher_feat)
+    t_pix, t_ch, t_pool = abs_mean_maps(teacher_feat, with_pool=True)
+    s_pool = None
     t_att = torch.softmax(t_pix.view(B, -1) / spatial_t, dim=1) * (H * W)
     if spatial_att == "teacher":
         att = t_att
     elif spatial_att == "teacher_student":
-        s_pix, _ = abs_mean_maps(student_feat.detach())
+        s_pix, _, s_pool = abs_mean_maps(student_feat.detach(), with_pool=True)
         s_att = torch.softmax(s_pix.view(B, -1) / spatial_t, dim=1) * (H * W)
         att = (t_att + s_att * s_ratio) / (1 + s_ratio)
     else:
@@ -219,11 +233,18 @@ def fgd_feature_losses(student_feat, teacher_feat, fg, fg_scale, bg_scale, *, w_
     if fp is not None:
         w_p = (fp * fp_scale * att).contiguous()
         cc = c_att
-    sums = masked_mse_sums(student_feat, teacher_feat, w_f.contiguous(), w_b.contiguous(), w_p, cc)
+    pools = None
+    if t_pool is not None and s_pool is not None and _is_nhwc(student_feat):
+        # channel means of both features came out of the attention pass; the student's re-enters autograd as a second
+        # output of the masked-MSE op so that its gradient is added inside the same dS kernel
+        sums, s_pool = masked_mse_sums(student_feat, teacher_feat, w_f.contiguous(), w_b.contiguous(), w_p, cc, s_pool)
+        pools = (t_pool, s_pool)
+    else:
+        sums = masked_mse_sums(student_feat, teacher_feat, w_f.contiguous(), w_b.contiguous(), w_p, cc)
     out = {"kd_fg_feat_loss": sums[0] * (w_fg / B), "kd_bg_feat_loss": sums[1] * (w_bg / B)}
     if fp is not None:
         out["kd_fp_bg_feat_loss"] = sums[2] * (w_fp / B)
-    return out, att, c_att
+    return out, att, c_att, pools
 
 
 class _UpsampleBilinearAC(Function):

@@ -283,17 +283,21 @@ int dbev_pillar_vfe_canvas(const float* points, int n_points, int num_features,
 
 /* Channels-last variants of the two loss kernels above: x, S, T are f32[B, HW, C] (the NHWC image of
  * [B, C, H, W]), so the channels-last activations of the dense stack are consumed / dS is produced without a
- * layout copy.  Same arguments and results otherwise; C % 4 == 0, C <= 1024, any HW. */
+ * layout copy.  Same arguments and results otherwise; C % 4 == 0, C <= 1024, any HW.  Two extras serve the spatial
+ * term of the FGD loss (torch.mean(feat, [1]) -> spatial adaptation -> MSE, bevdet_distill.py:1272-1278) without further
+ * passes over the features: pix_signed_mean f32[B, HW] (may be NULL) = mean_c x from the same read as the |x| means, and
+ * grad_pixel_mean f32[B, HW] (may be NULL) = gradient w.r.t. mean_c S, added as grad/C to every channel of dS. */
 size_t dbev_abs_mean_maps_nhwc_workspace_bytes(int B, int C, int HW);
 int dbev_abs_mean_maps_nhwc(const float* x_nhwc, int B, int C, int HW, float* pix_mean, float* ch_mean,
-                            void* workspace, size_t workspace_bytes, dbevStream_t stream);
+                            float* pix_signed_mean, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 size_t dbev_fgd_masked_mse_nhwc_workspace_bytes(int B, int C, int HW);
 int dbev_fgd_masked_mse_forward_nhwc(const float* S, const float* T, const float* Wfg, const float* Wbg,
                                      const float* Wfp, const float* Cc, int B, int C, int HW, float* out3,
                                      void* workspace, size_t workspace_bytes, dbevStream_t stream);
 int dbev_fgd_masked_mse_backward_nhwc(const float* S, const float* T, const float* Wfg, const float* Wbg,
-                                      const float* Wfp, const float* Cc, const float* grad_scale3, int B, int C,
-                                      int HW, float* dS, dbevStream_t stream);
+                                      const float* Wfp, const float* Cc, const float* grad_scale3,
+                                      const float* grad_pixel_mean, int B, int C, int HW, float* dS,
+                                      dbevStream_t stream);
 
 /* Bilinear upsampling with align_corners=True (nn.Upsample in the student adaptation layers of the
  * FGD loss, bevdet_distill.py:275-288; ATen upsample_bilinear2d index rule).  x f32[B,C,IH,IW] ->

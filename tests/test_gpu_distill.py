@@ -70,7 +70,7 @@ def test_fgd_losses_vs_fp64_oracle_and_autograd():
     dfg, dfs, dbs = r(H, W, boxes, dev)
     St = torch.from_numpy(S).to(dev).requires_grad_(True)
     Tt = torch.from_numpy(T).to(dev)
-    out, att, c_att = fgd_feature_losses(
+    out, att, c_att, _ = fgd_feature_losses(
         St, Tt, dfg, dfs, dbs, w_fg=6e-3, w_bg=4e-2, w_fp=6e-2,
         fp=torch.from_numpy(fp.astype(np.float32)).to(dev),
         fp_scale=torch.from_numpy(fpsc.astype(np.float32)).to(dev),
@@ -136,6 +136,38 @@ def test_channels_last_loss_kernels_match_nchw_kernels_and_fp64(B, C, H, W):
     # without the third term / channel factors
     o2 = masked_mse_sums(Scl, Tcl, wf, wb)
     assert float(o2[2]) == 0.0 and abs(float(o2[0]) - float(ref[0])) < 2e-6 * float(ref[0])
+
+
+def test_channel_mean_fused_into_attention_and_dS_kernels():
+    """spatial term of the FGD loss (bevdet_distill.py:1272-1278): mean_c of teacher / student comes out of the |x|-mean
+    pass, and the gradient of the student's mean is added inside the masked-MSE dS kernel."""
+    from distill_bev_amd.distill_loss import abs_mean_maps, masked_mse_sums
+    dev = _dev()
+    B, C, H, W = 2, 384, 32, 24
+    g = torch.Generator().manual_seed(1)
+    S = torch.randn((B, C, H, W), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    T = torch.randn((B, C, H, W), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wf = torch.rand((B, 1, H, W), generator=g).to(dev); wb = torch.rand((B, 1, H, W), generator=g).to(dev)
+    gmap = torch.randn((B, 1, H, W), generator=g).to(dev)
+    pix, ch, pool = abs_mean_maps(S, with_pool=True)
+    assert torch.allclose(pool, S.mean(1, keepdim=True), atol=1e-6)
+    assert torch.allclose(pix, S.abs().mean(1, keepdim=True), atol=1e-6, rtol=1e-5)
+    assert abs_mean_maps(S.contiguous(), with_pool=True)[2] is None          # NCHW: caller uses torch.mean
+    Sa = S.clone().requires_grad_(True)
+    sums, sp = masked_mse_sums(Sa, T, wf, wb, None, None, pool)
+    (sums[0] * 0.3 + sums[1] * 1.1 + (sp * gmap).sum()).backward()
+    Sb = S.clone().requires_grad_(True)
+    sums_b = masked_mse_sums(Sb, T, wf, wb)
+    (sums_b[0] * 0.3 + sums_b[1] * 1.1 + (Sb.mean(1, keepdim=True) * gmap).sum()).backward()
+    assert torch.equal(sums, sums_b)
+    assert float((Sa.grad - Sb.grad).abs().max()) <= 2e-6 * float(Sb.grad.abs().max())
+    # pooled output unused downstream: gradient of the sums alone is unchanged
+    Sc = S.clone().requires_grad_(True)
+    sums_c, _ = masked_mse_sums(Sc, T, wf, wb, None, None, pool)
+    sums_c[0].backward()
+    Sd = S.clone().requires_grad_(True)
+    masked_mse_sums(Sd, T, wf, wb)[0].backward()
+    assert torch.equal(Sc.grad, Sd.grad)
 
 
 def test_masked_mse_determinism_and_small_odd_channels():
