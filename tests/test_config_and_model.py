@@ -226,3 +226,20 @@ def test_norm_act_module_surgery_is_parameter_preserving_and_falls_back_on_cpu()
         for u, v in zip(a if isinstance(a, (tuple, list)) else [a], b if isinstance(b, (tuple, list)) else [b]):
             assert torch.equal(u, v)
     assert not BA.eligible(x8, net["cm"].norm)              # CPU tensor -> stock torch ops
+
+
+def test_accelerate_modules_rewires_upsampling_and_canvas_layout_without_renaming_parameters():
+    import torch.nn as nn
+    from distill_bev_amd.distill_loss import UpsampleBilinearAC
+    from distill_bev_amd.train_step import accelerate_modules, build_model
+    model, _ = build_model()
+    keys = list(model.state_dict().keys()); tkeys = list(model.teacher_model.state_dict().keys())
+    n_up_before = sum(type(m) is nn.Upsample and m.mode == "bilinear" and bool(m.align_corners)
+                      for r in (model, model.teacher_model) for m in r.modules())
+    n_bn, n_up = accelerate_modules(model)
+    assert n_up == n_up_before and n_up >= 2 and n_bn > 20
+    assert sum(isinstance(m, UpsampleBilinearAC) for m in model.modules()) >= n_up
+    assert not any(type(m) is nn.Upsample and m.mode == "bilinear" and m.align_corners for m in model.modules())
+    assert model.teacher_model.pts_middle_encoder.channels_last is True
+    assert list(model.state_dict().keys()) == keys and list(model.teacher_model.state_dict().keys()) == tkeys
+    assert accelerate_modules(model) == (0, 0)                  # idempotent

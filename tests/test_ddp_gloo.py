@@ -89,3 +89,38 @@ def test_two_rank_gloo_step_equals_single_process_big_batch(tmp_path, torch_ddp,
 def test_parse_losses_sums_only_loss_keys():
     d = {"loss_a": torch.tensor(1.0), "kd_fg_feat_loss_head_head": torch.tensor(2.0), "acc": torch.tensor(100.0)}
     assert float(parse_losses(d)) == 3.0
+
+
+def _reducer_buckets(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distill_bev_amd.train_step import GradReducer
+    torch.manual_seed(0)
+    params = [nn.Parameter(torch.randn(n)) for n in (300_000, 10, 200_000, 70_000, 5, 600_000)]
+    red = GradReducer(params, bucket_mb=1)                       # 1 MiB = 262 144 floats
+    ids = [id(p) for b in red.buckets for p in b]
+    sizes = [sum(p.numel() for p in b) for b in red.buckets]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(i + 1))
+    red.all_reduce_grads()
+    ok_vals = all(torch.equal(p.grad, torch.full_like(p, float(i + 1))) for i, p in enumerate(params))
+    params[1].grad = None
+    try:
+        red.all_reduce_grads()
+        raised = False
+    except RuntimeError:
+        raised = True
+    torch.save(dict(ids=ids, expect=[id(p) for p in reversed(params)], sizes=sizes, ok_vals=ok_vals, raised=raised), out)
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_buckets_cover_every_parameter_once_in_reverse_order(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "red.pt")
+    mp.spawn(_reducer_buckets, args=(1, port, out), nprocs=1, join=True)
+    r = torch.load(out)
+    assert r["ids"] == r["expect"]                               # every parameter once, last parameter first
+    assert all(sz * 4 >= (1 << 20) for sz in r["sizes"][:-1])    # all buckets but the last reach the cap
+    assert r["ok_vals"]                                          # world 1: average == own gradient, packed/unpacked exactly
+    assert r["raised"]                                           # a missing gradient is an error, as with DDP
