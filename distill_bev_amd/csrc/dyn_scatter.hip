@@ -119,6 +119,52 @@ __global__ __launch_bounds__(256) void ds_reduce(const float* __restrict__ feats
   }
 }
 
+// C % 4 == 0 and C/4 a power of two <= 64: a group of C/4 lanes per voxel (each lane 4 channels, one float4 row
+// gather per point), 64 / (C/4) voxels per wave.  LiDAR pillars hold ~2 points: the wave-per-voxel kernel above is
+// a chain of dependent loads per voxel with 1 KB of payload; several voxels per wave overlap those chains.
+// Same per-channel operation order (sequential in point-id order) -> bit-identical to ds_reduce.
+__global__ __launch_bounds__(256) void ds_reduce_vec4(const float4* __restrict__ feats,
+                                                      const int* __restrict__ vstart,
+                                                      const unsigned* __restrict__ vlist,
+                                                      float4* __restrict__ reduced, int m, int C4,
+                                                      int reduce_type) {
+  const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int v = static_cast<int>(tid / C4);
+  const int q = static_cast<int>(tid - static_cast<long long>(v) * C4);
+  if (v >= m) return;
+  const int st = vstart[v];
+  const int L = vstart[v + 1] - st;
+  const float init = reduce_type == 2 ? -INFINITY : 0.f;
+  float4 acc = make_float4(init, init, init, init);
+  int j = 0;
+  for (; j + 4 <= L; j += 4) {
+    float4 f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = feats[static_cast<size_t>(vlist[st + j + u]) * C4 + q];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (reduce_type == 2) {
+        acc.x = fmaxf(acc.x, f[u].x); acc.y = fmaxf(acc.y, f[u].y); acc.z = fmaxf(acc.z, f[u].z); acc.w = fmaxf(acc.w, f[u].w);
+      } else {
+        acc.x += f[u].x; acc.y += f[u].y; acc.z += f[u].z; acc.w += f[u].w;     // sequential point-id order
+      }
+    }
+  }
+  for (; j < L; ++j) {
+    const float4 f = feats[static_cast<size_t>(vlist[st + j]) * C4 + q];
+    if (reduce_type == 2) {
+      acc.x = fmaxf(acc.x, f.x); acc.y = fmaxf(acc.y, f.y); acc.z = fmaxf(acc.z, f.z); acc.w = fmaxf(acc.w, f.w);
+    } else {
+      acc.x += f.x; acc.y += f.y; acc.z += f.z; acc.w += f.w;
+    }
+  }
+  if (reduce_type == 1) {
+    const float fl = static_cast<float>(L);
+    acc.x = acc.x / fl; acc.y = acc.y / fl; acc.z = acc.z / fl; acc.w = acc.w / fl;
+  }
+  st_nt(reduced + static_cast<size_t>(v) * C4 + q, acc);
+}
+
 __global__ __launch_bounds__(256) void ds_bwd_add(float* __restrict__ grad_feats,
                                                   const float* __restrict__ grad_reduced,
                                                   const int* __restrict__ coors_map,
@@ -218,6 +264,16 @@ extern "C" int dbev_dynamic_scatter_reduce(const float* feats, const int32_t* vo
                                            dbevStream_t stream) {
   if (num_voxels < 0 || num_feats <= 0 || reduce_type < 0 || reduce_type > 2) return DBEV_EINVAL;
   if (num_voxels == 0) return 0;
+  const int C4 = num_feats >> 2;
+  if ((num_feats & 3) == 0 && C4 <= 64 && (C4 & (C4 - 1)) == 0) {
+    const long long threads = static_cast<long long>(num_voxels) * C4;
+    hipLaunchKernelGGL(ds_reduce_vec4, dim3(dbev_ceil_div(threads, 256)), dim3(256), 0, dbev_stream(stream),
+                       reinterpret_cast<const float4*>(feats), voxel_point_start,
+                       reinterpret_cast<const unsigned*>(voxel_point_list), reinterpret_cast<float4*>(reduced),
+                       num_voxels, C4, reduce_type);
+    DBEV_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(ds_reduce, dim3(dbev_ceil_div(num_voxels, 4)), dim3(256), 0, dbev_stream(stream), feats,
                      voxel_point_start, reinterpret_cast<const unsigned*>(voxel_point_list), reduced,
                      num_voxels, num_feats, reduce_type);
