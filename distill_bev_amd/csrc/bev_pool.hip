@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_vec4(
   for (long long r = wave * rpw + sub; r < n; r += nwaves * rpw) {
     const int4 g = geom[r];
     const size_t cell = ((static_cast<size_t>(g.w) * d + g.z) * h + g.x) * w + g.y;
-    x_grad[static_cast<size_t>(r) * c4 + q] = out_grad[cell * c4 + q];
+    st_nt(x_grad + static_cast<size_t>(r) * c4 + q, out_grad[cell * c4 + q]);   // 909 MB written once, streamed
   }
 }
 
