@@ -268,7 +268,64 @@ def make_fgmask():
         print(H, "fg cells per sample", [int(f.sum()) for f in fgs])
 
 
-SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask}
+def make_center():
+    """CenterHead targets of the distillation recipe's student head (6 tasks, 128x128 map): heat maps drawn with the
+    IMPORTED reference core/utils/gaussian.py (gaussian_radius on 0-dim float32 tensors, draw_heatmap_gaussian on torch
+    maps), slot assignment / regression rows restated from centerpoint_head.py:447-611 exactly as the reference orders
+    its python loop (per task: concatenate the per-class index lists, walk them in order)."""
+    G = R.gaussian()
+    rng = np.random.default_rng(21)
+    tasks = [["car"], ["truck", "construction_vehicle"], ["bus", "trailer"], ["barrier"], ["motorcycle", "bicycle"],
+             ["pedestrian", "traffic_cone"]]
+    grid, vs, pc, osf, max_objs, overlap, min_radius = (1024, 1024), (0.1, 0.1), (-51.2, -51.2), 8, 500, 0.1, 2
+    W, H = grid[0] // osf, grid[1] // osf
+    B = 2
+    boxes9, labels = [], []
+    hm = np.zeros((B, 10, H, W), np.float32)
+    anno = np.zeros((len(tasks), B, max_objs, 10), np.float32)
+    ind = np.zeros((len(tasks), B, max_objs), np.int64)
+    mask = np.zeros((len(tasks), B, max_objs), np.uint8)
+    for b in range(B):
+        bx, lab = syn.gt_boxes(40, rng)                        # bottom-centre boxes [M, 9]
+        g9 = bx.copy(); g9[:, 2] = g9[:, 2] + g9[:, 5] * 0.5    # gravity centre, as LiDARInstance3DBoxes.gravity_center
+        boxes9.append(g9.astype(np.float32)); labels.append(lab.astype(np.int64))
+        t9 = torch.from_numpy(boxes9[-1]); tl = torch.from_numpy(labels[-1])
+        flag = 0
+        for t, names in enumerate(tasks):
+            sel = [torch.where(tl == names.index(n) + flag) for n in names]
+            tb = torch.cat([t9[m] for m in sel], 0) if sel else t9[:0]
+            tc = torch.cat([tl[m] + 1 - flag for m in sel]) if sel else tl[:0]
+            hmt = torch.zeros((len(names), H, W))
+            for k in range(min(tb.shape[0], max_objs)):
+                cls_id = int(tc[k]) - 1
+                width = tb[k][3] / vs[0] / osf
+                length = tb[k][4] / vs[1] / osf
+                if width > 0 and length > 0:
+                    radius = G.gaussian_radius((length, width), min_overlap=overlap)
+                    radius = max(min_radius, int(radius))
+                    x, y, z = tb[k][0], tb[k][1], tb[k][2]
+                    coor_x = (x - pc[0]) / vs[0] / osf
+                    coor_y = (y - pc[1]) / vs[1] / osf
+                    center = torch.tensor([coor_x, coor_y], dtype=torch.float32)
+                    center_int = center.to(torch.int32)
+                    if not (0 <= center_int[0] < W and 0 <= center_int[1] < H):
+                        continue
+                    G.draw_heatmap_gaussian(hmt[cls_id], center_int, radius)
+                    xi, yi = int(center_int[0]), int(center_int[1])
+                    ind[t, b, k] = yi * W + xi
+                    mask[t, b, k] = 1
+                    anno[t, b, k] = torch.cat([center - torch.tensor([xi, yi], dtype=torch.float32), z.unsqueeze(0),
+                                               tb[k][3:6].log(), torch.sin(tb[k][6]).unsqueeze(0),
+                                               torch.cos(tb[k][6]).unsqueeze(0), tb[k][7:9]]).numpy()
+            s0 = sum(len(n) for n in tasks[:t])
+            hm[b, s0:s0 + len(names)] = hmt.numpy()
+            flag += len(names)
+    _save("center_targets.npz", boxes0=boxes9[0], boxes1=boxes9[1], labels0=labels[0], labels1=labels[1],
+          heatmap=hm, anno_box=anno, ind=ind, mask=mask)
+    print("objects per task", mask.sum(axis=(1, 2)).tolist(), "heat-map peaks", int((hm == 1).sum()))
+
+
+SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)

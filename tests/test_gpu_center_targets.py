@@ -85,3 +85,24 @@ def test_targets_are_deterministic_and_reject_cpu():
             assert torch.equal(u, v)
     with pytest.raises(DbevHipError):
         head.get_targets(*args, torch.device("cpu"))
+
+
+def test_targets_match_fixture_drawn_by_the_reference_gaussian_utils():
+    """tests/golden/center_targets.npz (make_golden.py 'center': imported core/utils/gaussian.py + the reference's loop)."""
+    from conftest import load_golden
+    from distill_bev_amd.center_head import LiDARBoxes
+    fx = load_golden("center_targets.npz")
+    head = _head()
+    boxes, labels = [], []
+    for b in range(2):
+        g9 = fx[f"boxes{b}"].copy()
+        bottom = g9.copy(); bottom[:, 2] = g9[:, 2] - g9[:, 5] * 0.5
+        boxes.append(LiDARBoxes(bottom)); labels.append(torch.from_numpy(fx[f"labels{b}"]))
+    hms, abox, inds, masks = head.get_targets(boxes, labels, torch.device("cuda:0"))
+    edges = np.cumsum([0] + [len(n) for n in head.class_names])
+    for t in range(6):
+        assert np.array_equal(masks[t].cpu().numpy(), fx["mask"][t])
+        assert np.array_equal(inds[t].cpu().numpy(), fx["ind"][t])
+        assert _ulps(hms[t].cpu().numpy(), fx["heatmap"][:, edges[t]:edges[t + 1]]).max() <= 1
+        u = _ulps(abox[t].cpu().numpy(), fx["anno_box"][t])
+        assert u[..., [0, 1, 8, 9]].max() == 0 and u.max() <= 2

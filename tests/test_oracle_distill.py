@@ -58,3 +58,30 @@ def test_fgd_losses_brute_force_tiny():
                         tot_bg += sq * sc * att[y, x]
     assert abs(out["kd_fg_feat_loss"] - tot_fg * 6e-3 / B) < 1e-12
     assert abs(out["kd_bg_feat_loss"] - tot_bg * 4e-2 / B) < 1e-12
+
+
+def test_center_targets_restatement_matches_fixture_from_imported_gaussian_utils():
+    """oracle/center_targets.py vs tests/golden/center_targets.npz (heat maps drawn by the reference's own
+    core/utils/gaussian.py, slot/regression logic of centerpoint_head.py:447-611; make_golden.py 'center')."""
+    import torch
+    from conftest import load_golden
+    from distill_bev_amd.center_head import LiDARBoxes
+    from distill_bev_amd.train_step import build_model
+    from oracle import center_targets as OCT
+    fx = load_golden("center_targets.npz")
+    head = build_model()[0].pts_bbox_head
+    boxes, labels = [], []
+    for b in range(2):
+        g9 = fx[f"boxes{b}"].copy()
+        bottom = g9.copy(); bottom[:, 2] = g9[:, 2] - g9[:, 5] * 0.5      # LiDARBoxes holds bottom centres
+        boxes.append(LiDARBoxes(bottom)); labels.append(torch.from_numpy(fx[f"labels{b}"]))
+    hms, abox, inds, masks = OCT.get_targets(head, boxes, labels, torch.device("cpu"))
+    edges = np.cumsum([0] + [len(n) for n in head.class_names])
+    for t in range(6):
+        assert np.array_equal(masks[t].numpy(), fx["mask"][t]) and np.array_equal(inds[t].numpy(), fx["ind"][t])
+        hm = hms[t].numpy(); ref = fx["heatmap"][:, edges[t]:edges[t + 1]]
+        assert np.array_equal(hm, ref)
+        a, r = abox[t].numpy(), fx["anno_box"][t]
+        ulp = np.abs(a.view(np.int32).astype(np.int64) - r.view(np.int32).astype(np.int64))
+        # z re-derived from bottom + h/2 and torch-vs-numpy float32 log/sin/cos: last-bit differences only
+        assert ulp[..., [0, 1, 8, 9]].max() == 0 and ulp.max() <= 2
