@@ -96,3 +96,27 @@ def test_fused_loss_is_bit_reproducible():
     for t in range(6):
         for k in KEYS:
             assert torch.equal(runs[0][1][t][k].grad, runs[1][1][t][k].grad)
+
+
+def test_batch_without_any_object():
+    """no GT box in the whole batch: targets all zero, avg factors fall back to 1 / 1e-4, losses finite, gradients flow
+    through the heat-map term only -- same as the op sequence."""
+    from distill_bev_amd.center_head import CenterHead
+    head, boxes, labels = _setup(2, (0, 0), 3)
+    la_leaf, lb_leaf = _leaves(head, 2, 2, True), _leaves(head, 2, 2, True)
+    la = head.loss(boxes, labels, _preds(la_leaf))
+    try:
+        CenterHead.fused_loss = False
+        lb = head.loss(boxes, labels, _preds(lb_leaf))
+    finally:
+        CenterHead.fused_loss = True
+    for k in lb:
+        a, b = float(la[k].detach()), float(lb[k].detach())
+        assert np.isfinite(a) and abs(a - b) <= 2e-6 * max(abs(b), 1e-3), (k, a, b)
+        if "heatmap" not in k:
+            assert a == 0.0
+    sum(la.values()).backward(); sum(lb.values()).backward()
+    for t in range(6):
+        assert float(la_leaf[t]["reg"].grad.abs().max()) == 0.0
+        ga, gb = la_leaf[t]["heatmap"].grad, lb_leaf[t]["heatmap"].grad
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
