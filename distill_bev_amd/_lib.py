@@ -67,6 +67,9 @@ _SIGNATURES = {
     "dbev_centerhead_loss_workspace_bytes": [_i, _i, _i, _i, _i],
     "dbev_centerhead_loss_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _sz, _p],
     "dbev_centerhead_loss_backward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p],
+    "dbev_skinny_conv3x3_workspace_bytes": [_i, _i],
+    "dbev_skinny_conv3x3_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dbev_skinny_conv3x3_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
     "dbev_bn_act_workspace_bytes": [_ll, _i],
     "dbev_bn_act_train_forward": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],
@@ -80,6 +83,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
              "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t,
              "dbev_bn_act_workspace_bytes": ctypes.c_size_t,
+             "dbev_skinny_conv3x3_workspace_bytes": ctypes.c_size_t,
              "dbev_centerhead_loss_workspace_bytes": ctypes.c_size_t,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,

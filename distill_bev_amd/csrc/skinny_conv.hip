@@ -1,0 +1,249 @@
+// 3x3 convolution (stride 1, padding 1) with a SKINNY output: Cout <= 3, channels-last fp32.
+//
+// The final layer of every CenterHead branch (mmdet3d/models/dense_heads/centerpoint_head.py:17-130 SeparateHead:
+// reg 2, height 1, dim 3, rot 2, vel 2, heatmap 1-2 channels from a 64-channel hidden map; 36 such convolutions in the
+// student head, 36 in the teacher's) has 0.15-0.45 GFLOP and reads a 33.5 MB input: it is HBM-bound streaming work,
+// not GEMM-shaped.  MIOpen's implicit-GEMM tiles (64x16 ... with N padded from 1-3 to 16) need 57 us forward, 18 us
+// data-gradient, 58 us weight-gradient plus ~6 SetTensor / bias / bias-gradient launches per convolution -- 0.6 TB/s.
+// Here: output-stationary forward and data-gradient, input-stationary weight-gradient, one lane group of Cin/4 lanes
+// per pixel (float4 = 4 input channels per lane), weights in LDS, fixed-order two-stage reductions (no float atomics).
+//
+//   x    f32[N, H, W, Cin]     (NHWC),  Cin/4 in {8, 16, 32, 64}
+//   wp   f32[Cout, 3, 3, Cin]  = weight.permute(0, 2, 3, 1) of the torch [Cout, Cin, 3, 3] parameter
+//   y    f32[N, H, W, Cout]    (NHWC image of [N, Cout, H, W])
+#include "common.h"
+
+namespace {
+
+constexpr int SK_MAX_CO = 3;
+
+struct SkDims { int N, H, W, C4; };
+
+__device__ __forceinline__ float dot4f(const float4& a, const float4& b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void sk_fwd(const float4* __restrict__ x, const float4* __restrict__ wp,
+                                              const float* __restrict__ bias, float* __restrict__ y, SkDims d) {
+  extern __shared__ __attribute__((aligned(16))) float4 sw[];        // [CO][9][C4]
+  const int G = d.C4;
+  for (int i = threadIdx.x; i < CO * 9 * G; i += blockDim.x) sw[i] = wp[i];
+  __syncthreads();
+  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
+  const long long p = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  const int q = threadIdx.x & (G - 1);
+  const bool live = p < npix;
+  const long long pp = live ? p : 0;
+  const int w = static_cast<int>(pp % d.W);
+  const int h = static_cast<int>((pp / d.W) % d.H);
+  const long long n = pp / (static_cast<long long>(d.W) * d.H);
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+    if (live && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) {
+      const float4 v = x[((n * d.H + hh) * d.W + ww) * G + q];
+#pragma unroll
+      for (int co = 0; co < CO; ++co) acc[co] += dot4f(v, sw[(co * 9 + tap) * G + q]);
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    float s = acc[co];
+    for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (live && q == 0) y[p * CO + co] = s + (bias ? bias[co] : 0.f);
+  }
+}
+
+// dx[n,h,w,ci] = sum_{tap,co} dy[n, h-(kh-1), w-(kw-1), co] * W[co,ci,kh,kw]
+template <int CO>
+__global__ __launch_bounds__(256) void sk_bwd_data(const float* __restrict__ dy, const float4* __restrict__ wp,
+                                                   float4* __restrict__ dx, SkDims d) {
+  extern __shared__ __attribute__((aligned(16))) float4 sw[];
+  const int G = d.C4;
+  for (int i = threadIdx.x; i < CO * 9 * G; i += blockDim.x) sw[i] = wp[i];
+  __syncthreads();
+  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
+  const long long p = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  if (p >= npix) return;
+  const int q = threadIdx.x & (G - 1);
+  const int w = static_cast<int>(p % d.W);
+  const int h = static_cast<int>((p / d.W) % d.H);
+  const long long n = p / (static_cast<long long>(d.W) * d.H);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
+    if (hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) {
+      const float* g = dy + ((n * d.H + hh) * d.W + ww) * CO;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        const float gv = g[co];
+        const float4 wv = sw[(co * 9 + tap) * G + q];
+        acc.x = fmaf(gv, wv.x, acc.x); acc.y = fmaf(gv, wv.y, acc.y);
+        acc.z = fmaf(gv, wv.z, acc.z); acc.w = fmaf(gv, wv.w, acc.w);
+      }
+    }
+  }
+  st_nt(dx + p * G + q, acc);
+}
+
+// input-stationary weight gradient: every lane keeps dWp[co][tap] for its 4 input channels (CO*9 float4 registers),
+// walks a contiguous range of pixels reading x ONCE and the 9*CO neighbouring dy scalars, then the lane groups of the
+// workgroup are merged through LDS and written as one partial per workgroup.  dbias in the same pass.
+template <int CO>
+__global__ __launch_bounds__(256) void sk_bwd_weight(const float4* __restrict__ x, const float* __restrict__ dy,
+                                                     float4* __restrict__ part_w /* [blocks][CO*9][C4] */,
+                                                     float* __restrict__ part_b /* [blocks][CO] */, SkDims d) {
+  __shared__ float4 red[256];
+  const int G = d.C4;
+  const int grp = threadIdx.x / G, q = threadIdx.x & (G - 1), ngrp = blockDim.x / G;
+  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
+  const long long per = (npix + gridDim.x - 1) / gridDim.x;
+  const long long p0 = static_cast<long long>(blockIdx.x) * per;
+  const long long p1 = p0 + per < npix ? p0 + per : npix;
+  float4 acc[CO * 9];
+#pragma unroll
+  for (int i = 0; i < CO * 9; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bsum[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) bsum[co] = 0.f;
+  for (long long p = p0 + grp; p < p1; p += ngrp) {
+    const int w = static_cast<int>(p % d.W);
+    const int h = static_cast<int>((p / d.W) % d.H);
+    const long long n = p / (static_cast<long long>(d.W) * d.H);
+    const float4 v = x[p * G + q];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) bsum[co] += dy[p * CO + co];     // same value in every lane of the group
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // x[p] is the (kh, kw) neighbour of the output pixel at (h - (kh-1), w - (kw-1))
+      const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
+      if (hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) {
+        const float* g = dy + ((n * d.H + hh) * d.W + ww) * CO;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const float gv = g[co];
+          float4& a = acc[co * 9 + tap];
+          a.x = fmaf(gv, v.x, a.x); a.y = fmaf(gv, v.y, a.y); a.z = fmaf(gv, v.z, a.z); a.w = fmaf(gv, v.w, a.w);
+        }
+      }
+    }
+  }
+  // merge the lane groups (fixed order: group 0, 1, 2, ...)
+#pragma unroll
+  for (int i = 0; i < CO * 9; ++i) {
+    __syncthreads();
+    red[threadIdx.x] = acc[i];
+    __syncthreads();
+    if (grp == 0) {
+      float4 t = red[q];
+      for (int k = 1; k < ngrp; ++k) {
+        const float4 u = red[k * G + q];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      part_w[(static_cast<size_t>(blockIdx.x) * CO * 9 + i) * G + q] = t;
+    }
+  }
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) reinterpret_cast<float*>(red)[grp * CO + co] = bsum[co];
+  }
+  __syncthreads();
+  if (threadIdx.x < CO) {
+    float t = 0.f;
+    for (int k = 0; k < ngrp; ++k) t += reinterpret_cast<float*>(red)[k * CO + threadIdx.x];
+    part_b[static_cast<size_t>(blockIdx.x) * CO + threadIdx.x] = t;
+  }
+}
+
+// fixed-order fp64 merge of the workgroup partials: 16 outputs x 16 partial phases per workgroup
+__global__ __launch_bounds__(256) void sk_final(const float* __restrict__ part, int nblk, int n_out, float* __restrict__ out) {
+  __shared__ double red[16][16];
+  const int ol = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + ol;
+  double s = 0.0;
+  if (i < n_out)
+    for (int b = ph; b < nblk; b += 16) s += static_cast<double>(part[static_cast<size_t>(b) * n_out + i]);
+  red[ph][ol] = s;
+  __syncthreads();
+  if (ph == 0 && i < n_out) {
+    for (int p = 1; p < 16; ++p) s += red[p][ol];
+    out[i] = static_cast<float>(s);
+  }
+}
+
+constexpr int SK_WG_BLOCKS = 512;
+
+bool sk_ok(int N, int Cin, int H, int W, int Cout, SkDims* d) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout < 1 || Cout > SK_MAX_CO) return false;
+  const int C4 = Cin >> 2;
+  if (C4 < 8 || C4 > 64 || (C4 & (C4 - 1))) return false;
+  if (static_cast<long long>(N) * H * W * C4 > 0x7fffffff0LL) return false;
+  *d = SkDims{N, H, W, C4};
+  return true;
+}
+
+#define SK_DISPATCH(CO, KERNEL, ...)                            \
+  switch (CO) {                                                 \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break; \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<3>), __VA_ARGS__); break; \
+  }
+
+}  // namespace
+
+extern "C" size_t dbev_skinny_conv3x3_workspace_bytes(int Cin, int Cout) {
+  if (Cin <= 0 || (Cin & 3) || Cout < 1 || Cout > SK_MAX_CO) return 0;
+  return sizeof(float) * static_cast<size_t>(SK_WG_BLOCKS) * (static_cast<size_t>(Cout) * 9 * Cin + Cout) + 256;
+}
+
+extern "C" int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* weight_ohwi, const float* bias, float* y_nhwc,
+                                           int N, int Cin, int H, int W, int Cout, dbevStream_t stream) {
+  SkDims d;
+  if (!sk_ok(N, Cin, H, W, Cout, &d) || x_nhwc == nullptr || weight_ohwi == nullptr || y_nhwc == nullptr) return DBEV_EINVAL;
+  const long long threads = static_cast<long long>(N) * H * W * d.C4;
+  const size_t lds = sizeof(float4) * Cout * 9 * d.C4;
+  SK_DISPATCH(Cout, sk_fwd, dim3(dbev_ceil_div(threads, 256)), dim3(256), lds, dbev_stream(stream),
+              reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<const float4*>(weight_ohwi), bias, y_nhwc, d);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const float* x_nhwc, const float* weight_ohwi,
+                                            float* grad_x_nhwc, float* grad_weight_ohwi, float* grad_bias, int N, int Cin,
+                                            int H, int W, int Cout, void* workspace, size_t workspace_bytes,
+                                            dbevStream_t stream) {
+  SkDims d;
+  if (!sk_ok(N, Cin, H, W, Cout, &d) || grad_y_nhwc == nullptr || x_nhwc == nullptr || weight_ohwi == nullptr)
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const long long threads = static_cast<long long>(N) * H * W * d.C4;
+  const size_t lds = sizeof(float4) * Cout * 9 * d.C4;
+  if (grad_x_nhwc != nullptr)
+    SK_DISPATCH(Cout, sk_bwd_data, dim3(dbev_ceil_div(threads, 256)), dim3(256), lds, s, grad_y_nhwc,
+                reinterpret_cast<const float4*>(weight_ohwi), reinterpret_cast<float4*>(grad_x_nhwc), d);
+  if (grad_weight_ohwi != nullptr) {
+    if (grad_bias == nullptr || workspace == nullptr || workspace_bytes < dbev_skinny_conv3x3_workspace_bytes(Cin, Cout))
+      return DBEV_EINVAL;
+    const long long npix = static_cast<long long>(N) * H * W;
+    const int rows_per_iter = 256 / d.C4;
+    long long blocks = (npix + rows_per_iter * 8 - 1) / (rows_per_iter * 8);
+    if (blocks > SK_WG_BLOCKS) blocks = SK_WG_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    float* part_w = static_cast<float*>(workspace);
+    float* part_b = part_w + static_cast<size_t>(SK_WG_BLOCKS) * Cout * 9 * Cin;
+    SK_DISPATCH(Cout, sk_bwd_weight, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                reinterpret_cast<const float4*>(x_nhwc), grad_y_nhwc, reinterpret_cast<float4*>(part_w), part_b, d);
+    const int nw = Cout * 9 * Cin;
+    hipLaunchKernelGGL(sk_final, dim3(dbev_ceil_div(nw, 16)), dim3(256), 0, s, part_w, static_cast<int>(blocks), nw,
+                       grad_weight_ohwi);
+    hipLaunchKernelGGL(sk_final, dim3(1), dim3(256), 0, s, part_b, static_cast<int>(blocks), Cout, grad_bias);
+  }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}

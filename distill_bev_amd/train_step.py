@@ -85,8 +85,10 @@ def accelerate_modules(detector):
     bilinear align_corners nn.Upsample (UpsampleBilinearAC), NHWC teacher canvas.  State-dict keys are unchanged."""
     from .bn_act import fuse_bn_relu_modules
     from .distill_loss import UpsampleBilinearAC
+    from .skinny_conv import use_skinny_convs
     roots = [detector] + ([detector.teacher_model] if getattr(detector, "teacher_model", None) is not None else [])
     n_bn = sum(fuse_bn_relu_modules(r) for r in roots)
+    detector.skinny_convs = sum(use_skinny_convs(r) for r in roots)    # final 64 -> 1..3 convs of the CenterHead branches
     n_up = 0
     for r in roots:
         for mod in r.modules():

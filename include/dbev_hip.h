@@ -375,6 +375,20 @@ int dbev_centerhead_loss_backward(const float* const* heads_host, const int32_t*
                                   float loss_weight_bbox, float loss_weight_cls, const float* avg_factors,
                                   const float* grad_losses, dbevStream_t stream);
 
+/* 3x3 convolution, stride 1, padding 1, with a skinny output (Cout <= 3), channels-last fp32: the final layer of every
+ * CenterHead branch (mmdet3d/models/dense_heads/centerpoint_head.py:17-130, SeparateHead: 64 -> 1..3 channels).  HBM-bound
+ * streaming work that MIOpen's implicit-GEMM tiles serve at 0.6 TB/s (N padded from 1-3 to 16).
+ *   x_nhwc f32[N,H,W,Cin] (Cin/4 in {8,16,32,64}); weight_ohwi f32[Cout,3,3,Cin] = torch weight.permute(0,2,3,1);
+ *   bias f32[Cout] or NULL; y_nhwc f32[N,H,W,Cout].
+ * backward: grad_x_nhwc (may be NULL) fully written; grad_weight_ohwi f32[Cout,3,3,Cin] + grad_bias f32[Cout] (both or
+ * neither) by fixed-order two-stage reductions (no float atomics; workspace from dbev_skinny_conv3x3_workspace_bytes). */
+size_t dbev_skinny_conv3x3_workspace_bytes(int Cin, int Cout);
+int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* weight_ohwi, const float* bias, float* y_nhwc, int N,
+                                int Cin, int H, int W, int Cout, dbevStream_t stream);
+int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const float* x_nhwc, const float* weight_ohwi,
+                                 float* grad_x_nhwc, float* grad_weight_ohwi, float* grad_bias, int N, int Cin, int H, int W,
+                                 int Cout, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
 /* Training-mode BatchNorm2d fused with the residual add and ReLU that follow it (channels-last fp32):
  *   y = relu( (x - mean_batch) / sqrt(var_batch + eps) * gamma + beta  [+ residual] )
  * = torch.nn.functional.batch_norm(training=True) [+ add] [+ relu] as the reference's dense blocks chain them
