@@ -23,38 +23,48 @@ __device__ __forceinline__ float dot4f(const float4& a, const float4& b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
+constexpr int SK_PERSIST_BLOCKS = 2048;   // forward / data-gradient: lane groups stride over the pixels, weights stay in registers
+
 template <int CO>
 __global__ __launch_bounds__(256) void sk_fwd(const float4* __restrict__ x, const float4* __restrict__ wp,
                                               const float* __restrict__ bias, float* __restrict__ y, SkDims d) {
-  extern __shared__ __attribute__((aligned(16))) float4 sw[];        // [CO][9][C4]
   const int G = d.C4;
-  for (int i = threadIdx.x; i < CO * 9 * G; i += blockDim.x) sw[i] = wp[i];
-  __syncthreads();
-  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
-  const long long p = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   const int q = threadIdx.x & (G - 1);
-  const bool live = p < npix;
-  const long long pp = live ? p : 0;
-  const int w = static_cast<int>(pp % d.W);
-  const int h = static_cast<int>((pp / d.W) % d.H);
-  const long long n = pp / (static_cast<long long>(d.W) * d.H);
-  float acc[CO];
+  float4 wr[CO * 9];                                 // this lane's 4 input channels of every (co, tap)
 #pragma unroll
-  for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+  for (int i = 0; i < CO * 9; ++i) wr[i] = wp[i * G + q];
+  float br[CO];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
-    if (live && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) {
-      const float4 v = x[((n * d.H + hh) * d.W + ww) * G + q];
+  for (int co = 0; co < CO; ++co) br[co] = bias ? bias[co] : 0.f;
+  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
+  const long long ngrp = static_cast<long long>(gridDim.x) * blockDim.x / G;
+  // all lanes of a wave run the same number of iterations (shuffles below): bound by the wave's first group
+  const long long g0 = (static_cast<long long>(blockIdx.x) * blockDim.x + (threadIdx.x & ~63)) / G;
+  const long long gme = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  for (long long pb = g0; pb < npix; pb += ngrp) {
+    const long long p = pb + (gme - g0);
+    const bool live = p < npix;
+    const long long pp = live ? p : 0;
+    const unsigned pu = static_cast<unsigned>(pp);            // N*H*W < 2^31 (sk_ok): 32-bit divisions
+    const unsigned rowi = pu / static_cast<unsigned>(d.W);
+    const int w = static_cast<int>(pu - rowi * d.W);
+    const long long n = rowi / static_cast<unsigned>(d.H);
+    const int h = static_cast<int>(rowi - static_cast<unsigned>(n) * d.H);
+    float4 v[9];
 #pragma unroll
-      for (int co = 0; co < CO; ++co) acc[co] += dot4f(v, sw[(co * 9 + tap) * G + q]);
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+      v[tap] = (live && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) ? x[((n * d.H + hh) * d.W + ww) * G + q]
+                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  }
 #pragma unroll
-  for (int co = 0; co < CO; ++co) {
-    float s = acc[co];
-    for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (live && q == 0) y[p * CO + co] = s + (bias ? bias[co] : 0.f);
+    for (int co = 0; co < CO; ++co) {
+      float s = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) s += dot4f(v[tap], wr[co * 9 + tap]);
+      for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (live && q == 0) y[p * CO + co] = s + br[co];
+    }
   }
 }
 
@@ -62,33 +72,39 @@ __global__ __launch_bounds__(256) void sk_fwd(const float4* __restrict__ x, cons
 template <int CO>
 __global__ __launch_bounds__(256) void sk_bwd_data(const float* __restrict__ dy, const float4* __restrict__ wp,
                                                    float4* __restrict__ dx, SkDims d) {
-  extern __shared__ __attribute__((aligned(16))) float4 sw[];
   const int G = d.C4;
-  for (int i = threadIdx.x; i < CO * 9 * G; i += blockDim.x) sw[i] = wp[i];
-  __syncthreads();
-  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
-  const long long p = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
-  if (p >= npix) return;
   const int q = threadIdx.x & (G - 1);
-  const int w = static_cast<int>(p % d.W);
-  const int h = static_cast<int>((p / d.W) % d.H);
-  const long long n = p / (static_cast<long long>(d.W) * d.H);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 wr[CO * 9];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
-    if (hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) {
+  for (int i = 0; i < CO * 9; ++i) wr[i] = wp[i * G + q];
+  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
+  const long long ngrp = static_cast<long long>(gridDim.x) * blockDim.x / G;
+  for (long long p = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G; p < npix; p += ngrp) {
+    const unsigned pu = static_cast<unsigned>(p);
+    const unsigned rowi = pu / static_cast<unsigned>(d.W);
+    const int w = static_cast<int>(pu - rowi * d.W);
+    const long long n = rowi / static_cast<unsigned>(d.H);
+    const int h = static_cast<int>(rowi - static_cast<unsigned>(n) * d.H);
+    float gv[9][CO];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
+      const bool in = hh >= 0 && hh < d.H && ww >= 0 && ww < d.W;
       const float* g = dy + ((n * d.H + hh) * d.W + ww) * CO;
 #pragma unroll
-      for (int co = 0; co < CO; ++co) {
-        const float gv = g[co];
-        const float4 wv = sw[(co * 9 + tap) * G + q];
-        acc.x = fmaf(gv, wv.x, acc.x); acc.y = fmaf(gv, wv.y, acc.y);
-        acc.z = fmaf(gv, wv.z, acc.z); acc.w = fmaf(gv, wv.w, acc.w);
-      }
+      for (int co = 0; co < CO; ++co) gv[tap][co] = in ? g[co] : 0.f;
     }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        const float4 wv = wr[co * 9 + tap];
+        acc.x = fmaf(gv[tap][co], wv.x, acc.x); acc.y = fmaf(gv[tap][co], wv.y, acc.y);
+        acc.z = fmaf(gv[tap][co], wv.z, acc.z); acc.w = fmaf(gv[tap][co], wv.w, acc.w);
+      }
+    st_nt(dx + p * G + q, acc);
   }
-  st_nt(dx + p * G + q, acc);
 }
 
 // input-stationary weight gradient: every lane keeps dWp[co][tap] for its 4 input channels (CO*9 float4 registers),
@@ -111,26 +127,47 @@ __global__ __launch_bounds__(256) void sk_bwd_weight(const float4* __restrict__ 
   float bsum[CO];
 #pragma unroll
   for (int co = 0; co < CO; ++co) bsum[co] = 0.f;
-  for (long long p = p0 + grp; p < p1; p += ngrp) {
-    const int w = static_cast<int>(p % d.W);
-    const int h = static_cast<int>((p / d.W) % d.H);
-    const long long n = p / (static_cast<long long>(d.W) * d.H);
-    const float4 v = x[p * G + q];
+  constexpr int U = CO == 3 ? 1 : 2;      // CO = 3 already holds 27 float4 accumulators per lane
+  for (long long pa = p0 + grp; pa < p1; pa += U * ngrp) {
+    // U pixels per iteration: every load is issued before the FMAs (the loop is latency-bound otherwise)
+    float4 v[U];
+    float gv[U][9][CO];
+    float gc[U][CO];
 #pragma unroll
-    for (int co = 0; co < CO; ++co) bsum[co] += dy[p * CO + co];     // same value in every lane of the group
+    for (int u = 0; u < U; ++u) {
+      const long long p = pa + u * ngrp;
+      const bool live = p < p1;
+      const long long pp = live ? p : p0;
+      const unsigned pu = static_cast<unsigned>(pp);
+      const unsigned rowi = pu / static_cast<unsigned>(d.W);
+      const int w = static_cast<int>(pu - rowi * d.W);
+      const long long n = rowi / static_cast<unsigned>(d.H);
+      const int h = static_cast<int>(rowi - static_cast<unsigned>(n) * d.H);
+      v[u] = live ? x[pp * G + q] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      // x[p] is the (kh, kw) neighbour of the output pixel at (h - (kh-1), w - (kw-1))
-      const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
-      if (hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) {
+      for (int co = 0; co < CO; ++co) gc[u][co] = live ? dy[pp * CO + co] : 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        // x[p] is the (kh, kw) neighbour of the output pixel at (h - (kh-1), w - (kw-1))
+        const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
+        const bool in = live && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W;
         const float* g = dy + ((n * d.H + hh) * d.W + ww) * CO;
 #pragma unroll
-        for (int co = 0; co < CO; ++co) {
-          const float gv = g[co];
-          float4& a = acc[co * 9 + tap];
-          a.x = fmaf(gv, v.x, a.x); a.y = fmaf(gv, v.y, a.y); a.z = fmaf(gv, v.z, a.z); a.w = fmaf(gv, v.w, a.w);
-        }
+        for (int co = 0; co < CO; ++co) gv[u][tap][co] = in ? g[co] : 0.f;
       }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int co = 0; co < CO; ++co) bsum[co] += gc[u][co];             // same value in every lane of the group
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          float4& a = acc[co * 9 + tap];
+          const float g1 = gv[u][tap][co];
+          a.x = fmaf(g1, v[u].x, a.x); a.y = fmaf(g1, v[u].y, a.y); a.z = fmaf(g1, v[u].z, a.z); a.w = fmaf(g1, v[u].w, a.w);
+        }
     }
   }
   // merge the lane groups (fixed order: group 0, 1, 2, ...)
@@ -177,13 +214,13 @@ __global__ __launch_bounds__(256) void sk_final(const float* __restrict__ part, 
   }
 }
 
-constexpr int SK_WG_BLOCKS = 512;
+constexpr int SK_WG_BLOCKS = 1024;
 
 bool sk_ok(int N, int Cin, int H, int W, int Cout, SkDims* d) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout < 1 || Cout > SK_MAX_CO) return false;
   const int C4 = Cin >> 2;
   if (C4 < 8 || C4 > 64 || (C4 & (C4 - 1))) return false;
-  if (static_cast<long long>(N) * H * W * C4 > 0x7fffffff0LL) return false;
+  if (static_cast<long long>(N) * H * W > 0x7fffffffLL) return false;
   *d = SkDims{N, H, W, C4};
   return true;
 }
@@ -207,8 +244,9 @@ extern "C" int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* wei
   SkDims d;
   if (!sk_ok(N, Cin, H, W, Cout, &d) || x_nhwc == nullptr || weight_ohwi == nullptr || y_nhwc == nullptr) return DBEV_EINVAL;
   const long long threads = static_cast<long long>(N) * H * W * d.C4;
-  const size_t lds = sizeof(float4) * Cout * 9 * d.C4;
-  SK_DISPATCH(Cout, sk_fwd, dim3(dbev_ceil_div(threads, 256)), dim3(256), lds, dbev_stream(stream),
+  long long blocks = (threads + 255) / 256;
+  if (blocks > SK_PERSIST_BLOCKS) blocks = SK_PERSIST_BLOCKS;
+  SK_DISPATCH(Cout, sk_fwd, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, dbev_stream(stream),
               reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<const float4*>(weight_ohwi), bias, y_nhwc, d);
   DBEV_LAUNCH_CHECK();
   return 0;
@@ -223,9 +261,10 @@ extern "C" int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const floa
     return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   const long long threads = static_cast<long long>(N) * H * W * d.C4;
-  const size_t lds = sizeof(float4) * Cout * 9 * d.C4;
+  long long pblocks = (threads + 255) / 256;
+  if (pblocks > SK_PERSIST_BLOCKS) pblocks = SK_PERSIST_BLOCKS;
   if (grad_x_nhwc != nullptr)
-    SK_DISPATCH(Cout, sk_bwd_data, dim3(dbev_ceil_div(threads, 256)), dim3(256), lds, s, grad_y_nhwc,
+    SK_DISPATCH(Cout, sk_bwd_data, dim3(static_cast<unsigned>(pblocks)), dim3(256), 0, s, grad_y_nhwc,
                 reinterpret_cast<const float4*>(weight_ohwi), reinterpret_cast<float4*>(grad_x_nhwc), d);
   if (grad_weight_ohwi != nullptr) {
     if (grad_bias == nullptr || workspace == nullptr || workspace_bytes < dbev_skinny_conv3x3_workspace_bytes(Cin, Cout))
