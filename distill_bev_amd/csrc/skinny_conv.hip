@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void sk_final(const float* __restrict__ part, 
   }
 }
 
-constexpr int SK_WG_BLOCKS = 1024;
+constexpr int SK_WG_BLOCKS = 512;    // swept 256..1024: fewer, longer workgroups amortise the 9*Cout LDS merge rounds
 
 bool sk_ok(int N, int Cin, int H, int W, int Cout, SkDims* d) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout < 1 || Cout > SK_MAX_CO) return false;
