@@ -31,8 +31,9 @@ class _Base:
 
 class BevPoolCfg1(_Base):
     """BASELINE.json configs[1]: the `bev_pool` op (reference call surface
-    mmdet3d/ops/bev_pool/bev_pool.py:83-97: rank, argsort, gather, interval detection,
-    extension forward; autograd backward) on 6-cam x D=59 x 16x44 frustum points,
+    mmdet3d/ops/bev_pool/bev_pool.py:83-97: the reference ranks, argsorts, gathers and sums intervals; here the
+    cell lists are built from the integer coordinates and the rows are summed in place; autograd backward)
+    on 6-cam x D=59 x 16x44 frustum points,
     C=64 -> 128x128 BEV.  One step = forward + backward over the per-GPU batch of
     B=8 samples x F=2 frames = 16 six-camera frames in ONE bev_pool call."""
     B, F, C = 8, 2, 64
@@ -66,20 +67,21 @@ class BevPoolCfg1(_Base):
         out.backward(self.gout)
 
     def begin_timed(self):
-        L.enable_timing("dbev_bev_pool_forward")
+        L.enable_timing("dbev_splat_forward")
 
     def algorithmic_bytes(self):
         # 4nC + 16n + 8 n_int + 4 B*Z*X*Y*C per forward launch
         return 4 * self.n * self.C + 16 * self.n + 8 * self.n_int + 4 * self.nf * 128 * 128 * self.C
 
     def roofline(self):
-        ms = L.timing_ms("dbev_bev_pool_forward")
+        ms = L.timing_ms("dbev_splat_forward")
         L.disable_timing()
         if not ms:
             return None
         avg_s = float(np.mean(ms)) * 1e-3
         ach = self.algorithmic_bytes() / avg_s / 1e9
-        return {"bound": "hbm", "kernel": "bev_pool_fwd_vec4 (+ zero-fill of out), per dbev_bev_pool_forward call",
+        return {"bound": "hbm", "kernel": "ls_forward_c64<false> + ls_forward_hot (segment sums of the feature rows in place, "
+                "every BEV cell written), per dbev_splat_forward call of the gather-free bev_pool()",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": len(ms),
                 "algorithmic_bytes_per_launch": self.algorithmic_bytes()}

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["bev_pool", "QuickCumsumCuda", "bev_pool_forward", "bev_pool_backward"]
+__all__ = ["bev_pool", "bev_pool_sorted", "QuickCumsumCuda", "bev_pool_forward", "bev_pool_backward"]
 
 
 def bev_pool_forward(x, geom_feats, interval_lengths, interval_starts, B, D, H, W):
@@ -74,10 +74,68 @@ class QuickCumsumCuda(torch.autograd.Function):
         return x_grad, None, None, None, None, None, None
 
 
+class _BevPoolCSR(torch.autograd.Function):
+    """bev_pool without the argsort + row gather: cell -> point-list CSR from the integer coordinates
+    (dbev_bev_pool_prepare), rows summed in place by dbev_splat_forward, gradient rows written by
+    dbev_splat_backward.  Summation order inside a cell = ascending point index (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, B, D, H, W):
+        dev = L.require_cuda(feats, coords)
+        feats = feats.contiguous()
+        n, C = feats.shape
+        n_cells = B * D * H * W
+        coords = coords.to(torch.int32).contiguous()
+        point_cell = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+        cell_start = torch.empty((n_cells + 1,), dtype=torch.int32, device=dev)
+        cell_points = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+        n_kept = torch.empty((1,), dtype=torch.int32, device=dev)
+        hot_cells = torch.empty((n_cells,), dtype=torch.int32, device=dev)
+        n_hot = torch.empty((1,), dtype=torch.int32, device=dev)
+        out = torch.empty((B, D, H, W, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nbytes = L.call("dbev_lift_splat_workspace_bytes", n, n_cells)
+            ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+            L.call("dbev_bev_pool_prepare", L.ptr(coords), n, B, D, H, W, L.ptr(point_cell), L.ptr(cell_start),
+                   L.ptr(cell_points), L.ptr(n_kept), L.ptr(hot_cells), L.ptr(n_hot), L.ptr(ws), ws.numel(),
+                   L.stream_ptr(dev))
+            L.call("dbev_splat_forward", L.ptr(feats), L.ptr(cell_start), L.ptr(cell_points), L.ptr(hot_cells),
+                   L.ptr(n_hot), L.ptr(out), n, C, n_cells, L.stream_ptr(dev))
+        ctx.save_for_backward(point_cell)
+        ctx.dims = (n, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        (point_cell,) = ctx.saved_tensors
+        n, C = ctx.dims
+        dev = out_grad.device
+        out_grad = out_grad.contiguous()
+        x_grad = torch.empty((n, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.call("dbev_splat_backward", L.ptr(out_grad), L.ptr(point_cell), L.ptr(x_grad), n, C, L.stream_ptr(dev))
+        return x_grad, None, None, None, None, None
+
+
 def bev_pool(feats, coords, B, D, H, W):
     """bev_pool.py:83-97.  feats f32[n, C]; coords int[n, 4] = (x, y, z, b) with
-    0<=x<H, 0<=y<W, 0<=z<D -> f32[B, C, D, H, W]."""
+    0<=x<H, 0<=y<W, 0<=z<D -> f32[B, C, D, H, W].
+
+    The reference ranks the points, argsorts, gathers `feats[indices]` and sums rank intervals
+    (QuickCumsumCuda, kept above for callers of that level).  Same result here without moving the feature rows:
+    see _BevPoolCSR (C must be a multiple of 4 and <= 256 for the row kernels; other widths take the
+    sorted-interval path)."""
     assert feats.shape[0] == coords.shape[0]
+    B, D, H, W = int(B), int(D), int(H), int(W)
+    C = feats.shape[1]
+    if feats.dtype == torch.float32 and C % 4 == 0 and C <= 256 and feats.shape[0] > 0:
+        x = _BevPoolCSR.apply(feats, coords, B, D, H, W)
+        return x.permute(0, 4, 1, 2, 3).contiguous()
+    return bev_pool_sorted(feats, coords, B, D, H, W)
+
+
+def bev_pool_sorted(feats, coords, B, D, H, W):
+    """the reference's own sequence (rank, argsort, gather, interval sums) on the HIP interval kernels"""
     B, D, H, W = int(B), int(D), int(H), int(W)
     ranks = (coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B)
              + coords[:, 2] * B + coords[:, 3])

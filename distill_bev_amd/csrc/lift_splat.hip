@@ -66,9 +66,11 @@ __device__ __forceinline__ int agg_insert(int* keys, int cell) {
 
 struct CamParams { const float* cam; const float* frustum; int DHW; };   // cam: [BN][24] = A(9) pt(3) C(9) t(3)
 
-// GEOM=false: geom tensor given.  GEOM=true: ego-frame point computed in-kernel from the camera matrices
-// with exactly the multiply-add order of lss._apply3x3 (no FMA) -> same bits as the torch geometry.
-template <bool GEOM>
+// MODE 0: geom tensor given.  MODE 1: ego-frame point computed in-kernel from the camera matrices with exactly
+// the multiply-add order of lss._apply3x3 (no FMA) -> same bits as the torch geometry.  MODE 2: integer voxel
+// coordinates (x, y, z, b) of the bev_pool surface (bev_pool.py:83-97): cell = ((b*D + z)*H + x)*W + y with
+// H = G.nx[0], W = G.nx[1], D = G.nx[2], B = pts_per_batch (reused); `geom` then points at int32[np, 4].
+template <int MODE>
 __global__ __launch_bounds__(256) void ls_cell_count_agg(const float* __restrict__ geom, CamParams cp, int np,
                                                          int pts_per_batch, GridParams G,
                                                          int* __restrict__ point_cell,
@@ -83,8 +85,19 @@ __global__ __launch_bounds__(256) void ls_cell_count_agg(const float* __restrict
   for (int k = 0; k < AGG_PTS / 256; ++k) {
     const int p = base + k * 256 + threadIdx.x;
     if (p >= np) continue;
+    if (MODE == 2) {
+      const int4 c = reinterpret_cast<const int4*>(geom)[p];
+      int lin = -1;
+      if (c.x >= 0 && c.x < G.nx[0] && c.y >= 0 && c.y < G.nx[1] && c.z >= 0 && c.z < G.nx[2] && c.w >= 0 &&
+          c.w < pts_per_batch) {
+        lin = ((c.w * G.nx[2] + c.z) * G.nx[0] + c.x) * G.nx[1] + c.y;
+        atomicAdd(&cnt[agg_insert(keys, lin)], 1);
+      }
+      point_cell[p] = lin;
+      continue;
+    }
     float gx, gy, gz;
-    if (GEOM) {
+    if (MODE == 1) {
       const int bn = p / cp.DHW;
       const int r = p - bn * cp.DHW;
       const float* m = cp.cam + static_cast<size_t>(bn) * 24;
@@ -503,10 +516,11 @@ extern "C" size_t dbev_lift_splat_workspace_bytes(int n_points, int n_cells) {
 
 static int prepare_impl(const float* geom, const float* cam, const float* frustum, int DHW, int n_points,
                         int batch, const float* dx_host, const float* bx_host, const int32_t* nx_host,
+                        const int32_t* coords,
                         int32_t* point_cell, int32_t* cell_start, int32_t* cell_points, int32_t* n_kept_out,
                         int32_t* hot_cells, int32_t* n_hot_out, void* workspace, size_t workspace_bytes,
                         dbevStream_t stream) {
-  if (n_points < 0 || batch <= 0 || n_points % batch != 0) return DBEV_EINVAL;
+  if (n_points < 0 || batch <= 0 || (coords == nullptr && n_points % batch != 0)) return DBEV_EINVAL;
   GridParams G;
   long long per = 1;
   for (int k = 0; k < 3; ++k) {
@@ -533,11 +547,14 @@ static int prepare_impl(const float* geom, const float* cam, const float* frustu
   const int nblk = dbev_ceil_div(n_points > 0 ? n_points : 1, AGG_PTS);
   if (n_points > 0) {
     CamParams cp{cam, frustum, DHW > 0 ? DHW : 1};
-    if (cam != nullptr)
-      hipLaunchKernelGGL(ls_cell_count_agg<true>, dim3(nblk), dim3(256), 0, s, nullptr, cp, n_points,
+    if (coords != nullptr)
+      hipLaunchKernelGGL(ls_cell_count_agg<2>, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const float*>(coords), cp,
+                         n_points, batch, G, point_cell, count);
+    else if (cam != nullptr)
+      hipLaunchKernelGGL(ls_cell_count_agg<1>, dim3(nblk), dim3(256), 0, s, nullptr, cp, n_points,
                          n_points / batch, G, point_cell, count);
     else
-      hipLaunchKernelGGL(ls_cell_count_agg<false>, dim3(nblk), dim3(256), 0, s, geom, cp, n_points,
+      hipLaunchKernelGGL(ls_cell_count_agg<0>, dim3(nblk), dim3(256), 0, s, geom, cp, n_points,
                          n_points / batch, G, point_cell, count);
   }
   int rc = dbev::exclusive_scan_i32(count, cell_start, ncell, false, n_kept_out, scanws, s);
@@ -560,7 +577,7 @@ extern "C" int dbev_lift_splat_prepare(const float* geom, int n_points, int batc
                                        int32_t* hot_cells, int32_t* n_hot_out, void* workspace,
                                        size_t workspace_bytes, dbevStream_t stream) {
   if (geom == nullptr && n_points > 0) return DBEV_EINVAL;
-  return prepare_impl(geom, nullptr, nullptr, 0, n_points, batch, dx_host, bx_host, nx_host, point_cell,
+  return prepare_impl(geom, nullptr, nullptr, 0, n_points, batch, dx_host, bx_host, nx_host, nullptr, point_cell,
                       cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace, workspace_bytes, stream);
 }
 
@@ -574,8 +591,21 @@ extern "C" int dbev_lift_splat_prepare_cam(const float* cam_params, const float*
   const long long np = static_cast<long long>(BN) * D * H * W;
   if (np > 0x7fffffffLL) return DBEV_EINVAL;
   return prepare_impl(nullptr, cam_params, frustum, D * H * W, static_cast<int>(np), batch, dx_host, bx_host,
-                      nx_host, point_cell, cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace,
+                      nx_host, nullptr, point_cell, cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace,
                       workspace_bytes, stream);
+}
+
+extern "C" int dbev_bev_pool_prepare(const int32_t* coords, int n_points, int B, int D, int H, int W,
+                                     int32_t* point_cell, int32_t* cell_start, int32_t* cell_points,
+                                     int32_t* n_kept_out, int32_t* hot_cells, int32_t* n_hot_out, void* workspace,
+                                     size_t workspace_bytes, dbevStream_t stream) {
+  if ((coords == nullptr && n_points > 0) || B <= 0 || D <= 0 || H <= 0 || W <= 0) return DBEV_EINVAL;
+  const float one[3] = {1.f, 1.f, 1.f}, zero[3] = {0.f, 0.f, 0.f};
+  const int32_t nx[3] = {H, W, D};          // (x, y, z) extents of the coords: 0<=x<H, 0<=y<W, 0<=z<D
+  static const int32_t dummy[4] = {0, 0, 0, 0};
+  return prepare_impl(nullptr, nullptr, nullptr, 0, n_points, B, one, zero, nx, coords != nullptr ? coords : dummy,
+                      point_cell, cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace, workspace_bytes,
+                      stream);
 }
 
 static int hot_grid(int n_cells) { return n_cells < 2048 ? (n_cells < 1 ? 1 : n_cells) : 2048; }

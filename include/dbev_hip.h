@@ -69,6 +69,17 @@ int dbev_bev_pool_backward(const float* out_grad, const int32_t* geom_feats,
                            float* x_grad, int n, int c, int n_intervals,
                            int b, int d, int h, int w, dbevStream_t stream);
 
+/* Gather-free form of the same op for the reference's Python surface `bev_pool(feats, coords, B, D, H, W)`
+ * (mmdet3d/ops/bev_pool/bev_pool.py:83-97: rank -> argsort -> feats[indices] -> interval sums): instead of sorting and
+ * permuting the [n, C] feature rows (0.9 GB moved twice per call at the training shapes), build the cell -> point-list CSR from
+ * the integer voxel coordinates once and let dbev_splat_forward / dbev_splat_backward read / write the rows in place.
+ *   coords i32[n, 4] = (x, y, z, b), 0<=x<H, 0<=y<W, 0<=z<D, 0<=b<B (rows outside are dropped, point_cell = -1)
+ *   cell = ((b*D + z)*H + x)*W + y, i.e. dbev_splat_forward writes out f32[B, D, H, W, C] exactly like dbev_bev_pool_forward.
+ * Outputs / workspace as dbev_lift_splat_prepare (workspace: dbev_lift_splat_workspace_bytes(n, B*D*H*W)). */
+int dbev_bev_pool_prepare(const int32_t* coords, int n_points, int B, int D, int H, int W, int32_t* point_cell,
+                          int32_t* cell_start, int32_t* cell_points, int32_t* n_kept_out, int32_t* hot_cells,
+                          int32_t* n_hot_out, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * voxel_layer  (replaces mmdet3d/ops/voxel/src/voxelization.cpp:6-11 bindings,
  *               voxelization.h:58-140, kernels voxelization_cuda.cu / scatter_points_cuda.cu)

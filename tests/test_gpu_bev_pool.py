@@ -64,6 +64,34 @@ def test_bev_pool_random_vs_oracle_channels(C):
     assert np.array_equal(ft.grad.cpu().numpy(), gref)
 
 
+def test_gather_free_and_sorted_interval_paths_agree():
+    """bev_pool() (CSR from the integer coordinates, rows summed in place) vs bev_pool_sorted() (the reference's
+    rank / argsort / gather / interval sequence on the interval kernels): same cells, same sums, same gradients;
+    out-of-range coordinates are dropped by the CSR path like points the reference filtered before the call."""
+    from distill_bev_amd.bev_pool import bev_pool, bev_pool_sorted
+    dev = _dev()
+    rng = np.random.default_rng(2)
+    B, D, H, W, n, C = 2, 1, 128, 128, 60000, 64
+    coords = np.stack([rng.integers(0, H, n), rng.integers(0, W, n), rng.integers(0, D, n), rng.integers(0, B, n)], 1)
+    coords[:3000, :3] = (5, 7, 0)                               # hot cells (> 128 points)
+    feats = rng.normal(size=(n, C)).astype(np.float32)
+    ct = torch.from_numpy(coords).to(dev)
+    fa = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    fb = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    oa, ob = bev_pool(fa, ct, B, D, H, W), bev_pool_sorted(fb, ct, B, D, H, W)
+    assert oa.shape == ob.shape == (B, C, D, H, W)
+    assert float((oa - ob).abs().max()) <= 1e-5 * float(ob.abs().max())
+    assert torch.equal(oa == 0, ob == 0)
+    g = torch.randn_like(oa)
+    oa.backward(g); ob.backward(g)
+    assert torch.equal(fa.grad, fb.grad)
+    assert torch.equal(bev_pool(fa.detach(), ct, B, D, H, W), oa.detach())          # deterministic
+    bad = ct.clone(); bad[:10, 0] = H; bad[10:20, 3] = -1
+    ok = torch.ones(n, dtype=torch.bool, device=dev); ok[:20] = False
+    ref = bev_pool(fa.detach()[ok], ct[ok], B, D, H, W)
+    assert torch.equal(bev_pool(fa.detach(), bad, B, D, H, W), ref)
+
+
 def test_bev_pool_empty_and_single():
     from distill_bev_amd.bev_pool import bev_pool_forward, bev_pool
     dev = _dev()
