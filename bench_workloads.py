@@ -253,10 +253,13 @@ class DistillStep(_Base):
     def config(self, world):
         return {"workload": "CenterPoint(pillar, dynamic voxelization) -> BEVDepth4D-R50 full distillation "
                             "training step, FGD loss at 3 positions (BASELINE configs[3]); fwd+bwd+clip+AdamW"
-                            + ("+DDP all-reduce" if world > 1 else ""),
+                            + ("+bucketed gradient all-reduce" if world > 1 else ""),
                 "global_batch": self.B * world, "per_gpu_batch": self.B, "images_per_sample": 12,
                 "image_size": [256, 704], "lidar_points_per_sample": self.N_POINTS, "gt_boxes_per_sample": 30,
                 "student_params": self.n_params, "parallelism": f"dp{world}", "memory_format": "channels_last",
+                # GEMM-shaped work of one step at per_gpu_batch 8 (tools/flops_count.py: forward hooks on every conv, x2/x1 for
+                # the data/weight gradients that actually run): context for ms_per_step, executed by MIOpen fp32 MFMA kernels
+                "dense_tflop_per_gpu_step": 12.92 * self.B / 8.0,
                 "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py"}
 
 
