@@ -74,12 +74,16 @@ def camera_params(rots, trans, intrins, post_rots, post_trans):
     return torch.cat([a, post_trans.reshape(B * N, 3), c, trans.reshape(B * N, 3)], dim=1).contiguous()
 
 
-def lift_splat_prepare_cam(frustum, rots, trans, intrins, post_rots, post_trans, dx, bx, nx):
-    """lift_splat_prepare with get_geometry fused into the index kernel (no [B,N,D,H,W,3] tensor)."""
+def lift_splat_prepare_cam(frustum, rots, trans, intrins, post_rots, post_trans, dx, bx, nx, cam=None):
+    """lift_splat_prepare with get_geometry fused into the index kernel (no [B,N,D,H,W,3] tensor).
+    cam: optional precomputed camera_params(...) tensor f32[B*N, 24] (e.g. a static buffer when the call is captured
+    into a HIP graph: the batched 3x3 inverses of camera_params go through rocSOLVER, which is not capturable)."""
     dev = L.require_cuda(frustum, rots)
     B, N = trans.shape[:2]
     D, H, W = frustum.shape[:3]
-    cam = camera_params(rots, trans, intrins, post_rots, post_trans)
+    if cam is None:
+        cam = camera_params(rots, trans, intrins, post_rots, post_trans)
+    assert cam.shape == (B * N, 24) and cam.is_contiguous()
     fr = frustum.contiguous()
     n_points = B * N * D * H * W
     X, Y, Z = (int(v) for v in nx)
