@@ -63,10 +63,15 @@ __device__ __forceinline__ void fma4v(float4& a, const float4& b, const float4& 
 
 // every workgroup streams ONE contiguous range of rows (HBM pages / TLB entries are walked once, in order):
 // returns the first row, *r_end = one past the last
+// REV: walk the tensor back to front.  The reduction passes (bn_stats, bn_bwd_reduce) run right after a producer /
+// before a consumer that streams the same tensor front to back, so the part that is still in (or will still be in) the
+// 256 MB memory-side cache is the END for the first pass and the START for the pass after it: measured -6 % / -12 %
+// on the forward+backward of 277 MB / 138 MB activations, neutral above 500 MB.
+template <bool REV = false>
 __device__ __forceinline__ int block_rows(const BnGeom& g, int* r_end) {
   int per = (g.M + gridDim.x - 1) / gridDim.x;
   per = (per + g.RP - 1) / g.RP * g.RP;
-  const long long b = static_cast<long long>(blockIdx.x) * per;
+  const long long b = static_cast<long long>(REV ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * per;
   const long long e = b + per;
   *r_end = static_cast<int>(e < g.M ? e : g.M);
   return static_cast<int>(b < g.M ? b : g.M);
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void bn_stats(const float4* __restrict__ x, fl
   float4 s = f4(0.f), ss = f4(0.f);
   const int stride = g.RP;
   int r_end;
-  int r = block_rows(g, &r_end) + rp;
+  int r = block_rows<true>(g, &r_end) + rp;
   for (; r + (BN_ROWS_UNROLL - 1) * stride < r_end; r += BN_ROWS_UNROLL * stride) {
     float4 v[BN_ROWS_UNROLL];
 #pragma unroll
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float4* __restrict__ 
   float4 db = f4(0.f), dg = f4(0.f);
   const int stride = g.RP;
   int r_end;
-  for (int r0 = block_rows(g, &r_end) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
+  for (int r0 = block_rows<true>(g, &r_end) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
     float4 a[BN_ROWS_UNROLL], v[BN_ROWS_UNROLL], o[BN_ROWS_UNROLL];
 #pragma unroll
     for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
