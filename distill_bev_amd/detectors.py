@@ -186,7 +186,7 @@ class BEVDepth4DDistill(CenterPoint):
     """Camera student (BEVDepth4D, two frames) distilled from a LiDAR teacher with the FGD loss."""
 
     def __init__(self, img_view_transformer, img_bev_encoder_backbone, img_bev_encoder_neck,
-                 teacher_config, teacher_ckpt, distill_type, distill_params, eval_teacher=True, self_ckpt=None,
+                 teacher_config=None, teacher_ckpt=None, distill_type=None, distill_params=None, eval_teacher=True, self_ckpt=None,
                  inherit_head=False, aligned=False, distill=None, pre_process=None, pre_process_neck=None,
                  detach=True, test_adj_ids=None, before=False, interpolation_mode="bilinear",
                  bevdepth_bev_forward=False, config_root=None, **kwargs):
@@ -201,6 +201,11 @@ class BEVDepth4DDistill(CenterPoint):
             self.pre_process_net = build_backbone(pre_process)
         # ---- teacher (bevdet_distill.py:160-166): a plain attribute, hidden from nn.Module ----
         self.eval_teacher = eval_teacher
+        self._epoch = 1
+        if teacher_config is None:                 # plain student (BEVDepth4D): no teacher, no distillation modules
+            self.teacher_model = None
+            self.distill_type, self.distill_params, self.inherit_head = None, None, False
+            return
         if isinstance(teacher_config, str):
             path = teacher_config
             if not os.path.isabs(path) and not os.path.exists(path) and config_root:
@@ -275,11 +280,13 @@ class BEVDepth4DDistill(CenterPoint):
             super().__setattr__(name, value)
 
     def _apply(self, fn, *args, **kwargs):
-        self.teacher_model._apply(fn)
+        if self.teacher_model is not None:
+            self.teacher_model._apply(fn)
         return super()._apply(fn, *args, **kwargs)
 
     def train(self, mode=True):
-        self.teacher_model.train(False if self.eval_teacher else mode)
+        if self.teacher_model is not None:
+            self.teacher_model.train(False if self.eval_teacher else mode)
         return super().train(mode)
 
     def set_epoch(self, epoch):
@@ -352,14 +359,18 @@ class BEVDepth4DDistill(CenterPoint):
         rots, trans, intrins, post_rots, post_trans = [[p.squeeze(1) for p in torch.split(t, 1, 1)] for t in extra]
         vt = self.img_view_transformer
         bev_feat_list, depth_digit_list = [], []
-        for im, intrin, post_rot, post_tran in zip(imgs, intrins, post_rots, post_trans):
+        for fi, (im, intrin, post_rot, post_tran) in enumerate(zip(imgs, intrins, post_rots, post_trans)):
             tran, rot = trans[0], rots[0]            # current-frame extrinsics for both frames (:389-393)
-            x = self.image_encoder(im)
-            Bx, Nx, C, fH, fW = x.shape
-            img_feat, depth_digit = vt.depth_and_feat(x.view(Bx * Nx, C, fH, fW), rot, tran, intrin, post_rot, post_tran)
-            depth = vt.get_depth_dist(depth_digit)
-            # get_geometry + lift + voxel_pooling (:411-421) in three library calls, no volume, no geom tensor
-            bev_feat_list.append(vt.lift_splat_cameras(rot, tran, intrin, post_rot, post_tran, depth, img_feat))
+            # the reference runs the adjacent frame under autograd and then detaches its BEV feature (:440-441): no
+            # gradient ever reaches this branch, so its graph (12 GB of saved activations at bs 8) is not recorded
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not (self.detach and fi == 1)):
+                x = self.image_encoder(im)
+                Bx, Nx, C, fH, fW = x.shape
+                img_feat, depth_digit = vt.depth_and_feat(x.view(Bx * Nx, C, fH, fW), rot, tran, intrin, post_rot,
+                                                          post_tran)
+                depth = vt.get_depth_dist(depth_digit)
+                # get_geometry + lift + voxel_pooling (:411-421) in three library calls, no volume, no geom tensor
+                bev_feat_list.append(vt.lift_splat_cameras(rot, tran, intrin, post_rot, post_tran, depth, img_feat))
             depth_digit_list.append(depth_digit)
         if self.before and self.pre_process:
             bev_feat_list = [self.pre_process_net(b)[0] for b in bev_feat_list]
@@ -503,3 +514,137 @@ class BEVDepth4DDistill(CenterPoint):
         losses.update(self.forward_distill(points, img_metas, gt_bboxes_3d, gt_labels_3d, img_feats, lss_feat,
                                            bev_backbone_feats, preds, heatmaps))
         return losses
+
+
+# ---- the other detectors of the reference's config surface --------------------------------------
+# One student/distillation implementation above; the siblings differ in the number of frames and in whether the
+# view transformer predicts (and is supervised on) depth.
+
+@MODELS.register_module()
+class BEVDepth4D(BEVDepth4DDistill):
+    """mmdet3d/models/detectors/bevdet.py:509-680: the two-frame BEVDepth student on its own -- no teacher, no
+    distillation; forward_train = depth loss + CenterHead losses (:631-680)."""
+
+    def __init__(self, **kwargs):
+        for k in ("teacher_config", "teacher_ckpt", "distill_type", "distill_params"):
+            assert kwargs.get(k) is None, f"BEVDepth4D takes no {k}"
+        super().__init__(**kwargs)
+
+    def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, gt_labels=None,
+                      gt_bboxes=None, img_inputs=None, proposals=None, gt_bboxes_ignore=None):
+        (img_feats,), depth = self.extract_img_feat(img_inputs, img_metas)
+        depth_gt = img_inputs[-1]
+        B, N, H, W = depth_gt.shape
+        depth_gt = depth_gt.view(B, 2, N // 2, H, W)[:, 0]
+        losses = dict(loss_depth=self.get_depth_loss(depth_gt, depth))
+        losses.update(self.forward_pts_train([img_feats], gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore))
+        return losses
+
+
+@MODELS.register_module()
+class BEVDepthDistill(BEVDepth4DDistill):
+    """bevdet_distill_more.py:168-330: single-frame BEVDepth student (ViewTransformerLSSBEVDepth: BEV feature + depth
+    logits) distilled from the LiDAR teacher.  img_inputs = (imgs[B,N,3,H,W], rots, trans, intrins, post_rots,
+    post_trans, depth_gt[B,N,h,w])."""
+
+    def extract_img_feat(self, img, img_metas=None, return_lss_feature=False, return_backbone_feature=False):
+        x = self.image_encoder(img[0])                                   # [B, N, C, fH, fW]
+        bev_feat, depth = self.img_view_transformer([x] + list(img[1:]))  # :245
+        outputs = []
+        if return_lss_feature:
+            outputs.append(bev_feat)
+        if return_backbone_feature:
+            x, backbone_feature = self.bev_encoder(bev_feat, True)
+            outputs.append(backbone_feature)
+            outputs.insert(0, x)
+        else:
+            outputs.insert(0, self.bev_encoder(bev_feat))
+        return outputs, depth
+
+    def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, gt_labels=None,
+                      gt_bboxes=None, img_inputs=None, proposals=None, gt_bboxes_ignore=None):
+        (img_feats, lss_feat, bev_backbone_feats), depth = self.extract_img_feat(
+            img_inputs, img_metas, return_lss_feature=True, return_backbone_feature=True)
+        img_feats = [img_feats]
+        losses = dict(loss_depth=self.get_depth_loss(img_inputs[-1], depth))            # :300-302
+        preds, (losses_pts, heatmaps, anno_boxes, inds, masks) = self.forward_pts_train(
+            img_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore, get_preds=True, get_targets=True)
+        losses.update(losses_pts)
+        losses.update(self.forward_distill(points, img_metas, gt_bboxes_3d, gt_labels_3d, img_feats, lss_feat,
+                                           bev_backbone_feats, preds, heatmaps))
+        return losses
+
+
+@MODELS.register_module()
+class BEVDetDistill(BEVDepthDistill):
+    """bevdet_distill.py:155-1560: single-frame BEVDet student (ViewTransformerLiftSplatShoot: no depth head, no depth
+    supervision) distilled from the LiDAR teacher."""
+
+    def extract_img_feat(self, img, img_metas=None, return_lss_feature=False, return_backbone_feature=False):
+        x = self.image_encoder(img[0])
+        bev_feat = self.img_view_transformer([x] + list(img[1:6]))       # bevdet.py:58-60
+        outputs = []
+        if return_lss_feature:
+            outputs.append(bev_feat)
+        feats = self.img_bev_encoder_backbone(bev_feat)
+        if return_backbone_feature:
+            outputs.append(feats)
+        outputs.insert(0, self.img_bev_encoder_neck(feats))
+        return outputs
+
+    def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, gt_labels=None,
+                      gt_bboxes=None, img_inputs=None, proposals=None, gt_bboxes_ignore=None):
+        img_feats, lss_feat, bev_backbone_feats = self.extract_img_feat(
+            img_inputs, img_metas, return_lss_feature=True, return_backbone_feature=True)
+        img_feats = [img_feats]
+        preds, (losses_pts, heatmaps, anno_boxes, inds, masks) = self.forward_pts_train(
+            img_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore, get_preds=True, get_targets=True)
+        losses = dict(losses_pts)
+        losses.update(self.forward_distill(points, img_metas, gt_bboxes_3d, gt_labels_3d, img_feats, lss_feat,
+                                           bev_backbone_feats, preds, heatmaps))
+        return losses
+
+
+@MODELS.register_module()
+class BEVDet4DDistill(BEVDepth4DDistill):
+    """bevdet_distill_more.py:15-166: two-frame BEVDet student (plain LSS view transformer: one 1x1 depthnet conv gives
+    the D depth logits and the C context channels, :121-126; no depth supervision) distilled from the LiDAR teacher."""
+
+    def extract_img_feat(self, img, img_metas=None, return_lss_feature=False, return_backbone_feature=False):
+        inputs = img
+        B, N, _, H, W = inputs[0].shape
+        N = N // 2
+        imgs = [t.squeeze(2) for t in torch.split(inputs[0].view(B, N, 2, 3, H, W), 1, 2)]
+        rots, trans, intrins, post_rots, post_trans = inputs[1:6]
+        extra = [rots.view(B, 2, N, 3, 3), trans.view(B, 2, N, 3), intrins.view(B, 2, N, 3, 3),
+                 post_rots.view(B, 2, N, 3, 3), post_trans.view(B, 2, N, 3)]
+        rots, trans, intrins, post_rots, post_trans = [[p.squeeze(1) for p in torch.split(t, 1, 1)] for t in extra]
+        vt = self.img_view_transformer
+        bev_feat_list = []
+        for fi, (im, intrin, post_rot, post_tran) in enumerate(zip(imgs, intrins, post_rots, post_trans)):
+            tran, rot = trans[0], rots[0]
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not (self.detach and fi == 1)):
+                x = self.image_encoder(im)
+                Bx, Nx, C, fH, fW = x.shape
+                x = vt.depthnet(x.view(Bx * Nx, C, fH, fW))
+                depth = vt.get_depth_dist(x[:, :vt.D])
+                img_feat = x[:, vt.D:(vt.D + vt.numC_Trans)]
+                bev_feat_list.append(vt.lift_splat_cameras(rot, tran, intrin, post_rot, post_tran, depth, img_feat))
+        if self.before and self.pre_process:
+            bev_feat_list = [self.pre_process_net(b)[0] for b in bev_feat_list]
+        bev_feat_list[1] = self.shift_feature(bev_feat_list[1], trans, rots)
+        if self.pre_process and not self.before:
+            bev_feat_list = [self.pre_process_net(b)[0] for b in bev_feat_list]
+        if self.detach:
+            bev_feat_list[1] = bev_feat_list[1].detach()
+        bev_feat = torch.cat(bev_feat_list, dim=1)
+        outputs = []
+        if return_lss_feature:
+            outputs.append(bev_feat)
+        feats = self.img_bev_encoder_backbone(bev_feat)
+        if return_backbone_feature:
+            outputs.append(feats)
+        outputs.insert(0, self.img_bev_encoder_neck(feats))
+        return outputs
+
+    forward_train = BEVDetDistill.forward_train          # no depth term (inherits BEVDetDistill.forward_train, :15-16)

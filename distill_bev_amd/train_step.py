@@ -159,7 +159,8 @@ class Trainer:
         self.detector.train()
         if channels_last:
             self.detector = self.detector.to(memory_format=torch.channels_last)
-            self.detector.teacher_model.to(memory_format=torch.channels_last)
+            if getattr(self.detector, "teacher_model", None) is not None:
+                self.detector.teacher_model.to(memory_format=torch.channels_last)
             self.detector.channels_last = True
             self.fused_bn_relu, self.swapped_upsample = accelerate_modules(self.detector)
         self.wrapper = _TrainWrapper(self.detector)

@@ -243,3 +243,22 @@ def test_accelerate_modules_rewires_upsampling_and_canvas_layout_without_renamin
     assert model.teacher_model.pts_middle_encoder.channels_last is True
     assert list(model.state_dict().keys()) == keys and list(model.teacher_model.state_dict().keys()) == tkeys
     assert accelerate_modules(model) == (0, 0)                  # idempotent
+
+
+def test_registry_covers_the_config_surface_of_the_hot_path():
+    """every mmdet3d type name the distillation configs of this path resolve."""
+    import distill_bev_amd.detectors  # noqa: F401
+    from distill_bev_amd import registry as R
+    names = set()
+    for v in vars(R).values():
+        if isinstance(v, R.Registry):
+            names |= set(v._modules)
+    want = ["BEVDepth4DDistill", "BEVDetDistill", "BEVDepthDistill", "BEVDet4DDistill", "BEVDepth4D", "CenterPoint",
+            "DynamicCenterPoint", "ViewTransformerLSSBEVDepth", "ViewTransformerLiftSplatShoot",
+            "OfficialViewTransformerLiftSplatShoot", "OfficialViewTransformerLSSBEVDepth", "FPNForBEVDet", "FPN_LSS",
+            "SECONDFPN", "ResNet", "ResNetForBEVDet", "SECOND", "PillarFeatureNet", "DynamicPillarFeatureNet",
+            "PointPillarsScatter", "CenterHead", "SeparateHead", "CenterPointBBoxCoder", "GaussianFocalLoss", "L1Loss",
+            "MSELoss", "SmoothL1Loss"]
+    assert [w for w in want if w not in names] == []
+    for conv in ("Conv2d", "DCNv2"):
+        assert R.build_conv_layer(dict(type=conv), 8, 8, kernel_size=3, padding=1) is not None
