@@ -103,6 +103,16 @@ def accelerate_modules(detector):
     return n_bn, n_up
 
 
+def _flat_view(g):
+    """1-D view of a dense gradient in MEMORY order (identical on every rank: same module, same memory format);
+    falls back to a logical-order copy for exotic strides (the copy is then written back through the same mapping)."""
+    if g.is_contiguous():
+        return g.view(-1)
+    if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last):
+        return g.permute(0, 2, 3, 1).reshape(-1)        # a view: NHWC is the physical order
+    return g.reshape(-1)
+
+
 class GradReducer:
     """Data-parallel gradient averaging for the one collective of the step: the student's 54 M fp32
     gradients (217 MB) in ~64 MB buckets.  Each bucket is packed with ONE concat kernel, pre-divided by the world
@@ -144,12 +154,16 @@ class GradReducer:
                     raise RuntimeError("GradReducer: a parameter received no gradient on this rank "
                                        "(all ranks must reduce the same set; find_unused_parameters is not supported)")
                 grads.append(p.grad)
-            flat = torch.cat([g.reshape(-1) for g in grads])
+            flats = [_flat_view(g) for g in grads]          # memory-order 1-D views: no per-tensor copy kernels
+            flat = torch.cat(flats)
             flat.div_(self.world)
-            pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, grads))
-        for work, flat, grads in pending:
+            pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, flats, grads))
+        for work, flat, flats, grads in pending:
             work.wait()
-            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+            torch._foreach_copy_(flats, list(flat.split([f.numel() for f in flats])))
+            for f, g in zip(flats, grads):                  # exotic strides: the flat tensor was a copy, write it back
+                if f.data_ptr() != g.data_ptr():
+                    g.copy_(f.view_as(g))
 
 
 class Trainer:
