@@ -28,6 +28,7 @@ from oracle import center_targets as OCT
 from oracle import dcn as ODCN
 from oracle import distill as OD
 from oracle import lss_torch as OT
+from oracle import step_ops as OS
 from oracle import voxel as OV
 
 
@@ -83,10 +84,27 @@ class CpuBEVDepth4DDistill(D.BEVDepth4DDistill):
         vt = self.img_view_transformer
         # the reference sequence: materialise the volume, then argsort + cumsum voxel_pooling
         def ref_lift_splat(rot, tran, intrin, post_rot, post_tran, depth, feat):
-            geom = vt.get_geometry(rot, tran, intrin, post_rot, post_tran)
+            # the reference's own geometry op order (torch.inverse + broadcast matmul), not the product's multiply-adds
+            geom = OS.get_geometry(vt.frustum, rot, tran, intrin, post_rot, post_tran)
             return OT.voxel_pooling_cumsum(geom, OT.lift(depth, feat, geom.shape[0], geom.shape[1]), vt.dx, vt.bx, vt.nx)
         vt.lift_splat_cameras = ref_lift_splat
         return super().extract_img_feat(img, img_metas, return_lss_feature, return_backbone_feature)
+
+    # the remaining step functions run their oracle restatements (oracle/step_ops.py, pinned against the imported
+    # reference files) -- nothing below is inherited from the product class
+    def shift_feature(self, input, trans, rots):
+        vt = self.img_view_transformer
+        return OS.shift_feature(input, trans, rots, vt.dx, vt.bx, self.interpolation_mode)
+
+    def get_depth_loss(self, depth_gt, depth):
+        vt = self.img_view_transformer
+        return OS.get_depth_loss(depth_gt, depth, vt.grid_config["dbound"], vt.D, vt.loss_depth_weight)
+
+    def add_fp_as_fg(self, mode, fg_mask, heatmaps, teacher_preds, student_preds):
+        dp = self.distill_params
+        return OS.add_fp_as_fg(mode, fg_mask, heatmaps, [tp[0]["heatmap"] for tp in teacher_preds],
+                               [sp[0]["heatmap"] for sp in student_preds], dp["output_threshold"],
+                               dp["groundtruth_threshold"])
 
     def fgd_distill_loss(self, teacher_feat, student_feat, gt_bboxes_3d, gt_labels_3d, canvas_feat, heatmaps,
                          teacher_preds, student_preds, index):
@@ -139,6 +157,15 @@ class CpuBEVDepth4DDistill(D.BEVDepth4DDistill):
         return super().forward_distill(*a, **k)
 
 
+def _reference_head_loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, get_targets=False, **kwargs):
+    """CenterHead.loss (centerpoint_head.py:615-686) = host targets + the op-by-op loss of oracle/step_ops.py"""
+    device = preds_dicts[0][0]["heatmap"].device
+    heatmaps, anno_boxes, inds, masks = self.get_targets(gt_bboxes_3d, gt_labels_3d, device)
+    loss_dict = OS.centerhead_loss(preds_dicts, heatmaps, anno_boxes, inds, masks, self.train_cfg["code_weights"],
+                                   self.loss_bbox.loss_weight, self.loss_cls.loss_weight, self.loss_prefix)
+    return (loss_dict, heatmaps, anno_boxes, inds, masks) if get_targets else loss_dict
+
+
 def to_cpu_reference(model):
     """Re-class a built (CPU) BEVDepth4DDistill into the reference-sequence CPU variant, in place."""
     model.__class__ = CpuBEVDepth4DDistill
@@ -150,6 +177,7 @@ def to_cpu_reference(model):
     for head in [getattr(model, "pts_bbox_head", None), getattr(getattr(model, "teacher_model", None), "pts_bbox_head", None)]:
         if head is not None:
             head.get_targets = OCT.get_targets.__get__(head)
+            head.loss = _reference_head_loss.__get__(head)
     for m in model.modules():                          # torch restatement of DCNv2 instead of the HIP kernels
         if type(m).__name__ == "ModulatedDeformConv2dPack":
             m.__class__ = type("TorchModulatedDeformConv2dPack", (m.__class__,), {"forward": ODCN.pack_forward})

@@ -9,9 +9,11 @@ center_to_corner_box3d :206-235, corner_to_surfaces_3d :404-423, surface_equ_3d 
 points_in_rbbox :426-446, _points_in_convex_polygon_3d_jit :719-753).
 
 Pinning: the geometry half (points_in_rbbox -> fg / fg_scale / bg_scale maps) is pinned
-against the imported reference box_np_ops (tests/golden/fgmask_*.npz).  The loss
-arithmetic half cannot be imported (bevdet_distill.py needs mmdet/mmcv/cv2): PARITY
-UNPINNED by reference outputs; it restates the source and is checked in fp64.
+against the imported reference box_np_ops (tests/golden/fgmask_*.npz); the loss half (attention
+masks, combine_gt scaling, fp re-scaling, the three masked sums, the spatial term, the adaptation
+layers) against losses computed by the reference's own bevdet_distill.py imported by path
+(BEVDetDistill.fgd_distill_loss on a bare instance: tests/golden/fgd_losses.npz, make_golden.py
+'fgd'; tests/test_oracle_step_ops.py).
 """
 import numpy as np
 
@@ -169,3 +171,64 @@ def fgd_feature_losses(student, teacher, fg, fg_scale, bg_scale, fp=None, fp_sca
         fpw = fp * fp_scale * att * c_att
         out["kd_fp_bg_feat_loss"] = (sq * fpw).sum() * w_fp / B
     return out, dict(att=att, c_att=c_att, fg_w=fg_w, bg_w=bg_w, scale=scale)
+
+
+# ---- adaptation layers + spatial term (fp64 yardstick) ----------------------------------------------
+def conv1x1(x, w, b=None):
+    """nn.Conv2d(k=1): x [B,Ci,H,W], w [Co,Ci,1,1] -> [B,Co,H,W] (bevdet_distill.py:232-234)."""
+    y = np.einsum("bchw,oc->bohw", x.astype(np.float64), w.reshape(w.shape[0], -1).astype(np.float64))
+    return y if b is None else y + b.astype(np.float64).reshape(1, -1, 1, 1)
+
+
+def upsample_bilinear_ac(x, s):
+    """nn.Upsample(scale_factor=s, mode='bilinear', align_corners=True) (:275-277)."""
+    B, C, H, W = x.shape
+    OH, OW = H * s, W * s
+    x = x.astype(np.float64)
+
+    def taps(n_in, n_out):
+        pos = np.arange(n_out, dtype=np.float64) * ((n_in - 1) / (n_out - 1) if n_out > 1 else 0.0)
+        i0 = np.minimum(np.floor(pos).astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        return i0, i1, pos - i0
+    y0, y1, fy = taps(H, OH)
+    x0, x1, fx = taps(W, OW)
+    top = x[:, :, y0][:, :, :, x0] * (1 - fx) + x[:, :, y0][:, :, :, x1] * fx
+    bot = x[:, :, y1][:, :, :, x0] * (1 - fx) + x[:, :, y1][:, :, :, x1] * fx
+    return top * (1 - fy)[None, None, :, None] + bot * fy[None, None, :, None]
+
+
+def bn_train_relu(x, gamma, beta, eps=1e-5):
+    """training-mode BatchNorm2d (biased batch variance) + ReLU"""
+    m = x.mean((0, 2, 3), keepdims=True)
+    v = x.var((0, 2, 3), keepdims=True)
+    y = (x - m) / np.sqrt(v + eps) * gamma.astype(np.float64).reshape(1, -1, 1, 1) + beta.astype(np.float64).reshape(1, -1, 1, 1)
+    return np.maximum(y, 0)
+
+
+def three_layer(x, sd, prefix=""):
+    """ThreeLayer (bevdet_distill.py:99-132), kernel 1 / stride 1: 3 x (1x1 conv -> BN(train) -> ReLU).
+    sd: mapping name -> array with keys '<prefix>conv1__weight' ... as stored by the golden generator."""
+    for i in (1, 2, 3):
+        x = conv1x1(x, sd[f"{prefix}conv{i}__weight"], sd[f"{prefix}conv{i}__bias"])
+        x = bn_train_relu(x, sd[f"{prefix}norm{i}__weight"], sd[f"{prefix}norm{i}__bias"])
+    return x
+
+
+def conv3x3_single(x, w, b):
+    """nn.Conv2d(1, 1, 3, padding=1) (spatial_wise_adaptations, :345-348): x [B,1,H,W]."""
+    B, _, H, W = x.shape
+    xp = np.zeros((B, H + 2, W + 2))
+    xp[:, 1:-1, 1:-1] = x[:, 0]
+    y = np.zeros((B, H, W))
+    for i in range(3):
+        for j in range(3):
+            y += float(w[0, 0, i, j]) * xp[:, i:i + H, j:j + W]
+    return (y + float(b[0]))[:, None]
+
+
+def spatial_loss(teacher, student, w, b, weight):
+    """kd_spatial_loss (:1272-1278): sum |mean_c T - conv3x3(mean_c S)| * weight / B."""
+    T = teacher.astype(np.float64).mean(1, keepdims=True)
+    S = conv3x3_single(student.astype(np.float64).mean(1, keepdims=True), w, b)
+    return np.abs(T - S).sum() * weight / teacher.shape[0]

@@ -120,7 +120,15 @@ def make_lss():
           n_kept=np.array(int(kept.sum())), n_cells=np.array(int((cnt > 0).sum())),
           max_per_cell=np.array(int(cnt.max())),
           idx_sha256=np.frombuffer(hashlib.sha256(idxf.numpy().astype(np.int32).tobytes()).digest(), dtype=np.uint8),
-          geom_full=geomf.numpy().astype(np.float32)[:, :, ::6].copy())
+          geom_full=geomf.numpy().astype(np.float32)[:, :, ::6].copy(),
+          # the reference's voxel of EVERY frustum point of the full-size rig (cell = (y*X + x)*Z + z, -1 = dropped by the
+          # range mask): what the fused in-kernel geometry + index of the product is held to on the GPU
+          cell_full=torch.where(kept, (idxf[..., 1] * nxl[0] + idxf[..., 0]) * nxl[2] + idxf[..., 2],
+                                torch.full_like(idxf[..., 0], -1)).numpy().astype(np.int16).reshape(-1),
+          # distance (in cells) of every point to its nearest cell border, quantised: lets a test show that a mismatching
+          # point sits on a border
+          border_dist_min=np.array(float((((geomf - (mf.bx - mf.dx / 2.)) / mf.dx) -
+                                          torch.round((geomf - (mf.bx - mf.dx / 2.)) / mf.dx)).abs()[..., :2].min())))
     print("full: kept", int(kept.sum()), "cells", int((cnt > 0).sum()), "max/cell", int(cnt.max()))
 
 
@@ -325,7 +333,306 @@ def make_center():
     print("objects per task", mask.sum(axis=(1, 2)).tolist(), "heat-map peaks", int((hm == 1).sum()))
 
 
-SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center}
+
+# --------------------------------------------------------------------------
+# Round 2: fixtures computed by the reference's own detector / head / encoder code
+# --------------------------------------------------------------------------
+RECIPE = dict(   # CFG_D:50-92 distill_params with the run script's overrides (RUN_D:30-41)
+    spatial_t=0.5, spatial_student_ratio=1.0, channel_t=0.5,
+    fg_feat_loss_weights=[6e-3], bg_feat_loss_weights=[4e-2], channel_loss_weights=[0.25],
+    spatial_loss_weights=[2.5e-3], spatial_attentions=["teacher_student"],
+    feat_criterion=dict(type="MSELoss", reduction="none"), spatial_criterion=dict(type="L1Loss", reduction="none"),
+    channel_criterion=dict(type="L1Loss", reduction="none"), transpose_mask=False, foreground_mask="gt",
+    background_mask="logical_not", scale_mask="combine_gt", spatial_mask=True, channel_mask=False,
+    non_empty_weight=0, output_threshold=0.1, groundtruth_threshold=None, fp_weight=6e-2, fp_epoch=0,
+    multi_scale_epoch=-1, fp_scale_mode="average", context_length=0, context_weight=0)
+
+
+def _sd(prefix, module):
+    return {prefix + k.replace(".", "__"): v.detach().numpy() for k, v in module.state_dict().items()}
+
+
+def make_fgd():
+    """fgd_distill_loss (+ foreground_scale_mask, add_fp_as_fg, the adaptation layers) executed by the reference's
+    bevdet_distill.py on a bare BEVDetDistill instance: (a) 'head' position = 1x1conv adaptation + fp_as_foreground
+    'teacher'; (b) 'backbone' position = Upsample x4 + ThreeLayer (training-mode BN), no fp term.  A 32x32 map over a
+    25.6 m square (grid 256, voxel 0.1, out_size_factor 8) keeps the fixture small; cell size 0.8 m as at 128^2."""
+    import torch.nn as nn
+    from types import SimpleNamespace
+    M = R.bevdet_distill()
+    torch.manual_seed(3)
+    rng = np.random.default_rng(33)
+    B, H, W = 2, 32, 32
+    train_cfg = dict(grid_size=[256, 256, 40], point_cloud_range=[-12.8, -12.8, -5.0, 12.8, 12.8, 3.0],
+                     voxel_size=[0.1, 0.1, 0.2], out_size_factor=8)
+    boxes = []
+    for b in range(B):
+        bx, _ = syn.gt_boxes(12 if b == 0 else 5, rng)
+        bx[:, :2] = rng.uniform(-11, 11, bx[:, :2].shape).astype(np.float32)
+        if b == 0:                      # a face through cell corners + overlapping pair (first-hit box wins)
+            bx[0, :7] = [-4.0, 2.4, -1.0, 1.6, 3.2, 1.5, 0.0]
+            bx[1, :7] = [-4.0, 2.4, -1.0, 3.2, 1.6, 1.5, 0.3]
+        boxes.append(bx)
+    gtb = [R.LiDARBoxesStub(b) for b in boxes]
+    # CenterHead-like heat maps: gt (sparse gaussians incl. exact ones), teacher logits, student sigmoids
+    ncls = [1, 2, 2, 1, 2, 2]
+    gt_hm = [torch.zeros(B, n, H, W) for n in ncls]
+    for hm in gt_hm:
+        for _ in range(4):
+            b, c, y, x = rng.integers(0, B), rng.integers(0, hm.shape[1]), rng.integers(1, H - 1), rng.integers(1, W - 1)
+            hm[b, c, y - 1:y + 2, x - 1:x + 2] = torch.maximum(hm[b, c, y - 1:y + 2, x - 1:x + 2], torch.tensor(
+                [[0.3, 0.6, 0.3], [0.6, 1.0, 0.6], [0.3, 0.6, 0.3]]))
+    t_logit = [torch.randn(B, n, H, W) * 1.5 - 3.0 for n in ncls]
+    s_sig = [torch.sigmoid(torch.randn(B, n, H, W) - 2.0) for n in ncls]
+    out = {}
+    for tag, cs, ct, fp in (("head", 12, 16, "teacher"), ("backbone", 6, 8, "none")):
+        dp = dict(RECIPE, student_channels=[cs], teacher_channels=[ct], fp_as_foreground=[fp], affinity_mode=["none"],
+                  student_feat_pos=[tag], teacher_feat_pos=[tag],
+                  student_adaptation_params=dict(kernel_size=1, stride=1, upsample_factor=4))
+        if tag == "head":
+            adapt = nn.Conv2d(cs, ct, kernel_size=1)
+            s_in = torch.randn(B, cs, H, W)
+        else:
+            adapt = nn.Sequential(nn.Upsample(scale_factor=4, mode="bilinear", align_corners=True),
+                                  M.ThreeLayer(in_features=cs, out_features=ct, kernel_size=1, stride=1))
+            for m in adapt.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+            s_in = torch.randn(B, cs, H // 4, W // 4)
+        spat = nn.Conv2d(1, 1, kernel_size=3, padding=1)
+        teacher = torch.randn(B, ct, H, W) * (1.0 + torch.rand(1, ct, 1, 1))
+        teacher[0, :, 3:6, 4:9] *= 4.0          # a hot region for the attention softmax
+        self = R.bare(M.BEVDetDistill, distill_params=dp, _epoch=1, count=0,
+                      pts_bbox_head=SimpleNamespace(train_cfg=train_cfg),
+                      teacher_adaptations=nn.ModuleList([nn.Identity()]),
+                      channel_wise_adaptations=nn.ModuleList([adapt]),
+                      spatial_wise_adaptations=nn.ModuleList([spat]))
+        torch.nn.Module.train(self, True)
+        sd0 = {**_sd(f"{tag}_adapt__", adapt), **_sd(f"{tag}_spat__", spat)}
+        s_in.requires_grad_(True)
+        canvas = torch.rand(B, 4, 4 * H, 4 * W)
+        tp = [[dict(heatmap=t.clone())] for t in t_logit]
+        sp = [[dict(heatmap=s.clone())] for s in s_sig]
+        losses = self.fgd_distill_loss(teacher.clone(), s_in, gtb, None, canvas, [h.clone() for h in gt_hm], tp, sp, 0)
+        total = sum(losses.values())
+        params = [p for p in list(adapt.parameters()) + list(spat.parameters())]
+        grads = torch.autograd.grad(total, [s_in] + params)
+        fg, fgs, bgs = self.foreground_scale_mask(H, W, gtb, 0, 0)
+        out.update({f"{tag}_student_in": s_in.detach().numpy(), f"{tag}_teacher": teacher.numpy(),
+                    f"{tag}_grad_student_in": grads[0].numpy(), f"{tag}_fg": fg.numpy(), f"{tag}_fg_scale": fgs.numpy(),
+                    f"{tag}_bg_scale": bgs.numpy()}, **sd0)
+        names = [n for n, _ in list(adapt.named_parameters())] + ["spat." + n for n, _ in spat.named_parameters()]
+        for n, g in zip(names, grads[1:]):
+            out[f"{tag}_grad__{n.replace('.', '__')}"] = g.numpy()
+        for k, v in losses.items():
+            out[f"{tag}_loss__{k}"] = np.array(float(v), np.float64)
+        if fp != "none":
+            tp2 = [[dict(heatmap=t.clone())] for t in t_logit]
+            fpm, fps, nfp = self.add_fp_as_fg(fp, fg, [h.clone() for h in gt_hm], tp2, sp)
+            out.update({f"{tag}_fp": fpm.numpy(), f"{tag}_fp_scale": fps.numpy(), f"{tag}_n_fp": nfp.numpy()})
+        print(tag, {k: float(v) for k, v in losses.items()})
+    out.update(boxes0=boxes[0], boxes1=boxes[1], grid_size=np.array(train_cfg["grid_size"]),
+               pc_range=np.array(train_cfg["point_cloud_range"], np.float32),
+               voxel_size=np.array(train_cfg["voxel_size"], np.float32),
+               gt_hm=torch.cat(gt_hm, 1).numpy(), t_logit=torch.cat(t_logit, 1).numpy(),
+               s_sig=torch.cat(s_sig, 1).numpy(), ncls=np.array(ncls))
+    _save("fgd_losses.npz", **out)
+
+
+def make_shift_depth():
+    """shift_feature (bevdet_distill_more.py:41-94) and get_depth_loss (:185-204) from the imported file."""
+    from types import SimpleNamespace
+    M = R.bevdet_distill_more()
+    rng = np.random.default_rng(44)
+    torch.manual_seed(4)
+    B, N, C, H, W = 2, 3, 5, 16, 16
+    vt = SimpleNamespace(dx=torch.tensor([0.8, 0.8, 20.0]), bx=torch.tensor([-6.0, -6.0, 0.0]),
+                         grid_config=dict(dbound=[1.0, 8.0, 1.0]), D=7, loss_depth_weight=100.0)
+    rig0 = syn.camera_rig(B, rng, n_cams=N)
+    rig1 = syn.camera_rig(B, rng, n_cams=N)
+    # adjacent frame: ego moved by (dx, dy) and yawed a little -> same rig seen from the current lidar frame
+    for b in range(B):
+        yaw = rng.uniform(-0.15, 0.15)
+        Rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]], np.float32)
+        rig1["rots"][b] = Rz @ rig0["rots"][b]
+        rig1["trans"][b] = (Rz @ rig0["trans"][b].T).T + np.array([rng.uniform(0.5, 2.0), rng.uniform(-0.6, 0.6), 0], np.float32)
+    x = torch.randn(B, C, H, W)
+    trans = [torch.from_numpy(rig0["trans"]), torch.from_numpy(rig1["trans"])]
+    rots = [torch.from_numpy(rig0["rots"]), torch.from_numpy(rig1["rots"])]
+    x.requires_grad_(True)
+    outs = {}
+    for mode in ("bilinear", "nearest"):
+        self = R.bare(M.BEVDet4DDistill, img_view_transformer=vt, interpolation_mode=mode)
+        y = self.shift_feature(x, trans, rots)
+        outs[f"shift_{mode}"] = y.detach().numpy()
+        if mode == "bilinear":
+            g = torch.randn_like(y)
+            outs["shift_grad_out"] = g.numpy()
+            outs["shift_grad_in"] = torch.autograd.grad(y, x, g)[0].numpy()
+    # depth loss: 6 cams x (4 x 6) map, D=7; gt depths in [1, 8) with ~40 % zeros; no gt >= dbound[1] (the
+    # reference's one_hot raises there)
+    self = R.bare(M.BEVDepthDistill, img_view_transformer=vt)
+    dg = rng.uniform(1.0, 7.999, (B, N, 4, 6)).astype(np.float32)
+    dg[rng.uniform(size=dg.shape) < 0.4] = 0
+    dg[0, 0, 0, :3] = [1.0, 2.0, 7.0]          # exact bin edges
+    logits = torch.randn(B * N, 7, 4, 6, requires_grad=True)
+    ld = self.get_depth_loss(torch.from_numpy(dg), logits)
+    gl = torch.autograd.grad(ld, logits)[0]
+    _save("shift_depth.npz", x=x.detach().numpy(), trans0=rig0["trans"], trans1=rig1["trans"], rots0=rig0["rots"],
+          rots1=rig1["rots"], dx=vt.dx.numpy(), bx=vt.bx.numpy(), depth_gt=dg, depth_logits=logits.detach().numpy(),
+          loss_depth=np.array(float(ld), np.float64), grad_logits=gl.numpy(), **outs)
+    print("loss_depth", float(ld))
+
+
+CENTER_TASKS = [["car"], ["truck", "construction_vehicle"], ["bus", "trailer"], ["barrier"], ["motorcycle", "bicycle"],
+                ["pedestrian", "traffic_cone"]]
+
+
+def make_centerloss():
+    """CenterHead.get_targets + CenterHead.loss (centerpoint_head.py:366-686) executed by the imported class on a bare
+    instance: 6 tasks, 32x32 map (grid 256 / out_size_factor 8), two samples, objects sharing a pixel, one box outside
+    the range, max_objs small enough to overflow in one task."""
+    M = R.centerpoint_head()
+    rng = np.random.default_rng(55)
+    torch.manual_seed(5)
+    B, H, W = 2, 32, 32
+    train_cfg = dict(grid_size=[256, 256, 40], point_cloud_range=[-12.8, -12.8, -5.0, 12.8, 12.8, 3.0],
+                     voxel_size=[0.1, 0.1, 0.2], out_size_factor=8, dense_reg=1, gaussian_overlap=0.1, max_objs=12,
+                     min_radius=2, code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2])
+    self = R.bare(M.CenterHead, train_cfg=train_cfg, class_names=CENTER_TASKS, task_heads=[None] * 6, norm_bbox=True,
+                  task_specific=True, loss_prefix="", loss_cls=R.build_loss(dict(type="GaussianFocalLoss", reduction="mean")),
+                  loss_bbox=R.build_loss(dict(type="L1Loss", reduction="mean", loss_weight=0.25)))
+    boxes, labels = [], []
+    for b in range(B):
+        bx, lab = syn.gt_boxes(40, rng)
+        bx[:, :2] = rng.uniform(-12.0, 12.0, bx[:, :2].shape).astype(np.float32)
+        if b == 0:
+            lab[:16] = 0                         # 16 cars > max_objs 12 -> truncated
+            bx[:16, 3:6] = syn.CLASS_DIMS[0]
+            bx[1, :2] = bx[0, :2] + 0.05         # two cars in one pixel
+            bx[2, :2] = [13.5, 0.0]              # outside the range -> skipped, slot stays empty
+        boxes.append(bx); labels.append(lab)
+    gtb = [R.LiDARBoxesStub(b) for b in boxes]
+    gtl = [torch.from_numpy(l) for l in labels]
+    heads = dict(reg=2, height=1, dim=3, rot=2, vel=2)
+    preds, leaves = [], {}
+    for t, names in enumerate(CENTER_TASKS):
+        d = {k: torch.randn(B, c, H, W, requires_grad=True) for k, c in heads.items()}
+        d["heatmap"] = (torch.randn(B, len(names), H, W) - 2.0).requires_grad_(True)
+        for k, v in d.items():
+            leaves[f"pred{t}_{k}"] = v
+        preds.append([{k: (v * 1.0) for k, v in d.items()}])       # non-leaf copies (clip_sigmoid is in place)
+    loss_dict, heatmaps, anno_boxes, inds, masks = self.loss(gtb, gtl, preds, get_targets=True)
+    total = sum(loss_dict.values())
+    grads = torch.autograd.grad(total, list(leaves.values()))
+    out = {k: v.detach().numpy() for k, v in leaves.items()}
+    out.update({"grad_" + k: g.numpy() for k, g in zip(leaves, grads)})
+    out.update({"loss__" + k.replace(".", "__"): np.array(float(v), np.float64) for k, v in loss_dict.items()})
+    out.update(boxes0=boxes[0], boxes1=boxes[1], labels0=labels[0], labels1=labels[1],
+               heatmap=torch.cat(heatmaps, 1).numpy(), anno_box=torch.stack(anno_boxes).numpy(),
+               ind=torch.stack(inds).numpy(), mask=torch.stack(masks).numpy(),
+               code_weights=np.array(train_cfg["code_weights"], np.float32))
+    _save("center_loss.npz", **out)
+    print({k: round(float(v), 5) for k, v in loss_dict.items()})
+    print("objects per task", torch.stack(masks).sum((1, 2)).tolist())
+
+
+def make_pfn():
+    """dynamic_scatter fwd/bwd through the reference's ops/voxel/scatter_points.py (ext entry points = the reference host
+    code's own ATen calls, see _ref_import._voxel_layer_stub) and DynamicPillarFeatureNet.forward/backward
+    (pillar_encoder.py:283-338) with training-mode BN1d, two samples, points outside the range."""
+    SP = R.scatter_points()
+    PE = R.pillar_encoder()
+    rng = np.random.default_rng(66)
+    torch.manual_seed(6)
+    out = {}
+    # -- op level: 3-D coordinates, ties for the max, invalid rows
+    N, C = 600, 6
+    coors = np.stack([rng.integers(0, 2, N), rng.integers(0, 6, N), rng.integers(0, 7, N)], 1).astype(np.int32)
+    coors[rng.uniform(size=N) < 0.1] = -1
+    coors[5] = [-1, 3, 2]                      # one negative entry invalidates the row
+    feats = rng.normal(size=(N, C)).astype(np.float32)
+    feats[40:80] = np.round(feats[40:80])      # many exact ties for the arg-max traceback
+    for red in ("max", "mean", "sum"):
+        f = torch.from_numpy(feats).requires_grad_(True)
+        vf, vc = SP.dynamic_scatter(f, torch.from_numpy(coors), red)
+        g = torch.randn_like(vf)
+        (gf,) = torch.autograd.grad(vf, f, g)
+        out.update({f"ds_{red}_feats": vf.detach().numpy(), f"ds_{red}_coors": vc.numpy(), f"ds_{red}_gout": g.numpy(),
+                    f"ds_{red}_gin": gf.numpy()})
+    out.update(ds_feats=feats, ds_coors=coors)
+    # -- DynamicPillarFeatureNet on a 16 x 16 pillar grid
+    vs, pcr = (0.2, 0.2, 8.0), (-1.6, -1.6, -5.0, 1.6, 1.6, 3.0)
+    m = PE.DynamicPillarFeatureNet(in_channels=5, feat_channels=(16,), with_distance=False, voxel_size=vs,
+                                   point_cloud_range=pcr, norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01))
+    m.pfn_layers[0][1].weight.data.uniform_(0.5, 1.5)
+    m.pfn_layers[0][1].bias.data.normal_(0, 0.3)
+    m.train()
+    pts, cos = [], []
+    for b in range(2):
+        p = syn.lidar_points(700, rng)
+        p[:, :2] = rng.uniform(-1.8, 1.8, (700, 2)).astype(np.float32)
+        c = np.floor((p[:, :3] - np.array(pcr[:3], np.float32)) / np.array(vs, np.float32)).astype(np.int32)
+        ok = ((c >= 0) & (c < np.array([16, 16, 1]))).all(1)
+        p, c = p[ok], c[ok]                    # DynamicCenterPoint drops nothing, but map_voxel_center_to_point indexes
+        pts.append(p)                          # a canvas with the raw coordinates -> the reference needs in-range rows
+        cos.append(np.concatenate([np.full((len(p), 1), b, np.int32), c[:, ::-1]], 1))
+    points = torch.from_numpy(np.concatenate(pts)).requires_grad_(False)
+    coors4 = torch.from_numpy(np.concatenate(cos))
+    vf, vc = m(points.clone(), coors4)
+    g = torch.randn_like(vf)
+    gw = torch.autograd.grad(vf, list(m.parameters()), g)
+    out.update(pfn_points=points.numpy(), pfn_coors=coors4.numpy(), pfn_voxel_feats=vf.detach().numpy(),
+               pfn_voxel_coors=vc.numpy(), pfn_gout=g.numpy(), voxel_size=np.array(vs, np.float32),
+               pc_range=np.array(pcr, np.float32), **_sd("pfn_sd__", m))
+    for (n, _), gg in zip(m.named_parameters(), gw):
+        out["pfn_grad__" + n.replace(".", "__")] = gg.numpy()
+    out["pfn_running_mean"] = m.pfn_layers[0][1].running_mean.numpy().copy()
+    out["pfn_running_var"] = m.pfn_layers[0][1].running_var.numpy().copy()
+    # the teacher's configuration: eval-mode BN (running statistics), no_grad, then PointPillarsScatter
+    m.pfn_layers[0][1].running_mean.normal_(0, 0.5)
+    m.pfn_layers[0][1].running_var.uniform_(0.5, 2.0)
+    m.eval()
+    out.update(_sd("pfn_eval_sd__", m))
+    with torch.no_grad():
+        vfe, vce = m(points.clone(), coors4)
+        canvas = R.pillar_scatter().PointPillarsScatter(16, [16, 16])(vfe, vce, 2)
+    assert torch.equal(vce, vc)
+    out.update(pfn_eval_voxel_feats=vfe.numpy(), pfn_eval_canvas=canvas.numpy(),
+               pfn_n0=np.array(len(pts[0])))
+    _save("pfn_scatter.npz", **out)
+    print("pillars", vf.shape[0], "points", points.shape[0])
+
+
+def make_second():
+    """SECOND (second.py:80-93) + SECONDFPN (second_fpn.py:77-93) outputs of the imported modules on seeded weights,
+    eval mode (the teacher runs under eval / no_grad), thin channels so that the state dict fits a fixture."""
+    S = R.second()
+    Fp = R.second_fpn()
+    torch.manual_seed(7)
+    bb = S.SECOND(in_channels=8, out_channels=[8, 16, 32], layer_nums=[1, 2, 2], layer_strides=[2, 2, 2],
+                  norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), conv_cfg=dict(type="Conv2d", bias=False))
+    nk = Fp.SECONDFPN(in_channels=[8, 16, 32], out_channels=[8, 8, 8], upsample_strides=[0.5, 1, 2],
+                      norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), upsample_cfg=dict(type="deconv", bias=False),
+                      use_conv_for_no_stride=True)
+    for m in list(bb.modules()) + list(nk.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+            m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0)
+    bb.eval(); nk.eval()
+    x = torch.randn(2, 8, 32, 32)
+    x[:, :, 10:20, 5:9] = 0
+    with torch.no_grad():
+        feats = bb(x)
+        y = nk(feats)
+    _save("second_fpn.npz", x=x.numpy(), f0=feats[0].numpy(), f1=feats[1].numpy(), f2=feats[2].numpy(),
+          y=y[0].numpy(), **_sd("bb__", bb), **_sd("nk__", nk))
+    print([tuple(f.shape) for f in feats], tuple(y[0].shape))
+
+
+SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center,
+            "fgd": make_fgd, "shift_depth": make_shift_depth, "centerloss": make_centerloss, "pfn": make_pfn,
+            "second": make_second}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)
