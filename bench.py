@@ -35,6 +35,19 @@ def _workloads():
     return W.WORKLOADS
 
 
+def _self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,12 +57,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: launch the N ranks ourselves, exactly as the documented command line does
+        # (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1); rank 0 prints the JSON line
+        raise SystemExit(_self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but launched with WORLD_SIZE={world}; "
+                         f"use --nproc-per-node {args.gpus} (or plain `python bench.py --gpus {args.gpus}`)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback "
                          "(only the cpu_baseline leg runs on the host)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: local rank {local_rank} of {world} but only {torch.cuda.device_count()} visible GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("DBEV_FORCE_DDP") == "1":
@@ -57,7 +79,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=dev)
-    n_gpus = world
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    n_gpus = dist.get_world_size() if dist.is_initialized() else 1
 
     W = _workloads()
     name = args.workload or W["default"]
@@ -109,7 +132,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": wl.config(world),
+            "config": dict(wl.config(world), world_size=n_gpus,
+                           collective_backend=(dist.get_backend() + " (RCCL)") if dist.is_initialized() else None),
             "roofline": roof,
             "cpu_baseline": cpu,
         }

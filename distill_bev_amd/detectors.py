@@ -173,6 +173,29 @@ class TwoLayer(nn.Module):
         return bn_act(self.conv2(bn_act(self.conv1(x), self.norm1, None, True)), self.norm2, None, True)
 
 
+def load_checkpoint(module, path, what="model", allow_missing=False):
+    """mmcv.runner.load_checkpoint for a local file in the mmdet3d format (dict with 'state_dict' [+ 'meta',
+    'optimizer']) or a bare state dict; a DataParallel 'module.' prefix is stripped.  A missing file raises (mmcv
+    does too); keys the checkpoint does not provide raise unless allow_missing (mmcv only logs them -- a teacher with
+    silently random layers would distil noise); keys the module does not have are reported and ignored."""
+    import warnings
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"{what} checkpoint '{path}' does not exist")
+    ck = torch.load(path, map_location="cpu")
+    sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if not k.endswith("num_batches_tracked")]
+    if unexpected:
+        warnings.warn(f"{what} checkpoint {path}: {len(unexpected)} unexpected keys ignored, e.g. {unexpected[:4]}")
+    if missing:
+        msg = f"{what} checkpoint {path}: {len(missing)} parameters/buffers not in the file, e.g. {missing[:6]}"
+        if not allow_missing:
+            raise RuntimeError(msg)
+        warnings.warn(msg)
+    return missing, unexpected
+
+
 def _as_list(v, n):
     return list(v) if isinstance(v, (list, tuple)) else [v for _ in range(n)]
 
@@ -213,12 +236,15 @@ class BEVDepth4DDistill(CenterPoint):
             teacher_config = Config.fromfile(path)
         tmodel = teacher_config["model"] if "model" in teacher_config else teacher_config
         self.teacher_model = build_detector(tmodel)
-        if isinstance(teacher_ckpt, str) and teacher_ckpt.lower() != "none" and os.path.exists(teacher_ckpt):
-            sd = torch.load(teacher_ckpt, map_location="cpu")
-            self.teacher_model.load_state_dict(sd.get("state_dict", sd), strict=False)
+        has_teacher_ckpt = isinstance(teacher_ckpt, str) and teacher_ckpt.lower() != "none"
+        if has_teacher_ckpt:
+            load_checkpoint(self.teacher_model, teacher_ckpt, what="teacher")       # bevdet_distill.py:163-166
         for p in self.teacher_model.parameters():
             p.requires_grad_(False)
+        self._self_ckpt = self_ckpt if isinstance(self_ckpt, str) and self_ckpt.lower() != "none" else None
         self.inherit_head = inherit_head
+        if self.inherit_head:                                                        # :175-176
+            assert has_teacher_ckpt, "inherit_head=True copies the TRAINED teacher heads: teacher_ckpt is required"
         assert distill_type == "fgd", "only the FGD recipe (the shipped distillation configs) is on the hot path"
         self.distill_type = distill_type
         dp = self.distill_params = distill_params
@@ -268,6 +294,14 @@ class BEVDepth4DDistill(CenterPoint):
         self.feat_criterion = build_loss(dp["feat_criterion"])
         self.spatial_criterion = build_loss(dp["spatial_criterion"])
         self.channel_criterion = build_loss(dp["channel_criterion"])
+        # the masked-MSE kernels ARE the feature criterion: only MSELoss(reduction='none', weight 1) is fused
+        fc = self.feat_criterion
+        assert type(fc).__name__ == "MSELoss" and fc.reduction == "none" and fc.loss_weight == 1.0, \
+            "feat_criterion must be dict(type='MSELoss', reduction='none'): the FGD feature terms run on the masked-MSE kernels"
+        assert getattr(self.spatial_criterion, "reduction", None) == "none", \
+            "spatial_criterion must use reduction='none' (fgd_distill_loss sums it, bevdet_distill.py:1275-1277)"
+        if self._self_ckpt is not None:                                              # :171-173 (after every module exists)
+            load_checkpoint(self, self._self_ckpt, what="student", allow_missing=True)
         tcfg = self.pts_bbox_head.train_cfg
         self._fg_raster = ForegroundMaskRasterizer(tcfg["grid_size"], tcfg["point_cloud_range"], tcfg["voxel_size"])
         self._epoch = 1
@@ -293,6 +327,10 @@ class BEVDepth4DDistill(CenterPoint):
         self._epoch = epoch
 
     def init_weights(self):
+        for name in ("img_backbone", "img_bev_encoder_backbone"):      # BaseModule.init_weights recursion (pretrained=...)
+            mod = getattr(self, name, None)
+            if mod is not None and hasattr(mod, "init_weights"):
+                mod.init_weights()
         if self.inherit_head:   # bevdet_distill.py:367-373
             self.pts_bbox_head.task_heads.load_state_dict(self.teacher_model.pts_bbox_head.task_heads.state_dict(),
                                                           strict=False)

@@ -134,6 +134,7 @@ class ResNet(nn.Module):
         block, stage_blocks = self.arch_settings[depth]
         stem_channels = stem_channels or base_channels
         self.depth, self.out_indices, self.norm_eval, self.frozen_stages = depth, out_indices, norm_eval, frozen_stages
+        self.pretrained, self.init_cfg = pretrained, init_cfg
         self.deep_stem = False
         self.conv1 = build_conv_layer(conv_cfg, in_channels, stem_channels, kernel_size=7, stride=2, padding=3, bias=False)
         self.norm1_name, norm1 = build_norm_layer(norm_cfg, stem_channels, postfix=1)
@@ -172,6 +173,7 @@ class ResNet(nn.Module):
                     nn.init.zeros_(getattr(m, m.norm3_name).weight)
                 elif isinstance(m, BasicBlock):
                     nn.init.zeros_(getattr(m, m.norm2_name).weight)
+        self._freeze_stages()
 
     @property
     def norm1(self):
@@ -186,8 +188,43 @@ class ResNet(nn.Module):
                 outs.append(x)
         return tuple(outs)
 
+    def _freeze_stages(self):
+        """mmdet ResNet._freeze_stages: stem and the first `frozen_stages` residual stages in eval mode without grads."""
+        if self.frozen_stages >= 0:
+            self.norm1.eval()
+            for m in (self.conv1, self.norm1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f"layer{i}")
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def init_weights(self):
+        """`pretrained` (a path or torchvision:// URL in the reference's configs) / init_cfg(type='Pretrained'): load a
+        local state dict when the file exists; otherwise say so -- never silently train from another initialisation."""
+        src = self.pretrained
+        if src is None and isinstance(self.init_cfg, dict) and self.init_cfg.get("type") == "Pretrained":
+            src = self.init_cfg.get("checkpoint")
+        if src is None:
+            return
+        import os
+        import warnings
+        if isinstance(src, str) and os.path.isfile(src):
+            sd = torch.load(src, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            missing, unexpected = self.load_state_dict(sd, strict=False)
+            missing = [k for k in missing if "num_batches_tracked" not in k]
+            if missing:
+                raise RuntimeError(f"ResNet pretrained weights {src}: missing keys {missing[:8]}...")
+        else:
+            warnings.warn(f"ResNet: pretrained weights '{src}' are not reachable from this machine (no network / no such "
+                          "file); the backbone keeps its random initialisation", RuntimeWarning)
+
     def train(self, mode=True):
         super().train(mode)
+        self._freeze_stages()
         if mode and self.norm_eval:
             for m in self.modules():
                 if isinstance(m, nn.modules.batchnorm._BatchNorm):

@@ -103,6 +103,15 @@ def build_norm_layer(cfg, num_features, postfix=""):
     cfg.setdefault("eps", 1e-5)
     if typ == "GN":
         layer = nn.GroupNorm(num_channels=num_features, **cfg)
+    elif typ == "SyncBN":
+        # mmcv maps 'SyncBN' to torch.nn.SyncBatchNorm.  In a process group it keeps that meaning (statistics
+        # all-reduced over the ranks); a single process has nothing to synchronise with and gets the local
+        # BatchNorm2d (same parameters, buffers and state-dict keys), which the fused norm-act kernels cover.
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            layer = nn.SyncBatchNorm(num_features, **cfg)
+        else:
+            layer = nn.BatchNorm2d(num_features, **cfg)
     else:
         layer = _NORMS[typ](num_features, **cfg)
     for p in layer.parameters():

@@ -53,10 +53,42 @@ def make_batch(B, rng, device, n_points=240000, n_boxes=30, n_cams=6, input_size
     return dict(points=points, img_inputs=img_inputs, gt_bboxes_3d=boxes, gt_labels_3d=labels)
 
 
+def synthetic_teacher_checkpoint(model_cfg, seed=0, directory=None):
+    """No trained CenterPoint weights are reachable from the build or GPU boxes (no network).  The distillation recipe
+    nevertheless REQUIRES a teacher checkpoint (`inherit_head=True` asserts one, bevdet_distill.py:175-176), so the
+    benchmark / tests write a seeded random-init teacher to disk in the mmdet3d checkpoint format
+    ({'meta': ..., 'state_dict': {mmdet3d key names}}) and hand the PATH to the detector -- the teacher then goes through
+    the same `teacher_ckpt` loading code a real epoch_20.pth would.  Returns the path."""
+    import hashlib
+    import tempfile
+    tc = model_cfg["teacher_config"]
+    if isinstance(tc, str):
+        root = model_cfg.get("config_root")
+        path = tc if os.path.isabs(tc) or os.path.exists(tc) or not root else os.path.join(root, tc)
+        tc = Config.fromfile(path)
+    tmodel = tc["model"] if "model" in tc else tc
+    tag = hashlib.sha1((repr(tmodel) + str(seed)).encode()).hexdigest()[:12]
+    out = os.path.join(directory or tempfile.gettempdir(), f"dbev_synthetic_teacher_{tag}_{os.getpid()}.pth")
+    if not os.path.isfile(out):
+        state = torch.random.get_rng_state()
+        torch.manual_seed(1000 + seed)
+        teacher = build_detector(tmodel)
+        torch.random.set_rng_state(state)
+        torch.save({"meta": {"note": "seeded random init (synthetic_teacher_checkpoint)", "seed": seed},
+                    "state_dict": teacher.state_dict()}, out)
+        import atexit
+        atexit.register(lambda p=out: os.path.isfile(p) and os.remove(p))
+    return out
+
+
 def build_model(config=None, cfg_options=None, seed=0):
     cfg = Config.fromfile(config or DEFAULT_CONFIG) if not isinstance(config, Config) else config
     if cfg_options:
         cfg.merge_from_args(cfg_options) if isinstance(cfg_options, (list, tuple)) else cfg.merge_from_dict(cfg_options)
+    m = cfg.model
+    ck = m.get("teacher_ckpt")
+    if m.get("teacher_config") is not None and m.get("inherit_head") and not (isinstance(ck, str) and ck.lower() != "none"):
+        m["teacher_ckpt"] = synthetic_teacher_checkpoint(m, seed)
     torch.manual_seed(seed)
     model = build_detector(cfg.model)
     model.init_weights()
@@ -104,8 +136,8 @@ def accelerate_modules(detector):
 
 
 def _flat_view(g):
-    """1-D view of a dense gradient in MEMORY order (identical on every rank: same module, same memory format);
-    falls back to a logical-order copy for exotic strides (the copy is then written back through the same mapping)."""
+    """1-D view of a dense gradient in MEMORY order; falls back to a logical-order copy for exotic strides (the copy is
+    then written back through the same mapping)."""
     if g.is_contiguous():
         return g.view(-1)
     if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last):
@@ -123,16 +155,31 @@ class GradReducer:
     step at this model size (per-parameter autograd hooks, 330 grad->bucket copies and divisions: measured 188 vs
     178 ms at one rank) to hide a collective that takes ~1.5-3 ms on 8 GPUs of one node -- the exposed all-reduce
     is cheaper than the machinery that overlaps it.  Semantics are DDP's: parameters (and buffers, once) are
-    broadcast from rank 0 at construction, every rank ends the step with identical averaged gradients, BatchNorm
-    statistics stay local, and a parameter without a gradient on any rank is an error (find_unused_parameters=False).
+    broadcast from rank 0 at construction, every rank ends the step with identical averaged gradients and BatchNorm
+    statistics stay local.
+
+    Parameters without a gradient (mmcv's `find_unused_parameters`; e.g. the 'backbone*' adaptation layers while
+    `_epoch < multi_scale_epoch`, bevdet_distill.py:1452-1455): a rank that has no gradient for a parameter
+    contributes zeros, one flag per parameter rides in the bucket, and a parameter that NO rank produced a gradient
+    for keeps `grad = None` (the optimizer skips it, as under DDP) -- ranks never block each other.
+
+    Layout: a gradient is packed in the PARAMETER's memory layout (a gradient that arrives with other strides, e.g. a
+    permuted view out of a custom backward, is first copied into that layout), so every rank packs every element at
+    the same bucket offset whatever kernels produced its gradients.
     """
 
     def __init__(self, params, buffers=(), bucket_mb=64):
         self.params = list(params)
         self.world = dist.get_world_size()
+        self.host_staged = dist.get_backend() == "gloo"      # gloo: device gradients travel through a host buffer
         with torch.no_grad():
             for t in list(self.params) + list(buffers):
-                dist.broadcast(t.data, 0)
+                if self.host_staged and t.is_cuda:
+                    h = t.data.cpu()
+                    dist.broadcast(h, 0)
+                    t.data.copy_(h)
+                else:
+                    dist.broadcast(t.data, 0)
         cap = int(bucket_mb) * (1 << 20)
         self.buckets, cur, size = [], [], 0
         for p in reversed(self.params):            # gradients become ready roughly in reverse parameter order
@@ -144,26 +191,49 @@ class GradReducer:
         if cur:
             self.buckets.append(cur)
 
+    @staticmethod
+    def _in_param_layout(p, g):
+        if g.shape == p.shape and g.stride() == p.stride():
+            return g
+        out = torch.empty_like(p)                  # preserve_format: p's strides
+        out.copy_(g)
+        return out
+
     @torch.no_grad()
     def all_reduce_grads(self):
         pending = []
         for bucket in self.buckets:
-            grads = []
+            grads, have = [], []
             for p in bucket:
-                if p.grad is None:
-                    raise RuntimeError("GradReducer: a parameter received no gradient on this rank "
-                                       "(all ranks must reduce the same set; find_unused_parameters is not supported)")
-                grads.append(p.grad)
+                have.append(p.grad is not None)
+                g = self._in_param_layout(p, p.grad) if p.grad is not None else torch.zeros_like(p)
+                if p.grad is not None and g is not p.grad:
+                    p.grad = g
+                grads.append(g)
             flats = [_flat_view(g) for g in grads]          # memory-order 1-D views: no per-tensor copy kernels
-            flat = torch.cat(flats)
+            flags = torch.tensor(have, dtype=flats[0].dtype).to(flats[0].device, non_blocking=True) * self.world
+            flat = torch.cat(flats + [flags])
             flat.div_(self.world)
-            pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, flats, grads))
-        for work, flat, flats, grads in pending:
+            if self.host_staged and flat.is_cuda:
+                host = flat.cpu()
+                pending.append((dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=True), flat, flats, grads, bucket, have, host))
+            else:
+                pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, flats, grads, bucket, have, None))
+        for work, flat, flats, grads, bucket, have, host in pending:
             work.wait()
-            torch._foreach_copy_(flats, list(flat.split([f.numel() for f in flats])))
+            if host is not None:
+                flat.copy_(host)
+            n = len(flats)
+            parts = list(flat.split([f.numel() for f in flats] + [n]))
+            torch._foreach_copy_(flats, parts[:n])
             for f, g in zip(flats, grads):                  # exotic strides: the flat tensor was a copy, write it back
                 if f.data_ptr() != g.data_ptr():
                     g.copy_(f.view_as(g))
+            if not all(have):                               # rare path (one host read-back): adopt what other ranks produced
+                any_rank = parts[n].cpu() > 0
+                for p, g, mine, someone in zip(bucket, grads, have, any_rank.tolist()):
+                    if not mine and someone:
+                        p.grad = g
 
 
 class Trainer:

@@ -83,11 +83,43 @@ def test_reference_config_builds_the_detector():
     from distill_bev_amd import detectors  # noqa: F401
     from distill_bev_amd.registry import build_detector
     ref = Config.fromfile(os.path.join(REF, CFG_D))
+    from distill_bev_amd.train_step import synthetic_teacher_checkpoint
     ref.merge_from_args(RUN_D_OPTIONS + [
-        "model.teacher_config='" + os.path.join(REF, CFG_T) + "'", "model.teacher_ckpt=None",
-        "model.img_backbone.pretrained=None"])
+        "model.teacher_config='" + os.path.join(REF, CFG_T) + "'", "model.img_backbone.pretrained=None"])
+    # the recipe asserts a teacher checkpoint (inherit_head=True): none is reachable, a seeded one is written in the
+    # mmdet3d format and loaded through the detector's own teacher_ckpt code path
+    with pytest.raises(AssertionError):
+        build_detector(dict(ref.model, teacher_ckpt=None))
+    with pytest.raises(FileNotFoundError):
+        build_detector(dict(ref.model, teacher_ckpt="/nonexistent/epoch_20.pth"))
+    ref.model["teacher_ckpt"] = synthetic_teacher_checkpoint(ref.model, seed=3)
     m = build_detector(ref.model)
     assert type(m).__name__ == "BEVDepth4DDistill" and type(m.teacher_model).__name__ == "DynamicCenterPoint"
+    ck = torch.load(ref.model["teacher_ckpt"], map_location="cpu")
+    assert set(ck) == {"meta", "state_dict"}
+    tsd = m.teacher_model.state_dict()
+    assert set(tsd) == set(ck["state_dict"]) and all(torch.equal(tsd[k], v) for k, v in ck["state_dict"].items())
+    m.init_weights()
+    assert torch.equal(m.pts_bbox_head.task_heads[2].dim[0].conv.weight,
+                       ck["state_dict"]["pts_bbox_head.task_heads.2.dim.0.conv.weight"])
+    os.remove(ref.model["teacher_ckpt"])
+
+
+def test_checkpoint_loading_rejects_incomplete_teacher_files_and_loads_student_self_ckpt(tmp_path):
+    from distill_bev_amd.detectors import load_checkpoint
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 1), torch.nn.BatchNorm2d(3))
+    full = str(tmp_path / "full.pth")
+    torch.save({"meta": {}, "state_dict": {"module." + k: v for k, v in net.state_dict().items()}, "optimizer": {}}, full)
+    other = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 1), torch.nn.BatchNorm2d(3))
+    load_checkpoint(other, full, what="teacher")                      # DataParallel prefix stripped, 'optimizer' ignored
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), other.state_dict().values()))
+    part = str(tmp_path / "part.pth")
+    torch.save({"state_dict": {k: v for k, v in net.state_dict().items() if not k.startswith("1.")}}, part)
+    with pytest.raises(RuntimeError, match="not in the file"):
+        load_checkpoint(other, part, what="teacher")
+    with pytest.warns(UserWarning):
+        missing, _ = load_checkpoint(other, part, what="student", allow_missing=True)
+    assert "1.weight" in missing
 
 
 def test_model_builds_with_reference_state_dict_keys_and_hidden_teacher():

@@ -105,12 +105,9 @@ def _reducer_buckets(rank, world, port, out):
         p.grad = torch.full_like(p, float(i + 1))
     red.all_reduce_grads()
     ok_vals = all(torch.equal(p.grad, torch.full_like(p, float(i + 1))) for i, p in enumerate(params))
-    params[1].grad = None
-    try:
-        red.all_reduce_grads()
-        raised = False
-    except RuntimeError:
-        raised = True
+    params[1].grad = None                                        # no gradient anywhere: stays None, nothing raised
+    red.all_reduce_grads()
+    raised = params[1].grad is not None
     torch.save(dict(ids=ids, expect=[id(p) for p in reversed(params)], sizes=sizes, ok_vals=ok_vals, raised=raised), out)
     dist.destroy_process_group()
 
@@ -123,4 +120,45 @@ def test_grad_reducer_buckets_cover_every_parameter_once_in_reverse_order(tmp_pa
     assert r["ids"] == r["expect"]                               # every parameter once, last parameter first
     assert all(sz * 4 >= (1 << 20) for sz in r["sizes"][:-1])    # all buckets but the last reach the cap
     assert r["ok_vals"]                                          # world 1: average == own gradient, packed/unpacked exactly
-    assert r["raised"]                                           # a missing gradient is an error, as with DDP
+    assert not r["raised"]                                       # a parameter nobody has a gradient for keeps grad=None
+
+
+def _reducer_unused_and_layout(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distill_bev_amd.train_step import GradReducer
+    torch.manual_seed(0)
+    params = [nn.Parameter(torch.randn(4, 3, 2, 2)), nn.Parameter(torch.randn(7)), nn.Parameter(torch.randn(5)),
+              nn.Parameter(torch.randn(6, 4, 3, 3).contiguous(memory_format=torch.channels_last))]
+    red = GradReducer(params, bucket_mb=1)
+    g0 = torch.arange(48.0).view(4, 3, 2, 2) * (rank + 1)
+    # the same logical gradient arrives with different strides on the two ranks (a permuted view on rank 1)
+    params[0].grad = g0 if rank == 0 else g0.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    params[1].grad = torch.full((7,), 2.0) if rank == 0 else None     # used on rank 0 only
+    params[2].grad = None                                            # used nowhere
+    g3 = torch.arange(216.0).view(6, 4, 3, 3) * (rank + 1)
+    params[3].grad = g3.contiguous(memory_format=torch.channels_last) if rank == 0 else g3.contiguous()
+    red.all_reduce_grads()
+    res = dict(p0=params[0].grad.clone(), p1=params[1].grad, p2=params[2].grad, p3=params[3].grad.clone(),
+               p3_stride=params[3].grad.stride() == params[3].stride())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_unused_parameters_and_mixed_gradient_layouts(tmp_path):
+    """world 2: a parameter unused on ONE rank receives the average of (grad, 0) on both ranks; a parameter unused on
+    ALL ranks keeps grad=None; gradients that arrive with rank-dependent strides are averaged element by element."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "red2.pt")
+    mp.spawn(_reducer_unused_and_layout, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out, weights_only=False)
+    g0 = torch.arange(48.0).view(4, 3, 2, 2)
+    g3 = torch.arange(216.0).view(6, 4, 3, 3)
+    for r in (r0, r1):
+        assert torch.equal(r["p0"], g0 * 1.5) and torch.equal(r["p3"], g3 * 1.5) and r["p3_stride"]
+        assert torch.equal(r["p1"], torch.full((7,), 1.0))
+        assert r["p2"] is None

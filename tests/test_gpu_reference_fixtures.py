@@ -241,7 +241,7 @@ def test_fgd_position_losses_and_gradients_vs_reference(tag, channels_last):
     assert np.abs(grads[0].cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
     for n, gr in zip(params, grads[1:]):
         ref = g[f"{tag}_grad__{n.replace('.', '__')}"]
-        assert np.abs(gr.cpu().numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-3), n
+        assert np.abs(gr.cpu().numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-2), n   # (a conv bias in front of a BatchNorm has a zero gradient: both sides carry 1e-7 noise)
 
 
 def test_foreground_and_fp_masks_vs_reference():
