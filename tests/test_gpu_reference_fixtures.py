@@ -37,8 +37,8 @@ def _t(a, dev):
 def test_fused_geometry_voxels_vs_reference_voxels_full_size():
     """Camera matrices -> cell id through dbev_lift_splat_prepare_cam (get_geometry evaluated inside the index kernel)
     against the cell the imported reference assigns (its own get_geometry: torch.inverse + broadcast matmul on the CPU,
-    then the truncating index and range mask of voxel_pooling).  The two geometries differ by float32 rounding order, so
-    a point lying within an ulp of a cell border may land in the neighbouring cell: counted and bounded here."""
+    then the truncating index and range mask of voxel_pooling) -- bit-exact voxel indices end to end, from the camera
+    matrices, not only "on a shared geometry tensor"."""
     from distill_bev_amd import lss as LSS
     from distill_bev_amd.lift_splat import lift_splat_prepare_cam
     dev = _dev()
@@ -53,13 +53,10 @@ def test_fused_geometry_voxels_vs_reference_voxels_full_size():
     assert got.shape == ref.shape == (249216,)
     bad = np.flatnonzero(got != ref)
     print(f"[a2] voxel mismatches vs reference: {bad.size} of {ref.size}; kept {int((got >= 0).sum())} vs {int(g['n_kept'])}")
-    assert bad.size <= 8, bad.size
-    assert abs(int((got >= 0).sum()) - int(g["n_kept"])) <= 8
-    for i in bad:                                   # every mismatch is a hop to an ADJACENT cell (or in/out of range)
-        a, b = got[i], ref[i]
-        if a >= 0 and b >= 0:
-            ya, xa, yb, xb = a // 128, a % 128, b // 128, b % 128
-            assert abs(ya - yb) + abs(xa - xb) == 1, (i, a, b)
+    # measured on MI355X: 0 mismatches of 249 216 (the in-kernel geometry follows the torch op order closely enough that
+    # no point of this rig crosses a border) -> held to exact equality; kept count 221 920 on both sides
+    assert bad.size == 0, (bad.size, bad[:8], got[bad[:8]], ref[bad[:8]])
+    assert int((got >= 0).sum()) == int(g["n_kept"])
 
 
 # ---- a9: dynamic scatter -------------------------------------------------------------------------------------
