@@ -12,6 +12,10 @@ from distill_bev_amd import synthetic as syn
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
+# HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 gfx950 wide-read correction + WRITE_SIZE),
+# profiles/r02_pmc_*.txt; filled in by the profiling pass of the round, None until then
+PMC_TRAFFIC = {"bn_apply_res": None, "source": None}
+
 
 def _grid():
     return LSS.gen_dx_bx([-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8], [-10.0, 10.0, 20.0])
@@ -130,15 +134,18 @@ class DistillStep(_Base):
     default_steps = 20
     default_warmup = 5
     N_POINTS = 240000
-    # dominant hand-written kernel timed for the roofline: teacher pillars scatter (write-bound)
-    ROOF_KERNEL = "dbev_pillars_canvas"
+    # `roofline` reports the hand-written kernel that takes the most TIME in the step: the apply pass of the fused
+    # BatchNorm + residual + ReLU (bn_apply<true, *>, 48 launches per step over 69 ... 554 MB activations), bracketed
+    # per LAUNCH by the library's kernel event log inside the timed region; the rest of the bn_* family and every
+    # other hand-written entry point are measured the same way in extra steps after it (`other_hot_kernels`).
+    ROOF_KERNEL = "bn_apply_res"
+    ROOF_KERNEL_NAME = "bn_apply<true,*>"
     EXTRA_INSTRUMENTED_STEPS = 3
     TIMED = ("dbev_pillars_canvas", "dbev_pillar_vfe_canvas", "dbev_lift_splat_prepare_cam", "dbev_lift_splat_forward",
              "dbev_lift_splat_backward", "dbev_abs_mean_maps", "dbev_abs_mean_maps_nhwc", "dbev_fgd_masked_mse_forward",
              "dbev_fgd_masked_mse_forward_nhwc", "dbev_fgd_masked_mse_backward", "dbev_fgd_masked_mse_backward_nhwc",
              "dbev_fg_scale_mask", "dbev_upsample_bilinear_ac_forward", "dbev_upsample_bilinear_ac_backward",
-             "dbev_dcnv2_im2col", "dbev_dcnv2_col2im", "dbev_bn_act_train_forward", "dbev_bn_act_backward",
-             "dbev_bn_act_infer")
+             "dbev_dcnv2_im2col", "dbev_dcnv2_col2im", "dbev_bn_act_infer")
 
     def __init__(self, dev, rank, world):
         from distill_bev_amd.train_step import Trainer, build_model, make_batch
@@ -161,49 +168,70 @@ class DistillStep(_Base):
         self.steps_timed = getattr(self, "steps_timed", 0) + 1
 
     def begin_timed(self):
-        # inside the timed region only the roofline kernel carries an event pair per launch; the other entry
-        # points (7000+ calls per 20 steps) are instrumented in EXTRA steps after it (roofline())
-        L.enable_timing(self.ROOF_KERNEL)
+        # inside the timed region only the roofline kernel's launches carry an event pair (48 per step); the other
+        # kernels / entry points (7000+ calls per 20 steps) are instrumented in EXTRA steps after it (roofline())
+        L.kernel_timing_read()
+        L.kernel_timing([self.ROOF_KERNEL])
+        self.steps_timed = 0
+
+    @staticmethod
+    def _fam(recs):
+        t = float(sum(r[0] for r in recs)) * 1e-3
+        b = float(sum(r[1] for r in recs))
+        return t, b
 
     def roofline(self):
-        ms = L.timing_ms(self.ROOF_KERNEL)
-        L.disable_timing()
-        if not ms:
+        roof = L.kernel_timing_read().get(self.ROOF_KERNEL_NAME)
+        L.kernel_timing(False)
+        if not roof:
             return None
-        for k in self.TIMED:                       # every rank runs these (DDP collectives stay matched)
+        steps_timed = self.steps_timed
+        for k in self.TIMED:                       # every rank runs these (collectives stay matched)
             L.enable_timing(k)
+        L.kernel_timing(True)
         self.steps_timed = 0
         for _ in range(self.EXTRA_INSTRUMENTED_STEPS):
             self.step()
         t = {k: L.timing_ms(k) for k in self.TIMED}
-        nbytes = {k: L.timing_bytes(k) for k in self.TIMED}
         L.disable_timing()
-        # pillars_scatter = M(4C+16) + 4*C*512^2*B ; M ~ pillars of the batch
-        C, B = 64, self.B
-        M = self.n_pillars
-        alg = M * (4 * C + 16) + 4 * C * 512 * 512 * B    # pillar rows + coords read, canvas written
-        avg_s = float(np.mean(ms)) * 1e-3
-        ach = alg / avg_s / 1e9
+        fam = L.kernel_timing_read()
+        L.kernel_timing(False)
+        n_extra = self.steps_timed
+        rt, rb = self._fam(roof)
+        ach = rb / rt / 1e9
         other = {}
-        for k, v in t.items():
+        for k, recs in sorted(fam.items()):         # per KERNEL: bytes and time summed over the launches of the extra steps
+            kt, kb = self._fam(recs)
+            other[k] = {"launches_per_step": len(recs) / n_extra, "ms_per_step": kt * 1e3 / n_extra,
+                        "algorithmic_GB_per_step": kb / 1e9 / n_extra, "achieved_GBps": kb / kt / 1e9,
+                        "frac": kb / kt / 1e9 / HBM_PEAK_GBS}
+        bn_t = sum(v["ms_per_step"] for k, v in other.items() if k.startswith("bn_"))
+        bn_b = sum(v["algorithmic_GB_per_step"] for k, v in other.items() if k.startswith("bn_"))
+        for k, v in t.items():                      # per ENTRY POINT (may launch several kernels)
             if v:
-                other[k] = {"avg_us": float(np.mean(v)) * 1e3, "launches": len(v), "ms_per_step": float(np.sum(v)) / self.steps_timed}
-                if sum(nbytes[k]) > 0:      # entries whose callers attach algorithmic bytes (multi-kernel entry points)
-                    other[k]["achieved_GBps"] = float(sum(nbytes[k])) / (float(np.sum(v)) * 1e-3) / 1e9
-        nhwc = bool(getattr(self.trainer.detector.teacher_model.pts_middle_encoder, "channels_last", False))
-        kname = "ps_canvas_nhwc_vec" if nhwc else "ps_canvas_nchw_wide"
-        return {"bound": "hbm", "kernel": kname + " (teacher PointPillarsScatter, 64x512x512 canvas per sample: the largest "
-                "single-launch HBM mover among the hand-written kernels), one launch per dbev_pillars_canvas call",
+                other[k] = {"avg_us": float(np.mean(v)) * 1e3, "launches_per_step": len(v) / n_extra,
+                            "ms_per_step": float(np.sum(v)) / n_extra}
+        # canvas: one launch per entry call; algorithmic bytes M(4C+16) + 4*C*512^2*B
+        if "dbev_pillars_canvas" in other:
+            alg = self.n_pillars * (4 * 64 + 16) + 4 * 64 * 512 * 512 * self.B
+            c = other["dbev_pillars_canvas"]
+            c["algorithmic_bytes_per_launch"] = alg
+            c["achieved_GBps"] = alg / (c["avg_us"] * 1e-6) / 1e9
+            c["frac"] = c["achieved_GBps"] / HBM_PEAK_GBS
+        return {"bound": "hbm",
+                "kernel": "bn_apply<true,true> (apply pass of the fused training BatchNorm + residual add + ReLU of the ResNet "
+                          "bottlenecks / BEV-encoder blocks: reads x and the identity branch, writes y; csrc/bn_act.hip) -- the "
+                          "hand-written kernel with the largest share of the step; one event pair per launch in the timed region",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                # PMC pass of the same kernel at the same shapes (profiles/r01_pmc_*.txt, tools/pmc_target.py):
-                # FETCH_SIZE 144187 KB (nhwc_vec) / 140048 KB (nchw_wide) x2 (gfx950 wide-read correction,
-                # calibrated on a 512 MiB copy) + WRITE_SIZE 524288 KB (factor 1, calibrated on a fill) per launch
-                "traffic": ((144186.7 if nhwc else 140047.6) * 2 + 524288.0) * 1024, "traffic_source": "profiles/r01_pmc_FETCH_SIZE.txt + "
-                "profiles/r01_pmc_WRITE_SIZE.txt (separate --pmc passes, not collected live)",
-                "avg_launch_us": avg_s * 1e6, "launches": len(ms), "algorithmic_bytes_per_launch": alg,
-                "pillars_per_launch": M,
-                "other_hot_kernels_note": "HIP-event brackets of every hand-written ABI entry point over %d extra "
-                "steps run AFTER the timed region (an entry point may launch several kernels)" % self.EXTRA_INSTRUMENTED_STEPS,
+                # separate --pmc passes of this kernel at its largest shape (profiles/r02_pmc_*.txt, tools/pmc_target.py)
+                "traffic": PMC_TRAFFIC.get("bn_apply_res"), "traffic_source": PMC_TRAFFIC.get("source"),
+                "avg_launch_us": rt / len(roof) * 1e6, "launches": len(roof), "launches_per_step": len(roof) / max(steps_timed, 1),
+                "algorithmic_bytes_per_launch": rb / len(roof), "ms_per_step": rt * 1e3 / max(steps_timed, 1),
+                "bn_family": {"ms_per_step": bn_t, "algorithmic_GB_per_step": bn_b,
+                              "achieved_GBps": bn_b / (bn_t * 1e-3) if bn_t else None,
+                              "frac": bn_b / (bn_t * 1e-3) / HBM_PEAK_GBS if bn_t else None},
+                "other_hot_kernels_note": "per-kernel rows (bn_*): the library's kernel event log; dbev_* rows: HIP-event "
+                "brackets of whole ABI entry points; both over %d extra steps run AFTER the timed region" % n_extra,
                 "other_hot_kernels": other}
 
     def cpu_baseline(self):

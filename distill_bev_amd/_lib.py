@@ -26,6 +26,9 @@ _ll = ctypes.c_longlong
 _SIGNATURES = {
     "dbev_abi_version": [],
     "dbev_target_arch": [],
+    "dbev_kernel_timing_enable": [_i],
+    "dbev_kernel_timing_read": [_p, _p, _p, _i],
+    "dbev_kernel_name": [_i],
     "dbev_bev_pool_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_bev_pool_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_bev_pool_prepare": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
@@ -77,6 +80,8 @@ _SIGNATURES = {
     "dbev_bn_act_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
+             "dbev_kernel_name": ctypes.c_char_p,
+             "dbev_kernel_timing_read": ctypes.c_int,
              "dbev_pillar_vfe_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_workspace_bytes": ctypes.c_size_t,
@@ -164,6 +169,39 @@ def call(name, *args, alg_bytes=0):
         return rc
     check(rc, name)
     return 0
+
+
+KERNEL_IDS = {"bn_stats": 1, "bn_finalize": 2, "bn_apply": 3, "bn_apply_res": 4, "bn_bwd_reduce": 5, "bn_bwd_reduce_y": 6,
+              "bn_bwd_finalize": 7, "bn_bwd_dx": 8, "bn_bwd_dx_res": 9}        # DBEV_K_* of include/dbev_hip.h
+
+
+def kernel_timing(which):
+    """Per-KERNEL event log of the library (dbev_kernel_timing_enable): which = False/None (off), True (every
+    instrumented kernel) or an iterable of KERNEL_IDS names."""
+    if which is True:
+        mask = -1
+    elif not which:
+        mask = 0
+    else:
+        mask = 0
+        for k in which:
+            mask |= 1 << KERNEL_IDS[k]
+    lib().dbev_kernel_timing_enable(mask)
+
+
+def kernel_timing_read():
+    """-> {kernel name: [(ms, algorithmic_bytes), ...]} of every kernel launched by the instrumented entry points since
+    the last read (synchronises on the recorded events)."""
+    h = lib()
+    cap = 1 << 16
+    kid = (ctypes.c_int * cap)()
+    ms = (ctypes.c_float * cap)()
+    by = (ctypes.c_longlong * cap)()
+    n = min(h.dbev_kernel_timing_read(kid, ms, by, cap), cap)
+    out = {}
+    for i in range(n):
+        out.setdefault(h.dbev_kernel_name(kid[i]).decode(), []).append((ms[i], by[i]))
+    return out
 
 
 def host_ptrs(tensors):

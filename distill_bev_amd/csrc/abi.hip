@@ -1,5 +1,60 @@
-// Library identity entry points of libdbev_hip.so (include/dbev_hip.h).
+// Library identity entry points of libdbev_hip.so and the per-kernel timing log (include/dbev_hip.h).
 #include "common.h"
+
+#include <mutex>
+#include <vector>
 
 extern "C" int dbev_abi_version(void) { return DBEV_ABI_VERSION; }
 extern "C" const char* dbev_target_arch(void) { return "gfx950"; }
+
+namespace {
+struct KtRec { hipEvent_t a, b; int kid; long long bytes; };
+std::vector<KtRec> g_log;
+std::mutex g_mu;
+}  // namespace
+
+unsigned g_dbev_kt_mask = 0;   // bit k set: kernel id k is logged
+
+void dbev_kt_push(hipEvent_t a, hipEvent_t b, int kid, long long bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_log.push_back(KtRec{a, b, kid, bytes});
+}
+
+extern "C" int dbev_kernel_timing_enable(int mask) {
+  g_dbev_kt_mask = mask < 0 ? 0xffffffffu : static_cast<unsigned>(mask);
+  return 0;
+}
+
+extern "C" int dbev_kernel_timing_read(int* kernel_id, float* ms, long long* algorithmic_bytes, int cap) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int n = static_cast<int>(g_log.size());
+  for (int i = 0; i < n; ++i) {
+    KtRec& r = g_log[i];
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess) (void)hipEventElapsedTime(&t, r.a, r.b);
+    if (i < cap && kernel_id != nullptr && ms != nullptr && algorithmic_bytes != nullptr) {
+      kernel_id[i] = r.kid;
+      ms[i] = t;
+      algorithmic_bytes[i] = r.bytes;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_log.clear();
+  return n;
+}
+
+extern "C" const char* dbev_kernel_name(int kid) {
+  switch (kid) {
+    case DBEV_K_BN_STATS: return "bn_stats";
+    case DBEV_K_BN_FINALIZE: return "bn_finalize";
+    case DBEV_K_BN_APPLY: return "bn_apply<false,*>";
+    case DBEV_K_BN_APPLY_RES: return "bn_apply<true,*>";
+    case DBEV_K_BN_BWD_REDUCE: return "bn_bwd_reduce<0|1>";
+    case DBEV_K_BN_BWD_REDUCE_Y: return "bn_bwd_reduce<2>";
+    case DBEV_K_BN_BWD_FINALIZE: return "bn_bwd_finalize";
+    case DBEV_K_BN_BWD_DX: return "bn_bwd_dx<*,false>";
+    case DBEV_K_BN_BWD_DX_RES: return "bn_bwd_dx<*,true>";
+    default: return "?";
+  }
+}

@@ -21,6 +21,8 @@
 // touches >= 1 KB of contiguous memory.  gridDim.y walks column chunks when C4 > 256.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int BN_MAX_BLOCKS_X = 2048;   // partial sums per channel merged by the finalize kernels
@@ -29,7 +31,26 @@ constexpr int BN_FIN_CH = 4, BN_FIN_PH = 64;   // finalize kernels: channels x p
 
 struct BnGeom {
   int M, C, C4, CH, RP, GY, NBX;
+  int RTPB, RRP, RUNR;     // reduction passes (bn_stats, bn_bwd_reduce): threads per block, row phases, row unroll
 };
+
+// Tunables of the reduction passes, overridable from the environment for A/B runs (tools/kbench_bn2.py):
+//   DBEV_BN_RTPB  threads per workgroup (256 / 512 / 1024)      DBEV_BN_RUNR  rows in flight per thread (4 / 8)
+//   DBEV_BN_RNBX  cap on workgroups (= partial rows the finalize kernel merges) per column chunk
+struct BnTune { int rtpb, runr, rnbx; };
+const BnTune& bn_tune() {
+  static const BnTune t = [] {
+    BnTune v{512, 4, 256};   // swept on MI355X (tools/sweep_bn.sh): 512-thread workgroups, 4 rows in flight, <= 256 partial rows
+    if (const char* e = getenv("DBEV_BN_RTPB")) v.rtpb = atoi(e);
+    if (const char* e = getenv("DBEV_BN_RUNR")) v.runr = atoi(e);
+    if (const char* e = getenv("DBEV_BN_RNBX")) v.rnbx = atoi(e);
+    if (v.rtpb != 256 && v.rtpb != 512 && v.rtpb != 1024) v.rtpb = 512;
+    if (v.runr != 4 && v.runr != 8) v.runr = 4;
+    if (v.rnbx < 1 || v.rnbx > BN_MAX_BLOCKS_X) v.rnbx = 256;
+    return v;
+  }();
+  return t;
+}
 
 bool bn_geom(long long M, int C, BnGeom* g) {
   if (M <= 0 || M > 0x3fffffffLL || C <= 0 || (C & 3)) return false;   // row indices stay clear of int overflow
@@ -48,8 +69,14 @@ bool bn_geom(long long M, int C, BnGeom* g) {
   g->CH = CH;
   g->RP = 256 / CH;
   g->GY = C4 / CH;
-  const long long tiles = (M + static_cast<long long>(g->RP) * 16 - 1) / (static_cast<long long>(g->RP) * 16);
-  long long nbx = BN_MAX_BLOCKS_X / g->GY;
+  const BnTune& t = bn_tune();
+  g->RTPB = t.rtpb;
+  g->RRP = t.rtpb / CH;
+  g->RUNR = t.runr;
+  // every reduction workgroup gets at least 4 unrolled trips over its rows; at most `rnbx` partial rows
+  const long long per = static_cast<long long>(g->RRP) * g->RUNR * 4;
+  const long long tiles = (M + per - 1) / per;
+  long long nbx = t.rnbx / g->GY;
   if (nbx < 1) nbx = 1;
   g->NBX = static_cast<int>(tiles < nbx ? tiles : nbx);
   return true;
@@ -68,9 +95,9 @@ __device__ __forceinline__ void fma4v(float4& a, const float4& b, const float4& 
 // 256 MB memory-side cache is the END for the first pass and the START for the pass after it: measured -6 % / -12 %
 // on the forward+backward of 277 MB / 138 MB activations, neutral above 500 MB.
 template <bool REV = false>
-__device__ __forceinline__ int block_rows(const BnGeom& g, int* r_end) {
+__device__ __forceinline__ int block_rows(const BnGeom& g, int* r_end, int rp_count) {
   int per = (g.M + gridDim.x - 1) / gridDim.x;
-  per = (per + g.RP - 1) / g.RP * g.RP;
+  per = (per + rp_count - 1) / rp_count * rp_count;
   const long long b = static_cast<long long>(REV ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * per;
   const long long e = b + per;
   *r_end = static_cast<int>(e < g.M ? e : g.M);
@@ -79,9 +106,10 @@ __device__ __forceinline__ int block_rows(const BnGeom& g, int* r_end) {
 
 // block-level merge of two float4 accumulators over the row phases, result written by phase 0:
 // partial[(blockIdx.x * 2 + which) * C + 4*q .. +4]
+template <int TPB>
 __device__ __forceinline__ void block_merge_store(float4 a, float4 b, float* __restrict__ partial, int C, int CH, int RP,
                                                   int q, int ql, int rp) {
-  __shared__ float4 sa[256], sb[256];
+  __shared__ float4 sa[TPB], sb[TPB];
   sa[threadIdx.x] = a;
   sb[threadIdx.x] = b;
   __syncthreads();
@@ -98,26 +126,27 @@ __device__ __forceinline__ void block_merge_store(float4 a, float4 b, float* __r
   }
 }
 
-__global__ __launch_bounds__(256) void bn_stats(const float4* __restrict__ x, float* __restrict__ partial, BnGeom g) {
+template <int TPB, int UNR>
+__global__ __launch_bounds__(TPB) void bn_stats(const float4* __restrict__ x, float* __restrict__ partial, BnGeom g) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   float4 s = f4(0.f), ss = f4(0.f);
-  const int stride = g.RP;
+  const int stride = g.RRP;
   int r_end;
-  int r = block_rows<true>(g, &r_end) + rp;
-  for (; r + (BN_ROWS_UNROLL - 1) * stride < r_end; r += BN_ROWS_UNROLL * stride) {
-    float4 v[BN_ROWS_UNROLL];
+  int r = block_rows<true>(g, &r_end, g.RRP) + rp;
+  for (; r + (UNR - 1) * stride < r_end; r += UNR * stride) {
+    float4 v[UNR];
 #pragma unroll
-    for (int u = 0; u < BN_ROWS_UNROLL; ++u) v[u] = x[static_cast<size_t>(r + u * stride) * g.C4 + q];
+    for (int u = 0; u < UNR; ++u) v[u] = x[static_cast<size_t>(r + u * stride) * g.C4 + q];
 #pragma unroll
-    for (int u = 0; u < BN_ROWS_UNROLL; ++u) { add4(s, v[u]); fma4v(ss, v[u], v[u]); }
+    for (int u = 0; u < UNR; ++u) { add4(s, v[u]); fma4v(ss, v[u], v[u]); }
   }
   for (; r < r_end; r += stride) {
     const float4 v = x[static_cast<size_t>(r) * g.C4 + q];
     add4(s, v);
     fma4v(ss, v, v);
   }
-  block_merge_store(s, ss, partial, g.C, g.CH, g.RP, q, ql, rp);
+  block_merge_store<TPB>(s, ss, partial, g.C, g.CH, g.RRP, q, ql, rp);
 }
 
 // 4 channels x 64 partial phases per workgroup; fp64 merge in a fixed order.  coef: [0] scale, [1] shift (forward) -- saved for backward.
@@ -134,15 +163,15 @@ __global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ par
   double s = 0.0, sq = 0.0;
   if (c < C) {
     int b = ph;
-    for (; b + 3 * BN_FIN_PH < nbx; b += 4 * BN_FIN_PH) {      // 8 independent loads in flight
-      float a[4], q2[4];
+    for (; b + 7 * BN_FIN_PH < nbx; b += 8 * BN_FIN_PH) {      // 16 independent loads in flight: <= 512 partial rows = ONE trip
+      float a[8], q2[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         a[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 0) * C + c];
         q2[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 1) * C + c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { s += static_cast<double>(a[u]); sq += static_cast<double>(q2[u]); }
+      for (int u = 0; u < 8; ++u) { s += static_cast<double>(a[u]); sq += static_cast<double>(q2[u]); }
     }
     for (; b < nbx; b += BN_FIN_PH) {
       s += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 0) * C + c]);
@@ -181,7 +210,7 @@ __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, co
   const float4 sh = reinterpret_cast<const float4*>(coef + g.C)[q];
   const int stride = g.RP;
   int r_end;
-  for (int r0 = block_rows(g, &r_end) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
+  for (int r0 = block_rows(g, &r_end, g.RP) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
     float4 v[BN_ROWS_UNROLL], w[BN_ROWS_UNROLL];
 #pragma unroll
     for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
@@ -227,8 +256,8 @@ __device__ __forceinline__ float4 gate(const float4& dy, const float4& x, const 
   return o;
 }
 
-template <int MASK>
-__global__ __launch_bounds__(256) void bn_bwd_reduce(const float4* __restrict__ dy, const float4* __restrict__ x,
+template <int MASK, int TPB, int UNR>
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ dy, const float4* __restrict__ x,
                                                      const float4* __restrict__ y, const float* __restrict__ coef,
                                                      const float* __restrict__ save_mean,
                                                      const float* __restrict__ save_invstd,
@@ -240,12 +269,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float4* __restrict__ 
   const float4 mu = reinterpret_cast<const float4*>(save_mean)[q];
   const float4 is = reinterpret_cast<const float4*>(save_invstd)[q];
   float4 db = f4(0.f), dg = f4(0.f);
-  const int stride = g.RP;
+  const int stride = g.RRP;
   int r_end;
-  for (int r0 = block_rows<true>(g, &r_end) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
-    float4 a[BN_ROWS_UNROLL], v[BN_ROWS_UNROLL], o[BN_ROWS_UNROLL];
+  for (int r0 = block_rows<true>(g, &r_end, g.RRP) + rp; r0 < r_end; r0 += UNR * stride) {
+    float4 a[UNR], v[UNR], o[UNR];
 #pragma unroll
-    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       const int r = r0 + u * stride;
       a[u] = f4(0.f); v[u] = f4(0.f); o[u] = f4(0.f);
       if (r < r_end) {
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float4* __restrict__ 
       }
     }
 #pragma unroll
-    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       const float4 dz = gate<MASK>(a[u], v[u], o[u], sc, sh);      // rows past M: dy = 0 -> no contribution
       float4 xh;
       xh.x = (v[u].x - mu.x) * is.x; xh.y = (v[u].y - mu.y) * is.y;
@@ -264,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float4* __restrict__ 
       fma4v(dg, dz, xh);
     }
   }
-  block_merge_store(db, dg, partial, g.C, g.CH, g.RP, q, ql, rp);
+  block_merge_store<TPB>(db, dg, partial, g.C, g.CH, g.RRP, q, ql, rp);
 }
 
 // dgamma, dbeta and the per-channel coefficients of dx = A * dz + B * x + Cc  (bcoef: [0] A, [1] B, [2] Cc)
@@ -280,15 +309,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__
   double s = 0.0, sq = 0.0;
   if (c < C) {
     int b = ph;
-    for (; b + 3 * BN_FIN_PH < nbx; b += 4 * BN_FIN_PH) {      // 8 independent loads in flight
-      float a[4], q2[4];
+    for (; b + 7 * BN_FIN_PH < nbx; b += 8 * BN_FIN_PH) {      // 16 independent loads in flight: <= 512 partial rows = ONE trip
+      float a[8], q2[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         a[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 0) * C + c];
         q2[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 1) * C + c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { s += static_cast<double>(a[u]); sq += static_cast<double>(q2[u]); }
+      for (int u = 0; u < 8; ++u) { s += static_cast<double>(a[u]); sq += static_cast<double>(q2[u]); }
     }
     for (; b < nbx; b += BN_FIN_PH) {
       s += static_cast<double>(partial[(static_cast<size_t>(b) * 2 + 0) * C + c]);
@@ -324,7 +353,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, 
   const float4 Cc = reinterpret_cast<const float4*>(bcoef + 2 * g.C)[q];
   const int stride = g.RP;
   int r_end;
-  for (int r0 = block_rows(g, &r_end) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
+  for (int r0 = block_rows(g, &r_end, g.RP) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
     float4 a[BN_ROWS_UNROLL], v[BN_ROWS_UNROLL], o[BN_ROWS_UNROLL];
 #pragma unroll
     for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
@@ -365,6 +394,27 @@ __global__ __launch_bounds__(256) void bn_infer_coef(const float* __restrict__ g
   coef[C + c] = fmaf(-mean[c], sc, beta[c]);
 }
 
+#define BN_DISPATCH_TPB_UNR(CALL)                                     \
+  do {                                                                \
+    if (g.RTPB == 1024) { if (g.RUNR == 8) CALL(1024, 8); else CALL(1024, 4); }   \
+    else if (g.RTPB == 512) { if (g.RUNR == 8) CALL(512, 8); else CALL(512, 4); } \
+    else { if (g.RUNR == 8) CALL(256, 8); else CALL(256, 4); }        \
+  } while (0)
+
+void launch_stats(const BnGeom& g, dim3 grid, hipStream_t s, const float4* x, float* partial) {
+#define BN_CALL(T, U) hipLaunchKernelGGL((bn_stats<T, U>), grid, dim3(T), 0, s, x, partial, g)
+  BN_DISPATCH_TPB_UNR(BN_CALL);
+#undef BN_CALL
+}
+
+template <int MASK>
+void launch_bwd_reduce(const BnGeom& g, dim3 grid, hipStream_t s, const float4* dy, const float4* x, const float4* y,
+                       const float* coef, const float* mean, const float* invstd, float* partial) {
+#define BN_CALL(T, U) hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, x, y, coef, mean, invstd, partial, g)
+  BN_DISPATCH_TPB_UNR(BN_CALL);
+#undef BN_CALL
+}
+
 struct BnWs { size_t partial, total; };
 BnWs bn_ws(const BnGeom& g) {
   BnWs w;
@@ -395,10 +445,12 @@ extern "C" int dbev_bn_act_train_forward(const float* x, const float* residual, 
   hipStream_t s = dbev_stream(stream);
   float* partial = static_cast<float*>(workspace);
   const dim3 grid(g.NBX, g.GY);
-  hipLaunchKernelGGL(bn_stats, grid, dim3(256), 0, s, reinterpret_cast<const float4*>(x), partial, g);
-  hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma, beta,
-                     running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
-                     num_batches_tracked);
+  const long long T = 4LL * g.M * C;                       // bytes of one full-tensor pass
+  { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, reinterpret_cast<const float4*>(x), partial); }
+  { DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * g.NBX * g.GY * C, s);
+    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
+                       num_batches_tracked); }
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* r4 = reinterpret_cast<const float4*>(residual);
   float4* y4 = reinterpret_cast<float4*>(y);
@@ -406,12 +458,15 @@ extern "C" int dbev_bn_act_train_forward(const float* x, const float* residual, 
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
-  if (residual != nullptr) {
-    if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
-    else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
-  } else {
-    if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
-    else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+  {
+    DbevKt kt(residual != nullptr ? DBEV_K_BN_APPLY_RES : DBEV_K_BN_APPLY, T * (residual != nullptr ? 3 : 2), s);
+    if (residual != nullptr) {
+      if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+      else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+    } else {
+      if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+      else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+    }
   }
   DBEV_LAUNCH_CHECK();
   return 0;
@@ -467,19 +522,23 @@ extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const f
   const float4* dy4 = reinterpret_cast<const float4*>(grad_y);
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* y4 = reinterpret_cast<const float4*>(y);
-  if (mask == 0)
-    hipLaunchKernelGGL((bn_bwd_reduce<0>), grid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, g);
-  else if (mask == 1)
-    hipLaunchKernelGGL((bn_bwd_reduce<1>), grid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, g);
-  else
-    hipLaunchKernelGGL((bn_bwd_reduce<2>), grid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, g);
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma,
-                     save_mean, save_invstd, grad_gamma, grad_beta, bcoef);
+  const long long T = 4LL * g.M * C;
+  {
+    DbevKt kt(mask == 2 ? DBEV_K_BN_BWD_REDUCE_Y : DBEV_K_BN_BWD_REDUCE, T * (mask == 2 ? 3 : 2), s);
+    if (mask == 0) launch_bwd_reduce<0>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial);
+    else if (mask == 1) launch_bwd_reduce<1>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial);
+    else launch_bwd_reduce<2>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial);
+  }
+  { DbevKt kt(DBEV_K_BN_BWD_FINALIZE, 8LL * g.NBX * g.GY * C, s);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma,
+                       save_mean, save_invstd, grad_gamma, grad_beta, bcoef); }
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
   float4* dx4 = reinterpret_cast<float4*>(grad_x);
   float4* dr4 = reinterpret_cast<float4*>(grad_residual);
+  DbevKt kt(grad_residual != nullptr ? DBEV_K_BN_BWD_DX_RES : DBEV_K_BN_BWD_DX,
+            T * (3 + (mask == 2 ? 1 : 0) + (grad_residual != nullptr && mask != 0 ? 1 : 0)), s);
   if (grad_residual != nullptr) {
     if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
     else hipLaunchKernelGGL((bn_bwd_dx<0, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);

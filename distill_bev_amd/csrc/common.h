@@ -45,3 +45,23 @@ __device__ __forceinline__ void st_nt(float4* p, const float4& v) {
   const v4f t = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
 }
+
+// per-kernel timing log (abi.hip): DbevKt brackets the launches of its scope with an event pair when enabled
+extern unsigned g_dbev_kt_mask;
+void dbev_kt_push(hipEvent_t a, hipEvent_t b, int kid, long long bytes);
+struct DbevKt {
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t s;
+  int kid;
+  long long bytes;
+  DbevKt(int kid_, long long bytes_, hipStream_t s_) : s(s_), kid(kid_), bytes(bytes_) {
+    if (((g_dbev_kt_mask >> kid_) & 1u) && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+    else a = nullptr;
+  }
+  ~DbevKt() {
+    if (a != nullptr) {
+      (void)hipEventRecord(b, s);
+      dbev_kt_push(a, b, kid, bytes);
+    }
+  }
+};

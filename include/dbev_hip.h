@@ -41,6 +41,23 @@ int dbev_abi_version(void);
 const char* dbev_target_arch(void);
 
 /* ------------------------------------------------------------------------------------
+ * Per-KERNEL timing (measurement aid, no counterpart in the reference; bench.py `roofline`).
+ * While enabled, the multi-kernel entry points bracket every kernel they launch with a
+ * hipEvent pair recorded on the launch stream and remember the kernel's algorithmic HBM bytes.
+ * dbev_kernel_timing_read synchronises on the recorded events, copies up to `cap` records
+ * (kernel id, milliseconds, algorithmic bytes) out in launch order, clears the log and returns
+ * the number of records it held.  dbev_kernel_timing_enable(mask): bit k of `mask` switches the
+ * log on for kernel id k (DBEV_K_*), -1 = every kernel, 0 (the default) = off: no events, no overhead.
+ * ---------------------------------------------------------------------------------- */
+enum {
+  DBEV_K_BN_STATS = 1, DBEV_K_BN_FINALIZE, DBEV_K_BN_APPLY, DBEV_K_BN_APPLY_RES, DBEV_K_BN_BWD_REDUCE,
+  DBEV_K_BN_BWD_REDUCE_Y, DBEV_K_BN_BWD_FINALIZE, DBEV_K_BN_BWD_DX, DBEV_K_BN_BWD_DX_RES, DBEV_K_COUNT
+};
+int dbev_kernel_timing_enable(int mask);
+int dbev_kernel_timing_read(int* kernel_id, float* ms, long long* algorithmic_bytes, int cap);
+const char* dbev_kernel_name(int kernel_id);
+
+/* ------------------------------------------------------------------------------------
  * bev_pool  (replaces bev_pool_ext: mmdet3d/ops/bev_pool/src/bev_pool.cpp:22-47,60-87,
  *            kernels src/bev_pool_cuda.cu:20-42,61-84)
  * ---------------------------------------------------------------------------------- */

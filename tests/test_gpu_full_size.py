@@ -1,0 +1,110 @@
+"""GPU, FULL SIZE: BASELINE configs[3] at the shape bench.py times (bs 8 per GPU, 12 images of 256x704, 240 000 LiDAR
+points and 30 boxes per sample, channels-last, every fused kernel) -- correctness of what the benchmark runs.
+
+  * every hand-written op of the step is bit-reproducible: two forward passes of the whole detector on the same weights
+    and batch give bit-identical values for all 47 losses (BN statistics are batch statistics in train mode, the
+    frozen teacher is in eval mode, MIOpen's forward convolutions are deterministic), and two runs of the teacher's
+    fused pillar path / the lift-splat produce bit-identical tensors;
+  * the teacher canvas (8 x 64 x 512 x 512, 1.09 M pillars) equals the CPU oracle's (oracle/voxel.c scatter +
+    oracle/step_ops.pillar_feature_net, the sequence pinned against the imported reference modules) at full size;
+  * the fused lift-splat BEV of one sample-frame of that batch vs the fp64 oracle (oracle/lss.py) L-inf < 1e-4, voxel
+    indices exact;
+  * all losses finite, one optimizer step runs.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B, N_POINTS = 8, 240000
+
+
+@pytest.fixture(scope="module")
+def full():
+    from distill_bev_amd.train_step import Trainer, build_model, make_batch
+    dev = torch.device("cuda:0")
+    model, cfg = build_model(seed=0)
+    tr = Trainer(model, cfg, dev, world_size=1, channels_last=True)
+    batch = make_batch(B, np.random.default_rng(1234), dev, n_points=N_POINTS)
+    return tr, batch, dev
+
+
+def test_full_size_forward_is_bit_reproducible_and_finite(full):
+    tr, batch, dev = full
+    a = tr.detector.forward_train(**batch)
+    b = tr.detector.forward_train(**batch)
+    assert len(a) == 47 and set(a) == set(b)
+    bad = [k for k in a if not torch.equal(a[k].detach(), b[k].detach())]
+    assert not bad, bad
+    assert all(bool(torch.isfinite(v.detach()).all()) for v in a.values())
+    loss, _ = tr.step(batch)                      # backward + clip + fused AdamW at full size
+    assert bool(torch.isfinite(loss))
+    assert all(bool(torch.isfinite(p).all()) for p in tr.params[:8])
+
+
+def test_full_size_teacher_canvas_equals_cpu_oracle(full):
+    from distill_bev_amd import pillar_encoder as PE
+    from oracle import step_ops as OS
+    from oracle import voxel as OV
+    tr, batch, dev = full
+    t = tr.detector.teacher_model
+    enc, vl, mid = t.pts_voxel_encoder, t.pts_voxel_layer, t.pts_middle_encoder
+    assert PE.fused_pillar_canvas_eligible(vl, enc, mid)
+    c1 = PE.fused_pillar_canvas(batch["points"], vl, enc, mid)
+    c2 = PE.fused_pillar_canvas(batch["points"], vl, enc, mid)
+    assert c1.shape == (B, 64, 512, 512) and torch.equal(c1, c2)                  # run-to-run bit identical
+    # CPU oracle at full size: voxelize -> drop out-of-range rows -> PFN (eval BN) -> scatter max -> canvas
+    pts, coors = [], []
+    for b, p in enumerate(batch["points"]):
+        pn = p.cpu().numpy()
+        co = OV.dynamic_voxelize(pn, vl.voxel_size, vl.point_cloud_range)
+        ok = (co >= 0).all(1)
+        pts.append(pn[ok])
+        coors.append(np.concatenate([np.full((int(ok.sum()), 1), b, np.int32), co[ok]], 1))
+    lin, bn = enc.pfn_layers[0][0], enc.pfn_layers[0][1]
+    vf, vc = OS.pillar_feature_net(torch.from_numpy(np.concatenate(pts)), torch.from_numpy(np.concatenate(coors)),
+                                   lin.weight.detach().cpu(), bn.weight.detach().cpu(), bn.bias.detach().cpu(),
+                                   bn.running_mean.cpu(), bn.running_var.cpu(), bn.eps, vl.voxel_size, vl.point_cloud_range,
+                                   training=False)
+    ref = OV.pillars_scatter(vf, vc, B, 512, 512)
+    got = c1.cpu().numpy()
+    assert vf.shape[0] > 1_000_000                                               # ~1.09 M occupied pillars
+    assert np.array_equal(got.any(1), ref.any(1)) or np.array_equal(np.abs(got).sum(1) > 0, np.abs(ref).sum(1) > 0)
+    err = np.abs(got - ref).max()
+    print("full-size teacher canvas: pillars", vf.shape[0], "L-inf vs CPU oracle", err)
+    assert err < 5e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_full_size_lift_splat_vs_fp64_oracle_on_one_sample_frame(full):
+    from distill_bev_amd import synthetic as syn
+    from oracle import lss as O
+    tr, batch, dev = full
+    vt = tr.detector.img_view_transformer
+    imgs, rots, trans, intrins, post_rots, post_trans, _ = batch["img_inputs"]
+    rig = [t[:, :6].contiguous() for t in (rots, trans, intrins, post_rots, post_trans)]      # current frame, B x 6 cams
+    rng = np.random.default_rng(77)
+    depth_np, feat_np = syn.lss_inputs(B, rng)
+    depth = torch.from_numpy(depth_np).to(dev)
+    feat = torch.from_numpy(feat_np).to(dev).contiguous(memory_format=torch.channels_last)
+    from distill_bev_amd.lift_splat import lift_splat, lift_splat_prepare_cam
+    from oracle import step_ops as OS
+    prep = lift_splat_prepare_cam(vt.frustum, *rig, vt._dx_host, vt._bx_host, vt._nx_host)
+    bev1 = lift_splat(depth, feat, prep)
+    bev2 = vt.lift_splat_cameras(*rig, depth, feat)
+    assert bev1.shape == (B, 64, 128, 128) and torch.equal(bev1, bev2)
+    s = 5                                                                                    # one sample of the batch
+    # oracle: the reference's own geometry op order on the CPU (torch.inverse + broadcast matmul), numpy index + fp64 sums
+    geom = OS.get_geometry(torch.from_numpy(O.create_frustum()), *[t[s:s + 1].cpu() for t in rig]).numpy()
+    dx, bx, nx = O.gen_dx_bx([-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8], [-10.0, 10.0, 20.0])
+    idx, kept = O.voxel_index(geom, dx, bx, nx)
+    ref_cell = np.where(kept, ((s * 128 + idx[..., 1]) * 128 + idx[..., 0]) * 1 + idx[..., 2], -1).reshape(-1)
+    n1 = ref_cell.size
+    got_cell = prep.point_cell[s * n1:(s + 1) * n1].cpu().numpy()
+    mism = int((got_cell != ref_cell).sum())
+    print("full-size sample-frame voxel mismatches vs reference-order geometry:", mism, "of", n1)
+    assert mism == 0
+    ref = O.lift_splat(depth_np[6 * s:6 * s + 6], feat_np[6 * s:6 * s + 6], geom, dx, bx, nx, exact=True)
+    err = np.abs(bev1[s].cpu().numpy() - ref[0]).max()
+    print("full-size lift-splat sample-frame L-inf vs fp64 oracle", err, "max |bev|", np.abs(ref).max())
+    assert err < 1e-4
