@@ -74,6 +74,9 @@ _SIGNATURES = {
     "dbev_skinny_conv3x3_workspace_bytes": [_i, _i],
     "dbev_skinny_conv3x3_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_skinny_conv3x3_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
+    "dbev_adapt_mse_map_slices": [_i, _i],
+    "dbev_adapt_mse_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "dbev_adapt_mse_backward_ds": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dbev_bn_act_workspace_bytes": [_ll, _i],
     "dbev_bn_act_train_forward": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],
@@ -94,7 +97,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
-_NO_CHECK = set(_RESTYPES)
+_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices"}
 
 
 class DbevHipError(RuntimeError):

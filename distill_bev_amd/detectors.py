@@ -20,7 +20,8 @@ import torch.nn.functional as F
 from .center_head import LiDARBoxes, clip_sigmoid  # noqa: F401
 from .config import Config
 from .bn_act import bn_act
-from .distill_loss import ForegroundMaskRasterizer, UpsampleBilinearAC, fgd_feature_losses
+from .distill_loss import (ForegroundMaskRasterizer, UpsampleBilinearAC, fgd_feature_losses, fgd_feature_losses_fused_adapt,
+                           fused_adapt_eligible)
 from .registry import MODELS, build_backbone, build_detector, build_head, build_loss, build_neck
 from .voxel import Voxelization
 
@@ -323,6 +324,8 @@ class BEVDepth4DDistill(CenterPoint):
             self.teacher_model.train(False if self.eval_teacher else mode)
         return super().train(mode)
 
+    fused_adapt_mse = True       # class-level switch (tests compare against the unfused conv -> loss kernels sequence)
+
     def set_epoch(self, epoch):
         self._epoch = epoch
 
@@ -476,20 +479,26 @@ class BEVDepth4DDistill(CenterPoint):
         assert dp["scale_mask"] == "combine_gt" and dp["non_empty_weight"] == 0
         assert dp["affinity_mode"][index] == "none" and dp["context_length"] == 0
         teacher_feat = self.teacher_adaptations[index](teacher_feat)
-        student_feat = self.channel_wise_adaptations[index](student_feat)
-        B, C, H, W = student_feat.shape
-        assert teacher_feat.shape == student_feat.shape
+        adapt = self.channel_wise_adaptations[index]
+        # 'head' recipe (1x1-conv adaptation): GEMM + loss reductions in one MFMA kernel, no adapted tensor in memory
+        fused = self.fused_adapt_mse and not dp["channel_mask"] and fused_adapt_eligible(adapt, student_feat, teacher_feat)
+        if not fused:
+            student_feat = adapt(student_feat)
+            assert teacher_feat.shape == student_feat.shape
+        B, C, H, W = teacher_feat.shape
         fg, fg_scale, bg_scale = self._fg_raster(H, W, [b.tensor for b in gt_bboxes_3d], student_feat.device)
         fp = fp_scale = n_fp = None
         use_fp = dp["fp_as_foreground"][index] != "none" and self._epoch >= dp["fp_epoch"]
         if use_fp:
             fp, fp_scale, n_fp = self.add_fp_as_fg(dp["fp_as_foreground"][index], fg, heatmaps, teacher_preds, student_preds)
-        losses, att, _, pools = fgd_feature_losses(
-            student_feat, teacher_feat, fg, fg_scale, bg_scale,
-            w_fg=_pick(dp["fg_feat_loss_weights"], index), w_bg=_pick(dp["bg_feat_loss_weights"], index),
-            spatial_t=dp["spatial_t"], channel_t=dp["channel_t"], s_ratio=dp["spatial_student_ratio"],
-            spatial_att=_pick(dp["spatial_attentions"], index), spatial_mask=dp["spatial_mask"],
-            channel_mask=dp["channel_mask"], fp=fp, fp_scale=fp_scale, n_fp=n_fp, w_fp=dp["fp_weight"])
+        kw = dict(w_fg=_pick(dp["fg_feat_loss_weights"], index), w_bg=_pick(dp["bg_feat_loss_weights"], index),
+                  spatial_t=dp["spatial_t"], channel_t=dp["channel_t"], s_ratio=dp["spatial_student_ratio"],
+                  spatial_att=_pick(dp["spatial_attentions"], index), spatial_mask=dp["spatial_mask"],
+                  channel_mask=dp["channel_mask"], fp=fp, fp_scale=fp_scale, n_fp=n_fp, w_fp=dp["fp_weight"])
+        if fused:
+            losses, att, _, pools = fgd_feature_losses_fused_adapt(student_feat, adapt, teacher_feat, fg, fg_scale, bg_scale, **kw)
+        else:
+            losses, att, _, pools = fgd_feature_losses(student_feat, teacher_feat, fg, fg_scale, bg_scale, **kw)
         if dp["spatial_mask"]:
             if pools is not None:                  # mean over channels fused into the attention / dS kernels
                 t_pool, s_pool = pools

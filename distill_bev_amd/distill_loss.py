@@ -247,6 +247,105 @@ def fgd_feature_losses(student_feat, teacher_feat, fg, fg_scale, bg_scale, *, w_
     return out, att, c_att, pools
 
 
+class _FusedAdaptMSE(Function):
+    """1x1-convolution adaptation + per-pixel reductions of the FGD loss on the fp32 matrix cores
+    (dbev_adapt_mse_forward, csrc/adapt_mse.hip).  forward(x, weight, bias, teacher, cc) ->
+      E    [B,1,H,W]  sum_c (s - t)^2            (differentiable)
+      Efp  [B,1,H,W]  sum_c cc[b,c] (s - t)^2    (differentiable; == E when cc is None)
+      A    [B,1,H,W]  mean_c |s|                 (attention input, no gradient -- detached in the reference)
+      P    [B,1,H,W]  mean_c s                   (differentiable; spatial term)
+    with s = conv1x1(x) never written to memory; the difference s - t is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, teacher, cc):
+        dev = L.require_cuda(x, weight, teacher)
+        B, Cs, H, W = x.shape
+        Ct = weight.shape[0]
+        S = int(L.call("dbev_adapt_mse_map_slices", Cs, Ct))
+        assert S > 0 and teacher.shape == (B, Ct, H, W)
+        x = x.contiguous(memory_format=torch.channels_last)
+        teacher = teacher.contiguous(memory_format=torch.channels_last)
+        w2 = weight.reshape(Ct, Cs).contiguous()
+        M = B * H * W
+        D = torch.empty((B, Ct, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        maps = torch.empty((S, 4, M), dtype=torch.float32, device=dev)
+        cc = cc.contiguous() if cc is not None else None
+        with torch.cuda.device(dev):
+            L.call("dbev_adapt_mse_forward", L.ptr(x), L.ptr(w2), L.ptr(bias.contiguous()), L.ptr(teacher), L.ptr(cc),
+                   B, H * W, Cs, Ct, L.ptr(D), L.ptr(maps), L.stream_ptr(dev))
+        m = maps.sum(0) if S > 1 else maps[0]
+        E, Efp = m[0].view(B, 1, H, W), m[1].view(B, 1, H, W)
+        A, P = (m[2] / Ct).view(B, 1, H, W), (m[3] / Ct).view(B, 1, H, W)
+        ctx.save_for_backward(x, weight, D, cc)
+        ctx.mark_non_differentiable(A)
+        return E, Efp, A, P
+
+    @staticmethod
+    def backward(ctx, gE, gEfp, gA, gP):
+        x, weight, D, cc = ctx.saved_tensors
+        B, Ct, H, W = D.shape
+        dev = D.device
+        z = lambda g: g.contiguous().float() if g is not None else None
+        gE = z(gE) if gE is not None else torch.zeros((B, 1, H, W), device=dev)
+        dS = torch.empty_like(D)
+        with torch.cuda.device(dev):
+            L.call("dbev_adapt_mse_backward_ds", L.ptr(D), L.ptr(gE), L.ptr(z(gEfp)), L.ptr(z(gP)), L.ptr(cc), B, H * W, Ct,
+                   L.ptr(dS), L.stream_ptr(dev))
+        # the convolution gradients are plain GEMMs on dS: MIOpen's NHWC fp32 MFMA kernels
+        dx, dw, db = torch.ops.aten.convolution_backward(dS, x, weight, [Ct], [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]])
+        return dx, dw, db, None, None
+
+
+def fused_adapt_eligible(conv, student_in, teacher_feat):
+    """the 'head' recipe: nn.Conv2d(Cs, Ct, 1) with bias on channels-last fp32 features, Cs % 32 == Ct % 32 == 0"""
+    if type(conv) is not torch.nn.Conv2d or conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) \
+            or conv.groups != 1 or conv.bias is None or conv.dilation != (1, 1):
+        return False
+    if not (student_in.is_cuda and student_in.dtype == torch.float32 and _is_nhwc(student_in) and _is_nhwc(teacher_feat)):
+        return False
+    return int(L.call("dbev_adapt_mse_map_slices", conv.in_channels, conv.out_channels)) > 0 \
+        and teacher_feat.shape[1] == conv.out_channels and teacher_feat.shape[2:] == student_in.shape[2:]
+
+
+def fgd_feature_losses_fused_adapt(student_in, conv, teacher_feat, fg, fg_scale, bg_scale, *, w_fg, w_bg, spatial_t=0.5,
+                                   channel_t=0.5, s_ratio=1.0, spatial_att="teacher_student", spatial_mask=True,
+                                   channel_mask=False, fp=None, fp_scale=None, n_fp=None, w_fp=0.0):
+    """fgd_feature_losses with the student adaptation folded in (see _FusedAdaptMSE): same recipe, same outputs; the
+    adapted student tensor does not exist, the three masked sums are per-pixel weighted sums of the kernel's maps."""
+    if channel_mask:
+        raise NotImplementedError("channel_mask=True is not part of the hot-path recipe")
+    B, Ct, H, W = teacher_feat.shape
+    teacher_feat = teacher_feat.detach()
+    t_pix, t_ch, t_pool = abs_mean_maps(teacher_feat, with_pool=True)
+    c_att = (torch.softmax(t_ch.view(B, -1) / channel_t, dim=1) * Ct).view(B, Ct).detach()
+    E, Efp, A, P = _FusedAdaptMSE.apply(student_in, conv.weight, conv.bias, teacher_feat, c_att if fp is not None else None)
+    t_att = torch.softmax(t_pix.view(B, -1) / spatial_t, dim=1) * (H * W)
+    if spatial_att == "teacher":
+        att = t_att
+    elif spatial_att == "teacher_student":
+        s_att = torch.softmax(A.view(B, -1) / spatial_t, dim=1) * (H * W)
+        att = (t_att + s_att * s_ratio) / (1 + s_ratio)
+    else:
+        raise NotImplementedError(spatial_att)
+    att = att.view(B, 1, H, W).detach()
+    bg = (fg == 0).float()
+    bgs = bg_scale
+    if fp is not None:
+        bg = bg * (fp == 0).float()
+        n_bg = H * W - fg.sum(dim=(1, 2, 3))
+        denom = n_bg - n_fp
+        bgs = torch.where(denom > 0, 1.0 / denom.clamp(min=1), torch.zeros_like(denom)).view(B, 1, 1, 1).expand_as(bg_scale)
+    scale = torch.maximum(fg_scale, bgs)
+    w_f, w_b = fg * scale, bg * scale
+    if spatial_mask:
+        w_f, w_b = w_f * att, w_b * att
+    out = {"kd_fg_feat_loss": (E * w_f).sum() * (w_fg / B), "kd_bg_feat_loss": (E * w_b).sum() * (w_bg / B)}
+    if fp is not None:
+        out["kd_fp_bg_feat_loss"] = (Efp * (fp * fp_scale * att)).sum() * (w_fp / B)
+    return out, att, c_att, (t_pool, P)
+
+
 class _UpsampleBilinearAC(Function):
     @staticmethod
     def forward(ctx, x, scale):

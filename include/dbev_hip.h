@@ -443,6 +443,27 @@ int dbev_bn_act_backward(const float* grad_y, const float* x, const float* y, co
                          int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                          long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused student adaptation (1x1 convolution) + masked-MSE reduction of the FGD loss, 'head' position
+ * (replaces the sequence nn.Conv2d(Cs, Ct, 1) -> mean_c|.| -> three masked sums of
+ *  mmdet3d/models/detectors/bevdet_distill.py:232-234,1003-1004,1089-1092,1253-1262,1272-1287).
+ * Channels-last operands: x [B*HW, Cs], weight [Ct, Cs] (the conv weight [Ct, Cs, 1, 1]), bias [Ct],
+ * teacher [B*HW, Ct], channel_weight [B, Ct] or NULL (the fp term's channel attention).
+ * forward: diff = (x W^T + bias) - teacher  -> diff_nhwc [B*HW, Ct]   (the adapted tensor itself is never stored)
+ *          maps [S][4][B*HW], S = dbev_adapt_mse_map_slices(Cs, Ct) channel slices to be summed by the caller:
+ *          [0] sum_c diff^2, [1] sum_c channel_weight diff^2, [2] sum_c |s|, [3] sum_c s.
+ * Cs % 32 == 0 and Ct % 32 == 0 (map_slices returns 0 otherwise).  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * backward_ds: ds = 2 diff (grad_e[p] + grad_efp[p] channel_weight[b, c]) + grad_pool[p] / Ct
+ *          (grad_efp / grad_pool / channel_weight may be NULL); the convolution gradients are ordinary GEMMs on ds.
+ * ---------------------------------------------------------------------------------- */
+int dbev_adapt_mse_map_slices(int Cs, int Ct);
+int dbev_adapt_mse_forward(const float* x_nhwc, const float* weight, const float* bias, const float* teacher_nhwc,
+                           const float* channel_weight, int B, int HW, int Cs, int Ct, float* diff_nhwc, float* maps,
+                           dbevStream_t stream);
+int dbev_adapt_mse_backward_ds(const float* diff_nhwc, const float* grad_e, const float* grad_efp,
+                               const float* grad_pool, const float* channel_weight, int B, int HW, int Ct,
+                               float* ds_nhwc, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
