@@ -32,6 +32,8 @@ _SIGNATURES = {
     "dbev_bev_pool_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_bev_pool_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_bev_pool_prepare": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "dbev_bev_pool_prepare_i64": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "dbev_transpose_bcs_to_bsc": [_p, _p, _i, _i, _i, _p],
     "dbev_dynamic_voxelize": [_p, _p, _i, _i, _p, _p, _i, _p],
     "dbev_hard_voxelize_workspace_bytes": [_i, _p, _p],
     "dbev_hard_voxelize": [_p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _sz, _p],

@@ -85,7 +85,8 @@ class _BevPoolCSR(torch.autograd.Function):
         feats = feats.contiguous()
         n, C = feats.shape
         n_cells = B * D * H * W
-        coords = coords.to(torch.int32).contiguous()
+        i64 = coords.dtype == torch.int64
+        coords = coords.contiguous() if i64 else coords.to(torch.int32).contiguous()    # int64 is consumed as it is
         point_cell = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
         cell_start = torch.empty((n_cells + 1,), dtype=torch.int32, device=dev)
         cell_points = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
@@ -96,21 +97,34 @@ class _BevPoolCSR(torch.autograd.Function):
         with torch.cuda.device(dev):
             nbytes = L.call("dbev_lift_splat_workspace_bytes", n, n_cells)
             ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
-            L.call("dbev_bev_pool_prepare", L.ptr(coords), n, B, D, H, W, L.ptr(point_cell), L.ptr(cell_start),
+            L.call("dbev_bev_pool_prepare_i64" if i64 else "dbev_bev_pool_prepare", L.ptr(coords), n, B, D, H, W,
+                   L.ptr(point_cell), L.ptr(cell_start),
                    L.ptr(cell_points), L.ptr(n_kept), L.ptr(hot_cells), L.ptr(n_hot), L.ptr(ws), ws.numel(),
                    L.stream_ptr(dev))
             L.call("dbev_splat_forward", L.ptr(feats), L.ptr(cell_start), L.ptr(cell_points), L.ptr(hot_cells),
                    L.ptr(n_hot), L.ptr(out), n, C, n_cells, L.stream_ptr(dev))
         ctx.save_for_backward(point_cell)
         ctx.dims = (n, C)
-        return out
+        # the reference returns x.permute(0, 4, 1, 2, 3).contiguous(); here the SAME logical [B, C, D, H, W] tensor is a
+        # zero-copy view of the cell-major rows (channels-last-3d strides) -- one 67 MB read + write less per call
+        return out.permute(0, 4, 1, 2, 3)
 
     @staticmethod
     def backward(ctx, out_grad):
         (point_cell,) = ctx.saved_tensors
         n, C = ctx.dims
         dev = out_grad.device
-        out_grad = out_grad.contiguous()
+        B, _, D, H, W = out_grad.shape
+        g = out_grad.permute(0, 2, 3, 4, 1)            # the kernels read cell-major rows [B, D, H, W, C]
+        if not g.is_contiguous():
+            if out_grad.is_contiguous() and out_grad.dtype == torch.float32:      # the reference's [B, C, D, H, W] layout
+                gt = torch.empty((B, D, H, W, C), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    L.call("dbev_transpose_bcs_to_bsc", L.ptr(out_grad), L.ptr(gt), B, C, D * H * W, L.stream_ptr(dev))
+                g = gt
+            else:
+                g = g.contiguous()
+        out_grad = g
         x_grad = torch.empty((n, C), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             L.call("dbev_splat_backward", L.ptr(out_grad), L.ptr(point_cell), L.ptr(x_grad), n, C, L.stream_ptr(dev))
@@ -129,8 +143,7 @@ def bev_pool(feats, coords, B, D, H, W):
     B, D, H, W = int(B), int(D), int(H), int(W)
     C = feats.shape[1]
     if feats.dtype == torch.float32 and C % 4 == 0 and C <= 256 and feats.shape[0] > 0:
-        x = _BevPoolCSR.apply(feats, coords, B, D, H, W)
-        return x.permute(0, 4, 1, 2, 3).contiguous()
+        return _BevPoolCSR.apply(feats, coords, B, D, H, W)
     return bev_pool_sorted(feats, coords, B, D, H, W)
 
 

@@ -177,3 +177,34 @@ extern "C" int dbev_bev_pool_backward(const float* out_grad, const int32_t* geom
   DBEV_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ---- [B, C, S] <-> [B, S, C] transposes for callers that hand bev_pool a gradient in the reference's contiguous
+// [B, C, D, H, W] layout (bev_pool.py:64-81 out_grad) while the kernels work on cell-major rows.  64 x 64 tiles
+// through LDS (+1 padding): both the read and the write side move 256-byte rows.
+namespace {
+__global__ __launch_bounds__(256) void transpose_cs(const float* __restrict__ in, float* __restrict__ out, int C, int S) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, s0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* ib = in + static_cast<size_t>(b) * C * S;
+  float* ob = out + static_cast<size_t>(b) * C * S;
+  for (int r = ty; r < 64; r += 4) {              // read rows of the [C, S] plane: c = c0 + r, s = s0 + tx
+    const int c = c0 + r, sidx = s0 + tx;
+    tile[r][tx] = (c < C && sidx < S) ? ib[static_cast<size_t>(c) * S + sidx] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {              // write rows of the [S, C] plane: s = s0 + r, c = c0 + tx
+    const int sidx = s0 + r, c = c0 + tx;
+    if (sidx < S && c < C) ob[static_cast<size_t>(sidx) * C + c] = tile[tx][r];
+  }
+}
+}  // namespace
+
+extern "C" int dbev_transpose_bcs_to_bsc(const float* in_bcs, float* out_bsc, int B, int C, int S, dbevStream_t stream) {
+  if (B <= 0 || C <= 0 || S <= 0 || in_bcs == nullptr || out_bsc == nullptr) return DBEV_EINVAL;
+  hipLaunchKernelGGL(transpose_cs, dim3(dbev_ceil_div(S, 64), dbev_ceil_div(C, 64), B), dim3(256), 0, dbev_stream(stream),
+                     in_bcs, out_bsc, C, S);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}

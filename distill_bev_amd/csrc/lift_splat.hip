@@ -85,8 +85,19 @@ __global__ __launch_bounds__(256) void ls_cell_count_agg(const float* __restrict
   for (int k = 0; k < AGG_PTS / 256; ++k) {
     const int p = base + k * 256 + threadIdx.x;
     if (p >= np) continue;
-    if (MODE == 2) {
-      const int4 c = reinterpret_cast<const int4*>(geom)[p];
+    if (MODE == 2 || MODE == 3) {
+      int4 c;
+      if (MODE == 2) {
+        c = reinterpret_cast<const int4*>(geom)[p];
+      } else {                       // int64 coordinates as the reference's Python surface passes them (bev_pool.py:83-97):
+        const longlong2 a = reinterpret_cast<const longlong2*>(geom)[2 * static_cast<size_t>(p)];       // no int32 copy pass
+        const longlong2 b = reinterpret_cast<const longlong2*>(geom)[2 * static_cast<size_t>(p) + 1];
+        const long long lim = 0x7fffffffLL;
+        c.x = (a.x < 0 || a.x > lim) ? -1 : static_cast<int>(a.x);
+        c.y = (a.y < 0 || a.y > lim) ? -1 : static_cast<int>(a.y);
+        c.z = (b.x < 0 || b.x > lim) ? -1 : static_cast<int>(b.x);
+        c.w = (b.y < 0 || b.y > lim) ? -1 : static_cast<int>(b.y);
+      }
       int lin = -1;
       if (c.x >= 0 && c.x < G.nx[0] && c.y >= 0 && c.y < G.nx[1] && c.z >= 0 && c.z < G.nx[2] && c.w >= 0 &&
           c.w < pts_per_batch) {
@@ -516,7 +527,7 @@ extern "C" size_t dbev_lift_splat_workspace_bytes(int n_points, int n_cells) {
 
 static int prepare_impl(const float* geom, const float* cam, const float* frustum, int DHW, int n_points,
                         int batch, const float* dx_host, const float* bx_host, const int32_t* nx_host,
-                        const int32_t* coords,
+                        const void* coords, bool coords_i64,
                         int32_t* point_cell, int32_t* cell_start, int32_t* cell_points, int32_t* n_kept_out,
                         int32_t* hot_cells, int32_t* n_hot_out, void* workspace, size_t workspace_bytes,
                         dbevStream_t stream) {
@@ -547,7 +558,10 @@ static int prepare_impl(const float* geom, const float* cam, const float* frustu
   const int nblk = dbev_ceil_div(n_points > 0 ? n_points : 1, AGG_PTS);
   if (n_points > 0) {
     CamParams cp{cam, frustum, DHW > 0 ? DHW : 1};
-    if (coords != nullptr)
+    if (coords != nullptr && coords_i64)
+      hipLaunchKernelGGL(ls_cell_count_agg<3>, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const float*>(coords), cp,
+                         n_points, batch, G, point_cell, count);
+    else if (coords != nullptr)
       hipLaunchKernelGGL(ls_cell_count_agg<2>, dim3(nblk), dim3(256), 0, s, reinterpret_cast<const float*>(coords), cp,
                          n_points, batch, G, point_cell, count);
     else if (cam != nullptr)
@@ -577,7 +591,7 @@ extern "C" int dbev_lift_splat_prepare(const float* geom, int n_points, int batc
                                        int32_t* hot_cells, int32_t* n_hot_out, void* workspace,
                                        size_t workspace_bytes, dbevStream_t stream) {
   if (geom == nullptr && n_points > 0) return DBEV_EINVAL;
-  return prepare_impl(geom, nullptr, nullptr, 0, n_points, batch, dx_host, bx_host, nx_host, nullptr, point_cell,
+  return prepare_impl(geom, nullptr, nullptr, 0, n_points, batch, dx_host, bx_host, nx_host, nullptr, false, point_cell,
                       cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace, workspace_bytes, stream);
 }
 
@@ -591,7 +605,7 @@ extern "C" int dbev_lift_splat_prepare_cam(const float* cam_params, const float*
   const long long np = static_cast<long long>(BN) * D * H * W;
   if (np > 0x7fffffffLL) return DBEV_EINVAL;
   return prepare_impl(nullptr, cam_params, frustum, D * H * W, static_cast<int>(np), batch, dx_host, bx_host,
-                      nx_host, nullptr, point_cell, cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace,
+                      nx_host, nullptr, false, point_cell, cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace,
                       workspace_bytes, stream);
 }
 
@@ -603,7 +617,21 @@ extern "C" int dbev_bev_pool_prepare(const int32_t* coords, int n_points, int B,
   const float one[3] = {1.f, 1.f, 1.f}, zero[3] = {0.f, 0.f, 0.f};
   const int32_t nx[3] = {H, W, D};          // (x, y, z) extents of the coords: 0<=x<H, 0<=y<W, 0<=z<D
   static const int32_t dummy[4] = {0, 0, 0, 0};
-  return prepare_impl(nullptr, nullptr, nullptr, 0, n_points, B, one, zero, nx, coords != nullptr ? coords : dummy,
+  return prepare_impl(nullptr, nullptr, nullptr, 0, n_points, B, one, zero, nx, coords != nullptr ? coords : dummy, false,
+                      point_cell, cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace, workspace_bytes,
+                      stream);
+}
+
+extern "C" int dbev_bev_pool_prepare_i64(const long long* coords, int n_points, int B, int D, int H, int W,
+                                         int32_t* point_cell, int32_t* cell_start, int32_t* cell_points,
+                                         int32_t* n_kept_out, int32_t* hot_cells, int32_t* n_hot_out, void* workspace,
+                                         size_t workspace_bytes, dbevStream_t stream) {
+  if ((coords == nullptr && n_points > 0) || B <= 0 || D <= 0 || H <= 0 || W <= 0) return DBEV_EINVAL;
+  const float one[3] = {1.f, 1.f, 1.f}, zero[3] = {0.f, 0.f, 0.f};
+  const int32_t nx[3] = {H, W, D};
+  static const long long dummy[4] = {0, 0, 0, 0};
+  return prepare_impl(nullptr, nullptr, nullptr, 0, n_points, B, one, zero, nx,
+                      coords != nullptr ? static_cast<const void*>(coords) : static_cast<const void*>(dummy), true,
                       point_cell, cell_start, cell_points, n_kept_out, hot_cells, n_hot_out, workspace, workspace_bytes,
                       stream);
 }

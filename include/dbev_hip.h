@@ -443,6 +443,14 @@ int dbev_bn_act_backward(const float* grad_y, const float* x, const float* y, co
                          int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                          long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
+/* bev_pool helpers of the Python surface (mmdet3d/ops/bev_pool/bev_pool.py:64-97): the cell lists straight from the
+ * int64 coordinates the reference's callers pass (no int32 conversion pass), and the [B, C, S] -> [B, S, C] transpose
+ * for an out_grad that arrives in the reference's contiguous [B, C, D, H, W] layout (S = D*H*W). */
+int dbev_bev_pool_prepare_i64(const long long* coords, int n_points, int B, int D, int H, int W, int32_t* point_cell,
+                              int32_t* cell_start, int32_t* cell_points, int32_t* n_kept_out, int32_t* hot_cells,
+                              int32_t* n_hot_out, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_transpose_bcs_to_bsc(const float* in_bcs, float* out_bsc, int B, int C, int S, dbevStream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Fused student adaptation (1x1 convolution) + masked-MSE reduction of the FGD loss, 'head' position
  * (replaces the sequence nn.Conv2d(Cs, Ct, 1) -> mean_c|.| -> three masked sums of

@@ -84,7 +84,17 @@ def test_full_size_hand_written_ops_are_bit_reproducible(full):
     a1, a2 = abs_mean_maps(T, with_pool=True), abs_mean_maps(T, with_pool=True)
     assert all(torch.equal(p, q) for p, q in zip(a1, a2))
     conv = nn.Conv2d(256, 384, 1).to(dev)
-    twice(lambda x, w, b: _FusedAdaptMSE.apply(x, w, b, T, cc), cl(8, 256, 128, 128), conv.weight.detach(), conv.bias.detach())
+    xin = cl(8, 256, 128, 128)
+    with torch.no_grad():          # forward only: the weight gradient behind it is a MIOpen split-K convolution (atomics)
+        f1 = _FusedAdaptMSE.apply(xin, conv.weight, conv.bias, T, cc)
+        f2 = _FusedAdaptMSE.apply(xin, conv.weight, conv.bias, T, cc)
+    assert all(torch.equal(p, q) for p, q in zip(f1, f2))
+    from distill_bev_amd import _lib as L
+    ds = [torch.empty_like(S), torch.empty_like(S)]
+    for o in ds:                   # the hand-written half of its backward: dS from the stored difference
+        L.call("dbev_adapt_mse_backward_ds", L.ptr(S), L.ptr(wf), L.ptr(wb), L.ptr(wp), L.ptr(cc), 8, 128 * 128, 384, L.ptr(o),
+               L.stream_ptr(dev))
+    assert torch.equal(ds[0], ds[1])
     # bilinear x4 upsampling of the adaptation layers, DCNv2 of the depth head, skinny head convolutions
     twice(lambda x: _UpsampleBilinearAC.apply(x, 4), cl(8, 256, 32, 32))
     twice(lambda x, om: _DCNv2Columns.apply(x, om, 3, 3, 1, 1, 1), cl(48, 256, 16, 44), cl(48, 27, 16, 44))
