@@ -472,6 +472,24 @@ int dbev_adapt_mse_backward_ds(const float* diff_nhwc, const float* grad_e, cons
                                const float* grad_pool, const float* channel_weight, int B, int HW, int Ct,
                                float* ds_nhwc, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Multi-scale deformable attention (replaces mmcv-full 1.6.0 `_ext.ms_deform_attn_forward/backward`, un-vendored;
+ * call site mmdet3d/models/transformer_modules/multi_scale_deformable_attn_function.py:10-12,42-49,70-82).
+ * value [B, S, NH, D] (S = sum_l H_l*W_l, D % 4 == 0, D/4 a power of two <= 64), spatial shapes (h, w) and level start
+ * offsets as HOST int32 arrays (L <= 8), sampling_loc [B, Q, NH, L, P, 2] normalised (x, y), attn_weight
+ * [B, Q, NH, L, P]  ->  out [B, Q, NH*D].  Bilinear sampling at loc * (W, H) - 0.5 with zero padding.
+ * backward fills grad_value [B, S, NH, D] (every element written; deterministic gather, no float atomics),
+ * grad_sampling_loc and grad_attn_weight; workspace of dbev_msda_backward_workspace_bytes (0 = unsupported size).
+ * ---------------------------------------------------------------------------------- */
+size_t dbev_msda_backward_workspace_bytes(int B, int S, int NH, int Q, int L, int P);
+int dbev_msda_forward(const float* value, const int32_t* spatial_shapes_hw_host, const int32_t* level_start_host,
+                      const float* sampling_loc, const float* attn_weight, int B, int S, int NH, int D, int Q, int L,
+                      int P, float* out, dbevStream_t stream);
+int dbev_msda_backward(const float* value, const int32_t* spatial_shapes_hw_host, const int32_t* level_start_host,
+                       const float* sampling_loc, const float* attn_weight, const float* grad_out, int B, int S, int NH,
+                       int D, int Q, int L, int P, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                       void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
