@@ -1,0 +1,379 @@
+// Sparse 3-D convolution for the voxel teachers: rulebook build + gather-GEMM on the fp32 matrix cores.
+//
+// Replaces the spconv v1.x extension bundled with the reference (mmdet3d/ops/spconv: rulebook kernels
+// include/spconv/indice.cu.h:24-215, gather / GEMM / scatter-add include/spconv/reordering.cu.h:22-128 and
+// spconv_ops.h:302-348, Python surface ops.py:46-126, conv.py:60-225) -- CUDA only there (src/all.cc:15).
+//
+// Reference data flow per layer: for each of the K kernel offsets: gather the input rows of the offset's (in, out) pairs
+// into a buffer, one GEMM with W[k], scatter-add the result rows into the output: 3 K kernel launches, 2 K passes over
+// temporary buffers, the output read-modify-written K times.
+// Here the rulebook is OUTPUT-STATIONARY: nbr[o, k] = input row that offset k pairs with output o (or -1).  One kernel
+// per layer: a wave owns 16 output sites, walks k = 0..K-1 (the reference's accumulation order), gathers the neighbour
+// rows straight into MFMA B operands, takes W[k] from LDS as the A operand and keeps the Cout x 16 accumulator tile in
+// registers (v_mfma_f32_16x16x4_f32, exact fp32); offsets no site of the workgroup uses are skipped.  The output is
+// written once.  No float atomics -> bit-reproducible.
+//
+// Rulebook: input coordinates -> open-addressing hash table (int32 linear cell id); output sites of a strided
+// convolution = set bits of a bitmap over the output grid, enumerated in ascending cell order by a popcount scan (the
+// reference sorts the unique cell ids: same order); neighbour table by K hash probes per output site.  The reference's
+// own (K, 2, N) pair lists are derived from the table for API compatibility (ops.get_indice_pairs).
+#include "common.h"
+#include "prims.h"
+
+namespace {
+
+constexpr int SP_EMPTY = -1;
+
+struct SpGeom {
+  int B, in_d[3], out_d[3], ks[3], st[3], pd[3], dl[3], K;
+};
+
+__device__ __forceinline__ unsigned sp_hash(int key, unsigned mask) {
+  return (static_cast<unsigned>(key) * 2654435761u >> 7) & mask;
+}
+
+__global__ __launch_bounds__(256) void sp_hash_insert(const int* __restrict__ idx, int n, SpGeom g, int* __restrict__ keys,
+                                                      int* __restrict__ vals, unsigned mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(idx)[i];                  // (b, z, y, x)
+  if (c.x < 0 || c.x >= g.B || c.y < 0 || c.y >= g.in_d[0] || c.z < 0 || c.z >= g.in_d[1] || c.w < 0 || c.w >= g.in_d[2])
+    return;
+  const int key = ((c.x * g.in_d[0] + c.y) * g.in_d[1] + c.z) * g.in_d[2] + c.w;
+  unsigned s = sp_hash(key, mask);
+  for (;;) {
+    const int old = atomicCAS(&keys[s], SP_EMPTY, key);
+    if (old == SP_EMPTY || old == key) {
+      if (old == key) atomicMin(&vals[s], i); else atomicMin(&vals[s], i);   // duplicate coordinates: lowest row wins
+      return;
+    }
+    s = (s + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ int sp_lookup(int key, const int* __restrict__ keys, const int* __restrict__ vals,
+                                         unsigned mask) {
+  unsigned s = sp_hash(key, mask);
+  for (;;) {
+    const int k = keys[s];
+    if (k == key) return vals[s];
+    if (k == SP_EMPTY) return -1;
+    s = (s + 1) & mask;
+  }
+}
+
+// strided / padded convolution: mark every output cell some (input, offset) pair reaches
+__global__ __launch_bounds__(256) void sp_mark_outputs(const int* __restrict__ idx, int n, SpGeom g,
+                                                       unsigned* __restrict__ bits) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<long long>(n) * g.K) return;
+  const int i = static_cast<int>(t / g.K), k = static_cast<int>(t - static_cast<long long>(i) * g.K);
+  const int4 c = reinterpret_cast<const int4*>(idx)[i];
+  const int kz = k / (g.ks[1] * g.ks[2]), ky = (k / g.ks[2]) % g.ks[1], kx = k % g.ks[2];
+  const int in[3] = {c.y, c.z, c.w}, kk[3] = {kz, ky, kx};
+  int o[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int num = in[a] + g.pd[a] - kk[a] * g.dl[a];
+    if (num < 0 || num % g.st[a]) return;
+    o[a] = num / g.st[a];
+    if (o[a] >= g.out_d[a]) return;
+  }
+  if (c.x < 0 || c.x >= g.B) return;
+  const long long lin = ((static_cast<long long>(c.x) * g.out_d[0] + o[0]) * g.out_d[1] + o[1]) * g.out_d[2] + o[2];
+  atomicOr(&bits[lin >> 5], 1u << (lin & 31));
+}
+
+__global__ __launch_bounds__(256) void sp_popcount(const unsigned* __restrict__ bits, int nwords, int* __restrict__ cnt) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < nwords) cnt[w] = __popc(bits[w]);
+}
+
+__global__ __launch_bounds__(256) void sp_emit_outputs(const unsigned* __restrict__ bits, const int* __restrict__ start,
+                                                       int nwords, SpGeom g, int* __restrict__ out_idx) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  unsigned b = bits[w];
+  int pos = start[w];
+  while (b) {
+    const int bit = __ffs(b) - 1;
+    b &= b - 1;
+    long long lin = (static_cast<long long>(w) << 5) + bit;
+    const int x = static_cast<int>(lin % g.out_d[2]); lin /= g.out_d[2];
+    const int y = static_cast<int>(lin % g.out_d[1]); lin /= g.out_d[1];
+    const int z = static_cast<int>(lin % g.out_d[0]); lin /= g.out_d[0];
+    reinterpret_cast<int4*>(out_idx)[pos++] = make_int4(static_cast<int>(lin), z, y, x);
+  }
+}
+
+// nbr[o, k] = input row at  o * stride - pad + k * dilation  (cross-correlation, like the dense convolution)
+__global__ __launch_bounds__(256) void sp_neighbors(const int* __restrict__ out_idx, int m, SpGeom g,
+                                                    const int* __restrict__ keys, const int* __restrict__ vals,
+                                                    unsigned mask, int* __restrict__ nbr, int* __restrict__ inv /* [N, K] or null */) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<long long>(m) * g.K) return;
+  const int o = static_cast<int>(t / g.K), k = static_cast<int>(t - static_cast<long long>(o) * g.K);
+  const int4 c = reinterpret_cast<const int4*>(out_idx)[o];
+  const int kz = k / (g.ks[1] * g.ks[2]), ky = (k / g.ks[2]) % g.ks[1], kx = k % g.ks[2];
+  const int z = c.y * g.st[0] - g.pd[0] + kz * g.dl[0], y = c.z * g.st[1] - g.pd[1] + ky * g.dl[1],
+            x = c.w * g.st[2] - g.pd[2] + kx * g.dl[2];
+  int r = -1;
+  if (z >= 0 && z < g.in_d[0] && y >= 0 && y < g.in_d[1] && x >= 0 && x < g.in_d[2] && c.x >= 0 && c.x < g.B)
+    r = sp_lookup(((c.x * g.in_d[0] + z) * g.in_d[1] + y) * g.in_d[2] + x, keys, vals, mask);
+  nbr[t] = r;
+  if (inv != nullptr && r >= 0) inv[static_cast<size_t>(r) * g.K + k] = o;     // unique writer per (input, offset)
+}
+
+// reference-format pair lists from the table: flags laid out [K, M]
+__global__ __launch_bounds__(256) void sp_pair_flags(const int* __restrict__ nbr, int m, int K, int* __restrict__ flags) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<long long>(m) * K) return;
+  const int k = static_cast<int>(t / m), o = static_cast<int>(t - static_cast<long long>(k) * m);
+  flags[t] = nbr[static_cast<size_t>(o) * K + k] >= 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void sp_pair_fill(const int* __restrict__ nbr, const int* __restrict__ pos, int m, int K,
+                                                    int n_in, int* __restrict__ pairs /* [K, 2, n_in] */,
+                                                    int* __restrict__ pair_num) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<long long>(m) * K) return;
+  const int k = static_cast<int>(t / m), o = static_cast<int>(t - static_cast<long long>(k) * m);
+  const int base = pos[static_cast<size_t>(k) * m];
+  if (o == 0) pair_num[k] = pos[static_cast<size_t>(k + 1) * m] - base;      // pos has K*M + 1 entries
+  const int r = nbr[static_cast<size_t>(o) * K + k];
+  if (r >= 0) {
+    const int p = pos[t] - base;
+    pairs[(static_cast<size_t>(k) * 2 + 0) * n_in + p] = r;
+    pairs[(static_cast<size_t>(k) * 2 + 1) * n_in + p] = o;
+  }
+}
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// out[o, :] = bias + sum_k in[nbr[o, k], :] @ W[k]        W [K, Cin, Cout], Cin % 16 == 0, Cout = 16 * CT
+template <int CT>
+__global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, const int* __restrict__ nbr,
+                                                   float* __restrict__ out, int M, int K, int Cin) {
+  extern __shared__ float sW[];                     // [Cin][COUT + 4]
+  constexpr int COUT = 16 * CT, STR = COUT + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const int o = blockIdx.x * 64 + 16 * wv + j;
+  floatx4 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const float4* W4 = reinterpret_cast<const float4*>(W);
+  for (int k = 0; k < K; ++k) {
+    const int nb = o < M ? nbr[static_cast<size_t>(o) * K + k] : -1;
+    const bool wave_any = __any(nb >= 0);
+    if (!__syncthreads_or(wave_any)) continue;      // also the barrier that lets sW be overwritten
+    for (int i = tid; i < Cin * (COUT / 4); i += 256) {
+      const int row = i / (COUT / 4), c4 = i - row * (COUT / 4);
+      *reinterpret_cast<float4*>(&sW[row * STR + 4 * c4]) = W4[(static_cast<size_t>(k) * Cin + row) * (COUT / 4) + c4];
+    }
+    __syncthreads();
+    if (wave_any) {
+      const float* row = in + static_cast<size_t>(nb >= 0 ? nb : 0) * Cin;
+      for (int g = 0; g < Cin / 16; ++g) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nb >= 0) bv = *reinterpret_cast<const float4*>(row + 16 * g + 4 * kk);   // cin = 16 g + 4 kk + t
+        const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float* wr = &sW[(16 * g + 4 * kk + t) * STR + j];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * ct], b4[t], acc[ct], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (o < M) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {               // accumulator rows = output channels 16 ct + 4 kk + (0..3)
+      float4 v = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
+      if (bias != nullptr) {
+        const float4 bi = *reinterpret_cast<const float4*>(bias + 16 * ct + 4 * kk);
+        v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+      }
+      *reinterpret_cast<float4*>(out + static_cast<size_t>(o) * COUT + 16 * ct + 4 * kk) = v;
+    }
+  }
+}
+
+// dense() of a sparse tensor in the channels-first layout the encoders return: canvas [B, C, D, H, W] (pre-zeroed)
+__global__ __launch_bounds__(256) void sp_to_dense(const float* __restrict__ feats, const int* __restrict__ idx, int n, int C,
+                                                   int D, int H, int Wd, float* __restrict__ canvas) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<long long>(n) * C) return;
+  const int i = static_cast<int>(t / C), c = static_cast<int>(t - static_cast<long long>(i) * C);
+  const int4 p = reinterpret_cast<const int4*>(idx)[i];
+  canvas[(((static_cast<size_t>(p.x) * C + c) * D + p.y) * H + p.z) * Wd + p.w] = feats[t];
+}
+
+bool sp_geom(int B, const int32_t* in_d, const int32_t* out_d, const int32_t* ks, const int32_t* st, const int32_t* pd,
+             const int32_t* dl, SpGeom* g) {
+  if (B <= 0 || !in_d || !out_d || !ks || !st || !pd || !dl) return false;
+  g->B = B;
+  long long vin = B, vout = B;
+  g->K = 1;
+  for (int a = 0; a < 3; ++a) {
+    g->in_d[a] = in_d[a]; g->out_d[a] = out_d[a]; g->ks[a] = ks[a]; g->st[a] = st[a]; g->pd[a] = pd[a]; g->dl[a] = dl[a];
+    if (in_d[a] <= 0 || out_d[a] <= 0 || ks[a] <= 0 || st[a] <= 0 || pd[a] < 0 || dl[a] <= 0) return false;
+    vin *= in_d[a]; vout *= out_d[a];
+    g->K *= ks[a];
+  }
+  return vin < 0x7fffffffLL && vout < (1LL << 36) && g->K <= 125;
+}
+
+unsigned hash_capacity(int n) {
+  unsigned c = 1024;
+  while (c < 2u * static_cast<unsigned>(n > 0 ? n : 1)) c <<= 1;
+  return c;
+}
+
+size_t sp_align(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+
+}  // namespace
+
+// ---- rulebook --------------------------------------------------------------------------------------------------------
+// workspace: hash keys + values, bitmap + per-word counts/starts (strided only), scan scratch
+extern "C" size_t dbev_spconv_build_workspace_bytes(int n_in, int B, const int32_t* out_dims_host, int K, int max_out) {
+  if (n_in < 0 || B <= 0 || out_dims_host == nullptr) return 0;
+  const unsigned cap = hash_capacity(n_in);
+  const long long vout = static_cast<long long>(B) * out_dims_host[0] * out_dims_host[1] * out_dims_host[2];
+  const long long nwords = (vout + 31) / 32;
+  const long long nflag = static_cast<long long>(K) * (max_out > 0 ? max_out : 1) + 1;
+  const long long nscan = nwords > nflag ? nwords : nflag;
+  return sp_align(sizeof(int) * cap) * 2 + sp_align(sizeof(int) * nwords) * 2 + sp_align(sizeof(int) * (nwords + 1)) +
+         sp_align(sizeof(int) * nflag) * 2 + sp_align(sizeof(int) * dbev::scan_workspace_ints(nscan)) + 4096;
+}
+
+// Step 1 (strided / padded convolutions only; submanifold convolutions keep the input sites): enumerate the output sites.
+// -> *n_out_device, out_indices [<= max_out, 4] in ascending cell order.  The caller reads n_out back (the reference
+// does the same through num_act_out) and calls dbev_spconv_neighbors with it.
+extern "C" int dbev_spconv_outputs(const int32_t* indices, int n_in, int B, const int32_t* in_dims_host,
+                                   const int32_t* out_dims_host, const int32_t* ksize_host, const int32_t* stride_host,
+                                   const int32_t* padding_host, const int32_t* dilation_host, int32_t* out_indices,
+                                   int max_out, int32_t* n_out_device, void* workspace, size_t workspace_bytes,
+                                   dbevStream_t stream) {
+  SpGeom g;
+  if (!sp_geom(B, in_dims_host, out_dims_host, ksize_host, stride_host, padding_host, dilation_host, &g)) return DBEV_EINVAL;
+  if (n_in < 0 || (n_in > 0 && indices == nullptr) || out_indices == nullptr || n_out_device == nullptr ||
+      workspace == nullptr || workspace_bytes < dbev_spconv_build_workspace_bytes(n_in, B, out_dims_host, g.K, max_out))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const unsigned cap = hash_capacity(n_in);
+  const long long vout = static_cast<long long>(B) * g.out_d[0] * g.out_d[1] * g.out_d[2];
+  const int nwords = static_cast<int>((vout + 31) / 32);
+  char* ws = static_cast<char*>(workspace);
+  size_t o = sp_align(sizeof(int) * cap) * 2;
+  unsigned* bits = reinterpret_cast<unsigned*>(ws + o); o += sp_align(sizeof(int) * nwords);
+  int* cnt = reinterpret_cast<int*>(ws + o);            o += sp_align(sizeof(int) * nwords);
+  int* start = reinterpret_cast<int*>(ws + o);          o += sp_align(sizeof(int) * (nwords + 1));
+  o += sp_align(sizeof(int) * (static_cast<long long>(g.K) * (max_out > 0 ? max_out : 1) + 1)) * 2;
+  int* scanws = reinterpret_cast<int*>(ws + o);
+  DBEV_HIP_TRY(hipMemsetAsync(bits, 0, sizeof(int) * nwords, s));
+  if (n_in > 0)
+    hipLaunchKernelGGL(sp_mark_outputs, dim3(dbev_ceil_div(static_cast<long long>(n_in) * g.K, 256)), dim3(256), 0, s,
+                       indices, n_in, g, bits);
+  hipLaunchKernelGGL(sp_popcount, dim3(dbev_ceil_div(nwords, 256)), dim3(256), 0, s, bits, nwords, cnt);
+  int rc = dbev::exclusive_scan_i32(cnt, start, nwords, false, n_out_device, scanws, s);
+  if (rc) return rc;
+  // an output set larger than max_out cannot happen for max_out >= min(n_in * K, grid volume) -- the Python side sizes it so
+  hipLaunchKernelGGL(sp_emit_outputs, dim3(dbev_ceil_div(nwords, 256)), dim3(256), 0, s, bits, start, nwords, g, out_indices);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+// Step 2: neighbour table nbr [n_out, K] (+ the inverse table inv [n_in, K] for SparseInverseConv, + the reference's pair
+// lists indice_pairs [K, 2, n_in] / indice_pair_num [K]; either may be NULL).
+extern "C" int dbev_spconv_neighbors(const int32_t* indices, int n_in, const int32_t* out_indices, int n_out, int B,
+                                     const int32_t* in_dims_host, const int32_t* out_dims_host, const int32_t* ksize_host,
+                                     const int32_t* stride_host, const int32_t* padding_host,
+                                     const int32_t* dilation_host, int32_t* nbr, int32_t* inv, int32_t* indice_pairs,
+                                     int32_t* indice_pair_num, void* workspace, size_t workspace_bytes,
+                                     dbevStream_t stream) {
+  SpGeom g;
+  if (!sp_geom(B, in_dims_host, out_dims_host, ksize_host, stride_host, padding_host, dilation_host, &g)) return DBEV_EINVAL;
+  if (n_in < 0 || n_out < 0 || (n_in > 0 && indices == nullptr) || (n_out > 0 && (out_indices == nullptr || nbr == nullptr)) ||
+      workspace == nullptr || workspace_bytes < dbev_spconv_build_workspace_bytes(n_in, B, out_dims_host, g.K, n_out))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const unsigned cap = hash_capacity(n_in);
+  char* ws = static_cast<char*>(workspace);
+  int* keys = reinterpret_cast<int*>(ws);
+  int* vals = reinterpret_cast<int*>(ws + sp_align(sizeof(int) * cap));
+  const long long vout = static_cast<long long>(B) * g.out_d[0] * g.out_d[1] * g.out_d[2];
+  const long long nwords = (vout + 31) / 32;
+  size_t o = sp_align(sizeof(int) * cap) * 2 + sp_align(sizeof(int) * nwords) * 2 + sp_align(sizeof(int) * (nwords + 1));
+  const long long nflag = static_cast<long long>(g.K) * (n_out > 0 ? n_out : 1) + 1;
+  int* flags = reinterpret_cast<int*>(ws + o); o += sp_align(sizeof(int) * nflag);
+  int* pos = reinterpret_cast<int*>(ws + o);   o += sp_align(sizeof(int) * nflag);
+  int* scanws = reinterpret_cast<int*>(ws + o);
+  DBEV_HIP_TRY(hipMemsetAsync(keys, 0xff, sizeof(int) * cap, s));
+  DBEV_HIP_TRY(hipMemsetAsync(vals, 0x7f, sizeof(int) * cap, s));
+  if (n_in > 0)
+    hipLaunchKernelGGL(sp_hash_insert, dim3(dbev_ceil_div(n_in, 256)), dim3(256), 0, s, indices, n_in, g, keys, vals, cap - 1);
+  if (inv != nullptr && n_in > 0) DBEV_HIP_TRY(hipMemsetAsync(inv, 0xff, sizeof(int) * static_cast<size_t>(n_in) * g.K, s));
+  if (n_out > 0) {
+    const long long nt = static_cast<long long>(n_out) * g.K;
+    hipLaunchKernelGGL(sp_neighbors, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, out_indices, n_out, g, keys, vals, cap - 1,
+                       nbr, inv);
+    if (indice_pairs != nullptr && indice_pair_num != nullptr && n_in > 0) {
+      DBEV_HIP_TRY(hipMemsetAsync(indice_pairs, 0xff, sizeof(int) * static_cast<size_t>(g.K) * 2 * n_in, s));
+      hipLaunchKernelGGL(sp_pair_flags, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, n_out, g.K, flags);
+      int rc = dbev::exclusive_scan_i32(flags, pos, nt, false, nullptr, scanws, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(sp_pair_fill, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, pos, n_out, g.K, n_in,
+                         indice_pairs, indice_pair_num);
+    }
+  } else if (indice_pair_num != nullptr) {
+    DBEV_HIP_TRY(hipMemsetAsync(indice_pair_num, 0, sizeof(int) * g.K, s));
+  }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- convolution -----------------------------------------------------------------------------------------------------
+extern "C" int dbev_spconv_forward(const float* features, const float* weight, const float* bias, const int32_t* nbr,
+                                   int n_out, int K, int Cin, int Cout, float* out_features, dbevStream_t stream) {
+  if (n_out < 0 || K <= 0 || Cin <= 0 || (Cin & 15) || Cout <= 0 || (Cout & 15) || Cout > 128 || Cin > 256) return DBEV_EINVAL;
+  if (n_out == 0) return 0;
+  if (features == nullptr || weight == nullptr || nbr == nullptr || out_features == nullptr) return DBEV_EINVAL;
+  const size_t lds = sizeof(float) * static_cast<size_t>(Cin) * (Cout + 4);
+  const dim3 grid(dbev_ceil_div(n_out, 64));
+  hipStream_t s = dbev_stream(stream);
+#define SP_LAUNCH(CTV)                                                                                              \
+  do {                                                                                                              \
+    if (lds > 64 * 1024)                                                                                            \
+      DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sp_conv_fwd<CTV>),                             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));         \
+    hipLaunchKernelGGL((sp_conv_fwd<CTV>), grid, dim3(256), lds, s, features, weight, bias, nbr, out_features, n_out, K, Cin); \
+  } while (0)
+  switch (Cout / 16) {
+    case 1: SP_LAUNCH(1); break;
+    case 2: SP_LAUNCH(2); break;
+    case 3: SP_LAUNCH(3); break;
+    case 4: SP_LAUNCH(4); break;
+    case 5: SP_LAUNCH(5); break;
+    case 6: SP_LAUNCH(6); break;
+    case 7: SP_LAUNCH(7); break;
+    default: SP_LAUNCH(8); break;
+  }
+#undef SP_LAUNCH
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_sparse_to_dense(const float* features, const int32_t* indices, int n, int C, int B, int D, int H, int W,
+                                    float* canvas_ncdhw, dbevStream_t stream) {
+  if (n < 0 || C <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || canvas_ncdhw == nullptr) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  DBEV_HIP_TRY(hipMemsetAsync(canvas_ncdhw, 0, sizeof(float) * static_cast<size_t>(B) * C * D * H * W, s));
+  if (n > 0)
+    hipLaunchKernelGGL(sp_to_dense, dim3(dbev_ceil_div(static_cast<long long>(n) * C, 256)), dim3(256), 0, s, features,
+                       indices, n, C, D, H, W, canvas_ncdhw);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}

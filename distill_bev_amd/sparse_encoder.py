@@ -1,0 +1,215 @@
+"""Voxel-teacher encoders of the MVP / LidarFormer configs -- registry mirrors of
+  ``mmdet3d/ops/sparse_block.py``            SparseBasicBlock :66-121, make_sparse_convmodule :124-186
+  ``mmdet3d/models/middle_encoders/sparse_encoder.py``   SparseEncoder :11-204
+  ``mmdet3d/models/voxel_encoders/dynamic_voxel_encoder.py``  voxelization :8-18, voxelization_virtual :19-68,
+                                                              DynamicVoxelEncoder :70-102
+on the sparse-convolution kernels (spconv.py) and the dynamic-scatter kernels (voxel.py).  State-dict keys follow the
+reference (conv_input.0.weight, encoder_layers.encoder_layer1.0.conv1.weight, ...bn1..., conv_out.0.weight)."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import spconv
+from .registry import MODELS, build_conv_layer, build_norm_layer
+from .voxel import dynamic_scatter
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    """mmdet BasicBlock (conv1-bn1-relu-conv2-bn2, + identity, relu) over sparse tensors; expansion 1."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        norm_cfg = norm_cfg or dict(type="BN1d")
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 3, stride=stride, padding=1, dilation=1, bias=False)
+        self.add_module(self.norm1_name, norm1)
+        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3, padding=1, bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    @property
+    def norm1(self):
+        return getattr(self, self.norm1_name)
+
+    @property
+    def norm2(self):
+        return getattr(self, self.norm2_name)
+
+    def forward(self, x):
+        identity = x.features
+        assert x.features.dim() == 2, f"x.features.dim()={x.features.dim()}"
+        out = self.conv1(x)
+        out.features = self.relu(self.norm1(out.features))
+        out = self.conv2(out)
+        out.features = self.norm2(out.features)
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out.features = self.relu(out.features + identity)
+        return out
+
+
+def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, stride=1, padding=0, conv_type="SubMConv3d",
+                           norm_cfg=None, order=("conv", "norm", "act")):
+    """sparse_block.py:124-186"""
+    assert isinstance(order, tuple) and len(order) <= 3
+    assert set(order) | {"conv", "norm", "act"} == {"conv", "norm", "act"}
+    conv_cfg = dict(type=conv_type, indice_key=indice_key)
+    layers = []
+    for layer in order:
+        if layer == "conv":
+            if conv_type not in ("SparseInverseConv3d", "SparseInverseConv2d", "SparseInverseConv1d"):
+                layers.append(build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                               padding=padding, bias=False))
+            else:
+                layers.append(build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, bias=False))
+        elif layer == "norm":
+            layers.append(build_norm_layer(norm_cfg, out_channels)[1])
+        elif layer == "act":
+            layers.append(nn.ReLU(inplace=True))
+    return spconv.SparseSequential(*layers)
+
+
+@MODELS.register_module()
+class SparseEncoder(nn.Module):
+    """sparse_encoder.py:11-204"""
+
+    def __init__(self, in_channels, sparse_shape, order=("conv", "norm", "act"),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type="conv_module"):
+        super().__init__()
+        assert block_type in ["conv_module", "basicblock"]
+        order = tuple(order)
+        self.sparse_shape, self.in_channels, self.order = sparse_shape, in_channels, order
+        self.base_channels, self.output_channels = base_channels, output_channels
+        self.encoder_channels, self.encoder_paddings = encoder_channels, encoder_paddings
+        self.stage_num = len(self.encoder_channels)
+        assert len(order) == 3 and set(order) == {"conv", "norm", "act"}
+        if order[0] != "conv":      # pre activate
+            self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                     indice_key="subm1", conv_type="SubMConv3d", order=("conv",))
+        else:
+            self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                     indice_key="subm1", conv_type="SubMConv3d")
+        encoder_out_channels = self.make_encoder_layers(make_sparse_convmodule, norm_cfg, base_channels, block_type=block_type)
+        self.conv_out = make_sparse_convmodule(encoder_out_channels, output_channels, kernel_size=(3, 1, 1), stride=(2, 1, 1),
+                                               norm_cfg=norm_cfg, padding=0, indice_key="spconv_down2",
+                                               conv_type="SparseConv3d")
+
+    def forward(self, voxel_features, coors, batch_size):
+        """voxel_features [N, C], coors int [N, 4] = (batch, z, y, x) -> [B, C * D, H, W] dense BEV map."""
+        coors = coors.int()
+        x = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        x = self.conv_input(x)
+        encode_features = []
+        for encoder_layer in self.encoder_layers:
+            x = encoder_layer(x)
+            encode_features.append(x)
+        out = self.conv_out(encode_features[-1])
+        spatial_features = out.dense()
+        N, C, D, H, W = spatial_features.shape
+        return spatial_features.view(N, C * D, H, W)
+
+    def make_encoder_layers(self, make_block, norm_cfg, in_channels, block_type="conv_module",
+                            conv_cfg=dict(type="SubMConv3d")):
+        assert block_type in ["conv_module", "basicblock"]
+        self.encoder_layers = spconv.SparseSequential()
+        for i, blocks in enumerate(self.encoder_channels):
+            blocks_list = []
+            for j, out_channels in enumerate(tuple(blocks)):
+                padding = tuple(self.encoder_paddings[i])[j]
+                if i != 0 and j == 0 and block_type == "conv_module":
+                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2, padding=padding,
+                                                  indice_key=f"spconv{i + 1}", conv_type="SparseConv3d"))
+                elif block_type == "basicblock":
+                    if j == len(blocks) - 1 and i != len(self.encoder_channels) - 1:
+                        blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
+                                                      padding=padding, indice_key=f"spconv{i + 1}",
+                                                      conv_type="SparseConv3d"))
+                    else:
+                        blocks_list.append(SparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg, conv_cfg=conv_cfg))
+                else:
+                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, padding=padding,
+                                                  indice_key=f"subm{i + 1}", conv_type="SubMConv3d"))
+                in_channels = out_channels
+            self.encoder_layers.add_module(f"encoder_layer{i + 1}", spconv.SparseSequential(*blocks_list))
+        return out_channels
+
+
+# ---- dynamic_voxel_encoder.py ---------------------------------------------------------------------------------------------
+def _voxel_mean(rows, points_xyz, pc_range, voxel_size):
+    """coords = trunc((xyz - min) / size) in (z, y, x) order; unique rows in lexicographic order + per-voxel mean of `rows`
+    (the reference: coords.unique(return_inverse, dim=0) + scatter_mean, :14-17) on the dynamic-scatter kernels."""
+    coords = ((points_xyz[:, [2, 1, 0]] - pc_range[[2, 1, 0]]) / voxel_size[[2, 1, 0]]).to(torch.int64)
+    voxels, unique_coords = dynamic_scatter(rows.contiguous(), coords.int().contiguous(), "mean")
+    return voxels, unique_coords.long()
+
+
+def _keep(points, pc_range):
+    return ((points[:, 0] >= pc_range[0]) & (points[:, 0] <= pc_range[3]) & (points[:, 1] >= pc_range[1])
+            & (points[:, 1] <= pc_range[4]) & (points[:, 2] >= pc_range[2]) & (points[:, 2] <= pc_range[5]))
+
+
+def voxelization(points, pc_range, voxel_size):
+    """dynamic_voxel_encoder.py:8-18"""
+    points = points[_keep(points, pc_range), :]
+    return _voxel_mean(points, points[:, :3], pc_range, voxel_size)
+
+
+def voxelization_virtual(points, pc_range, voxel_size):
+    """dynamic_voxel_encoder.py:19-68 (MVP virtual points; channel -2 = 1 real / 0 painted / -1 virtual)."""
+    points = points[_keep(points, pc_range), :]
+    real_points_mask = points[:, -2] == 1
+    painted_points_mask = points[:, -2] == 0
+    virtual_points_mask = points[:, -2] == -1
+    real_points = points[real_points_mask][:, [0, 1, 2, 3, 4, -1]]
+    painted_point = points[painted_points_mask]
+    virtual_point = points[virtual_points_mask]
+    nr, npnt = len(real_points), len(painted_point)
+    padded_points = torch.zeros(len(points), 24, device=points.device, dtype=points.dtype)
+    padded_points[:nr, :6] = real_points
+    padded_points[:nr, -1] = 1
+    padded_points[nr:nr + npnt, 6:21] = painted_point[:, :-2]
+    padded_points[nr:nr + npnt, 21] = painted_point[:, -2]
+    padded_points[nr:nr + npnt, 22] = 1
+    padded_points[nr:nr + npnt, 23] = 0
+    padded_points[nr + npnt:, 6:21] = virtual_point[:, :-2]
+    padded_points[nr + npnt:, 21] = virtual_point[:, -2]
+    padded_points[nr + npnt:, 22] = 0
+    padded_points[nr + npnt:, 23] = 0
+    points_xyz = torch.cat([real_points[:, :3], painted_point[:, :3], virtual_point[:, :3]], dim=0)
+    voxels, unique_coords = _voxel_mean(padded_points, points_xyz, pc_range, voxel_size)
+    indicator = voxels[:, -1]
+    mix_mask = (indicator > 0) * (indicator < 1)
+    voxels = voxels[:, :-1]
+    voxels[mix_mask, :6] = voxels[mix_mask, :6] / indicator[mix_mask].unsqueeze(-1)
+    voxels[mix_mask, 6:] = voxels[mix_mask, 6:] / (1 - indicator[mix_mask].unsqueeze(-1))
+    return voxels, unique_coords
+
+
+@MODELS.register_module()
+class DynamicVoxelEncoder(nn.Module):
+    """dynamic_voxel_encoder.py:70-102"""
+
+    def __init__(self, pc_range, voxel_size, virtual=False):
+        super().__init__()
+        self.pc_range = torch.tensor(pc_range)
+        self.voxel_size = torch.tensor(voxel_size)
+        self.shape = torch.round((self.pc_range[3:] - self.pc_range[:3]) / self.voxel_size)
+        self.shape_np = self.shape.numpy().astype(np.int32)
+        self.virtual = virtual
+
+    @torch.no_grad()
+    def forward(self, points):
+        coors, voxels = [], []
+        for res in points:
+            fn = voxelization_virtual if self.virtual else voxelization
+            voxel, coor = fn(res, self.pc_range.to(res.device), self.voxel_size.to(res.device))
+            voxels.append(voxel)
+            coors.append(coor)
+        coors_batch = torch.cat([F.pad(c, (1, 0), mode="constant", value=i) for i, c in enumerate(coors)], dim=0)
+        return torch.cat(voxels, dim=0), coors_batch, self.shape_np

@@ -1,0 +1,402 @@
+"""Sparse convolution -- Python mirror of the reference's ``mmdet3d.ops.spconv`` surface (spconv v1.x fork:
+``structure.py`` SparseConvTensor :21-69, ``modules.py`` SparseModule / SparseSequential / ToDense :43-196, ``conv.py``
+SparseConvolution :60-225 and its SparseConv{2,3}d / SubMConv{2,3}d / SparseInverseConv{2,3}d subclasses,
+``ops.py`` get_conv_output_size / get_indice_pairs / indice_conv :19-126, ``functional.py``) on the gfx950 kernels of
+csrc/spconv.hip instead of the CUDA-only ``sparse_conv_ext``.
+
+Differences that are MI355X design choices, not semantics:
+  * the rulebook is output-stationary (``Rulebook.nbr [n_out, K]``): one gather-GEMM kernel per layer instead of K
+    gather / GEMM / scatter-add rounds; the reference's pair lists (``indice_pairs [K, 2, N]``, ``indice_pair_num [K]``)
+    are still produced and cached under ``SparseConvTensor.indice_dict[indice_key]`` in the reference's tuple layout;
+  * rulebooks are also cached for layers WITHOUT an ``indice_key`` (the reference rebuilds them: every SubMConv3d of a
+    SparseBasicBlock, sparse_block.py:66-121, recomputes the same pairs), keyed on the index tensor and the geometry;
+  * the backward (``indice_conv_backward``) runs per kernel offset on torch GEMMs over the pair lists -- the voxel teachers
+    are frozen (``torch.no_grad``) on the distillation path, only the forward is hot.
+"""
+import math
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.nn import init
+from torch.nn.parameter import Parameter
+
+from . import _lib as L
+from .registry import register_conv
+
+
+# ---- ops.py ------------------------------------------------------------------------------------------------------------
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """ops.py:19-30"""
+    out = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        out.append(1 if kernel_size[i] == -1 else size)
+    return out
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    """ops.py:33-43"""
+    out = []
+    for i in range(len(input_size)):
+        if kernel_size[i] == -1:
+            raise ValueError("deconv don't support kernel_size < 0")
+        out.append((input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i])
+    return out
+
+
+def _t3(v, ndim):
+    v = list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+    return [1] * (3 - len(v)) + [int(x) for x in v] if len(v) < 3 else [int(x) for x in v]
+
+
+class Rulebook:
+    """One convolution geometry on one index set."""
+    __slots__ = ("nbr", "inv", "outids", "indice_pairs", "indice_pair_num", "n_in", "n_out", "K", "out_shape", "_pn_host")
+
+    def pair_num_host(self):
+        if self._pn_host is None:
+            self._pn_host = self.indice_pair_num.cpu().tolist()
+        return self._pn_host
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm):
+    """-> Rulebook.  indices int32 [n, ndim + 1] (batch first), ndim in (2, 3)."""
+    dev = L.require_cuda(indices)
+    ndim = indices.shape[1] - 1
+    assert ndim in (2, 3), "sparse convolutions over 2 or 3 spatial dimensions"
+    ks, st, pd, dl = _t3(ksize, ndim), _t3(stride, ndim), _t3(padding, ndim), _t3(dilation, ndim)
+    if subm:      # spconv_ops.h:76-80: a submanifold convolution ignores the configured stride / padding (1, ksize // 2)
+        st, pd = [1, 1, 1], [k // 2 for k in ks]
+    in_shape = [1] * (3 - ndim) + [int(v) for v in spatial_shape]
+    idx4 = indices.int().contiguous()
+    if ndim == 2:
+        idx4 = torch.cat([idx4[:, :1], torch.zeros_like(idx4[:, :1]), idx4[:, 1:]], dim=1).contiguous()
+    out_shape = in_shape if subm else get_conv_output_size(in_shape, ks, st, pd, dl)
+    n_in = idx4.shape[0]
+    K = ks[0] * ks[1] * ks[2]
+    rb = Rulebook()
+    rb.n_in, rb.K, rb._pn_host = n_in, K, None
+    rb.out_shape = out_shape[3 - ndim:]
+    hi = L.host_ints
+    with torch.cuda.device(dev):
+        vol = batch_size * out_shape[0] * out_shape[1] * out_shape[2]
+        max_out = n_in if subm else int(min(max(n_in * K, 1), vol))
+        nbytes = int(L.call("dbev_spconv_build_workspace_bytes", n_in, batch_size, hi(out_shape), K, max_out))
+        ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
+        if subm:
+            out4, n_out = idx4, n_in
+        else:
+            out4 = torch.empty((max(max_out, 1), 4), dtype=torch.int32, device=dev)
+            n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+            L.call("dbev_spconv_outputs", L.ptr(idx4), n_in, batch_size, hi(in_shape), hi(out_shape), hi(ks), hi(st), hi(pd),
+                   hi(dl), L.ptr(out4), max_out, L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+            n_out = int(n_dev.item())                       # num_act_out of the reference (one read-back per rulebook)
+            out4 = out4[:n_out]
+        rb.n_out = n_out
+        rb.nbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
+        rb.inv = torch.empty((max(n_in, 1), K), dtype=torch.int32, device=dev)
+        rb.indice_pairs = torch.empty((K, 2, max(n_in, 1)), dtype=torch.int32, device=dev)
+        rb.indice_pair_num = torch.zeros((K,), dtype=torch.int32, device=dev)
+        L.call("dbev_spconv_neighbors", L.ptr(idx4), n_in, L.ptr(out4), n_out, batch_size, hi(in_shape), hi(out_shape), hi(ks),
+               hi(st), hi(pd), hi(dl), L.ptr(rb.nbr), L.ptr(rb.inv), L.ptr(rb.indice_pairs), L.ptr(rb.indice_pair_num),
+               L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    rb.outids = indices if subm else (out4 if ndim == 3 else out4[:, [0, 2, 3]].contiguous())
+    return rb
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
+                     subm=False, transpose=False, grid=None):
+    """ops.py:46-104 -> (outids, indice_pairs [K, 2, N], indice_pair_num [K])."""
+    assert not transpose, "transposed sparse convolutions are not used by the reference's encoders"
+    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+    return rb.outids, rb.indice_pairs, rb.indice_pair_num
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+class _SparseConvFn(Function):
+    """features [n_in, Cin] x weight [K, Cin, Cout] through table [n_out, K] -> [n_out, Cout] (dbev_spconv_forward)."""
+
+    @staticmethod
+    def forward(ctx, features, weight, table, n_out, pairs, pair_num_fn, swap):
+        dev = L.require_cuda(features, weight)
+        K, Cin, Cout = weight.shape
+        f = features.float()
+        w = weight.float()
+        ci, co = _pad16(Cin), _pad16(Cout)
+        if ci != Cin:
+            f = torch.nn.functional.pad(f, (0, ci - Cin))
+            w = torch.nn.functional.pad(w, (0, 0, 0, ci - Cin))
+        if co != Cout:
+            w = torch.nn.functional.pad(w, (0, co - Cout))
+        f, w = f.contiguous(), w.contiguous()
+        out = torch.empty((n_out, co), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.call("dbev_spconv_forward", L.ptr(f), L.ptr(w), L.ptr(None), L.ptr(table), n_out, K, ci, co, L.ptr(out),
+                   L.stream_ptr(dev))
+        ctx.save_for_backward(features, weight, pairs)
+        ctx.meta = (pair_num_fn, swap, n_out)
+        return out[:, :Cout] if co != Cout else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        """indice_conv_backward (spconv_ops.h:352-420): per offset, dW[k] = in_k^T @ dout_k, din rows += dout_k @ W[k]^T."""
+        features, weight, pairs = ctx.saved_tensors
+        pair_num_fn, swap, n_out = ctx.meta
+        nums = pair_num_fn()
+        gin = torch.zeros_like(features)
+        gw = torch.zeros_like(weight)
+        src, dst = (1, 0) if swap else (0, 1)              # inverse convolution: the pair roles are exchanged
+        go = grad_out.contiguous()
+        for k, n in enumerate(nums):
+            if n == 0:
+                continue
+            i_in = pairs[k, src, :n].long()
+            i_out = pairs[k, dst, :n].long()
+            a, g = features[i_in], go[i_out]
+            gw[k] = a.t() @ g
+            gin.index_add_(0, i_in, g @ weight[k].t())
+        return gin, gw, None, None, None, None, None
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
+    """ops.py:107-126 with the reference's arguments (pair lists): converts the lists to a table and runs the kernel."""
+    K = indice_pairs.shape[0]
+    dev = features.device
+    table = torch.full((max(num_activate_out, 1), K), -1, dtype=torch.int32, device=dev)
+    nums = indice_pair_num.cpu().tolist()
+    src, dst = (1, 0) if inverse else (0, 1)
+    for k, n in enumerate(nums):
+        if n:
+            table[indice_pairs[k, dst, :n].long(), k] = indice_pairs[k, src, :n]
+    w = filters.reshape(K, filters.shape[-2], filters.shape[-1])
+    return _SparseConvFn.apply(features, w, table, num_activate_out, indice_pairs, lambda: nums, inverse)
+
+
+# ---- structure.py ----------------------------------------------------------------------------------------------------
+class SparseConvTensor(object):
+    """structure.py:21-69"""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices.int() if indices.dtype != torch.int32 else indices
+        self.spatial_shape = spatial_shape
+        self.batch_size = batch_size
+        self.indice_dict = {}
+        self.rulebooks = {}           # Rulebook objects (same keys as indice_dict + the automatic ones)
+        self.grid = grid
+
+    @property
+    def spatial_size(self):
+        return np.prod(self.spatial_shape)
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def dense(self, channels_first=True):
+        """[B, C, *spatial] (channels_first) or [B, *spatial, C]: zero where no voxel is active."""
+        dev = self.features.device
+        shape = [int(v) for v in self.spatial_shape]
+        C = self.features.shape[1]
+        ndim = len(shape)
+        d3 = [1] * (3 - ndim) + shape
+        idx4 = self.indices.int().contiguous()
+        if ndim == 2:
+            idx4 = torch.cat([idx4[:, :1], torch.zeros_like(idx4[:, :1]), idx4[:, 1:]], dim=1).contiguous()
+        canvas = torch.empty([self.batch_size, C] + d3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.call("dbev_sparse_to_dense", L.ptr(self.features.float().contiguous()), L.ptr(idx4), idx4.shape[0], C,
+                   self.batch_size, d3[0], d3[1], d3[2], L.ptr(canvas), L.stream_ptr(dev))
+        canvas = canvas.view([self.batch_size, C] + shape)
+        if channels_first:
+            return canvas
+        return canvas.permute(0, *range(2, ndim + 2), 1).contiguous()
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+
+
+# ---- modules.py --------------------------------------------------------------------------------------------------------
+class SparseModule(nn.Module):
+    """place holder: modules derived from it take / return a SparseConvTensor inside SparseSequential"""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """modules.py:49-150"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+        self._sparity_dict = {}
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError("index {} is out of range".format(idx))
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    @property
+    def sparity_dict(self):
+        return self._sparity_dict
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for k, module in self._modules.items():
+            if is_spconv_module(module):
+                assert isinstance(input, SparseConvTensor)
+                self._sparity_dict[k] = input.sparity
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input.features = module(input.features)
+            else:
+                input = module(input)
+        return input
+
+
+class ToDense(SparseModule):
+    def forward(self, x):
+        return x.dense()
+
+
+class RemoveGrid(SparseModule):
+    def forward(self, x):
+        x.grid = None
+        return x
+
+
+# ---- conv.py ---------------------------------------------------------------------------------------------------------------
+def _fan_hwio(tensor):
+    """conv.py:26-45 (_calculate_fan_in_and_fan_out_hwio)"""
+    if tensor.ndimension() == 2:
+        return tensor.size(-2), tensor.size(-1)
+    rf = 1
+    if tensor.dim() > 2:
+        rf = tensor[..., 0, 0].numel()
+    return tensor.size(-2) * rf, tensor.size(-1) * rf
+
+
+class SparseConvolution(SparseModule):
+    """conv.py:60-225; weight [*kernel_size, in_channels, out_channels]"""
+
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None, fused_bn=False):
+        super().__init__()
+        assert groups == 1 and not transposed, "grouped / transposed sparse convolutions are not part of the encoders"
+        lst = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+        kernel_size, stride, padding, dilation = lst(kernel_size), lst(stride), lst(padding), lst(dilation)
+        for d, s in zip(dilation, stride):
+            assert any([s == 1, d == 1]), "don't support this."
+        self.ndim, self.in_channels, self.out_channels = ndim, in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+        self.conv1x1 = np.prod(kernel_size) == 1
+        self.transposed, self.inverse, self.output_padding = transposed, inverse, lst(output_padding)
+        self.groups, self.subm, self.indice_key, self.fused_bn = groups, subm, indice_key, fused_bn
+        self.weight = Parameter(torch.Tensor(*kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = _fan_hwio(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -bound, bound)
+
+    def _auto_key(self, input):
+        return ("auto", input.indices.data_ptr(), input.indices.shape[0], tuple(self.kernel_size), tuple(self.stride),
+                tuple(self.padding), tuple(self.dilation), self.subm)
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        features, indices = input.features, input.indices
+        spatial_shape, batch_size = input.spatial_shape, input.batch_size
+        if self.conv1x1:
+            features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                features = features + self.bias
+            out = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
+            out.indice_dict, out.rulebooks, out.grid = input.indice_dict, input.rulebooks, input.grid
+            return out
+        K = int(np.prod(self.kernel_size))
+        w = self.weight.view(K, self.in_channels, self.out_channels)
+        if self.inverse:
+            datas = input.find_indice_pair(self.indice_key)
+            assert datas is not None and self.indice_key is not None
+            _, outids, indice_pairs, indice_pair_num, out_spatial_shape = datas
+            assert indice_pairs.shape[0] == K, "inverse conv must have same kernel size as its couple conv"
+            rb = input.rulebooks[self.indice_key]
+            out_features = _SparseConvFn.apply(features, w, rb.inv, rb.n_in, rb.indice_pairs, rb.pair_num_host, True)
+        else:
+            key = self.indice_key if self.indice_key is not None else self._auto_key(input)
+            rb = input.rulebooks.get(key)
+            if rb is None:
+                rb = build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,
+                                    self.dilation, self.subm)
+                input.rulebooks[key] = rb
+                if self.indice_key is not None:         # the reference's cache entry, same tuple layout (conv.py:176-180)
+                    input.indice_dict[self.indice_key] = (rb.outids, indices, rb.indice_pairs, rb.indice_pair_num,
+                                                          spatial_shape)
+            outids, out_spatial_shape = rb.outids, (spatial_shape if self.subm else rb.out_shape)
+            out_features = _SparseConvFn.apply(features, w, rb.nbr, rb.n_out, rb.indice_pairs, rb.pair_num_host, False)
+        if self.bias is not None:
+            out_features = out_features + self.bias
+        out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+        out.indice_dict, out.rulebooks, out.grid = input.indice_dict, input.rulebooks, input.grid
+        return out
+
+
+def _make(name, ndim, **fixed):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        kw = dict(stride=stride, padding=padding, dilation=dilation, groups=groups, bias=bias, indice_key=indice_key)
+        if fixed.get("inverse"):
+            kw = dict(bias=bias, indice_key=indice_key)
+        SparseConvolution.__init__(self, ndim, in_channels, out_channels, kernel_size, **kw, **fixed)
+    cls = type(name, (SparseConvolution,), {"__init__": __init__, "__doc__": "conv.py:" + name})
+    register_conv(name, cls)
+    return cls
+
+
+SparseConv2d = _make("SparseConv2d", 2)
+SparseConv3d = _make("SparseConv3d", 3)
+SubMConv2d = _make("SubMConv2d", 2, subm=True)
+SubMConv3d = _make("SubMConv3d", 3, subm=True)
+SparseInverseConv2d = _make("SparseInverseConv2d", 2, inverse=True)
+SparseInverseConv3d = _make("SparseInverseConv3d", 3, inverse=True)

@@ -490,6 +490,37 @@ int dbev_msda_backward(const float* value, const int32_t* spatial_shapes_hw_host
                        int D, int Q, int L, int P, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
                        void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Sparse 3-D convolution (replaces the bundled spconv v1.x extension `sparse_conv_ext`:
+ * mmdet3d/ops/spconv/src/all.cc:21-51 get_indice_pairs_3d / indice_conv_fp32 / fused_indice_conv_fp32;
+ * kernels include/spconv/indice.cu.h:24-215, reordering.cu.h:22-128, spconv_ops.h:302-348).
+ * indices int32 [n, 4] = (batch, z, y, x); dims / ksize / stride / padding / dilation: HOST int32[3] in (z, y, x) order.
+ *  dbev_spconv_outputs    output sites of a strided / padded convolution in ascending cell order (the order the
+ *                         reference gets from sorting the unique cell ids) -> out_indices, *n_out_device
+ *  dbev_spconv_neighbors  output-stationary rulebook nbr [n_out, K]: nbr[o, k] = input row paired with output o by
+ *                         kernel offset k (offsets in (kz, ky, kx) row-major order, as the reference's weight
+ *                         [kz, ky, kx, Cin, Cout]) or -1; optional inverse table inv [n_in, K] (SparseInverseConv) and
+ *                         the reference's own pair lists indice_pairs [K, 2, n_in] (-1 padded) / indice_pair_num [K].
+ *                         For a submanifold convolution pass out_indices = indices, n_out = n_in.
+ *  dbev_spconv_forward    out[o, :] = bias + sum_k features[nbr[o, k], :] @ weight[k]   (weight [K, Cin, Cout];
+ *                         Cin % 16 == 0, Cout % 16 == 0, Cout <= 128, Cin <= 256; fp32 MFMA; bias may be NULL)
+ *  dbev_sparse_to_dense   SparseConvTensor.dense(): [B, C, D, H, W] canvas, zero elsewhere (structure.py:52-62)
+ * ---------------------------------------------------------------------------------- */
+size_t dbev_spconv_build_workspace_bytes(int n_in, int B, const int32_t* out_dims_host, int K, int max_out);
+int dbev_spconv_outputs(const int32_t* indices, int n_in, int B, const int32_t* in_dims_host, const int32_t* out_dims_host,
+                        const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
+                        const int32_t* dilation_host, int32_t* out_indices, int max_out, int32_t* n_out_device,
+                        void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_spconv_neighbors(const int32_t* indices, int n_in, const int32_t* out_indices, int n_out, int B,
+                          const int32_t* in_dims_host, const int32_t* out_dims_host, const int32_t* ksize_host,
+                          const int32_t* stride_host, const int32_t* padding_host, const int32_t* dilation_host,
+                          int32_t* nbr, int32_t* inv, int32_t* indice_pairs, int32_t* indice_pair_num, void* workspace,
+                          size_t workspace_bytes, dbevStream_t stream);
+int dbev_spconv_forward(const float* features, const float* weight, const float* bias, const int32_t* nbr, int n_out,
+                        int K, int Cin, int Cout, float* out_features, dbevStream_t stream);
+int dbev_sparse_to_dense(const float* features, const int32_t* indices, int n, int C, int B, int D, int H, int W,
+                         float* canvas_ncdhw, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,237 @@
+"""GPU: sparse convolution kernels (csrc/spconv.hip) through the reference's module surface (SubMConv3d, SparseConv3d,
+SparseInverseConv3d, SparseConv2d, SparseSequential, SparseEncoder, DynamicVoxelEncoder) against the fp64 oracle
+(oracle/spconv.py: dense conv3d definition): output sites in the reference's order, features 2e-5 of the output scale,
+gradients (features, weight) 1e-4; the reference's pair lists; run-to-run bit identity."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(seed, B, shape, n, C):
+    rng = np.random.default_rng(seed)
+    vol = B * int(np.prod(shape))
+    lin = rng.choice(vol, size=n, replace=False)
+    rng.shuffle(lin)
+    coords = np.stack(np.unravel_index(lin, (B, *shape)), 1).astype(np.int32)
+    return coords, rng.normal(size=(n, C)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,kw,Cin,Cout", [
+    ("SubMConv3d", dict(kernel_size=3, padding=1), 16, 16),
+    ("SubMConv3d", dict(kernel_size=3, padding=0), 23, 16),                  # conv_input of the MVP encoder: 23 channels, padding ignored
+    ("SparseConv3d", dict(kernel_size=3, stride=2, padding=1), 16, 32),
+    ("SparseConv3d", dict(kernel_size=3, stride=2, padding=[0, 1, 1]), 32, 64),
+    ("SparseConv3d", dict(kernel_size=(3, 1, 1), stride=(2, 1, 1), padding=0), 64, 128),   # conv_out
+    ("SparseConv3d", dict(kernel_size=3, stride=1, padding=2, dilation=2), 16, 24),
+])
+def test_sparse_conv3d_vs_dense_definition(name, kw, Cin, Cout):
+    from distill_bev_amd import spconv
+    from oracle import spconv as OS
+    dev = torch.device("cuda:0")
+    shape, B = (9, 14, 12), 2
+    idx, feats = _cloud(11 + Cin, B, shape, 500, Cin)
+    conv = getattr(spconv, name)(Cin, Cout, bias=True, indice_key="k1", **kw).to(dev)
+    f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    x = spconv.SparseConvTensor(f, torch.from_numpy(idx).to(dev), list(shape), B)
+    y = conv(x)
+    subm = name.startswith("SubM")
+    ref, oi, osh = OS.sparse_conv_dense(feats, idx, shape, B, conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(),
+                                        kw.get("stride", 1), kw.get("padding", 0), kw.get("dilation", 1), subm)
+    assert list(y.spatial_shape) == list(osh)
+    got_idx = y.indices.cpu().numpy().astype(np.int64)
+    got = y.features.detach().cpu().double().numpy()
+    if subm:
+        order = np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))
+        assert np.array_equal(got_idx, idx.astype(np.int64))           # submanifold: rows stay in the input order
+        got = got[order]
+    else:
+        assert np.array_equal(got_idx, oi.numpy())                    # strided: ascending cell order, as the reference
+    assert np.abs(got - ref.numpy()).max() <= 2e-5 * np.abs(ref.numpy()).max()
+    # dense() == the dense convolution itself
+    dense = y.dense().cpu().double()
+    assert dense.shape == (B, Cout, *osh)
+    assert abs(float(dense.abs().sum()) - float(ref.abs().sum())) <= 1e-4 * float(ref.abs().sum())
+    # the reference's pair lists are cached under the indice_key in its own tuple layout
+    outids, in_idx, pairs, pair_num, sshape = x.indice_dict["k1"]
+    _, opairs = OS.rulebook_pairs(idx, shape, B, conv.kernel_size, kw.get("stride", 1), kw.get("padding", 0), kw.get("dilation", 1), subm)
+    nums = pair_num.cpu().tolist()
+    assert nums == [len(p) for p in opairs] and pairs.shape == (int(np.prod(conv.kernel_size)), 2, 500)
+    for k, n in enumerate(nums):
+        a = set(map(tuple, pairs[k, :, :n].t().cpu().tolist()))
+        assert a == set(map(tuple, opairs[k].tolist()))
+        assert bool((pairs[k, :, n:] == -1).all())
+    # gradients vs autograd through the dense fp64 definition
+    g = torch.randn(y.features.shape, generator=torch.Generator().manual_seed(1))
+    gf, gw, gb = torch.autograd.grad(y.features, (f, conv.weight, conv.bias), g.to(dev))
+    f64 = torch.from_numpy(feats).double().requires_grad_(True)
+    w64 = conv.weight.detach().cpu().double().requires_grad_(True)
+    b64 = conv.bias.detach().cpu().double().requires_grad_(True)
+    D, H, W = shape
+    dn = torch.zeros((B, Cin, D, H, W), dtype=torch.float64)
+    ii = torch.from_numpy(idx).long()
+    dn = dn.index_put((ii[:, 0], slice(None), ii[:, 1], ii[:, 2], ii[:, 3]), f64)
+    st, pd, dl = kw.get("stride", 1), kw.get("padding", 0), kw.get("dilation", 1)
+    if subm:
+        st, pd = 1, [k // 2 for k in conv.kernel_size]
+    yy = torch.nn.functional.conv3d(dn, w64.permute(4, 3, 0, 1, 2), None, st, pd, dl)
+    oi_t = torch.from_numpy(got_idx)
+    rows = yy[oi_t[:, 0], :, oi_t[:, 1], oi_t[:, 2], oi_t[:, 3]] + b64
+    rf, rw, rb = torch.autograd.grad(rows, (f64, w64, b64), g.double())
+    for nm, a, b in (("features", gf, rf), ("weight", gw, rw), ("bias", gb, rb)):
+        assert float((a.cpu().double() - b).abs().max()) <= 1e-4 * float(b.abs().max()), nm
+    y2 = conv(spconv.SparseConvTensor(f.detach(), torch.from_numpy(idx).to(dev), list(shape), B))
+    assert torch.equal(y2.features, y.features.detach())
+
+
+def test_inverse_conv_and_2d_variants():
+    from distill_bev_amd import spconv
+    from oracle import spconv as OS
+    dev = torch.device("cuda:0")
+    shape, B = (8, 10, 9), 1
+    idx, feats = _cloud(5, B, shape, 200, 16)
+    down = spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key="d").to(dev)
+    up = spconv.SparseInverseConv3d(32, 16, 3, indice_key="d", bias=False).to(dev)
+    x = spconv.SparseConvTensor(torch.from_numpy(feats).to(dev), torch.from_numpy(idx).to(dev), list(shape), B)
+    mid = down(x)
+    back = up(mid)
+    assert torch.equal(back.indices, x.indices) and back.features.shape == (200, 16)
+    # definition: out[i] = sum over the couple conv's pairs (i, o) of mid[o] @ W_inv[k]
+    _, pairs = OS.rulebook_pairs(idx, shape, B, 3, 2, 1, 1, False)
+    ref = np.zeros((200, 16))
+    wi = up.weight.detach().cpu().double().numpy().reshape(27, 32, 16)
+    m = mid.features.detach().cpu().double().numpy()
+    for k, pr in enumerate(pairs):
+        if len(pr):
+            np.add.at(ref, pr[:, 0], m[pr[:, 1]] @ wi[k])
+    assert np.abs(back.features.detach().cpu().double().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    # 2-D convolution = 3-D with a unit depth
+    i2 = np.unique(idx[:, [0, 2, 3]], axis=0)
+    f2 = np.random.default_rng(2).normal(size=(i2.shape[0], 16)).astype(np.float32)
+    c2 = spconv.SparseConv2d(16, 16, 3, stride=2, padding=1, bias=False).to(dev)
+    y2 = c2(spconv.SparseConvTensor(torch.from_numpy(f2).to(dev), torch.from_numpy(i2).to(dev), [10, 9], B))
+    i3 = np.concatenate([i2[:, :1], np.zeros_like(i2[:, :1]), i2[:, 1:]], 1)
+    w3 = c2.weight.detach().cpu().numpy()[None]
+    ref2, oi2, osh2 = OS.sparse_conv_dense(f2, i3, (1, 10, 9), B, w3, None, (1, 2, 2), (0, 1, 1), 1, False)
+    assert np.array_equal(y2.indices.cpu().numpy(), oi2.numpy()[:, [0, 2, 3]])
+    assert np.abs(y2.features.detach().cpu().double().numpy() - ref2.numpy()).max() <= 2e-5 * np.abs(ref2.numpy()).max()
+
+
+def test_sparse_encoder_of_the_mvp_teacher_vs_dense_reference_network():
+    """SparseEncoder (configs/teacher_transformer/mvpformer.py:44-52 channel plan, small grid) in eval mode against the same
+    network evaluated with dense fp64 convolutions and active-site masking (the definition of the sparse layers)."""
+    from distill_bev_amd import sparse_encoder  # noqa: F401
+    from distill_bev_amd.registry import build_middle_encoder
+    from oracle import spconv as OS
+    dev = torch.device("cuda:0")
+    shape, B = [17, 24, 20], 2
+    enc = build_middle_encoder(dict(
+        type="SparseEncoder", in_channels=23, sparse_shape=shape, output_channels=128, order=("conv", "norm", "act"),
+        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+        encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type="basicblock")).to(dev).eval()
+    g = torch.Generator().manual_seed(4)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    idx, feats = _cloud(9, B, shape, 1500, 23)
+    with torch.no_grad():
+        out = enc(torch.from_numpy(feats).to(dev), torch.from_numpy(idx).to(dev), B)
+    # dense fp64 evaluation of the same layers
+    def bn(m, x):
+        return (x - m.running_mean.cpu().double()) / torch.sqrt(m.running_var.cpu().double() + m.eps) * m.weight.detach().cpu().double() \
+            + m.bias.detach().cpu().double()
+
+    def run(conv, f, ii, sh):
+        subm = conv.subm
+        o, oi, osh = OS.sparse_conv_dense(f, ii, sh, B, conv.weight.detach().cpu().numpy(), None, conv.stride, conv.padding,
+                                          conv.dilation, subm)
+        if subm:                                   # back to the input row order
+            order = np.lexsort((ii[:, 3], ii[:, 2], ii[:, 1], ii[:, 0]))
+            inv = np.empty_like(order); inv[order] = np.arange(len(order))
+            return o[inv], ii, sh
+        return o, oi.numpy(), osh
+
+    f, ii, sh = torch.from_numpy(feats).double(), idx.astype(np.int64), shape
+    f, ii, sh = run(enc.conv_input[0], f, ii, sh)
+    f = torch.relu(bn(enc.conv_input[1], f))
+    for stage in enc.encoder_layers:
+        for blk in stage:
+            if type(blk).__name__ == "SparseBasicBlock":
+                idn = f
+                o, _, _ = run(blk.conv1, f, ii, sh)
+                o = torch.relu(bn(blk.norm1, o))
+                o, _, _ = run(blk.conv2, o, ii, sh)
+                f = torch.relu(bn(blk.norm2, o) + idn)
+            else:
+                f, ii, sh = run(blk[0], f, ii, sh)
+                f = torch.relu(bn(blk[1], f))
+    f, ii, sh = run(enc.conv_out[0], f, ii, sh)
+    f = torch.relu(bn(enc.conv_out[1], f))
+    dense = torch.zeros((B, 128, *sh), dtype=torch.float64)
+    it = torch.from_numpy(np.asarray(ii)).long()
+    dense[it[:, 0], :, it[:, 1], it[:, 2], it[:, 3]] = f
+    ref = dense.view(B, 128 * sh[0], sh[1], sh[2])
+    assert out.shape == ref.shape
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err <= 1e-4 * float(ref.abs().max()), (err, float(ref.abs().max()))
+    sd = enc.state_dict()
+    for k in ("conv_input.0.weight", "encoder_layers.encoder_layer1.0.conv1.weight", "encoder_layers.encoder_layer1.0.bn2.running_var",
+              "encoder_layers.encoder_layer1.2.0.weight", "encoder_layers.encoder_layer4.1.conv2.weight", "conv_out.1.bias"):
+        assert k in sd, k
+    assert sd["conv_input.0.weight"].shape == (3, 3, 3, 23, 16)
+
+
+def test_dynamic_voxel_encoder_plain_and_virtual():
+    """voxelization / voxelization_virtual (dynamic_voxel_encoder.py:8-68) vs the reference's op sequence restated with
+    torch.unique + an fp64 index_add mean on the CPU."""
+    from distill_bev_amd.sparse_encoder import DynamicVoxelEncoder
+    dev = torch.device("cuda:0")
+    pcr, vs = [-4.0, -4.0, -1.0, 4.0, 4.0, 1.0], [0.5, 0.5, 0.5]
+    rng = np.random.default_rng(3)
+
+    def ref_mean(rows, xyz):
+        pr, v = torch.tensor(pcr), torch.tensor(vs)
+        coords = ((xyz[:, [2, 1, 0]] - pr[[2, 1, 0]]) / v[[2, 1, 0]]).to(torch.int64)
+        uc, inv = coords.unique(return_inverse=True, dim=0)
+        s = torch.zeros((uc.shape[0], rows.shape[1]), dtype=torch.float64).index_add_(0, inv, rows.double())
+        cnt = torch.zeros(uc.shape[0], dtype=torch.float64).index_add_(0, inv, torch.ones(len(inv), dtype=torch.float64))
+        return (s / cnt[:, None]).float(), uc
+
+    def keep(p):
+        return p[(p[:, 0] >= pcr[0]) & (p[:, 0] <= pcr[3]) & (p[:, 1] >= pcr[1]) & (p[:, 1] <= pcr[4]) & (p[:, 2] >= pcr[2]) & (p[:, 2] <= pcr[5])]
+
+    pts = [torch.from_numpy(np.concatenate([rng.uniform(-4.5, 4.5, (900, 2)), rng.uniform(-1.2, 1.2, (900, 1)), rng.uniform(0, 1, (900, 2))], 1).astype(np.float32))
+           for _ in range(2)]
+    v, c, shp = DynamicVoxelEncoder(pcr, vs)( [p.to(dev) for p in pts])
+    assert list(shp) == [16, 16, 4]
+    off = 0
+    for b, p in enumerate(pts):
+        rv, rc = ref_mean(keep(p), keep(p)[:, :3])
+        n = rc.shape[0]
+        assert np.array_equal(c[off:off + n, 1:].cpu().numpy(), rc.numpy()) and bool((c[off:off + n, 0] == b).all())
+        assert float((v[off:off + n].cpu() - rv).abs().max()) < 1e-5
+        off += n
+    assert off == c.shape[0]
+    # virtual points: 18 columns, column -2 = 1 real / 0 painted / -1 virtual
+    p = torch.from_numpy(rng.uniform(-3.9, 3.9, (600, 18)).astype(np.float32))
+    p[:, 2] = torch.from_numpy(rng.uniform(-0.9, 0.9, 600).astype(np.float32))
+    p[:, -2] = torch.from_numpy(rng.choice([1.0, 0.0, -1.0], 600).astype(np.float32))
+    vv, cv, _ = DynamicVoxelEncoder(pcr, vs, virtual=True)([p.to(dev)])
+    real, paint, virt = p[p[:, -2] == 1][:, [0, 1, 2, 3, 4, -1]], p[p[:, -2] == 0], p[p[:, -2] == -1]
+    pad = torch.zeros(600, 24)
+    nr, npn = len(real), len(paint)
+    pad[:nr, :6] = real; pad[:nr, -1] = 1
+    pad[nr:nr + npn, 6:21] = paint[:, :-2]; pad[nr:nr + npn, 21] = paint[:, -2]; pad[nr:nr + npn, 22] = 1
+    pad[nr + npn:, 6:21] = virt[:, :-2]; pad[nr + npn:, 21] = virt[:, -2]
+    rv, rc = ref_mean(pad, torch.cat([real[:, :3], paint[:, :3], virt[:, :3]]))
+    ind = rv[:, -1]
+    mix = (ind > 0) & (ind < 1)
+    rv = rv[:, :-1]
+    rv[mix, :6] = rv[mix, :6] / ind[mix].unsqueeze(-1)
+    rv[mix, 6:] = rv[mix, 6:] / (1 - ind[mix].unsqueeze(-1))
+    assert vv.shape == (rc.shape[0], 23) and np.array_equal(cv[:, 1:].cpu().numpy(), rc.numpy())
+    assert float((vv.cpu() - rv).abs().max()) < 1e-4 and int(mix.sum()) > 5
