@@ -69,9 +69,9 @@ def test_sparse_conv3d_vs_dense_definition(name, kw, Cin, Cout):
     w64 = conv.weight.detach().cpu().double().requires_grad_(True)
     b64 = conv.bias.detach().cpu().double().requires_grad_(True)
     D, H, W = shape
-    dn = torch.zeros((B, Cin, D, H, W), dtype=torch.float64)
     ii = torch.from_numpy(idx).long()
-    dn = dn.index_put((ii[:, 0], slice(None), ii[:, 1], ii[:, 2], ii[:, 3]), f64)
+    dn = torch.zeros((B, D, H, W, Cin), dtype=torch.float64).index_put((ii[:, 0], ii[:, 1], ii[:, 2], ii[:, 3]), f64)
+    dn = dn.permute(0, 4, 1, 2, 3)
     st, pd, dl = kw.get("stride", 1), kw.get("padding", 0), kw.get("dilation", 1)
     if subm:
         st, pd = 1, [k // 2 for k in conv.kernel_size]
@@ -125,7 +125,7 @@ def test_sparse_encoder_of_the_mvp_teacher_vs_dense_reference_network():
     from distill_bev_amd.registry import build_middle_encoder
     from oracle import spconv as OS
     dev = torch.device("cuda:0")
-    shape, B = [17, 24, 20], 2
+    shape, B = [41, 24, 20], 2          # depth 41 -> 21 -> 11 -> 5 -> 2 (conv_out), as the full-size grid
     enc = build_middle_encoder(dict(
         type="SparseEncoder", in_channels=23, sparse_shape=shape, output_channels=128, order=("conv", "norm", "act"),
         encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
@@ -216,8 +216,8 @@ def test_dynamic_voxel_encoder_plain_and_virtual():
         assert float((v[off:off + n].cpu() - rv).abs().max()) < 1e-5
         off += n
     assert off == c.shape[0]
-    # virtual points: 18 columns, column -2 = 1 real / 0 painted / -1 virtual
-    p = torch.from_numpy(rng.uniform(-3.9, 3.9, (600, 18)).astype(np.float32))
+    # virtual points: 17 columns (MVP), column -2 = 1 real / 0 painted / -1 virtual
+    p = torch.from_numpy(rng.uniform(-3.9, 3.9, (600, 17)).astype(np.float32))
     p[:, 2] = torch.from_numpy(rng.uniform(-0.9, 0.9, 600).astype(np.float32))
     p[:, -2] = torch.from_numpy(rng.choice([1.0, 0.0, -1.0], 600).astype(np.float32))
     vv, cv, _ = DynamicVoxelEncoder(pcr, vs, virtual=True)([p.to(dev)])
