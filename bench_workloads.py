@@ -14,7 +14,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 gfx950 wide-read correction + WRITE_SIZE),
 # profiles/r02_pmc_*.txt; filled in by the profiling pass of the round, None until then
-PMC_TRAFFIC = {"bn_apply_res": None, "source": None}
+# bn_apply<true,true> at 48x256x64x176: FETCH_SIZE 540 702.1 KB x 2 + WRITE_SIZE 540 672.0 KB = 1 661 029 786 B per launch
+# against 3 x 553 648 128 B = 1 660 944 384 B algorithmic -> ratio 1.00005 (no over-fetch, no write amplification)
+PMC_TRAFFIC = {"bn_apply_res_ratio": (540702.1 * 2 + 540672.0) * 1024 / (3 * 553648128.0),
+               "source": "profiles/r02_pmc_FETCH_SIZE.txt (x2 gfx950 wide-read correction) + profiles/r02_pmc_WRITE_SIZE.txt, separate "
+                         "--pmc passes at the kernel's largest shape (48x256x64x176); traffic = algorithmic bytes of the timed "
+                         "launches x that measured ratio (not collected live)"}
 
 
 def _grid():
@@ -224,7 +229,7 @@ class DistillStep(_Base):
                           "hand-written kernel with the largest share of the step; one event pair per launch in the timed region",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 # separate --pmc passes of this kernel at its largest shape (profiles/r02_pmc_*.txt, tools/pmc_target.py)
-                "traffic": PMC_TRAFFIC.get("bn_apply_res"), "traffic_source": PMC_TRAFFIC.get("source"),
+                "traffic": rb / len(roof) * PMC_TRAFFIC["bn_apply_res_ratio"], "traffic_source": PMC_TRAFFIC["source"],
                 "avg_launch_us": rt / len(roof) * 1e6, "launches": len(roof), "launches_per_step": len(roof) / max(steps_timed, 1),
                 "algorithmic_bytes_per_launch": rb / len(roof), "ms_per_step": rt * 1e3 / max(steps_timed, 1),
                 "bn_family": {"ms_per_step": bn_t, "algorithmic_GB_per_step": bn_b,

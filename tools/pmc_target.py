@@ -40,6 +40,41 @@ S = torch.randn((B, 384, 128, 128), device=dev); T = torch.randn((B, 384, 128, 1
 w = torch.rand((B, 1, 128, 128), device=dev)
 for _ in range(5):
     masked_mse_sums(S, T, w, w)
+# round 2: fused 1x1 adaptation + masked-MSE MFMA kernel at the head position (8 x 256 -> 384 x 128 x 128)
+from distill_bev_amd.distill_loss import _FusedAdaptMSE
+conv = nn.Conv2d(256, 384, 1).to(dev)
+xa = torch.randn((B, 256, 128, 128), device=dev).contiguous(memory_format=torch.channels_last)
+Tn = T.contiguous(memory_format=torch.channels_last)
+cc = torch.rand((B, 384), device=dev)
+with torch.no_grad():
+    for _ in range(5):
+        _FusedAdaptMSE.apply(xa, conv.weight, conv.bias, Tn, cc)
+# round 2: bev_pool surface at the bench shape (16 six-camera frames)
+from distill_bev_amd import lss as LSS
+from distill_bev_amd.bev_pool import bev_pool
+rig = {k: torch.from_numpy(v) for k, v in syn.camera_rig(16, np.random.default_rng(1234)).items()}
+dx, bx, nx = LSS.gen_dx_bx([-51.2, 51.2, 0.8], [-51.2, 51.2, 0.8], [-10.0, 10.0, 20.0])
+geom = LSS.get_geometry(LSS.create_frustum(), rig["rots"], rig["trans"], rig["intrins"], rig["post_rots"], rig["post_trans"])
+coords, _ = LSS.voxel_coords_torch(geom, dx, bx, nx)
+coords = coords.to(dev)
+fe = torch.randn((coords.shape[0], 64), device=dev).requires_grad_(True)
+go = torch.randn((16, 64, 1, 128, 128), device=dev)
+print("bev_pool n =", coords.shape[0])
+for _ in range(3):
+    fe.grad = None
+    bev_pool(fe, coords, 16, 1, 128, 128).backward(go)
+# round 2: multi-scale deformable attention at BEVFormer's spatial cross-attention geometry (6 cams, 4 FPN levels, 8 points)
+from distill_bev_amd.msda import multi_scale_deformable_attn
+shapes = torch.tensor([[116, 200], [58, 100], [29, 50], [15, 25]], device=dev)
+starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+Sk = int((shapes[:, 0] * shapes[:, 1]).sum())
+val = torch.randn((6, Sk, 8, 32), device=dev).requires_grad_(True)
+loc = torch.rand((6, 10000, 8, 4, 8, 2), device=dev).requires_grad_(True)
+att = torch.softmax(torch.randn((6, 10000, 8, 32), device=dev), -1).view(6, 10000, 8, 4, 8).requires_grad_(True)
+for _ in range(3):
+    o = multi_scale_deformable_attn(val, shapes, starts, loc, att)
+    o.backward(torch.ones_like(o))
+    val.grad = None; loc.grad = None; att.grad = None
 # calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (MI355X_MICROARCH.md, HBM section)
 buf = torch.empty((128 * 1024 * 1024,), device=dev); src = torch.randn_like(buf)   # 512 MiB each
 for _ in range(3):
