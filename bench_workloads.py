@@ -150,7 +150,8 @@ class DistillStep(_Base):
              "dbev_lift_splat_backward", "dbev_abs_mean_maps", "dbev_abs_mean_maps_nhwc", "dbev_fgd_masked_mse_forward",
              "dbev_fgd_masked_mse_forward_nhwc", "dbev_fgd_masked_mse_backward", "dbev_fgd_masked_mse_backward_nhwc",
              "dbev_fg_scale_mask", "dbev_upsample_bilinear_ac_forward", "dbev_upsample_bilinear_ac_backward",
-             "dbev_dcnv2_im2col", "dbev_dcnv2_col2im", "dbev_bn_act_infer")
+             "dbev_dcnv2_im2col", "dbev_dcnv2_col2im", "dbev_bn_act_infer", "dbev_adapt_mse_forward",
+             "dbev_adapt_mse_backward_ds")
 
     def __init__(self, dev, rank, world):
         from distill_bev_amd.train_step import Trainer, build_model, make_batch
@@ -216,6 +217,13 @@ class DistillStep(_Base):
             if v:
                 other[k] = {"avg_us": float(np.mean(v)) * 1e3, "launches_per_step": len(v) / n_extra,
                             "ms_per_step": float(np.sum(v)) / n_extra}
+        # fused adaptation GEMM + loss reductions (MFMA-bound): 2 * B*HW * Cs * Ct flop, bytes x + teacher + difference
+        if "dbev_adapt_mse_forward" in other:
+            a = other["dbev_adapt_mse_forward"]
+            flop = 2.0 * self.B * 128 * 128 * 256 * 384
+            a["tflops"] = flop / (a["avg_us"] * 1e-6) / 1e12
+            a["frac_of_fp32_mfma_peak"] = a["tflops"] / 157.3
+            a["algorithmic_bytes_per_launch"] = 4 * self.B * 128 * 128 * (256 + 384 + 384)
         # canvas: one launch per entry call; algorithmic bytes M(4C+16) + 4*C*512^2*B
         if "dbev_pillars_canvas" in other:
             alg = self.n_pillars * (4 * 64 + 16) + 4 * 64 * 512 * 512 * self.B

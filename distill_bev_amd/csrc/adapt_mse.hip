@@ -18,7 +18,9 @@
 // 16 channel rows per 32x32 tile: the per-pixel reductions are in-register sums plus one cross-half shuffle, and
 // teacher / difference rows move as float4 (4 consecutive channels = accumulator registers 4q..4q+3).
 // K is walked in chunks of 32 through a double-buffered, k-major LDS stage (conflict-free ds_read_b32 for both
-// operands, one barrier per chunk); global loads of chunk c+1 are in flight while chunk c is multiplied.
+// operands, one barrier per chunk); global loads of chunk c+1 are in flight while chunk c is multiplied; the loader
+// reads whole 128-byte row chunks per 8 lanes (a 16-byte-per-row mapping thrashed the 32 KB L1: 38 % of MFMA peak).
+// Teacher and difference tiles go through LDS so that both move as whole rows.
 #include "common.h"
 
 namespace {
@@ -28,26 +30,33 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int AM_PXB = 128;   // pixels per workgroup (4 waves x 32)
 constexpr int AM_KC = 32;     // K chunk
 
+constexpr int AM_STR = AM_PXB + 1;   // LDS row stride of the k-major operand stages (pad 1: the coalesced loader's writes spread over banks)
+
 template <int NT>
 __global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict__ X, const float* __restrict__ Wt,
                                                          const float* __restrict__ bias, const float* __restrict__ T,
                                                          const float* __restrict__ Cc, float* __restrict__ D,
                                                          float* __restrict__ maps, int M, int K, int N, int HW) {
   constexpr int NCH = NT * 32;
-  __shared__ float sX[2][AM_KC][AM_PXB];
-  __shared__ float sW[2][AM_KC][NCH];
+  constexpr int WSTR = NCH + 1;
+  constexpr int TSTR = NCH + 4;                               // epilogue tile [pixel][channel], 16-byte aligned rows
+  constexpr int OPER = 2 * AM_KC * (AM_STR + WSTR);           // floats of the two double-buffered operand stages
+  constexpr int TILE = AM_PXB * TSTR;
+  __shared__ float smem[OPER > TILE ? OPER : TILE];
+  float (*sX)[AM_KC][AM_STR] = reinterpret_cast<float (*)[AM_KC][AM_STR]>(smem);
+  float (*sW)[AM_KC][WSTR] = reinterpret_cast<float (*)[AM_KC][WSTR]>(smem + 2 * AM_KC * AM_STR);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int m0 = blockIdx.x * AM_PXB, n0 = blockIdx.y * NCH;
   const int half = lane >> 5, l31 = lane & 31;
 
-  constexpr int XV = AM_PXB * AM_KC / 4 / 256;   // float4 loads per thread per chunk (4)
+  // loader: 8 consecutive lanes read one row's 128-byte chunk (whole cache lines per wave instruction)
+  constexpr int XV = AM_PXB * AM_KC / 4 / 256;                // float4 loads per thread per chunk
   constexpr int WV = (NCH * AM_KC / 4 + 255) / 256;
   float4 rx[XV], rw[WV];
-
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int f = tid + 256 * i, px = f % AM_PXB, kq = f / AM_PXB;
+      const int f = tid + 256 * i, px = f >> 3, kq = f & 7;
       const int m = m0 + px;
       rx[i] = m < M ? *reinterpret_cast<const float4*>(X + static_cast<size_t>(m) * K + kc * AM_KC + 4 * kq)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict_
     for (int i = 0; i < WV; ++i) {
       const int f = tid + 256 * i;
       if (f < NCH * AM_KC / 4) {
-        const int ch = f % NCH, kq = f / NCH;
+        const int ch = f >> 3, kq = f & 7;
         rw[i] = *reinterpret_cast<const float4*>(Wt + static_cast<size_t>(n0 + ch) * K + kc * AM_KC + 4 * kq);
       }
     }
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict_
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int f = tid + 256 * i, px = f % AM_PXB, kq = f / AM_PXB;
+      const int f = tid + 256 * i, px = f >> 3, kq = f & 7;
       sX[buf][4 * kq + 0][px] = rx[i].x; sX[buf][4 * kq + 1][px] = rx[i].y;
       sX[buf][4 * kq + 2][px] = rx[i].z; sX[buf][4 * kq + 3][px] = rx[i].w;
     }
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict_
     for (int i = 0; i < WV; ++i) {
       const int f = tid + 256 * i;
       if (f < NCH * AM_KC / 4) {
-        const int ch = f % NCH, kq = f / NCH;
+        const int ch = f >> 3, kq = f & 7;
         sW[buf][4 * kq + 0][ch] = rw[i].x; sW[buf][4 * kq + 1][ch] = rw[i].y;
         sW[buf][4 * kq + 2][ch] = rw[i].z; sW[buf][4 * kq + 3][ch] = rw[i].w;
       }
@@ -106,32 +115,45 @@ __global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict_
     __syncthreads();
   }
 
-  // ---- epilogue: lane = pixel column p, accumulator rows = channels n0 + 32 t + 8 q + 4 half + (0..3) ----
-  const int p = m0 + 32 * w + l31;
+  // ---- epilogue ----------------------------------------------------------------------------------------------------
+  // 1. the teacher tile [128 pixels][NCH channels] comes in with whole-row coalesced float4 loads into LDS (the operand
+  //    stages are free now); 2. every lane (= one pixel column of the accumulators) reads its teacher values from LDS,
+  //    forms d = s - t and the per-pixel sums in registers and puts d back; 3. the d tile leaves with coalesced stores.
+  float* tile = smem;
+  constexpr int C4 = NCH / 4;                                 // float4 per row of the slice
+  for (int f = tid; f < AM_PXB * C4; f += 256) {
+    const int px = f / C4, c4 = f - px * C4;
+    const int m = m0 + px;
+    const float4 tv = m < M ? *reinterpret_cast<const float4*>(T + static_cast<size_t>(m) * N + n0 + 4 * c4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&tile[px * TSTR + 4 * c4]) = tv;
+  }
+  __syncthreads();
+  const int pl = 32 * w + l31;                                // pixel of this lane inside the tile
+  const int p = m0 + pl;
   const bool live = p < M;
   const int bidx = live ? p / HW : 0;
   float e = 0.f, efp = 0.f, sa = 0.f, sp = 0.f;
-  if (live) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cb = n0 + 32 * t + 8 * q + 4 * half;
-        const float4 bi = *reinterpret_cast<const float4*>(bias + cb);
-        const float4 tv = *reinterpret_cast<const float4*>(T + static_cast<size_t>(p) * N + cb);
-        float4 cw = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (Cc != nullptr) cw = *reinterpret_cast<const float4*>(Cc + static_cast<size_t>(bidx) * N + cb);
-        const float s0 = acc[t][4 * q + 0] + bi.x, s1 = acc[t][4 * q + 1] + bi.y;
-        const float s2 = acc[t][4 * q + 2] + bi.z, s3 = acc[t][4 * q + 3] + bi.w;
-        float4 d;
-        d.x = s0 - tv.x; d.y = s1 - tv.y; d.z = s2 - tv.z; d.w = s3 - tv.w;
-        *reinterpret_cast<float4*>(D + static_cast<size_t>(p) * N + cb) = d;     // plain store: L2 merges a row's 16-byte pieces (nt: 1.6x write amplification, measured)
-        const float q0 = d.x * d.x, q1 = d.y * d.y, q2 = d.z * d.z, q3 = d.w * d.w;
-        e += (q0 + q1) + (q2 + q3);
-        efp += (cw.x * q0 + cw.y * q1) + (cw.z * q2 + cw.w * q3);
-        sa += (fabsf(s0) + fabsf(s1)) + (fabsf(s2) + fabsf(s3));
-        sp += (s0 + s1) + (s2 + s3);
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int cl = 32 * t + 8 * q + 4 * half;               // accumulator rows 4q..4q+3 = channels n0 + cl + (0..3)
+      const float4 bi = *reinterpret_cast<const float4*>(bias + n0 + cl);
+      float4 cw = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (Cc != nullptr) cw = *reinterpret_cast<const float4*>(Cc + static_cast<size_t>(bidx) * N + n0 + cl);
+      float4* tp = reinterpret_cast<float4*>(&tile[pl * TSTR + cl]);
+      const float4 tv = *tp;
+      const float s0 = acc[t][4 * q + 0] + bi.x, s1 = acc[t][4 * q + 1] + bi.y;
+      const float s2 = acc[t][4 * q + 2] + bi.z, s3 = acc[t][4 * q + 3] + bi.w;
+      float4 d;
+      d.x = s0 - tv.x; d.y = s1 - tv.y; d.z = s2 - tv.z; d.w = s3 - tv.w;
+      *tp = d;
+      const float q0 = d.x * d.x, q1 = d.y * d.y, q2 = d.z * d.z, q3 = d.w * d.w;
+      e += (q0 + q1) + (q2 + q3);
+      efp += (cw.x * q0 + cw.y * q1) + (cw.z * q2 + cw.w * q3);
+      sa += (fabsf(s0) + fabsf(s1)) + (fabsf(s2) + fabsf(s3));
+      sp += (s0 + s1) + (s2 + s3);
     }
   }
   // the other half-wave holds the other 16 rows of every tile for the same pixel
@@ -139,6 +161,13 @@ __global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict_
   if (live && half == 0) {
     float* mp = maps + static_cast<size_t>(blockIdx.y) * 4 * M;
     mp[p] = e; mp[static_cast<size_t>(M) + p] = efp; mp[2 * static_cast<size_t>(M) + p] = sa; mp[3 * static_cast<size_t>(M) + p] = sp;
+  }
+  __syncthreads();
+  for (int f = tid; f < AM_PXB * C4; f += 256) {
+    const int px = f / C4, c4 = f - px * C4;
+    const int m = m0 + px;
+    if (m < M)
+      *reinterpret_cast<float4*>(D + static_cast<size_t>(m) * N + n0 + 4 * c4) = *reinterpret_cast<const float4*>(&tile[px * TSTR + 4 * c4]);
   }
 }
 
