@@ -120,7 +120,7 @@ def main():
     if rank == 0:
         units = wl.units_per_step * world * steps
         line = {
-            "metric": "distill-train samples/sec (6-cam nuScenes, BEVDepth-R50) at 1/2/4/8 MI355X",
+            "metric": getattr(wl, "metric", "distill-train samples/sec (6-cam nuScenes, BEVDepth-R50) at 1/2/4/8 MI355X"),
             "value": units / dt,
             "unit": "samples/s",
             "n_gpus": n_gpus,

@@ -304,4 +304,156 @@ class DistillStep(_Base):
                 "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py"}
 
 
-WORKLOADS = {"bev_pool": BevPoolCfg1, "distill_step": DistillStep, "default": "distill_step"}
+MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* at the fp32 vector rate
+
+
+class VoxelTeacher(_Base):
+    """BASELINE configs[4], teacher half: the MVP virtual-point teacher's feature path at full size --
+    DynamicVoxelEncoder(virtual) -> SparseEncoder on the (41, 1600, 1600) grid -> SECOND -> FPN, under no_grad / eval as the
+    distillation runs it (configs/teacher_transformer/mvpformer.py:37-67), bs = 4 samples per GPU, each sample 200 k real +
+    50 k painted + 150 k virtual points (17 columns)."""
+    B = 4
+    units_per_step = 4
+    default_steps = 20
+    default_warmup = 3
+    N_REAL, N_PAINT, N_VIRT = 200000, 50000, 150000
+    metric = "voxel-teacher feature-path samples/sec (MVP virtual points, SparseEncoder 41x1600x1600) -- auxiliary workload"
+
+    def __init__(self, dev, rank, world):
+        from distill_bev_amd import detectors  # noqa: F401
+        from distill_bev_amd import spconv
+        from distill_bev_amd.registry import build_detector
+        self.dev = dev
+        pcr, vs = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.064, 0.064, 0.2]
+        model = dict(
+            type="MVPFormer",
+            pts_voxel_encoder=dict(type="DynamicVoxelEncoder", pc_range=pcr, voxel_size=vs, virtual=True),
+            pts_middle_encoder=dict(type="SparseEncoder", in_channels=23, sparse_shape=[41, 1600, 1600], output_channels=128,
+                                    order=("conv", "norm", "act"),
+                                    encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                                    encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type="basicblock"),
+            pts_backbone=dict(type="SECOND", in_channels=256, out_channels=[128, 256], layer_nums=[5, 5], layer_strides=[1, 2],
+                              norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), conv_cfg=dict(type="Conv2d", bias=False)),
+            pts_neck=dict(type="FPN", norm_cfg=dict(type="BN2d", eps=1e-3, momentum=0.01), act_cfg=dict(type="ReLU"),
+                          in_channels=[128, 256], out_channels=256, start_level=0, num_outs=4))
+        torch.manual_seed(0)
+        self.model = build_detector(model).to(dev).eval()
+        rng = np.random.default_rng(1234 + rank)
+        self.points = []
+        for _ in range(self.B):
+            n = self.N_REAL + self.N_PAINT + self.N_VIRT
+            p = rng.uniform(0.0, 1.0, (n, 17)).astype(np.float32)
+            p[:, 0] = rng.uniform(-54.0, 54.0, n); p[:, 1] = rng.uniform(-54.0, 54.0, n); p[:, 2] = rng.uniform(-5.5, 3.5, n)
+            p[:self.N_REAL, -2] = 1.0
+            p[self.N_REAL:self.N_REAL + self.N_PAINT, -2] = 0.0
+            p[self.N_REAL + self.N_PAINT:, -2] = -1.0
+            self.points.append(torch.from_numpy(p).to(dev))
+        self.gather_bytes = 0
+        self._spconv = spconv
+
+    @torch.no_grad()
+    def step(self):
+        return self.model.extract_pts_feat(self.points)
+
+    def begin_timed(self):
+        L.kernel_timing_read()
+        L.kernel_timing(["sp_conv_fwd"])
+
+    def roofline(self):
+        rec = L.kernel_timing_read().get("sp_conv_fwd")
+        L.kernel_timing(False)
+        if not rec:
+            return None
+        # gathered input rows of one forward: sum over the sparse layers of (#pairs x padded Cin x 4 B), from the rulebooks
+        total = torch.zeros((), dtype=torch.float64, device=self.dev)
+        convs = [m for m in self.model.modules() if isinstance(m, self._spconv.SparseConvolution) and not m.conv1x1]
+        hooks = []
+
+        def hook(mod, inp, out):
+            nonlocal total
+            x = inp[0]
+            rb = x.rulebooks[mod.indice_key if mod.indice_key is not None else mod._auto_key(x)]
+            total = total + rb.indice_pair_num.sum().double() * (4 * ((mod.in_channels + 15) // 16 * 16))
+        for m in convs:
+            hooks.append(m.register_forward_hook(hook))
+        self.step()
+        for h in hooks:
+            h.remove()
+        gather = float(total.item())
+        n_launch_per_step = len(convs)
+        steps = len(rec) / n_launch_per_step
+        t = float(sum(r[0] for r in rec)) * 1e-3
+        b = float(sum(r[1] for r in rec)) + gather * steps
+        ach = b / t / 1e9
+        return {"bound": "hbm", "kernel": "sp_conv_fwd (output-stationary gather-GEMM of the sparse 3-D convolutions, fp32 MFMA 16x16x4; "
+                "21 launches per forward, csrc/spconv.hip): gathered neighbour rows + neighbour table + weights read, output rows written",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": t / len(rec) * 1e6, "launches": len(rec), "launches_per_step": n_launch_per_step,
+                "algorithmic_bytes_per_launch": b / len(rec), "ms_per_step": t * 1e3 / steps,
+                "gathered_row_bytes_per_step": gather}
+
+    def config(self, world):
+        return {"workload": "MVP virtual-point teacher feature path (BASELINE configs[4], teacher half): DynamicVoxelEncoder(virtual) -> "
+                            "SparseEncoder (41x1600x1600) -> SECOND -> FPN, eval / no_grad",
+                "global_batch": self.B * world, "per_gpu_batch": self.B, "points_per_sample": self.N_REAL + self.N_PAINT + self.N_VIRT,
+                "parallelism": f"dp{world}"}
+
+
+class MsdaOp(_Base):
+    """BASELINE configs[4], student half: the multi-scale deformable attention op of BEVFormer's spatial
+    cross-attention, forward + backward, at bs = 4 samples x 6 cameras: value 4 FPN levels (116x200 ... 15x25) x 8 heads x 32
+    channels, 10 000 visible BEV queries per camera, 4 levels x 8 points."""
+    B = 4
+    units_per_step = 4
+    default_steps = 20
+    default_warmup = 3
+    metric = "multi-scale deformable attention fwd+bwd samples/sec (BEVFormer SCA geometry) -- auxiliary workload"
+
+    def __init__(self, dev, rank, world):
+        from distill_bev_amd.msda import multi_scale_deformable_attn
+        self.fn, self.dev = multi_scale_deformable_attn, dev
+        g = torch.Generator().manual_seed(1234 + rank)
+        self.shapes = torch.tensor([[116, 200], [58, 100], [29, 50], [15, 25]], device=dev)
+        self.starts = torch.cat([self.shapes.new_zeros(1), (self.shapes[:, 0] * self.shapes[:, 1]).cumsum(0)[:-1]])
+        S = int((self.shapes[:, 0] * self.shapes[:, 1]).sum())
+        bn, Q = self.B * 6, 10000
+        self.value = torch.randn((bn, S, 8, 32), generator=g).to(dev).requires_grad_(True)
+        self.loc = torch.rand((bn, Q, 8, 4, 8, 2), generator=g).to(dev).requires_grad_(True)
+        self.att = torch.softmax(torch.randn((bn, Q, 8, 32), generator=g), -1).view(bn, Q, 8, 4, 8).to(dev).requires_grad_(True)
+        self.gout = torch.randn((bn, Q, 256), generator=g).to(dev)
+        self.dims = (bn, S, Q)
+
+    def step(self):
+        self.value.grad = None; self.loc.grad = None; self.att.grad = None
+        self.fn(self.value, self.shapes, self.starts, self.loc, self.att).backward(self.gout)
+
+    def begin_timed(self):
+        L.kernel_timing_read()
+        L.kernel_timing(["msda_fwd", "msda_bwd_sample", "msda_gv_gather"])
+
+    def roofline(self):
+        rec = L.kernel_timing_read()
+        L.kernel_timing(False)
+        f = rec.get("msda_fwd")
+        if not f:
+            return None
+        t = float(sum(r[0] for r in f)) * 1e-3
+        b = float(sum(r[1] for r in f))
+        ach = b / t / 1e9
+        other = {k: {"avg_us": float(np.mean([r[0] for r in v])) * 1e3, "achieved_GBps": float(sum(r[1] for r in v)) / (float(sum(r[0] for r in v)) * 1e-3) / 1e9}
+                 for k, v in rec.items()}
+        bn, S, Q = self.dims
+        return {"bound": "hbm", "kernel": "msda_fwd<8> (one wave per query: 8 heads x 8 lanes x float4; value + locations + weights read once, "
+                "output written; the 4 x 32 corner-row gathers per query-head are served by L2 / the memory-side cache)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": t / len(f) * 1e6, "launches": len(f), "algorithmic_bytes_per_launch": b / len(f),
+                "gathered_bytes_per_launch": 4.0 * bn * Q * 8 * 32 * 4 * 32 * 4, "other_hot_kernels": other}
+
+    def config(self, world):
+        return {"workload": "multi-scale deformable attention fwd+bwd (BEVFormer spatial cross-attention geometry; BASELINE configs[4], "
+                            "student half): 24 camera-batches x 10 000 queries x 8 heads x 4 levels x 8 points, D = 32",
+                "global_batch": self.B * world, "per_gpu_batch": self.B, "parallelism": f"dp{world}"}
+
+
+WORKLOADS = {"bev_pool": BevPoolCfg1, "distill_step": DistillStep, "voxel_teacher": VoxelTeacher, "msda": MsdaOp,
+             "default": "distill_step"}

@@ -55,6 +55,11 @@ extern "C" const char* dbev_kernel_name(int kid) {
     case DBEV_K_BN_BWD_FINALIZE: return "bn_bwd_finalize";
     case DBEV_K_BN_BWD_DX: return "bn_bwd_dx<*,false>";
     case DBEV_K_BN_BWD_DX_RES: return "bn_bwd_dx<*,true>";
+    case DBEV_K_SPCONV_FWD: return "sp_conv_fwd";
+    case DBEV_K_MSDA_FWD: return "msda_fwd";
+    case DBEV_K_MSDA_BWD_SAMPLE: return "msda_bwd_sample";
+    case DBEV_K_MSDA_GV_GATHER: return "msda_gv_gather";
+    case DBEV_K_ADAPT_MSE_FWD: return "adapt_mse_fwd";
     default: return "?";
   }
 }

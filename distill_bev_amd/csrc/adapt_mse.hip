@@ -222,6 +222,7 @@ extern "C" int dbev_adapt_mse_forward(const float* x_nhwc, const float* weight, 
   const dim3 grid(dbev_ceil_div(M, AM_PXB), Ct / (32 * nt));
 #define AM_LAUNCH(NTV) hipLaunchKernelGGL((adapt_mse_fwd<NTV>), grid, dim3(256), 0, s, x_nhwc, weight, bias, teacher_nhwc, \
                                          channel_weight, diff_nhwc, maps, static_cast<int>(M), Cs, Ct, HW)
+  DbevKt kt(DBEV_K_ADAPT_MSE_FWD, 4LL * M * (Cs + 2LL * Ct), s);      // x + teacher read, difference written
   switch (nt) {
     case 4: AM_LAUNCH(4); break;
     case 3: AM_LAUNCH(3); break;

@@ -276,6 +276,8 @@ extern "C" int dbev_msda_forward(const float* value, const int32_t* spatial_shap
   const long long rows = static_cast<long long>(B) * Q * NH;
   const long long threads = rows * d.D4;
   const dim3 grid(static_cast<unsigned>((threads + 255) / 256));
+  // algorithmic bytes: value read once, locations + weights, output (the 4 x L x P corner gathers hit L2 / MALL)
+  DbevKt kt(DBEV_K_MSDA_FWD, 4LL * B * S * NH * D + 12LL * rows * L * P + 4LL * rows * D, dbev_stream(stream));
   if (P >= 8)
     hipLaunchKernelGGL((msda_fwd<8>), grid, dim3(256), 0, dbev_stream(stream), reinterpret_cast<const float4*>(value),
                        sampling_loc, attn_weight, reinterpret_cast<float4*>(out), d, rows);
@@ -308,8 +310,9 @@ extern "C" int dbev_msda_backward(const float* value, const int32_t* spatial_sha
   unsigned* sorted = reinterpret_cast<unsigned*>(ws + Lw.sorted);
   const float4* v4 = reinterpret_cast<const float4*>(value);
   const float4* g4 = reinterpret_cast<const float4*>(grad_out);
+  { DbevKt kt(DBEV_K_MSDA_BWD_SAMPLE, 4LL * B * S * NH * D + 24LL * nsamples + 4LL * rows * D, s);
   hipLaunchKernelGGL(msda_bwd_sample, dim3(static_cast<unsigned>((rows * d.D4 + 255) / 256)), dim3(256), 0, s, v4,
-                     sampling_loc, attn_weight, g4, grad_sampling_loc, grad_attn_weight, d, rows);
+                     sampling_loc, attn_weight, g4, grad_sampling_loc, grad_attn_weight, d, rows); }
   DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * vrows, s));
   const dim3 sgrid(static_cast<unsigned>((nsamples + 255) / 256));
   hipLaunchKernelGGL((msda_corner_bin<false>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
@@ -318,6 +321,7 @@ extern "C" int dbev_msda_backward(const float* value, const int32_t* spatial_sha
   hipLaunchKernelGGL((msda_corner_bin<true>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
   rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(vrows), reinterpret_cast<int*>(ws + Lw.sortws), s);
   if (rc) return rc;
+  DbevKt kt(DBEV_K_MSDA_GV_GATHER, 4LL * B * S * NH * D + 16LL * nsamples + 4LL * rows * D, s);
   hipLaunchKernelGGL(msda_gv_gather, dim3(static_cast<unsigned>((vrows * d.D4 + 255) / 256)), dim3(256), 0, s, g4,
                      sampling_loc, attn_weight, start, sorted, reinterpret_cast<float4*>(grad_value), d, vrows);
   DBEV_LAUNCH_CHECK();

@@ -351,6 +351,8 @@ extern "C" int dbev_spconv_forward(const float* features, const float* weight, c
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));         \
     hipLaunchKernelGGL((sp_conv_fwd<CTV>), grid, dim3(256), lds, s, features, weight, bias, nbr, out_features, n_out, K, Cin); \
   } while (0)
+  // log entry: output rows + neighbour table + weights (the gathered input rows depend on the rulebook: added by the caller)
+  DbevKt kt(DBEV_K_SPCONV_FWD, 4LL * n_out * (Cout + K) + 4LL * K * Cin * Cout, s);
   switch (Cout / 16) {
     case 1: SP_LAUNCH(1); break;
     case 2: SP_LAUNCH(2); break;

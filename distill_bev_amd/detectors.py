@@ -28,6 +28,7 @@ from .voxel import Voxelization
 # make every registered component importable through this module
 from . import lss as LSS  # noqa: E402
 from . import nets, pillar_encoder, pillars, view_transformer  # noqa: F401,E402
+from . import msda, sparse_encoder, spconv  # noqa: F401,E402  (voxel teachers / deformable attention of the 'next' rows)
 
 MODELS.register_module(name="PointPillarsScatter", module=pillars.PointPillarsScatter)
 

@@ -213,3 +213,100 @@ class DynamicVoxelEncoder(nn.Module):
             coors.append(coor)
         coors_batch = torch.cat([F.pad(c, (1, 0), mode="constant", value=i) for i, c in enumerate(coors)], dim=0)
         return torch.cat(voxels, dim=0), coors_batch, self.shape_np
+
+
+# ---- the voxel teachers of configs/teacher_transformer/{lidarformer,mvpformer}.py: feature-extraction path ---------------
+@MODELS.register_module()
+class HardSimpleVFE(nn.Module):
+    """voxel_encoders/voxel_encoder.py:14-45: mean of the points of a (hard) voxel."""
+
+    def __init__(self, num_features=4):
+        super().__init__()
+        self.num_features = num_features
+
+    def forward(self, features, num_points, coors):
+        return (features[:, :, :self.num_features].sum(dim=1) / num_points.type_as(features).view(-1, 1)).contiguous()
+
+
+@MODELS.register_module()
+class FPN(nn.Module):
+    """mmdet==2.24.0 FPN (un-vendored; configured at mvpformer.py:60-67 with norm_cfg BN2d / act_cfg ReLU, 2 inputs -> 4
+    outputs): lateral 1x1 ConvModules, top-down nearest upsampling, 3x3 fpn ConvModules, extra levels by stride-2
+    max-pooling (add_extra_convs=False)."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 upsample_cfg=dict(mode="nearest"), init_cfg=None):
+        super().__init__()
+        from .registry import ConvModule
+        assert not add_extra_convs, "extra conv levels are not configured by the reference's teachers"
+        self.in_channels, self.out_channels, self.num_outs = in_channels, out_channels, num_outs
+        self.start_level = start_level
+        self.backbone_end_level = len(in_channels) if end_level == -1 else end_level
+        self.upsample_cfg = dict(upsample_cfg)
+        self.lateral_convs, self.fpn_convs = nn.ModuleList(), nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, conv_cfg=conv_cfg,
+                                                 norm_cfg=norm_cfg if not no_norm_on_lateral else None, act_cfg=act_cfg,
+                                                 inplace=False))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                                             act_cfg=act_cfg, inplace=False))
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [l(inputs[i + self.start_level]) for i, l in enumerate(self.lateral_convs)]
+        for i in range(len(laterals) - 1, 0, -1):
+            laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], **self.upsample_cfg)
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(len(laterals))]
+        for _ in range(self.num_outs - len(outs)):
+            outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+        return tuple(outs)
+
+
+class _VoxelTeacher(nn.Module):
+    """Shared part of LidarFormer (lidarformer.py:11-53) and MVPFormer (mvpformer.py:11-49): voxel encoder -> SparseEncoder ->
+    SECOND -> FPN.  Only the feature path the distillation reads is built (the DGCNN3D transformer head is inference /
+    teacher-training machinery outside the hot path)."""
+
+    def __init__(self, pts_voxel_layer=None, pts_voxel_encoder=None, pts_middle_encoder=None, pts_backbone=None, pts_neck=None,
+                 pts_bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None, **unused):
+        super().__init__()
+        from .registry import build_backbone, build_neck
+        from .voxel import Voxelization
+        if pts_voxel_layer:
+            self.pts_voxel_layer = Voxelization(**pts_voxel_layer)
+        self.pts_voxel_encoder = MODELS.build(pts_voxel_encoder)
+        self.pts_middle_encoder = MODELS.build(pts_middle_encoder)
+        self.pts_backbone = build_backbone(pts_backbone)
+        self.pts_neck = build_neck(pts_neck) if pts_neck is not None else None
+        self.head_cfg = pts_bbox_head
+
+    def _dense(self, voxel_features, coors, batch_size):
+        x = self.pts_middle_encoder(voxel_features, coors, batch_size)
+        x = self.pts_backbone(x)
+        return self.pts_neck(x) if self.pts_neck is not None else x
+
+
+@MODELS.register_module()
+class MVPFormer(_VoxelTeacher):
+    def extract_pts_feat(self, pts, img_feats=None, img_metas=None):
+        voxel_features, coors, _ = self.pts_voxel_encoder(pts)
+        return self._dense(voxel_features, coors, len(pts))
+
+
+@MODELS.register_module()
+class LidarFormer(_VoxelTeacher):
+    @torch.no_grad()
+    def voxelize(self, points):
+        """mvx_two_stage.py:217-242"""
+        voxels, coors, num_points = [], [], []
+        for res in points:
+            v, c, n = self.pts_voxel_layer(res)
+            voxels.append(v); coors.append(c); num_points.append(n)
+        coors_batch = torch.cat([F.pad(c, (1, 0), mode="constant", value=i) for i, c in enumerate(coors)], dim=0)
+        return torch.cat(voxels, dim=0), torch.cat(num_points, dim=0), coors_batch
+
+    def extract_pts_feat(self, pts, img_feats=None, img_metas=None):
+        voxels, num_points, coors = self.voxelize(pts)
+        voxel_features = self.pts_voxel_encoder(voxels, num_points, coors)
+        return self._dense(voxel_features, coors, len(pts))

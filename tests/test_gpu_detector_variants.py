@@ -23,6 +23,9 @@ def _cfg():
 def _build(m):
     from distill_bev_amd.registry import build_detector
     import distill_bev_amd.detectors  # noqa: F401
+    if m.get("teacher_config") is not None and m.get("inherit_head") and not m.get("teacher_ckpt"):
+        from distill_bev_amd.train_step import synthetic_teacher_checkpoint      # the recipe asserts a teacher checkpoint
+        m["teacher_ckpt"] = synthetic_teacher_checkpoint(m, 0)
     torch.manual_seed(0)
     det = build_detector(m)
     det.init_weights()
