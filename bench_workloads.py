@@ -364,33 +364,40 @@ class VoxelTeacher(_Base):
         L.kernel_timing(False)
         if not rec:
             return None
-        # gathered input rows of one forward: sum over the sparse layers of (#pairs x padded Cin x 4 B), from the rulebooks
-        total = torch.zeros((), dtype=torch.float64, device=self.dev)
+        # per forward, from the rulebooks: active (input, output) pairs of every sparse layer -> flop and gathered bytes
+        flop = torch.zeros((), dtype=torch.float64, device=self.dev)
+        gath = torch.zeros((), dtype=torch.float64, device=self.dev)
         convs = [m for m in self.model.modules() if isinstance(m, self._spconv.SparseConvolution) and not m.conv1x1]
-        hooks = []
+        hooks, sites = [], []
 
         def hook(mod, inp, out):
-            nonlocal total
+            nonlocal flop, gath
             x = inp[0]
             rb = x.rulebooks[mod.indice_key if mod.indice_key is not None else mod._auto_key(x)]
-            total = total + rb.indice_pair_num.sum().double() * (4 * ((mod.in_channels + 15) // 16 * 16))
+            ci, co = (mod.in_channels + 15) // 16 * 16, (mod.out_channels + 15) // 16 * 16
+            pairs = rb.indice_pair_num.sum().double()
+            flop = flop + pairs * (2.0 * ci * co)
+            gath = gath + pairs * (4.0 * ci)
+            sites.append((rb.n_in, rb.n_out, mod.in_channels, mod.out_channels))
         for m in convs:
             hooks.append(m.register_forward_hook(hook))
         self.step()
         for h in hooks:
             h.remove()
-        gather = float(total.item())
+        flop, gath = float(flop.item()), float(gath.item())
         n_launch_per_step = len(convs)
         steps = len(rec) / n_launch_per_step
         t = float(sum(r[0] for r in rec)) * 1e-3
-        b = float(sum(r[1] for r in rec)) + gather * steps
-        ach = b / t / 1e9
-        return {"bound": "hbm", "kernel": "sp_conv_fwd (output-stationary gather-GEMM of the sparse 3-D convolutions, fp32 MFMA 16x16x4; "
-                "21 launches per forward, csrc/spconv.hip): gathered neighbour rows + neighbour table + weights read, output rows written",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        b = float(sum(r[1] for r in rec)) / steps + gath
+        ach = flop * steps / t / 1e12
+        return {"bound": "mfma", "kernel": "sp_conv_fwd (output-stationary gather-GEMM of the sparse 3-D convolutions on v_mfma_f32_16x16x4_f32; "
+                "21 launches per forward, csrc/spconv.hip).  Uniform synthetic points make the two coarsest stages of the encoder "
+                "nearly dense (27 neighbours per site): 95 % of the flop",
+                "achieved": ach, "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_FP32_PEAK_TFLOPS, "traffic": None,
                 "avg_launch_us": t / len(rec) * 1e6, "launches": len(rec), "launches_per_step": n_launch_per_step,
-                "algorithmic_bytes_per_launch": b / len(rec), "ms_per_step": t * 1e3 / steps,
-                "gathered_row_bytes_per_step": gather}
+                "gflop_per_step": flop / 1e9, "ms_per_step": t * 1e3 / steps,
+                "algorithmic_bytes_per_step": b, "of_which_gathered_rows": gath, "bytes_rate_GBps": b * steps / t / 1e9,
+                "active_sites_in_out_first_last_layer": [sites[0][:2], sites[-1][:2]] if sites else None}
 
     def config(self, world):
         return {"workload": "MVP virtual-point teacher feature path (BASELINE configs[4], teacher half): DynamicVoxelEncoder(virtual) -> "
@@ -447,7 +454,8 @@ class MsdaOp(_Base):
                 "output written; the 4 x 32 corner-row gathers per query-head are served by L2 / the memory-side cache)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": t / len(f) * 1e6, "launches": len(f), "algorithmic_bytes_per_launch": b / len(f),
-                "gathered_bytes_per_launch": 4.0 * bn * Q * 8 * 32 * 4 * 32 * 4, "other_hot_kernels": other}
+                "gathered_bytes_per_launch": 1.0 * bn * Q * 8 * 32 * 4 * 128,      # (query, head) x 32 samples x 4 corner rows of 128 B: L2 / MALL
+                "other_hot_kernels": other}
 
     def config(self, world):
         return {"workload": "multi-scale deformable attention fwd+bwd (BEVFormer spatial cross-attention geometry; BASELINE configs[4], "
