@@ -151,6 +151,11 @@ __global__ __launch_bounds__(256) void sp_pair_fill(const int* __restrict__ nbr,
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // out[o, :] = bias + sum_k in[nbr[o, k], :] @ W[k]        W [K, Cin, Cout], Cin % 16 == 0, Cout = 16 * CT
+// A wave owns NS = 2 sub-tiles of 16 output sites (a workgroup 128 sites): every A operand read from LDS (a weight
+// column) feeds two MFMAs, and the weight slice W[k] is staged once per 128 sites.
+constexpr int SP_NS = 2;
+constexpr int SP_SITES = 64 * SP_NS;        // output sites per workgroup
+
 template <int CT>
 __global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in, const float* __restrict__ W,
                                                    const float* __restrict__ bias, const int* __restrict__ nbr,
@@ -159,44 +164,91 @@ __global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in,
   constexpr int COUT = 16 * CT, STR = COUT + 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
-  const int o = blockIdx.x * 64 + 16 * wv + j;
-  floatx4 acc[CT];
+  int o[SP_NS];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < SP_NS; ++s) o[s] = blockIdx.x * SP_SITES + 16 * SP_NS * wv + 16 * s + j;
+  floatx4 acc[SP_NS][CT];
+#pragma unroll
+  for (int s = 0; s < SP_NS; ++s)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[s][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
   const float4* W4 = reinterpret_cast<const float4*>(W);
+  const int G16 = Cin / 16;
+  int nb_next[SP_NS];
+#pragma unroll
+  for (int s = 0; s < SP_NS; ++s) nb_next[s] = o[s] < M ? nbr[static_cast<size_t>(o[s]) * K] : -1;
   for (int k = 0; k < K; ++k) {
-    const int nb = o < M ? nbr[static_cast<size_t>(o) * K + k] : -1;
-    const bool wave_any = __any(nb >= 0);
+    int nb[SP_NS];
+    bool mine = false;
+#pragma unroll
+    for (int s = 0; s < SP_NS; ++s) {
+      nb[s] = nb_next[s];
+      if (k + 1 < K) nb_next[s] = o[s] < M ? nbr[static_cast<size_t>(o[s]) * K + k + 1] : -1;   // next offset's row ids in flight
+      mine = mine || nb[s] >= 0;
+    }
+    const bool wave_any = __any(mine);
     if (!__syncthreads_or(wave_any)) continue;      // also the barrier that lets sW be overwritten
     for (int i = tid; i < Cin * (COUT / 4); i += 256) {
       const int row = i / (COUT / 4), c4 = i - row * (COUT / 4);
       *reinterpret_cast<float4*>(&sW[row * STR + 4 * c4]) = W4[(static_cast<size_t>(k) * Cin + row) * (COUT / 4) + c4];
     }
+    // this lane's slices of the two neighbour rows (cin = 16 g + 4 kk + t), 2 groups (32 input channels) at a time: requested
+    // before the barrier so that the gathers overlap the weight staging, the next pair is fetched under the MFMAs
+    const float* row[SP_NS];
+    float4 bv[SP_NS][2];
+#pragma unroll
+    for (int s = 0; s < SP_NS; ++s) {
+      row[s] = in + static_cast<size_t>(nb[s] >= 0 ? nb[s] : 0) * Cin + 4 * kk;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        bv[s][u] = (nb[s] >= 0 && u < G16) ? *reinterpret_cast<const float4*>(row[s] + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
     if (wave_any) {
-      const float* row = in + static_cast<size_t>(nb >= 0 ? nb : 0) * Cin;
-      for (int g = 0; g < Cin / 16; ++g) {
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nb >= 0) bv = *reinterpret_cast<const float4*>(row + 16 * g + 4 * kk);   // cin = 16 g + 4 kk + t
-        const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+      for (int g0 = 0; g0 < G16; g0 += 2) {
+        float4 nx[SP_NS][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float* wr = &sW[(16 * g + 4 * kk + t) * STR + j];
+        for (int s = 0; s < SP_NS; ++s)
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16 * ct], b4[t], acc[ct], 0, 0, 0);
+          for (int u = 0; u < 2; ++u)
+            nx[s][u] = (nb[s] >= 0 && g0 + 2 + u < G16) ? *reinterpret_cast<const float4*>(row[s] + 16 * (g0 + 2 + u))
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (g0 + u < G16) {
+            const float b0[4] = {bv[0][u].x, bv[0][u].y, bv[0][u].z, bv[0][u].w};
+            const float b1[4] = {bv[1][u].x, bv[1][u].y, bv[1][u].z, bv[1][u].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float* wr = &sW[(16 * (g0 + u) + 4 * kk + t) * STR + j];
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) {
+                const float a = wr[16 * ct];
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[t], acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[t], acc[1][ct], 0, 0, 0);
+              }
+            }
+          }
         }
+#pragma unroll
+        for (int s = 0; s < SP_NS; ++s)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) bv[s][u] = nx[s][u];
       }
     }
   }
-  if (o < M) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {               // accumulator rows = output channels 16 ct + 4 kk + (0..3)
-      float4 v = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
-      if (bias != nullptr) {
-        const float4 bi = *reinterpret_cast<const float4*>(bias + 16 * ct + 4 * kk);
-        v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+  for (int s = 0; s < SP_NS; ++s) {
+    if (o[s] < M) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {             // accumulator rows = output channels 16 ct + 4 kk + (0..3)
+        float4 v = make_float4(acc[s][ct][0], acc[s][ct][1], acc[s][ct][2], acc[s][ct][3]);
+        if (bias != nullptr) {
+          const float4 bi = *reinterpret_cast<const float4*>(bias + 16 * ct + 4 * kk);
+          v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+        }
+        *reinterpret_cast<float4*>(out + static_cast<size_t>(o[s]) * COUT + 16 * ct + 4 * kk) = v;
       }
-      *reinterpret_cast<float4*>(out + static_cast<size_t>(o) * COUT + 16 * ct + 4 * kk) = v;
     }
   }
 }
@@ -342,7 +394,7 @@ extern "C" int dbev_spconv_forward(const float* features, const float* weight, c
   if (n_out == 0) return 0;
   if (features == nullptr || weight == nullptr || nbr == nullptr || out_features == nullptr) return DBEV_EINVAL;
   const size_t lds = sizeof(float) * static_cast<size_t>(Cin) * (Cout + 4);
-  const dim3 grid(dbev_ceil_div(n_out, 64));
+  const dim3 grid(dbev_ceil_div(n_out, SP_SITES));
   hipStream_t s = dbev_stream(stream);
 #define SP_LAUNCH(CTV)                                                                                              \
   do {                                                                                                              \
