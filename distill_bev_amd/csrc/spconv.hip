@@ -159,7 +159,9 @@ constexpr int SP_SITES = 64 * SP_NS;        // output sites per workgroup
 template <int CT>
 __global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in, const float* __restrict__ W,
                                                    const float* __restrict__ bias, const int* __restrict__ nbr,
-                                                   float* __restrict__ out, int M, int K, int Cin) {
+                                                   float* __restrict__ out, int M, int K, int Cin,
+                                                   const float* __restrict__ scale, const float* __restrict__ residual,
+                                                   int relu) {
   extern __shared__ float sW[];                     // [Cin][COUT + 4]
   constexpr int COUT = 16 * CT, STR = COUT + 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -243,10 +245,19 @@ __global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in,
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {             // accumulator rows = output channels 16 ct + 4 kk + (0..3)
         float4 v = make_float4(acc[s][ct][0], acc[s][ct][1], acc[s][ct][2], acc[s][ct][3]);
+        if (scale != nullptr) {                     // folded eval-mode BatchNorm1d: y = conv * scale + shift (shift in `bias`)
+          const float4 sc = *reinterpret_cast<const float4*>(scale + 16 * ct + 4 * kk);
+          v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+        }
         if (bias != nullptr) {
           const float4 bi = *reinterpret_cast<const float4*>(bias + 16 * ct + 4 * kk);
           v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
         }
+        if (residual != nullptr) {
+          const float4 rs = *reinterpret_cast<const float4*>(residual + static_cast<size_t>(o[s]) * COUT + 16 * ct + 4 * kk);
+          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4*>(out + static_cast<size_t>(o[s]) * COUT + 16 * ct + 4 * kk) = v;
       }
     }
@@ -387,9 +398,48 @@ extern "C" int dbev_spconv_neighbors(const int32_t* indices, int n_in, const int
   return 0;
 }
 
+// Step 2b (on demand): the reference's pair lists from an existing neighbour table. The training backward and the
+// get_indice_pairs() API read them; an inference forward never does, so the rulebook builds them lazily.
+extern "C" size_t dbev_spconv_pair_lists_workspace_bytes(int n_out, int K) {
+  const long long nflag = static_cast<long long>(K) * (n_out > 0 ? n_out : 1) + 1;
+  return sp_align(sizeof(int) * nflag) * 2 + sp_align(sizeof(int) * dbev::scan_workspace_ints(nflag)) + 256;
+}
+
+extern "C" int dbev_spconv_pair_lists(const int32_t* nbr, int n_out, int K, int n_in, int32_t* indice_pairs,
+                                      int32_t* indice_pair_num, void* workspace, size_t workspace_bytes,
+                                      dbevStream_t stream) {
+  if (n_out < 0 || n_in < 0 || K <= 0 || indice_pairs == nullptr || indice_pair_num == nullptr || workspace == nullptr ||
+      workspace_bytes < dbev_spconv_pair_lists_workspace_bytes(n_out, K) || (n_out > 0 && nbr == nullptr))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  DBEV_HIP_TRY(hipMemsetAsync(indice_pair_num, 0, sizeof(int) * K, s));
+  if (n_out == 0 || n_in == 0) return 0;
+  const long long nt = static_cast<long long>(n_out) * K;
+  char* ws = static_cast<char*>(workspace);
+  size_t o = 0;
+  int* flags = reinterpret_cast<int*>(ws + o); o += sp_align(sizeof(int) * (nt + 1));
+  int* pos = reinterpret_cast<int*>(ws + o);   o += sp_align(sizeof(int) * (nt + 1));
+  int* scanws = reinterpret_cast<int*>(ws + o);
+  DBEV_HIP_TRY(hipMemsetAsync(indice_pairs, 0xff, sizeof(int) * static_cast<size_t>(K) * 2 * n_in, s));
+  hipLaunchKernelGGL(sp_pair_flags, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, n_out, K, flags);
+  int rc = dbev::exclusive_scan_i32(flags, pos, nt, false, nullptr, scanws, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sp_pair_fill, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, pos, n_out, K, n_in, indice_pairs,
+                     indice_pair_num);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- convolution -----------------------------------------------------------------------------------------------------
 extern "C" int dbev_spconv_forward(const float* features, const float* weight, const float* bias, const int32_t* nbr,
                                    int n_out, int K, int Cin, int Cout, float* out_features, dbevStream_t stream) {
+  return dbev_spconv_forward_fused(features, weight, nullptr, bias, nullptr, 0, nbr, n_out, K, Cin, Cout, out_features, stream);
+}
+
+extern "C" int dbev_spconv_forward_fused(const float* features, const float* weight, const float* scale, const float* shift,
+                                         const float* residual, int relu, const int32_t* nbr, int n_out, int K, int Cin,
+                                         int Cout, float* out_features, dbevStream_t stream) {
+  const float* bias = shift;
   if (n_out < 0 || K <= 0 || Cin <= 0 || (Cin & 15) || Cout <= 0 || (Cout & 15) || Cout > 128 || Cin > 256) return DBEV_EINVAL;
   if (n_out == 0) return 0;
   if (features == nullptr || weight == nullptr || nbr == nullptr || out_features == nullptr) return DBEV_EINVAL;
@@ -401,7 +451,8 @@ extern "C" int dbev_spconv_forward(const float* features, const float* weight, c
     if (lds > 64 * 1024)                                                                                            \
       DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sp_conv_fwd<CTV>),                             \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));         \
-    hipLaunchKernelGGL((sp_conv_fwd<CTV>), grid, dim3(256), lds, s, features, weight, bias, nbr, out_features, n_out, K, Cin); \
+    hipLaunchKernelGGL((sp_conv_fwd<CTV>), grid, dim3(256), lds, s, features, weight, bias, nbr, out_features, n_out, K, Cin,  \
+                       scale, residual, relu);                                                                      \
   } while (0)
   // log entry: output rows + neighbour table + weights (the gathered input rows depend on the rulebook: added by the caller)
   DbevKt kt(DBEV_K_SPCONV_FWD, 4LL * n_out * (Cout + K) + 4LL * K * Cin * Cout, s);

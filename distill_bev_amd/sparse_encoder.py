@@ -42,6 +42,12 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         identity = x.features
         assert x.features.dim() == 2, f"x.features.dim()={x.features.dim()}"
+        if spconv.fusable_norm(self.conv1, self.norm1) and spconv.fusable_norm(self.conv2, self.norm2):
+            # inference: both norm / add / relu tails run in the convolutions' epilogues
+            if self.downsample is not None:
+                identity = self.downsample(x)
+            out = self.conv1(x, fused=(self.norm1, None, True))
+            return self.conv2(out, fused=(self.norm2, identity, True))
         out = self.conv1(x)
         out.features = self.relu(self.norm1(out.features))
         out = self.conv2(out)

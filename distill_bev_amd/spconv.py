@@ -54,13 +54,60 @@ def _t3(v, ndim):
 
 
 class Rulebook:
-    """One convolution geometry on one index set."""
-    __slots__ = ("nbr", "inv", "outids", "indice_pairs", "indice_pair_num", "n_in", "n_out", "K", "out_shape", "_pn_host")
+    """One convolution geometry on one index set: the neighbour table the kernel reads, plus -- on demand -- the reference's
+    pair lists (the backward pass and get_indice_pairs() read them; an inference forward never does)."""
+    __slots__ = ("nbr", "inv", "outids", "_pairs", "_pair_num", "n_in", "n_out", "K", "out_shape", "_pn_host")
+
+    def _build_pairs(self):
+        dev = self.nbr.device
+        self._pairs = torch.empty((self.K, 2, max(self.n_in, 1)), dtype=torch.int32, device=dev)
+        self._pair_num = torch.zeros((self.K,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            nbytes = int(L.call("dbev_spconv_pair_lists_workspace_bytes", self.n_out, self.K))
+            ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
+            L.call("dbev_spconv_pair_lists", L.ptr(self.nbr), self.n_out, self.K, self.n_in, L.ptr(self._pairs),
+                   L.ptr(self._pair_num), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+
+    @property
+    def indice_pairs(self):
+        if self._pairs is None:
+            self._build_pairs()
+        return self._pairs
+
+    @property
+    def indice_pair_num(self):
+        if self._pair_num is None:
+            self._build_pairs()
+        return self._pair_num
 
     def pair_num_host(self):
         if self._pn_host is None:
             self._pn_host = self.indice_pair_num.cpu().tolist()
         return self._pn_host
+
+
+class IndiceData(object):
+    """The reference's cache entry (outids, indices, indice_pairs, indice_pair_num, spatial_shape) of conv.py:176-180; reads
+    like that 5-tuple, the pair lists materialise on first access."""
+
+    def __init__(self, rulebook, indices, spatial_shape):
+        self.rulebook, self.indices, self.spatial_shape = rulebook, indices, spatial_shape
+
+    def _get(self, i):
+        rb = self.rulebook
+        return (lambda: rb.outids, lambda: self.indices, lambda: rb.indice_pairs, lambda: rb.indice_pair_num,
+                lambda: self.spatial_shape)[i]()
+
+    def __len__(self):
+        return 5
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self._get(j) for j in range(5)[i])
+        return self._get(i)
+
+    def __iter__(self):
+        return (self._get(j) for j in range(5))
 
 
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm):
@@ -79,7 +126,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     n_in = idx4.shape[0]
     K = ks[0] * ks[1] * ks[2]
     rb = Rulebook()
-    rb.n_in, rb.K, rb._pn_host = n_in, K, None
+    rb.n_in, rb.K, rb._pn_host, rb._pairs, rb._pair_num = n_in, K, None, None, None
     rb.out_shape = out_shape[3 - ndim:]
     hi = L.host_ints
     with torch.cuda.device(dev):
@@ -99,11 +146,9 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
         rb.n_out = n_out
         rb.nbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
         rb.inv = torch.empty((max(n_in, 1), K), dtype=torch.int32, device=dev)
-        rb.indice_pairs = torch.empty((K, 2, max(n_in, 1)), dtype=torch.int32, device=dev)
-        rb.indice_pair_num = torch.zeros((K,), dtype=torch.int32, device=dev)
         L.call("dbev_spconv_neighbors", L.ptr(idx4), n_in, L.ptr(out4), n_out, batch_size, hi(in_shape), hi(out_shape), hi(ks),
-               hi(st), hi(pd), hi(dl), L.ptr(rb.nbr), L.ptr(rb.inv), L.ptr(rb.indice_pairs), L.ptr(rb.indice_pair_num),
-               L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+               hi(st), hi(pd), hi(dl), L.ptr(rb.nbr), L.ptr(rb.inv), L.ptr(None), L.ptr(None), L.ptr(ws), ws.numel(),
+               L.stream_ptr(dev))
     rb.outids = indices if subm else (out4 if ndim == 3 else out4[:, [0, 2, 3]].contiguous())
     return rb
 
@@ -120,36 +165,55 @@ def _pad16(n):
     return (n + 15) // 16 * 16
 
 
+class _PairsView(object):
+    """pair lists handed in by the caller (indice_conv): same two members the backward reads from a Rulebook"""
+
+    def __init__(self, indice_pairs, nums):
+        self.indice_pairs, self._nums = indice_pairs, nums
+
+    def pair_num_host(self):
+        return self._nums
+
+
+def _conv_forward(features, weight, table, n_out, scale=None, shift=None, residual=None, relu=False):
+    """dbev_spconv_forward_fused on channel counts padded to multiples of 16."""
+    dev = L.require_cuda(features, weight)
+    K, Cin, Cout = weight.shape
+    f, w = features.float(), weight.float()
+    ci, co = _pad16(Cin), _pad16(Cout)
+    pad = torch.nn.functional.pad
+    if ci != Cin:
+        f, w = pad(f, (0, ci - Cin)), pad(w, (0, 0, 0, ci - Cin))
+    if co != Cout:
+        w = pad(w, (0, co - Cout))
+        scale = None if scale is None else pad(scale, (0, co - Cout))
+        shift = None if shift is None else pad(shift, (0, co - Cout))
+        residual = None if residual is None else pad(residual, (0, co - Cout))
+    c = lambda t: None if t is None else t.float().contiguous()
+    f, w, scale, shift, residual = c(f), c(w), c(scale), c(shift), c(residual)
+    out = torch.empty((n_out, co), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dbev_spconv_forward_fused", L.ptr(f), L.ptr(w), L.ptr(scale), L.ptr(shift), L.ptr(residual), int(bool(relu)),
+               L.ptr(table), n_out, K, ci, co, L.ptr(out), L.stream_ptr(dev))
+    return out[:, :Cout] if co != Cout else out
+
+
 class _SparseConvFn(Function):
     """features [n_in, Cin] x weight [K, Cin, Cout] through table [n_out, K] -> [n_out, Cout] (dbev_spconv_forward)."""
 
     @staticmethod
-    def forward(ctx, features, weight, table, n_out, pairs, pair_num_fn, swap):
-        dev = L.require_cuda(features, weight)
-        K, Cin, Cout = weight.shape
-        f = features.float()
-        w = weight.float()
-        ci, co = _pad16(Cin), _pad16(Cout)
-        if ci != Cin:
-            f = torch.nn.functional.pad(f, (0, ci - Cin))
-            w = torch.nn.functional.pad(w, (0, 0, 0, ci - Cin))
-        if co != Cout:
-            w = torch.nn.functional.pad(w, (0, co - Cout))
-        f, w = f.contiguous(), w.contiguous()
-        out = torch.empty((n_out, co), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            L.call("dbev_spconv_forward", L.ptr(f), L.ptr(w), L.ptr(None), L.ptr(table), n_out, K, ci, co, L.ptr(out),
-                   L.stream_ptr(dev))
-        ctx.save_for_backward(features, weight, pairs)
-        ctx.meta = (pair_num_fn, swap, n_out)
-        return out[:, :Cout] if co != Cout else out
+    def forward(ctx, features, weight, table, n_out, book, swap):
+        out = _conv_forward(features, weight, table, n_out)
+        ctx.save_for_backward(features, weight)
+        ctx.meta = (book, swap, n_out)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         """indice_conv_backward (spconv_ops.h:352-420): per offset, dW[k] = in_k^T @ dout_k, din rows += dout_k @ W[k]^T."""
-        features, weight, pairs = ctx.saved_tensors
-        pair_num_fn, swap, n_out = ctx.meta
-        nums = pair_num_fn()
+        features, weight = ctx.saved_tensors
+        book, swap, n_out = ctx.meta
+        pairs, nums = book.indice_pairs, book.pair_num_host()
         gin = torch.zeros_like(features)
         gw = torch.zeros_like(weight)
         src, dst = (1, 0) if swap else (0, 1)              # inverse convolution: the pair roles are exchanged
@@ -162,7 +226,7 @@ class _SparseConvFn(Function):
             a, g = features[i_in], go[i_out]
             gw[k] = a.t() @ g
             gin.index_add_(0, i_in, g @ weight[k].t())
-        return gin, gw, None, None, None, None, None
+        return gin, gw, None, None, None, None
 
 
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
@@ -176,7 +240,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
         if n:
             table[indice_pairs[k, dst, :n].long(), k] = indice_pairs[k, src, :n]
     w = filters.reshape(K, filters.shape[-2], filters.shape[-1])
-    return _SparseConvFn.apply(features, w, table, num_activate_out, indice_pairs, lambda: nums, inverse)
+    return _SparseConvFn.apply(features, w, table, num_activate_out, _PairsView(indice_pairs, nums), inverse)
 
 
 # ---- structure.py ----------------------------------------------------------------------------------------------------
@@ -274,10 +338,21 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        mods = list(self._modules.items())
+        i = 0
+        while i < len(mods):
+            k, module = mods[i]
+            i += 1
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity
+                # inference: conv -> eval BatchNorm1d [-> ReLU] runs as one kernel (the reference's fused() of modules.py:152-196)
+                if isinstance(module, SparseConvolution) and i < len(mods) and fusable_norm(module, mods[i][1]):
+                    norm = mods[i][1]
+                    relu = i + 1 < len(mods) and isinstance(mods[i + 1][1], nn.ReLU)
+                    input = module(input, fused=(norm, None, relu))
+                    i += 2 if relu else 1
+                    continue
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
@@ -285,6 +360,24 @@ class SparseSequential(SparseModule):
             else:
                 input = module(input)
         return input
+
+
+def fusable_norm(conv, norm):
+    """conv -> norm can run in the convolution's epilogue: gradients off, BatchNorm1d with running statistics in eval mode."""
+    return (not torch.is_grad_enabled() and isinstance(norm, nn.BatchNorm1d) and not norm.training and
+            norm.running_mean is not None and not conv.conv1x1 and conv.weight.is_cuda)
+
+
+def folded_norm(norm, bias):
+    """eval BatchNorm1d (after an optional convolution bias) as y = x * scale + shift"""
+    scale = torch.rsqrt(norm.running_var.float() + norm.eps)
+    if norm.weight is not None:
+        scale = scale * norm.weight.float()
+    mean = norm.running_mean.float() if bias is None else norm.running_mean.float() - bias.float()
+    shift = -mean * scale
+    if norm.bias is not None:
+        shift = shift + norm.bias.float()
+    return scale, shift
 
 
 class ToDense(SparseModule):
@@ -340,14 +433,18 @@ class SparseConvolution(SparseModule):
             init.uniform_(self.bias, -bound, bound)
 
     def _auto_key(self, input):
-        return ("auto", input.indices.data_ptr(), input.indices.shape[0], tuple(self.kernel_size), tuple(self.stride),
-                tuple(self.padding), tuple(self.dilation), self.subm)
+        # identifies the geometry on this index tensor (a submanifold convolution ignores its stride / padding)
+        sp = () if self.subm else (tuple(self.stride), tuple(self.padding))
+        return ("auto", input.indices.data_ptr(), input.indices.shape[0], tuple(self.kernel_size), sp, tuple(self.dilation),
+                self.subm)
 
-    def forward(self, input):
+    def forward(self, input, fused=None):
+        """fused = (BatchNorm1d in eval mode, residual features or None, relu) folds that tail into the kernel (no autograd)."""
         assert isinstance(input, SparseConvTensor)
         features, indices = input.features, input.indices
         spatial_shape, batch_size = input.spatial_shape, input.batch_size
         if self.conv1x1:
+            assert fused is None
             features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
             if self.bias is not None:
                 features = features + self.bias
@@ -359,24 +456,33 @@ class SparseConvolution(SparseModule):
         if self.inverse:
             datas = input.find_indice_pair(self.indice_key)
             assert datas is not None and self.indice_key is not None
-            _, outids, indice_pairs, indice_pair_num, out_spatial_shape = datas
-            assert indice_pairs.shape[0] == K, "inverse conv must have same kernel size as its couple conv"
+            outids, out_spatial_shape = datas[1], datas[4]
             rb = input.rulebooks[self.indice_key]
-            out_features = _SparseConvFn.apply(features, w, rb.inv, rb.n_in, rb.indice_pairs, rb.pair_num_host, True)
+            assert rb.K == K, "inverse conv must have same kernel size as its couple conv"
+            table, n_out = rb.inv, rb.n_in
         else:
-            key = self.indice_key if self.indice_key is not None else self._auto_key(input)
+            auto = self._auto_key(input)
+            key = self.indice_key if self.indice_key is not None else auto
             rb = input.rulebooks.get(key)
             if rb is None:
-                rb = build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,
-                                    self.dilation, self.subm)
-                input.rulebooks[key] = rb
-                if self.indice_key is not None:         # the reference's cache entry, same tuple layout (conv.py:176-180)
-                    input.indice_dict[self.indice_key] = (rb.outids, indices, rb.indice_pairs, rb.indice_pair_num,
-                                                          spatial_shape)
+                rb = input.rulebooks.get(auto)          # the same geometry built under another (or no) indice_key
+                if rb is None:
+                    rb = build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,
+                                        self.dilation, self.subm)
+                input.rulebooks[key] = input.rulebooks[auto] = rb
+                if self.indice_key is not None:         # the reference's cache entry, same layout (conv.py:176-180)
+                    input.indice_dict[self.indice_key] = IndiceData(rb, indices, spatial_shape)
             outids, out_spatial_shape = rb.outids, (spatial_shape if self.subm else rb.out_shape)
-            out_features = _SparseConvFn.apply(features, w, rb.nbr, rb.n_out, rb.indice_pairs, rb.pair_num_host, False)
-        if self.bias is not None:
-            out_features = out_features + self.bias
+            table, n_out = rb.nbr, rb.n_out
+        if fused is not None:
+            norm, residual, relu = fused
+            assert not torch.is_grad_enabled() and not norm.training
+            scale, shift = folded_norm(norm, self.bias)
+            out_features = _conv_forward(features, w, table, n_out, scale, shift, residual, relu)
+        else:
+            out_features = _SparseConvFn.apply(features, w, table, n_out, rb, self.inverse)
+            if self.bias is not None:
+                out_features = out_features + self.bias
         out = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
         out.indice_dict, out.rulebooks, out.grid = input.indice_dict, input.rulebooks, input.grid
         return out

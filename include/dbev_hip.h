@@ -517,8 +517,19 @@ int dbev_spconv_neighbors(const int32_t* indices, int n_in, const int32_t* out_i
                           const int32_t* stride_host, const int32_t* padding_host, const int32_t* dilation_host,
                           int32_t* nbr, int32_t* inv, int32_t* indice_pairs, int32_t* indice_pair_num, void* workspace,
                           size_t workspace_bytes, dbevStream_t stream);
+/* the pair lists alone, from an existing table (what dbev_spconv_neighbors writes when indice_pairs != NULL): built on demand
+ * for the backward pass and for get_indice_pairs() (ops.py:46-104); an inference forward never reads them */
+size_t dbev_spconv_pair_lists_workspace_bytes(int n_out, int K);
+int dbev_spconv_pair_lists(const int32_t* nbr, int n_out, int K, int n_in, int32_t* indice_pairs, int32_t* indice_pair_num,
+                           void* workspace, size_t workspace_bytes, dbevStream_t stream);
 int dbev_spconv_forward(const float* features, const float* weight, const float* bias, const int32_t* nbr, int n_out,
                         int K, int Cin, int Cout, float* out_features, dbevStream_t stream);
+/* dbev_spconv_forward with the epilogue of a conv -> eval BatchNorm1d -> (+ residual) -> ReLU chain folded in (the reference's
+ * fused_indice_conv + SparseSequential.fused(), modules.py:152-196, and the tail of SparseBasicBlock, sparse_block.py:101-121):
+ * out = [relu]( conv * scale + shift [+ residual] );  scale / shift [Cout] (NULL = 1 / 0), residual [n_out, Cout] or NULL */
+int dbev_spconv_forward_fused(const float* features, const float* weight, const float* scale, const float* shift,
+                              const float* residual, int relu, const int32_t* nbr, int n_out, int K, int Cin, int Cout,
+                              float* out_features, dbevStream_t stream);
 int dbev_sparse_to_dense(const float* features, const int32_t* indices, int n, int C, int B, int D, int H, int W,
                          float* canvas_ncdhw, dbevStream_t stream);
 

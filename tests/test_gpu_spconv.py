@@ -178,6 +178,20 @@ def test_sparse_encoder_of_the_mvp_teacher_vs_dense_reference_network():
     assert out.shape == ref.shape
     err = float((out.cpu().double() - ref).abs().max())
     assert err <= 1e-4 * float(ref.abs().max()), (err, float(ref.abs().max()))
+    # the inference forward above ran conv + norm (+ identity) + relu as one kernel per layer; the autograd-recording forward
+    # (separate BatchNorm1d / add / ReLU) gives the same features, and neither builds a pair list before a backward needs it
+    from distill_bev_amd import spconv
+    with torch.enable_grad():
+        out2 = enc(torch.from_numpy(feats).to(dev).requires_grad_(True), torch.from_numpy(idx).to(dev), B)
+    assert float((out2 - out).abs().max()) <= 2e-5 * float(ref.abs().max())
+    x = spconv.SparseConvTensor(torch.from_numpy(feats).to(dev), torch.from_numpy(idx).to(dev), shape, B)
+    with torch.no_grad():
+        y = enc.encoder_layers(enc.conv_input(x))
+    books = {id(rb): rb for rb in y.rulebooks.values()}
+    assert len(books) == 7                    # 4 submanifold geometries (conv_input shares stage 1's) + 3 strided convolutions
+    assert all(rb._pairs is None for rb in books.values())
+    pairs = y.indice_dict["subm1"][2]          # on demand, in the reference's layout
+    assert pairs.shape == (27, 2, 1500) and int(y.indice_dict["subm1"][3].sum()) == int((pairs[:, 0] >= 0).sum())
     sd = enc.state_dict()
     for k in ("conv_input.0.weight", "encoder_layers.encoder_layer1.0.conv1.weight", "encoder_layers.encoder_layer1.0.bn2.running_var",
               "encoder_layers.encoder_layer1.2.0.weight", "encoder_layers.encoder_layer4.1.conv2.weight", "conv_out.1.bias"):
