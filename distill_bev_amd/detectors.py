@@ -206,6 +206,63 @@ def _pick(lst, index):
     return lst[index] if len(lst) > 1 else lst[0]
 
 
+def install_fgd_modules(self, dp):
+    """The trainable pieces of the FGD recipe (bevdet_distill.py:178-357 == bevformer_distill.py:130-262): per feature
+    position one student adaptation + one teacher adaptation (+ the 3x3 spatial-attention conv), and the criteria."""
+    sc, tc = dp["student_channels"], dp["teacher_channels"]
+    n = len(sc)
+    assert n == len(tc)
+    dp["affinity_mode"] = _as_list(dp["affinity_mode"], n)
+    dp["fp_as_foreground"] = _as_list(dp["fp_as_foreground"], n)
+    dp["adaptation_type"] = _as_list(dp["adaptation_type"], n)
+    dp["teacher_adaptation_type"] = _as_list(dp["teacher_adaptation_type"], n)
+    sap = dp["student_adaptation_params"]
+    cwa, ta = [], []
+    for at, tat, s_c, t_c in zip(dp["adaptation_type"], dp["teacher_adaptation_type"], sc, tc):
+        if at == "1x1conv":
+            cwa.append(nn.Conv2d(s_c, t_c, kernel_size=1, stride=1, padding=0))
+        elif at == "3x3conv":
+            cwa.append(nn.Conv2d(s_c, t_c, kernel_size=3, stride=1, padding=1))
+        elif at == "identity":
+            cwa.append(nn.Identity())
+        elif at in ("2layer", "3layer"):
+            cls = TwoLayer if at == "2layer" else ThreeLayer
+            cwa.append(cls(in_features=s_c, out_features=t_c, kernel_size=sap["kernel_size"], stride=sap["stride"]))
+        elif at in ("upsample_2layer", "upsample_3layer"):
+            cls = TwoLayer if at == "upsample_2layer" else ThreeLayer
+            cwa.append(nn.Sequential(
+                UpsampleBilinearAC(sap["upsample_factor"]),     # == nn.Upsample(bilinear, align_corners=True)
+                cls(in_features=s_c, out_features=t_c, kernel_size=sap["kernel_size"], stride=sap["stride"])))
+        elif at == "upsample_1x1conv":
+            cwa.append(nn.Sequential(
+                UpsampleBilinearAC(sap["upsample_factor"]),
+                nn.Conv2d(s_c, t_c, kernel_size=1, stride=1, padding=0)))
+        else:
+            raise NotImplementedError(at)
+        if tat == "identity":
+            ta.append(nn.Identity())
+        elif tat == "avgpool":
+            ta.append(nn.AvgPool2d(**dp["teacher_adaptation_params"]))
+        elif tat == "maxpool":
+            ta.append(nn.MaxPool2d(**dp["teacher_adaptation_params"]))
+        else:
+            raise NotImplementedError(tat)
+    self.channel_wise_adaptations = nn.ModuleList(cwa)
+    self.teacher_adaptations = nn.ModuleList(ta)
+    if dp["spatial_mask"]:
+        self.spatial_wise_adaptations = nn.ModuleList(
+            [nn.Conv2d(1, 1, kernel_size=3, stride=1, padding=1) for _ in sc])
+    self.feat_criterion = build_loss(dp["feat_criterion"])
+    self.spatial_criterion = build_loss(dp["spatial_criterion"])
+    self.channel_criterion = build_loss(dp["channel_criterion"])
+    # the masked-MSE kernels ARE the feature criterion: only MSELoss(reduction='none', weight 1) is fused
+    fc = self.feat_criterion
+    assert type(fc).__name__ == "MSELoss" and fc.reduction == "none" and fc.loss_weight == 1.0, \
+        "feat_criterion must be dict(type='MSELoss', reduction='none'): the FGD feature terms run on the masked-MSE kernels"
+    assert getattr(self.spatial_criterion, "reduction", None) == "none", \
+        "spatial_criterion must use reduction='none' (fgd_distill_loss sums it, bevdet_distill.py:1275-1277)"
+
+
 @MODELS.register_module()
 class BEVDepth4DDistill(CenterPoint):
     """Camera student (BEVDepth4D, two frames) distilled from a LiDAR teacher with the FGD loss."""
@@ -250,58 +307,7 @@ class BEVDepth4DDistill(CenterPoint):
         assert distill_type == "fgd", "only the FGD recipe (the shipped distillation configs) is on the hot path"
         self.distill_type = distill_type
         dp = self.distill_params = distill_params
-        sc, tc = dp["student_channels"], dp["teacher_channels"]
-        n = len(sc)
-        assert n == len(tc)
-        dp["affinity_mode"] = _as_list(dp["affinity_mode"], n)
-        dp["fp_as_foreground"] = _as_list(dp["fp_as_foreground"], n)
-        dp["adaptation_type"] = _as_list(dp["adaptation_type"], n)
-        dp["teacher_adaptation_type"] = _as_list(dp["teacher_adaptation_type"], n)
-        sap = dp["student_adaptation_params"]
-        cwa, ta = [], []
-        for at, tat, s_c, t_c in zip(dp["adaptation_type"], dp["teacher_adaptation_type"], sc, tc):
-            if at == "1x1conv":
-                cwa.append(nn.Conv2d(s_c, t_c, kernel_size=1, stride=1, padding=0))
-            elif at == "3x3conv":
-                cwa.append(nn.Conv2d(s_c, t_c, kernel_size=3, stride=1, padding=1))
-            elif at == "identity":
-                cwa.append(nn.Identity())
-            elif at in ("2layer", "3layer"):
-                cls = TwoLayer if at == "2layer" else ThreeLayer
-                cwa.append(cls(in_features=s_c, out_features=t_c, kernel_size=sap["kernel_size"], stride=sap["stride"]))
-            elif at in ("upsample_2layer", "upsample_3layer"):
-                cls = TwoLayer if at == "upsample_2layer" else ThreeLayer
-                cwa.append(nn.Sequential(
-                    UpsampleBilinearAC(sap["upsample_factor"]),     # == nn.Upsample(bilinear, align_corners=True)
-                    cls(in_features=s_c, out_features=t_c, kernel_size=sap["kernel_size"], stride=sap["stride"])))
-            elif at == "upsample_1x1conv":
-                cwa.append(nn.Sequential(
-                    UpsampleBilinearAC(sap["upsample_factor"]),
-                    nn.Conv2d(s_c, t_c, kernel_size=1, stride=1, padding=0)))
-            else:
-                raise NotImplementedError(at)
-            if tat == "identity":
-                ta.append(nn.Identity())
-            elif tat == "avgpool":
-                ta.append(nn.AvgPool2d(**dp["teacher_adaptation_params"]))
-            elif tat == "maxpool":
-                ta.append(nn.MaxPool2d(**dp["teacher_adaptation_params"]))
-            else:
-                raise NotImplementedError(tat)
-        self.channel_wise_adaptations = nn.ModuleList(cwa)
-        self.teacher_adaptations = nn.ModuleList(ta)
-        if dp["spatial_mask"]:
-            self.spatial_wise_adaptations = nn.ModuleList(
-                [nn.Conv2d(1, 1, kernel_size=3, stride=1, padding=1) for _ in sc])
-        self.feat_criterion = build_loss(dp["feat_criterion"])
-        self.spatial_criterion = build_loss(dp["spatial_criterion"])
-        self.channel_criterion = build_loss(dp["channel_criterion"])
-        # the masked-MSE kernels ARE the feature criterion: only MSELoss(reduction='none', weight 1) is fused
-        fc = self.feat_criterion
-        assert type(fc).__name__ == "MSELoss" and fc.reduction == "none" and fc.loss_weight == 1.0, \
-            "feat_criterion must be dict(type='MSELoss', reduction='none'): the FGD feature terms run on the masked-MSE kernels"
-        assert getattr(self.spatial_criterion, "reduction", None) == "none", \
-            "spatial_criterion must use reduction='none' (fgd_distill_loss sums it, bevdet_distill.py:1275-1277)"
+        install_fgd_modules(self, dp)
         if self._self_ckpt is not None:                                              # :171-173 (after every module exists)
             load_checkpoint(self, self._self_ckpt, what="student", allow_missing=True)
         tcfg = self.pts_bbox_head.train_cfg

@@ -44,7 +44,10 @@ class ForegroundMaskRasterizer:
     """``foreground_scale_mask`` bound to one head train_cfg (grid_size / point_cloud_range /
     voxel_size, bevdet_distill.py:756-758).  Caches the per-resolution cell coordinates."""
 
-    def __init__(self, grid_size, point_cloud_range, voxel_size):
+    def __init__(self, grid_size, point_cloud_range, voxel_size, cell_center=False):
+        # cell_center: the BEVFormer variant (bevformer_distill.py:409-419) -- a fractional out_size_factor
+        # (grid 512 over 200 cells) and coordinates at the cell centres instead of the lower cell corners
+        self.cell_center = cell_center
         self.grid_size = torch.tensor(grid_size)
         self.pc_range = torch.tensor(point_cloud_range, dtype=torch.float32)
         self.voxel_size = torch.tensor(voxel_size, dtype=torch.float32)
@@ -54,11 +57,16 @@ class ForegroundMaskRasterizer:
         key = (H, W, str(dev))
         if key not in self._coords:
             assert int(self.grid_size[0]) == int(self.grid_size[1]) and H == W
-            assert int(self.grid_size[0]) % W == 0
-            osf = self.grid_size[0] // W
-            # same 0-dim float32 tensor arithmetic as bevdet_distill.py:766-767
-            xs = torch.stack([i * self.voxel_size[0] * osf + self.pc_range[0] for i in range(W)])
-            ys = torch.stack([i * self.voxel_size[1] * osf + self.pc_range[1] for i in range(H)])
+            if self.cell_center:
+                osf = self.grid_size[0] / W
+                xs = torch.stack([i * self.voxel_size[0] * osf + self.pc_range[0] + self.voxel_size[0] * osf / 2 for i in range(W)])
+                ys = torch.stack([i * self.voxel_size[1] * osf + self.pc_range[1] + self.voxel_size[1] * osf / 2 for i in range(H)])
+            else:
+                assert int(self.grid_size[0]) % W == 0
+                osf = self.grid_size[0] // W
+                # same 0-dim float32 tensor arithmetic as bevdet_distill.py:766-767
+                xs = torch.stack([i * self.voxel_size[0] * osf + self.pc_range[0] for i in range(W)])
+                ys = torch.stack([i * self.voxel_size[1] * osf + self.pc_range[1] for i in range(H)])
             area = self.voxel_size[0] * self.voxel_size[1] * osf * osf
             self._coords[key] = (xs.float().to(dev), ys.float().to(dev), area)
         return self._coords[key]

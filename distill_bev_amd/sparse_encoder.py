@@ -237,15 +237,20 @@ class HardSimpleVFE(nn.Module):
 @MODELS.register_module()
 class FPN(nn.Module):
     """mmdet==2.24.0 FPN (un-vendored; configured at mvpformer.py:60-67 with norm_cfg BN2d / act_cfg ReLU, 2 inputs -> 4
-    outputs): lateral 1x1 ConvModules, top-down nearest upsampling, 3x3 fpn ConvModules, extra levels by stride-2
-    max-pooling (add_extra_convs=False)."""
+    outputs, and as the BEVFormer image neck with add_extra_convs='on_output', 3 inputs -> 4 outputs): lateral 1x1
+    ConvModules, top-down nearest upsampling, 3x3 fpn ConvModules; extra levels by stride-2 max-pooling or by stride-2 3x3
+    convolutions on the input / lateral / output of the last level."""
 
     def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
                  relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None, act_cfg=None,
                  upsample_cfg=dict(mode="nearest"), init_cfg=None):
         super().__init__()
         from .registry import ConvModule
-        assert not add_extra_convs, "extra conv levels are not configured by the reference's teachers"
+        assert isinstance(add_extra_convs, (str, bool))
+        if add_extra_convs is True:
+            add_extra_convs = "on_input"
+        assert add_extra_convs in (False, "on_input", "on_lateral", "on_output")
+        self.add_extra_convs, self.relu_before_extra_convs = add_extra_convs, relu_before_extra_convs
         self.in_channels, self.out_channels, self.num_outs = in_channels, out_channels, num_outs
         self.start_level = start_level
         self.backbone_end_level = len(in_channels) if end_level == -1 else end_level
@@ -257,27 +262,47 @@ class FPN(nn.Module):
                                                  inplace=False))
             self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
                                              act_cfg=act_cfg, inplace=False))
+        extra = num_outs - self.backbone_end_level + self.start_level
+        if self.add_extra_convs and extra >= 1:
+            for i in range(extra):
+                cin = in_channels[self.backbone_end_level - 1] if (i == 0 and self.add_extra_convs == "on_input") else out_channels
+                self.fpn_convs.append(ConvModule(cin, out_channels, 3, stride=2, padding=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                                                 act_cfg=act_cfg, inplace=False))
+
+    def init_weights(self):
+        for m in self.modules():                 # init_cfg=dict(type='Xavier', layer='Conv2d', distribution='uniform')
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
 
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
         laterals = [l(inputs[i + self.start_level]) for i, l in enumerate(self.lateral_convs)]
-        for i in range(len(laterals) - 1, 0, -1):
+        used = len(laterals)
+        for i in range(used - 1, 0, -1):
             laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], **self.upsample_cfg)
-        outs = [self.fpn_convs[i](laterals[i]) for i in range(len(laterals))]
-        for _ in range(self.num_outs - len(outs)):
-            outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(used)]
+        if self.num_outs > len(outs):
+            if not self.add_extra_convs:
+                for _ in range(self.num_outs - used):
+                    outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+            else:
+                src = {"on_input": inputs[self.backbone_end_level - 1], "on_lateral": laterals[-1], "on_output": outs[-1]}
+                outs.append(self.fpn_convs[used](src[self.add_extra_convs]))
+                for i in range(used + 1, self.num_outs):
+                    outs.append(self.fpn_convs[i](F.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]))
         return tuple(outs)
 
 
 class _VoxelTeacher(nn.Module):
     """Shared part of LidarFormer (lidarformer.py:11-53) and MVPFormer (mvpformer.py:11-49): voxel encoder -> SparseEncoder ->
-    SECOND -> FPN.  Only the feature path the distillation reads is built (the DGCNN3D transformer head is inference /
-    teacher-training machinery outside the hot path)."""
+    SECOND -> FPN -> DGCNN3DHead (whose ``bev_embed`` the BEVFormer distillation reads)."""
 
     def __init__(self, pts_voxel_layer=None, pts_voxel_encoder=None, pts_middle_encoder=None, pts_backbone=None, pts_neck=None,
                  pts_bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None, **unused):
         super().__init__()
-        from .registry import build_backbone, build_neck
+        from .registry import build_backbone, build_head, build_neck
         from .voxel import Voxelization
         if pts_voxel_layer:
             self.pts_voxel_layer = Voxelization(**pts_voxel_layer)
@@ -285,7 +310,32 @@ class _VoxelTeacher(nn.Module):
         self.pts_middle_encoder = MODELS.build(pts_middle_encoder)
         self.pts_backbone = build_backbone(pts_backbone)
         self.pts_neck = build_neck(pts_neck) if pts_neck is not None else None
-        self.head_cfg = pts_bbox_head
+        if pts_bbox_head:                                    # mvx_two_stage.py:60-66
+            from . import detr_head  # noqa: F401
+            head = dict(pts_bbox_head)
+            head.update(train_cfg=train_cfg["pts"] if train_cfg else None, test_cfg=test_cfg["pts"] if test_cfg else None)
+            self.pts_bbox_head = build_head(head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    def init_weights(self):
+        head = getattr(self, "pts_bbox_head", None)
+        if head is not None:
+            head.init_weights()
+
+    def extract_feat(self, points, img=None, img_metas=None):
+        """mvpformer.py:51-55 -> (img_feats = None, pts_feats)"""
+        return None, self.extract_pts_feat(points, None, img_metas)
+
+    def forward_pts_train(self, pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas=None, gt_bboxes_ignore=None):
+        """mvpformer.py:57-81"""
+        return self.pts_bbox_head.loss(gt_bboxes_3d, gt_labels_3d, self.pts_bbox_head(pts_feats))
+
+    def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, **kwargs):
+        return dict(self.forward_pts_train(self.extract_feat(points, None, img_metas)[1], gt_bboxes_3d, gt_labels_3d, img_metas))
+
+    def simple_test_pts(self, x, img_metas, rescale=False):
+        """mvpformer.py:84-103 -> per sample (boxes, scores, labels)"""
+        return self.pts_bbox_head.get_bboxes(self.pts_bbox_head(x), img_metas, rescale=rescale)
 
     def _dense(self, voxel_features, coors, batch_size):
         x = self.pts_middle_encoder(voxel_features, coors, batch_size)

@@ -61,6 +61,20 @@ def lidar_points(n_points, rng, n_feats=5):
     return p
 
 
+def mvp_virtual_points(n_real, n_painted, n_virtual, rng):
+    """MVP multi-sweep cloud f32[n, 17] (configs/teacher_transformer/mvpformer.py:160-172, use_dim=range(17)): xyz + 14
+    attribute columns; column -2 marks the kind -- 1 real LiDAR return, 0 painted, -1 virtual (dynamic_voxel_encoder.py:19-34)."""
+    n = n_real + n_painted + n_virtual
+    p = rng.uniform(0.0, 1.0, (n, 17)).astype(np.float32)
+    p[:, 0] = rng.uniform(-54.0, 54.0, n)
+    p[:, 1] = rng.uniform(-54.0, 54.0, n)
+    p[:, 2] = rng.uniform(-5.5, 3.5, n)
+    p[:n_real, -2] = 1.0
+    p[n_real:n_real + n_painted, -2] = 0.0
+    p[n_real + n_painted:, -2] = -1.0
+    return p
+
+
 CLASS_DIMS = np.array([  # (w, l, h) class-typical sizes, nuScenes 10 classes
     [1.95, 4.60, 1.73], [2.50, 6.90, 2.80], [2.80, 6.40, 3.20], [2.95, 11.0, 3.50],
     [2.90, 12.3, 3.90], [2.50, 0.50, 1.00], [0.77, 2.10, 1.50], [0.60, 1.70, 1.30],

@@ -73,6 +73,8 @@ def synthetic_teacher_checkpoint(model_cfg, seed=0, directory=None):
         state = torch.random.get_rng_state()
         torch.manual_seed(1000 + seed)
         teacher = build_detector(tmodel)
+        if hasattr(teacher, "init_weights"):        # e.g. the level embeddings of the transformer heads are allocated uninitialised
+            teacher.init_weights()
         torch.random.set_rng_state(state)
         torch.save({"meta": {"note": "seeded random init (synthetic_teacher_checkpoint)", "seed": seed},
                     "state_dict": teacher.state_dict()}, out)
@@ -236,6 +238,31 @@ class GradReducer:
                         p.grad = g
 
 
+def param_groups(detector, opt):
+    """mmcv DefaultOptimizerConstructor for ``paramwise_cfg=dict(custom_keys={substring: dict(lr_mult=, decay_mult=)})`` (the
+    BEVFormer recipes train the image backbone at lr x 0.1): pops ``paramwise_cfg`` from ``opt`` and returns the optimizer's
+    parameter groups -- the longest matching key wins, as in mmcv."""
+    pw = opt.pop("paramwise_cfg", None) or {}
+    keys = sorted(pw.get("custom_keys", {}), key=lambda k: (-len(k), k))
+    named = [(n, p) for n, p in detector.named_parameters() if p.requires_grad]
+    if not keys:
+        return [p for _, p in named]
+    groups = {}
+    for n, p in named:
+        hit = next((k for k in keys if k in n), None)
+        groups.setdefault(hit, []).append(p)
+    out = []
+    for k, ps in groups.items():
+        g = dict(params=ps)
+        if k is not None:
+            c = pw["custom_keys"][k]
+            g["lr"] = opt["lr"] * c.get("lr_mult", 1.0)
+            if opt.get("weight_decay") is not None:
+                g["weight_decay"] = opt["weight_decay"] * c.get("decay_mult", 1.0)
+        out.append(g)
+    return out
+
+
 class Trainer:
     def __init__(self, model, cfg, device, world_size=1, channels_last=False):
         self.device = device
@@ -269,7 +296,7 @@ class Trainer:
         opt = dict(cfg.get("optimizer", dict(type="AdamW", lr=2e-4, weight_decay=0.01)))
         assert opt.pop("type") == "AdamW"
         params = [p for p in self.detector.parameters() if p.requires_grad]
-        self.optimizer = torch.optim.AdamW(params, **opt, fused=(device.type == "cuda"))
+        self.optimizer = torch.optim.AdamW(param_groups(self.detector, opt), **opt, fused=(device.type == "cuda"))
         oc = cfg.get("optimizer_config", {}) or {}
         gc = oc.get("grad_clip", None)
         self.grad_clip = dict(gc) if gc else None

@@ -436,3 +436,464 @@ def bare(cls, **attrs):
     for k, v in attrs.items():
         object.__setattr__(obj, k, v) if not isinstance(v, nn.Module) else nn.Module.__setattr__(obj, k, v)
     return obj
+
+
+# =====================================================================================
+# BEVFormer / set-prediction family (transformer_modules/*.py, dense_heads/bevformer_head.py, dgcnn3d_head.py,
+# core/bbox/{util,coders/nms_free_coder,assigners/hungarian_assigner_3d,match_costs/match_cost}.py, utils/grid_mask.py,
+# detectors/bevformer_distill.py).  The un-vendored bricks those files sit on (mmcv 1.x FFN / MultiheadAttention /
+# TransformerLayerSequence / registries, mmdet 2.24 DETRHead constructor / FocalLoss / FocalLossCost / PseudoSampler /
+# positional encodings, torchvision rotate) are restated below from their published definitions; wherever the reference
+# carries its own copy of a brick it is used instead of a restatement (mmcv BaseTransformerLayer <- the reference's
+# MyCustomBaseTransformerLayer, mmcv MultiScaleDeformableAttention <- the reference's CustomMSDeformableAttention,
+# multi_scale_deformable_attn_pytorch <- oracle/msda.py's grid_sample form).
+# =====================================================================================
+import copy as _copy  # noqa: E402
+import math as _math  # noqa: E402
+
+
+class _RealRegistry:
+    def __init__(self, name):
+        self.name, self.table = name, {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.table[name or cls.__name__] = cls
+            return cls
+        return deco(module) if module is not None else deco
+
+    def get(self, key):
+        return self.table.get(key)
+
+    def build(self, cfg, default_args=None):
+        cfg = dict(cfg)
+        for k, v in (default_args or {}).items():
+            cfg.setdefault(k, v)
+        typ = cfg.pop("type")
+        cls = typ if isinstance(typ, type) else self.table[typ]
+        return cls(**cfg)
+
+
+class _ConfigDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _install_transformer_stubs():
+    install_full_stubs()
+    mmcv = sys.modules["mmcv"]
+    if getattr(mmcv, "_dbev_tf", False):
+        return
+    mmcv._dbev_tf = True
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import msda as OM
+
+    R = {k: _RealRegistry(k) for k in ("ATTENTION", "FEEDFORWARD_NETWORK", "POSITIONAL_ENCODING", "TRANSFORMER_LAYER",
+                                       "TRANSFORMER_LAYER_SEQUENCE", "TRANSFORMER", "HEADS", "BBOX_CODERS", "BBOX_ASSIGNERS",
+                                       "MATCH_COST", "LOSSES", "DETECTORS")}
+
+    def xavier_init(module, gain=1, bias=0, distribution="normal"):
+        if hasattr(module, "weight") and module.weight is not None:
+            (nn.init.xavier_uniform_ if distribution == "uniform" else nn.init.xavier_normal_)(module.weight, gain=gain)
+        if hasattr(module, "bias") and module.bias is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def constant_init(module, val, bias=0):
+        if hasattr(module, "weight") and module.weight is not None:
+            nn.init.constant_(module.weight, val)
+        if hasattr(module, "bias") and module.bias is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def build_norm_layer(cfg, n, postfix=""):
+        t = cfg.get("type", "BN")
+        if t == "LN":
+            return "ln", nn.LayerNorm(n)
+        kw = {k: v for k, v in cfg.items() if k in ("eps", "momentum")}
+        return "bn", (nn.BatchNorm1d if t == "BN1d" else nn.BatchNorm2d)(n, **kw)
+
+    cnn = sys.modules["mmcv.cnn"]
+    cnn.xavier_init, cnn.constant_init, cnn.Linear, cnn.build_norm_layer = xavier_init, constant_init, nn.Linear, build_norm_layer
+    cnn.bias_init_with_prob = lambda p: float(-np.log((1 - p) / p))
+    mmcv.ConfigDict = _ConfigDict
+    mmcv.deprecated_api_warning = _identity_decorator_factory
+    runner = sys.modules["mmcv.runner"]
+    bm = _mod("mmcv.runner.base_module", BaseModule=runner.BaseModule, ModuleList=nn.ModuleList, Sequential=nn.Sequential)
+    runner.base_module = bm
+    _mod("mmcv.utils", ConfigDict=_ConfigDict, build_from_cfg=lambda cfg, reg, default_args=None: reg.build(cfg, default_args),
+         deprecated_api_warning=_identity_decorator_factory, to_2tuple=lambda v: (v, v), TORCH_VERSION=torch.__version__,
+         digit_version=lambda v: tuple(int(x) for x in str(v).split("+")[0].split(".")[:2]),
+         ext_loader=types.SimpleNamespace(load_ext=lambda *a, **k: None))
+    bricks = _mod("mmcv.cnn.bricks"); bricks.__path__ = []
+    _mod("mmcv.cnn.bricks.registry", ATTENTION=R["ATTENTION"], FEEDFORWARD_NETWORK=R["FEEDFORWARD_NETWORK"],
+         POSITIONAL_ENCODING=R["POSITIONAL_ENCODING"], TRANSFORMER_LAYER=R["TRANSFORMER_LAYER"],
+         TRANSFORMER_LAYER_SEQUENCE=R["TRANSFORMER_LAYER_SEQUENCE"])
+
+    # ---- mmcv.cnn.bricks.transformer --------------------------------------------------------------------------------
+    class FFN(runner.BaseModule):
+        def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type="ReLU", inplace=True),
+                     ffn_drop=0.0, dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+            super().__init__(init_cfg)
+            layers, in_channels = [], embed_dims
+            for _ in range(num_fcs - 1):
+                layers.append(nn.Sequential(nn.Linear(in_channels, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)))
+                in_channels = feedforward_channels
+            layers.append(nn.Linear(feedforward_channels, embed_dims))
+            layers.append(nn.Dropout(ffn_drop))
+            self.layers = nn.Sequential(*layers)
+            self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
+            self.add_identity = add_identity
+
+        def forward(self, x, identity=None):
+            out = self.layers(x)
+            if not self.add_identity:
+                return self.dropout_layer(out)
+            if identity is None:
+                identity = x
+            return identity + self.dropout_layer(out)
+
+    R["FEEDFORWARD_NETWORK"].register_module(module=FFN)
+
+    class MultiheadAttention(runner.BaseModule):
+        def __init__(self, embed_dims, num_heads, attn_drop=0.0, proj_drop=0.0, dropout_layer=dict(type="Dropout", drop_prob=0.0),
+                     init_cfg=None, batch_first=False, **kwargs):
+            super().__init__(init_cfg)
+            if "dropout" in kwargs:
+                attn_drop = kwargs["dropout"]
+                dropout_layer["drop_prob"] = kwargs.pop("dropout")
+            self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
+            self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop, **kwargs)
+            self.proj_drop = nn.Dropout(proj_drop)
+            self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
+
+        def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                    key_padding_mask=None, **kwargs):
+            if key is None:
+                key = query
+            if value is None:
+                value = key
+            if identity is None:
+                identity = query
+            if key_pos is None:
+                if query_pos is not None and query_pos.shape == key.shape:
+                    key_pos = query_pos
+            if query_pos is not None:
+                query = query + query_pos
+            if key_pos is not None:
+                key = key + key_pos
+            if self.batch_first:
+                query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+            out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask, key_padding_mask=key_padding_mask)[0]
+            if self.batch_first:
+                out = out.transpose(0, 1)
+            return identity + self.dropout_layer(self.proj_drop(out))
+
+    R["ATTENTION"].register_module(module=MultiheadAttention)
+
+    class TransformerLayerSequence(runner.BaseModule):
+        def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+            super().__init__(init_cfg)
+            if isinstance(transformerlayers, dict):
+                transformerlayers = [_copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+            self.num_layers = num_layers
+            self.layers = nn.ModuleList([R["TRANSFORMER_LAYER"].build(c) for c in transformerlayers])
+            self.embed_dims = self.layers[0].embed_dims
+            self.pre_norm = self.layers[0].pre_norm
+
+        def forward(self, query, key, value, query_pos=None, key_pos=None, attn_masks=None, query_key_padding_mask=None,
+                    key_padding_mask=None, **kwargs):
+            for layer in self.layers:
+                query = layer(query, key, value, query_pos=query_pos, key_pos=key_pos, attn_masks=attn_masks,
+                              query_key_padding_mask=query_key_padding_mask, key_padding_mask=key_padding_mask, **kwargs)
+            return query
+
+    tf = _mod("mmcv.cnn.bricks.transformer", FFN=FFN, MultiheadAttention=MultiheadAttention,
+              TransformerLayerSequence=TransformerLayerSequence,
+              build_attention=lambda cfg, default_args=None: R["ATTENTION"].build(cfg, default_args),
+              build_feedforward_network=lambda cfg, default_args=None: R["FEEDFORWARD_NETWORK"].build(cfg, default_args),
+              build_positional_encoding=lambda cfg, default_args=None: R["POSITIONAL_ENCODING"].build(cfg, default_args),
+              build_transformer_layer=lambda cfg, default_args=None: R["TRANSFORMER_LAYER"].build(cfg, default_args),
+              build_transformer_layer_sequence=lambda cfg, default_args=None: R["TRANSFORMER_LAYER_SEQUENCE"].build(cfg, default_args))
+    mops = _mod("mmcv.ops"); mops.__path__ = []
+
+    def multi_scale_deformable_attn_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
+        return OM.msda_grid_sample(value, [(int(h), int(w)) for h, w in value_spatial_shapes.tolist()], sampling_locations,
+                                   attention_weights)
+
+    msd = _mod("mmcv.ops.multi_scale_deform_attn", multi_scale_deformable_attn_pytorch=multi_scale_deformable_attn_pytorch)
+
+    # torchvision.transforms.functional.rotate for tensors (nearest, no expand, fill 0): published algorithm of
+    # torchvision/transforms/{functional,_functional_tensor}.py (0.9 - 0.15) -- un-vendored, NOT importable here
+    def rotate(img, angle, interpolation=None, expand=False, center=None, fill=None):
+        h, w = img.shape[-2], img.shape[-1]
+        center_f = [0.0, 0.0]
+        if center is not None:
+            center_f = [1.0 * (c - s * 0.5) for c, s in zip(center, [w, h])]
+        rot = _math.radians(-angle)
+        cx, cy = center_f
+        a, b, c, d = _math.cos(rot), -_math.sin(rot), _math.sin(rot), _math.cos(rot)
+        matrix = [d, -b, 0.0, -c, a, 0.0]
+        matrix[2] += matrix[0] * (-cx) + matrix[1] * (-cy)
+        matrix[5] += matrix[3] * (-cx) + matrix[4] * (-cy)
+        matrix[2] += cx
+        matrix[5] += cy
+        theta = torch.tensor(matrix, dtype=img.dtype).reshape(1, 2, 3)
+        base_grid = torch.empty(1, h, w, 3, dtype=img.dtype)
+        base_grid[..., 0].copy_(torch.linspace(-w * 0.5 + 0.5, w * 0.5 + 0.5 - 1, steps=w))
+        base_grid[..., 1].copy_(torch.linspace(-h * 0.5 + 0.5, h * 0.5 + 0.5 - 1, steps=h).unsqueeze_(-1))
+        base_grid[..., 2].fill_(1)
+        rescaled_theta = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=img.dtype)
+        grid = base_grid.view(1, h * w, 3).bmm(rescaled_theta).view(1, h, w, 2)
+        return F.grid_sample(img.unsqueeze(0), grid, mode="nearest", padding_mode="zeros", align_corners=False).squeeze(0)
+
+    tv = _mod("torchvision"); tv.__path__ = []
+    tvt = _mod("torchvision.transforms"); tvt.__path__ = []
+    _mod("torchvision.transforms.functional", rotate=rotate)
+    _mod("matplotlib").__path__ = []
+    _mod("matplotlib.pyplot")
+
+    # ---- mmdet pieces -----------------------------------------------------------------------------------------------
+    mu = _mod("mmdet.models.utils"); mu.__path__ = []
+    _mod("mmdet.models.utils.builder", TRANSFORMER=R["TRANSFORMER"])
+
+    def inverse_sigmoid(x, eps=1e-5):
+        x = x.clamp(min=0, max=1)
+        return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+    _mod("mmdet.models.utils.transformer", inverse_sigmoid=inverse_sigmoid)
+
+    class Transformer(runner.BaseModule):
+        def __init__(self, encoder=None, decoder=None, init_cfg=None):
+            super().__init__(init_cfg)
+            self.encoder = R["TRANSFORMER_LAYER_SEQUENCE"].build(encoder)
+            self.decoder = R["TRANSFORMER_LAYER_SEQUENCE"].build(decoder)
+            self.embed_dims = self.encoder.embed_dims
+
+    mu.Transformer = Transformer
+
+    class SinePositionalEncoding(runner.BaseModule):
+        def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * _math.pi, eps=1e-6, offset=0.0, init_cfg=None):
+            super().__init__(init_cfg)
+            self.num_feats, self.temperature, self.normalize, self.scale, self.eps, self.offset = \
+                num_feats, temperature, normalize, scale, eps, offset
+
+        def forward(self, mask):
+            mask = mask.to(torch.int)
+            not_mask = 1 - mask
+            y_embed = not_mask.cumsum(1, dtype=torch.float32)
+            x_embed = not_mask.cumsum(2, dtype=torch.float32)
+            if self.normalize:
+                y_embed = (y_embed + self.offset) / (y_embed[:, -1:, :] + self.eps) * self.scale
+                x_embed = (x_embed + self.offset) / (x_embed[:, :, -1:] + self.eps) * self.scale
+            dim_t = torch.arange(self.num_feats, dtype=torch.float32, device=mask.device)
+            dim_t = self.temperature ** (2 * (dim_t // 2) / self.num_feats)
+            pos_x = x_embed[:, :, :, None] / dim_t
+            pos_y = y_embed[:, :, :, None] / dim_t
+            B, H, W = mask.size()
+            pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
+            pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
+            return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+    class LearnedPositionalEncoding(runner.BaseModule):
+        def __init__(self, num_feats, row_num_embed=50, col_num_embed=50, init_cfg=None):
+            super().__init__(init_cfg)
+            self.row_embed = nn.Embedding(row_num_embed, num_feats)
+            self.col_embed = nn.Embedding(col_num_embed, num_feats)
+
+        def forward(self, mask):
+            h, w = mask.shape[-2:]
+            x = torch.arange(w, device=mask.device)
+            y = torch.arange(h, device=mask.device)
+            x_embed, y_embed = self.col_embed(x), self.row_embed(y)
+            pos = torch.cat((x_embed.unsqueeze(0).repeat(h, 1, 1), y_embed.unsqueeze(1).repeat(1, w, 1)), dim=-1)
+            return pos.permute(2, 0, 1).unsqueeze(0).repeat(mask.shape[0], 1, 1, 1)
+
+    R["POSITIONAL_ENCODING"].register_module(module=SinePositionalEncoding)
+    R["POSITIONAL_ENCODING"].register_module(module=LearnedPositionalEncoding)
+
+    class FocalLoss(nn.Module):
+        """mmdet FocalLoss(use_sigmoid=True) in its pure-PyTorch form (py_sigmoid_focal_loss)"""
+
+        def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean", loss_weight=1.0, activated=False):
+            super().__init__()
+            self.use_sigmoid, self.gamma, self.alpha, self.reduction, self.loss_weight = use_sigmoid, gamma, alpha, reduction, loss_weight
+
+        def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+            num_classes = pred.size(1)
+            target = F.one_hot(target, num_classes=num_classes + 1)[:, :num_classes]
+            pred_sigmoid = pred.sigmoid()
+            target = target.type_as(pred)
+            pt = (1 - pred_sigmoid) * target + pred_sigmoid * (1 - target)
+            focal_weight = (self.alpha * target + (1 - self.alpha) * (1 - target)) * pt.pow(self.gamma)
+            loss = F.binary_cross_entropy_with_logits(pred, target, reduction="none") * focal_weight
+            if weight is not None and weight.shape != loss.shape:
+                weight = weight.view(-1, 1) if weight.size(0) == loss.size(0) else weight.view(loss.size(0), -1)
+            return self.loss_weight * _weight_reduce_loss(loss, weight, reduction_override or self.reduction, avg_factor)
+
+    _LOSSES["FocalLoss"] = FocalLoss
+    _LOSSES["GIoULoss"] = type("GIoULoss", (_MmdetLoss,), {"__init__": lambda self, eps=1e-6, reduction="mean", loss_weight=1.0:
+                                                           _MmdetLoss.__init__(self, reduction, loss_weight)})
+
+    class FocalLossCost:
+        def __init__(self, weight=1.0, alpha=0.25, gamma=2, eps=1e-12, binary_input=False):
+            self.weight, self.alpha, self.gamma, self.eps = weight, alpha, gamma, eps
+
+        def __call__(self, cls_pred, gt_labels):
+            cls_pred = cls_pred.sigmoid()
+            neg_cost = -(1 - cls_pred + self.eps).log() * (1 - self.alpha) * cls_pred.pow(self.gamma)
+            pos_cost = -(cls_pred + self.eps).log() * self.alpha * (1 - cls_pred).pow(self.gamma)
+            return (pos_cost[:, gt_labels] - neg_cost[:, gt_labels]) * self.weight
+
+    R["MATCH_COST"].register_module(module=FocalLossCost)
+    R["MATCH_COST"].register_module(name="IoUCost", module=type("IoUCost", (), {"__init__": lambda self, iou_mode="giou", weight=1.0: None}))
+
+    class AssignResult:
+        def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+            self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+    class PseudoSampler:
+        def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
+            r = types.SimpleNamespace()
+            r.pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+            r.neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+            r.pos_assigned_gt_inds = assign_result.gt_inds[r.pos_inds] - 1
+            r.pos_gt_bboxes = gt_bboxes[r.pos_assigned_gt_inds.long(), :]
+            return r
+
+    mcore = sys.modules["mmdet.core"]
+    mcore.__path__ = []
+    mcore.reduce_mean = lambda t: t
+    mb = _mod("mmdet.core.bbox", BaseBBoxCoder=object); mb.__path__ = []
+    _mod("mmdet.core.bbox.builder", BBOX_CODERS=R["BBOX_CODERS"], BBOX_ASSIGNERS=R["BBOX_ASSIGNERS"])
+    _mod("mmdet.core.bbox.assigners", AssignResult=AssignResult, BaseAssigner=object)
+    mc = _mod("mmdet.core.bbox.match_costs", build_match_cost=lambda cfg: R["MATCH_COST"].build(cfg)); mc.__path__ = []
+    _mod("mmdet.core.bbox.match_costs.builder", MATCH_COST=R["MATCH_COST"])
+
+    class DETRHead(runner.BaseModule):
+        """mmdet 2.24 DETRHead.__init__ (AnchorFreeHead's constructor is bypassed there as well)"""
+
+        def __init__(self, num_classes, in_channels, num_query=100, num_reg_fcs=2, transformer=None, sync_cls_avg_factor=False,
+                     positional_encoding=None, loss_cls=None, loss_bbox=None, loss_iou=None, train_cfg=None, test_cfg=None,
+                     init_cfg=None, **kwargs):
+            super().__init__(init_cfg)
+            self.bg_cls_weight = 0
+            self.sync_cls_avg_factor = sync_cls_avg_factor
+            if train_cfg:
+                assigner = train_cfg["assigner"]
+                assert loss_cls["loss_weight"] == assigner["cls_cost"]["weight"]
+                assert loss_bbox["loss_weight"] == assigner["reg_cost"]["weight"]
+                assert loss_iou["loss_weight"] == assigner["iou_cost"]["weight"]
+                self.assigner = R["BBOX_ASSIGNERS"].build(assigner)
+                self.sampler = PseudoSampler()
+            self.num_query, self.num_classes, self.in_channels, self.num_reg_fcs = num_query, num_classes, in_channels, num_reg_fcs
+            self.train_cfg, self.test_cfg, self.fp16_enabled = train_cfg, test_cfg, False
+            self.loss_cls, self.loss_bbox, self.loss_iou = build_loss(loss_cls), build_loss(loss_bbox), build_loss(loss_iou)
+            self.cls_out_channels = num_classes if self.loss_cls.use_sigmoid else num_classes + 1
+            self.act_cfg = transformer.get("act_cfg", dict(type="ReLU", inplace=True))
+            self.activate = nn.ReLU(inplace=True)
+            self.positional_encoding = R["POSITIONAL_ENCODING"].build(positional_encoding)
+            self.transformer = R["TRANSFORMER"].build(transformer)
+            self.embed_dims = self.transformer.embed_dims
+            assert positional_encoding["num_feats"] * 2 == self.embed_dims
+            self._init_layers()
+
+    sys.modules["mmdet.models"].HEADS = R["HEADS"]
+    sys.modules["mmdet.models"].DETECTORS = R["DETECTORS"]
+    _mod("mmdet.models.dense_heads", DETRHead=DETRHead)
+
+    # ---- the reference's own files ----------------------------------------------------------------------------------
+    util = load("mmdet3d/core/bbox/util.py", "mmdet3d.core.bbox.util")
+    sys.modules["mmdet3d.core.bbox"].__path__ = []
+    sys.modules["mmdet3d.core.bbox"].util = util
+    load("mmdet3d/core/bbox/match_costs/match_cost.py", "refpkg_match_cost")
+    load("mmdet3d/core/bbox/assigners/hungarian_assigner_3d.py", "refpkg_hungarian")
+    load("mmdet3d/core/bbox/coders/nms_free_coder.py", "refpkg_nms_free_coder")
+    _mod("mmdet3d.core.bbox.coders", build_bbox_coder=lambda cfg: R["BBOX_CODERS"].build(cfg))
+    tm = _mod("refpkg.models.transformer_modules"); tm.__path__ = []
+    load("mmdet3d/models/transformer_modules/multi_scale_deformable_attn_function.py",
+         "refpkg.models.transformer_modules.multi_scale_deformable_attn_function")
+    cb = load("mmdet3d/models/transformer_modules/custom_base_transformer_layer.py",
+              "refpkg.models.transformer_modules.custom_base_transformer_layer")
+
+    class BaseTransformerLayer(cb.MyCustomBaseTransformerLayer):          # mmcv's class == the reference's copy, batch_first=False
+        def __init__(self, *a, batch_first=False, **k):
+            super().__init__(*a, batch_first=batch_first, **k)
+
+    R["TRANSFORMER_LAYER"].register_module(module=BaseTransformerLayer)
+
+    class DetrTransformerDecoderLayer(BaseTransformerLayer):
+        def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                     act_cfg=dict(type="ReLU", inplace=True), norm_cfg=dict(type="LN"), ffn_num_fcs=2, **kwargs):
+            super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels, ffn_dropout=ffn_dropout,
+                             operation_order=operation_order, norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
+
+    R["TRANSFORMER_LAYER"].register_module(module=DetrTransformerDecoderLayer)
+
+    class DetrTransformerEncoder(TransformerLayerSequence):
+        def __init__(self, *args, post_norm_cfg=dict(type="LN"), **kwargs):
+            super().__init__(*args, **kwargs)
+            self.post_norm = nn.LayerNorm(self.embed_dims) if (post_norm_cfg is not None and self.pre_norm) else None
+
+        def forward(self, *args, **kwargs):
+            x = super().forward(*args, **kwargs)
+            return self.post_norm(x) if self.post_norm is not None else x
+
+    R["TRANSFORMER_LAYER_SEQUENCE"].register_module(module=DetrTransformerEncoder)
+    tf.BaseTransformerLayer = BaseTransformerLayer
+    for f in ("temporal_self_attention", "spatial_cross_attention", "decoder", "encoder"):
+        load(f"mmdet3d/models/transformer_modules/{f}.py", f"refpkg.models.transformer_modules.{f}")
+    dec = sys.modules["refpkg.models.transformer_modules.decoder"]
+    msd.MultiScaleDeformableAttention = type("MultiScaleDeformableAttention", (dec.CustomMSDeformableAttention,), {})
+    R["ATTENTION"].register_module(module=msd.MultiScaleDeformableAttention)
+    load("mmdet3d/models/transformer_modules/perception_transformer.py", "refpkg.models.transformer_modules.perception_transformer")
+    load("mmdet3d/models/transformer_modules/detr_transformer.py", "refpkg.models.transformer_modules.detr_transformer")
+    mcore.multi_apply = multi_apply
+    sys.modules["mmdet3d.core"].bbox3d2result = None
+    load("mmdet3d/models/dense_heads/bevformer_head.py", "refpkg.models.dense_heads.bevformer_head")
+    load("mmdet3d/models/dense_heads/dgcnn3d_head.py", "refpkg.models.dense_heads.dgcnn3d_head")
+    mmcv._dbev_R = R
+
+
+def transformer_registries():
+    """-> dict of the live stub registries (HEADS builds BEVFormerHead / DGCNN3DHead from the reference's files)"""
+    _install_transformer_stubs()
+    return sys.modules["mmcv"]._dbev_R
+
+
+def grid_mask():
+    install_full_stubs()
+
+    class _Img:                       # PIL.Image.fromarray(a).rotate(0) round trip (GridMask is built with rotate=1 -> r == 0)
+        def __init__(self, a):
+            self.a = a
+
+        def rotate(self, r):
+            assert r == 0
+            return self
+
+        def __array__(self, dtype=None, copy=None):
+            return self.a if dtype is None else self.a.astype(dtype)
+
+    sys.modules["PIL.Image"].fromarray = _Img
+    return load("mmdet3d/models/utils/grid_mask.py", "refpkg_grid_mask")
+
+
+def bevformer_distill():
+    """detectors/bevformer_distill.py on class shells for its sibling detectors (the fixture calls foreground_scale_mask and
+    fgd_distill_loss on a bare instance; nothing of BEVFormer / the teachers is executed)."""
+    _install_transformer_stubs()
+    core = sys.modules["mmdet3d.core"]
+    for n in ("Box3DMode", "Coord3DMode", "bbox3d2result", "merge_aug_bboxes_3d", "show_result"):
+        setattr(core, n, None)
+    shell = type("Shell", (nn.Module,), {})
+    _mod("refpkg.models.detectors.bevformer", BEVFormer=type("BEVFormer", (shell,), {}))
+    _mod("refpkg.models.detectors.lidarformer", LidarFormer=type("LidarFormer", (shell,), {}))
+    _mod("refpkg.models.detectors.mvpformer", MVPFormer=type("MVPFormer", (shell,), {}))
+    if "torch.utils.tensorboard" not in sys.modules:
+        _mod("torch.utils.tensorboard", SummaryWriter=lambda *a, **k: None)
+    return load("mmdet3d/models/detectors/bevformer_distill.py", "refpkg.models.detectors.bevformer_distill")

@@ -28,7 +28,8 @@ from distill_bev_amd import synthetic as syn  # noqa: E402
 def _save(name, **arrs):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrs)
-    print("wrote", path, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+    shapes = {k: getattr(v, "shape", None) for k, v in arrs.items() if "__" not in k}
+    print("wrote", path, shapes, f"+ {len(arrs) - len(shapes)} state-dict / prefixed arrays")
 
 
 # --------------------------------------------------------------------------
@@ -630,9 +631,181 @@ def make_second():
     print([tuple(f.shape) for f in feats], tuple(y[0].shape))
 
 
+# --------------------------------------------------------------------------
+# BEVFormer student head / teacher head (configs[4]) -- small instances of the SAME config dicts the reference ships
+# (configs/lidar2camera_bev_distillation/teacher_to_bevformer/*.py, configs/teacher_transformer/mvpformer.py), built by the
+# reference's own head / transformer / attention / coder / assigner files on the stubs of _ref_import.py.
+from bevformer_cfgs import PCR, small_bevformer_head_cfg, small_dgcnn_head_cfg  # noqa: E402
+
+
+def _randomize(module, gen, scale=0.15):
+    """every parameter away from its init (zero attention weights / offset weights would hide index mistakes); the offset
+    prior of the deformable attentions is kept and perturbed"""
+    for name, p in module.named_parameters():
+        if name.endswith("sampling_offsets.bias"):
+            p.data += torch.randn(p.shape, generator=gen) * 0.3
+        elif name.endswith("code_weights"):
+            continue
+        elif p.dim() == 1 and ("norm" in name or name.split(".")[-2].isdigit() and "LayerNorm" in type(module.get_submodule(name.rsplit(".", 1)[0])).__name__):
+            p.data = (1.0 if name.endswith("weight") else 0.0) + torch.randn(p.shape, generator=gen) * 0.1
+        else:
+            p.data = torch.randn(p.shape, generator=gen) * scale
+
+
+def small_camera_metas(bs, cams, img_hw, rng, with_prev=True):
+    """img_metas of one frame: can_bus [18], lidar2img per camera (pinhole rig looking outwards), img_shape"""
+    H, W = img_hw
+    metas = []
+    for b in range(bs):
+        l2i = []
+        for n in range(cams):
+            yaw = 2 * np.pi * n / cams + rng.uniform(-0.1, 0.1)
+            c, s = np.cos(yaw), np.sin(yaw)
+            Rz = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+            R_c2l = Rz @ np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+            t = np.array([1.0, 0.0, 1.5]) + rng.uniform(-0.2, 0.2, 3)
+            ext = np.eye(4); ext[:3, :3] = R_c2l.T; ext[:3, 3] = -R_c2l.T @ t
+            K = np.eye(4); K[0, 0] = K[1, 1] = 0.6 * W; K[0, 2] = W / 2; K[1, 2] = H / 2
+            l2i.append(K @ ext)
+        can_bus = rng.normal(0, 0.1, 18)
+        can_bus[:3] = [rng.uniform(0.5, 3.0), rng.uniform(-0.5, 0.5), 0.0]
+        can_bus[-2] = rng.uniform(-0.3, 0.3)
+        can_bus[-1] = rng.uniform(-25.0, 25.0)
+        metas.append(dict(can_bus=can_bus, lidar2img=l2i, img_shape=[(H, W, 3)] * cams, prev_bev_exists=with_prev))
+    return metas
+
+
+def _gt(bs, rng, n=(5, 0, 7)):
+    boxes, labels = [], []
+    for b in range(bs):
+        bx, lb = syn.gt_boxes(n[b % len(n)], rng)
+        boxes.append(bx); labels.append(lb)
+    return boxes, labels
+
+
+def _flat_losses(prefix, d):
+    return {prefix + k.replace(".", "_"): np.float64(v.item()) for k, v in d.items()}
+
+
+def make_bevformer():
+    regs = R.transformer_registries()
+    rng = np.random.default_rng(31)
+    g = torch.Generator().manual_seed(31)
+    dim, bev, levels, cams, bs = 32, 10, 2, 3, 2
+    img_hw = (48, 80)
+    head = regs["HEADS"].build(small_bevformer_head_cfg(dim, bev, levels, cams))
+    head.init_weights()
+    _randomize(head, g)
+    head.eval()
+    feats = [torch.randn((bs, cams, dim, 6, 10), generator=g), torch.randn((bs, cams, dim, 3, 5), generator=g)]
+    metas = small_camera_metas(bs, cams, img_hw, rng)
+    prev_bev = torch.randn((bs, bev * bev, dim), generator=g) * 0.5
+    boxes, labels = _gt(bs, rng)
+    gtb = [R.LiDARBoxesStub(b) for b in boxes]
+    gtl = [torch.from_numpy(l) for l in labels]
+    out = {}
+    with torch.no_grad():
+        bev0 = head(feats, metas, None, only_bev=True)                       # first frame: no history
+        outs = head(feats, metas, prev_bev.clone())
+        losses = head.loss(gtb, gtl, outs, img_metas=metas)
+        dec = head.get_bboxes({k: (v.clone() if torch.is_tensor(v) else v) for k, v in outs.items()},
+                              [dict(box_type_3d=lambda t, d: t) for _ in range(bs)])
+    # encoder internals (the pieces of point_sampling a wrong axis order would silently permute)
+    enc = head.transformer.encoder
+    ref3d = enc.get_reference_points(bev, bev, PCR[5] - PCR[2], 4, dim="3d", bs=bs, device="cpu", dtype=torch.float32)
+    rpc, bmask = enc.point_sampling(ref3d, PCR, metas)
+    out.update(feat0=feats[0].numpy(), feat1=feats[1].numpy(), prev_bev=prev_bev.numpy(),
+               can_bus=np.stack([m["can_bus"] for m in metas]), lidar2img=np.stack([np.stack(m["lidar2img"]) for m in metas]),
+               img_hw=np.array(img_hw), bev_first=bev0.numpy(), bev_embed=outs["bev_embed"].numpy(),
+               all_cls_scores=outs["all_cls_scores"].numpy(), all_bbox_preds=outs["all_bbox_preds"].numpy(), hs=outs["hs"].numpy(),
+               ref_3d=ref3d.numpy(), reference_points_cam=rpc.numpy(), bev_mask=bmask.numpy(),
+               **{f"gt_boxes{b}": boxes[b] for b in range(bs)}, **{f"gt_labels{b}": labels[b] for b in range(bs)},
+               **{f"dec_boxes{b}": dec[b][0].numpy() for b in range(bs)}, **{f"dec_scores{b}": dec[b][1].numpy() for b in range(bs)},
+               **{f"dec_labels{b}": dec[b][2].numpy() for b in range(bs)}, **_flat_losses("loss__", losses), **_sd("head__", head))
+    _save("bevformer_head.npz", **out)
+    print({k: float(v) for k, v in losses.items()})
+    print("visible queries per camera (sample 0):", bmask[:, 0].any(-1).sum(-1).tolist())
+
+    # ---- teacher head: DGCNN3DHead on a 3-level BEV pyramid -----------------------------------------------------------
+    g = torch.Generator().manual_seed(32)
+    th = regs["HEADS"].build(small_dgcnn_head_cfg(dim, bev, 3))
+    th.init_weights()
+    _randomize(th, g)
+    th.eval()
+    tfeats = [torch.randn((bs, dim, 10, 10), generator=g), torch.randn((bs, dim, 5, 5), generator=g),
+              torch.randn((bs, dim, 3, 3), generator=g)]
+    with torch.no_grad():
+        touts = th(tfeats)
+        tlosses = th.loss(gtb, gtl, touts)
+        tdec = th.get_bboxes({k: (v.clone() if torch.is_tensor(v) else v) for k, v in touts.items()},
+                             [dict(box_type_3d=lambda t, d: t) for _ in range(bs)])
+    _save("dgcnn3d_head.npz", f0=tfeats[0].numpy(), f1=tfeats[1].numpy(), f2=tfeats[2].numpy(), bev_embed=touts["bev_embed"].numpy(),
+          all_cls_scores=touts["all_cls_scores"].numpy(), all_bbox_preds=touts["all_bbox_preds"].numpy(), hs=touts["hs"].numpy(),
+          **{f"gt_boxes{b}": boxes[b] for b in range(bs)}, **{f"gt_labels{b}": labels[b] for b in range(bs)},
+          **{f"dec_boxes{b}": tdec[b][0].numpy() for b in range(bs)}, **{f"dec_scores{b}": tdec[b][1].numpy() for b in range(bs)},
+          **_flat_losses("loss__", tlosses), **_sd("head__", th))
+    print({k: float(v) for k, v in tlosses.items()})
+
+    # ---- GridMask: the reference's class with the seeded numpy draws (its .cuda() calls run on the host here) ----------
+    GM = R.grid_mask()
+    gm = GM.GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=0.7)
+    gm.train()
+    x = torch.randn((4, 3, 24, 40), generator=g)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    ys = []
+    for seed in (0, 1, 2, 3, 4, 5):
+        np.random.seed(seed)
+        ys.append(gm(x.clone()).numpy())
+    _save("grid_mask.npz", x=x.numpy(), y=np.stack(ys))
+
+
+def make_bevformer_fgd():
+    """BEVFormerDistill.foreground_scale_mask (cell centres, fractional out_size_factor 512 / 20) and fgd_distill_loss
+    (bevformer_distill.py:404-496,634-812) executed by the reference's file on a bare instance with the shipped
+    distill_params of mvpformer_to_bevformer_nus_1x1conv_r50.py:39-79 (one 'head' position, 1x1conv adaptation)."""
+    import types
+    D = R.bevformer_distill()
+    rng = np.random.default_rng(41)
+    g = torch.Generator().manual_seed(41)
+    C, HW, B = 32, 20, 3
+    dp = dict(student_channels=[C], teacher_channels=[C], spatial_t=0.5, spatial_student_ratio=1.0, channel_t=0.5,
+              fg_feat_loss_weights=[3e-3], bg_feat_loss_weights=[4e-2], spatial_loss_weights=[1e-3], adaptation_type=["1x1conv"],
+              teacher_adaptation_type=["identity"], spatial_attentions=["teacher"],
+              feat_criterion=dict(type="MSELoss", reduction="none"), spatial_criterion=dict(type="L1Loss", reduction="none"),
+              channel_criterion=dict(type="L1Loss", reduction="none"), transpose_mask=False, foreground_mask="gt",
+              background_mask="logical_not", scale_mask="combine_gt", spatial_mask=True, channel_mask=False,
+              affinity_mode=["none"], fp_as_foreground=["none"], fp_weight=0, fp_epoch=0, context_length=0, context_weight=0,
+              output_threshold=0.1, groundtruth_threshold=None, fp_scale_mode="average")
+    self = R.bare(D.BEVFormerDistill, distill_params=dp, _epoch=0, no_bg=False,
+                  pts_bbox_head=types.SimpleNamespace(train_cfg=dict(grid_size=[512, 512, 1], point_cloud_range=PCR,
+                                                                      voxel_size=[0.2, 0.2, 8])))
+    self.channel_wise_adaptations = torch.nn.ModuleList([torch.nn.Conv2d(C, C, 1)])
+    self.teacher_adaptations = torch.nn.ModuleList([torch.nn.Identity()])
+    self.spatial_wise_adaptations = torch.nn.ModuleList([torch.nn.Conv2d(1, 1, 3, padding=1)])
+    for p in self.parameters():
+        p.data = torch.randn(p.shape, generator=g) * 0.2
+    boxes = []
+    for b in range(B):
+        bx, _ = syn.gt_boxes((6, 0, 9)[b], rng)
+        bx[:, 3:5] *= 3.0                          # 5.12 m cells: make the boxes cover a few of them
+        boxes.append(bx)
+    gtb = [R.LiDARBoxesStub(b) for b in boxes]
+    fg, fgs, bgs = self.foreground_scale_mask(HW, HW, gtb, 0, 0)
+    teacher = torch.randn((B, C, HW, HW), generator=g)
+    student = torch.randn((B, C, HW, HW), generator=g, requires_grad=True)
+    losses = self.fgd_distill_loss(teacher, student, gtb, None, None, None, None, None, 0)
+    total = sum(losses.values())
+    grads = torch.autograd.grad(total, [student] + list(self.parameters()))
+    _save("bevformer_fgd.npz", teacher=teacher.numpy(), student=student.detach().numpy(), fg=fg.numpy(), fg_scale=fgs.numpy(),
+          bg_scale=bgs.numpy(), g_student=grads[0].numpy(), **{f"gt_boxes{b}": boxes[b] for b in range(B)},
+          **_flat_losses("loss__", losses), **_sd("cwa__", self.channel_wise_adaptations), **_sd("swa__", self.spatial_wise_adaptations),
+          **{f"g__{i}": gr.numpy() for i, gr in enumerate(grads[1:])})
+    print({k: float(v) for k, v in losses.items()}, "fg cells per sample", fg.sum(dim=(1, 2, 3)).tolist())
+
+
 SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center,
             "fgd": make_fgd, "shift_depth": make_shift_depth, "centerloss": make_centerloss, "pfn": make_pfn,
-            "second": make_second}
+            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)

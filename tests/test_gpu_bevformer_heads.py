@@ -1,0 +1,177 @@
+"""GPU: the BEVFormer student head and the DGCNN3D teacher head (transformer.py / detr_head.py on dbev_msda_*) against
+fixtures computed by the REFERENCE's own files (tests/golden/make_golden.py bevformer: bevformer_head.py, dgcnn3d_head.py,
+transformer_modules/*.py, nms_free_coder.py, hungarian_assigner_3d.py, match_cost.py, util.py on stubs of the un-vendored
+mmcv / mmdet bricks).  The reference's state dict loads into the product's modules key for key (strict), then: BEV embedding
+with and without history, per-layer class scores / boxes, decoder states 1e-4 of their scale; the four losses 1e-4; decoded
+boxes; the camera projection (reference_points_cam 1e-4 of the image, bev_mask equal up to points on an image border)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLD)
+
+
+def _load(module, fx, prefix="head__"):
+    sd = {k[len(prefix):].replace("__", "."): torch.from_numpy(fx[k]) for k in fx.files if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def _close(got, ref, tol, what):
+    ref = torch.as_tensor(ref)
+    err = float((got.detach().cpu().double() - ref.double()).abs().max())
+    scale = max(float(ref.abs().max()), 1e-6)
+    assert err <= tol * scale, (what, err, scale)
+
+
+def _metas(fx, bs):
+    H, W = [int(v) for v in fx["img_hw"]]
+    cams = fx["lidar2img"].shape[1]
+    from distill_bev_amd.center_head import LiDARBoxes
+    return [dict(can_bus=fx["can_bus"][b].copy(), lidar2img=[fx["lidar2img"][b, n] for n in range(cams)],
+                 img_shape=[(H, W, 3)] * cams, prev_bev_exists=True, box_type_3d=lambda t, d=9: LiDARBoxes(t)) for b in range(bs)]
+
+
+def _gts(fx, bs, dev):
+    from distill_bev_amd.center_head import LiDARBoxes
+    return ([LiDARBoxes(fx[f"gt_boxes{b}"]) for b in range(bs)],
+            [torch.from_numpy(fx[f"gt_labels{b}"]).to(dev) for b in range(bs)])
+
+
+def test_bevformer_head_vs_reference_fixture():
+    import bevformer_cfgs as C
+    from distill_bev_amd import bevformer  # noqa: F401
+    from distill_bev_amd.registry import build_head
+    fx = np.load(os.path.join(GOLD, "bevformer_head.npz"))
+    dev = torch.device("cuda:0")
+    head = build_head(C.small_bevformer_head_cfg())
+    _load(head, fx)
+    head = head.to(dev).eval()
+    bs = fx["feat0"].shape[0]
+    feats = [torch.from_numpy(fx["feat0"]).to(dev), torch.from_numpy(fx["feat1"]).to(dev)]
+    metas = _metas(fx, bs)
+    # camera projection of the pillar points
+    enc = head.transformer.encoder
+    ref3d = enc.get_reference_points(10, 10, C.PCR[5] - C.PCR[2], 4, dim="3d", bs=bs, device=dev, dtype=torch.float32)
+    _close(ref3d, fx["ref_3d"], 1e-6, "ref_3d")
+    rpc, mask = enc.point_sampling(ref3d, C.PCR, metas)
+    m_ref = torch.from_numpy(fx["bev_mask"])
+    differ = (mask.cpu() != m_ref)
+    assert int(differ.sum()) <= 2, int(differ.sum())                 # a point exactly on an image border may flip
+    vis = m_ref & ~differ
+    d = (rpc.cpu() - torch.from_numpy(fx["reference_points_cam"])).abs()[vis]
+    assert float(d.max()) <= 1e-4
+    with torch.no_grad():
+        bev0 = head(feats, metas, None, only_bev=True)
+        outs = head(feats, metas, torch.from_numpy(fx["prev_bev"]).to(dev))
+    _close(bev0, fx["bev_first"], 1e-4, "bev (no history)")
+    _close(outs["bev_embed"], fx["bev_embed"], 1e-4, "bev_embed")
+    _close(outs["hs"], fx["hs"], 1e-4, "hs")
+    _close(outs["all_cls_scores"], fx["all_cls_scores"], 1e-4, "cls")
+    _close(outs["all_bbox_preds"], fx["all_bbox_preds"], 1e-4, "boxes")
+    gtb, gtl = _gts(fx, bs, dev)
+    with torch.no_grad():
+        losses = head.loss(gtb, gtl, outs, img_metas=metas)
+        dec = head.get_bboxes({k: (v.clone() if torch.is_tensor(v) else v) for k, v in outs.items()}, metas)
+    assert set(losses) == {"loss_cls", "loss_bbox", "d0.loss_cls", "d0.loss_bbox"}
+    for k, v in losses.items():
+        ref = float(fx["loss__" + k.replace(".", "_")])
+        assert abs(float(v) - ref) <= 1e-4 * abs(ref), (k, float(v), ref)
+    for b in range(bs):
+        assert torch.equal(dec[b][2].cpu(), torch.from_numpy(fx[f"dec_labels{b}"]))
+        _close(dec[b][1], fx[f"dec_scores{b}"], 1e-4, "scores")
+        _close(dec[b][0].tensor, fx[f"dec_boxes{b}"], 1e-4, "decoded boxes")
+
+
+def test_bevformer_head_trains_and_is_reproducible():
+    """train mode with dropout 0: gradients reach every parameter of the encoder / decoder / branches, and two runs of
+    forward + backward give bit-identical losses and gradients (deterministic deformable-attention backward, ordered
+    camera scatter)."""
+    import bevformer_cfgs as C
+    from distill_bev_amd import bevformer  # noqa: F401
+    from distill_bev_amd.registry import build_head
+    fx = np.load(os.path.join(GOLD, "bevformer_head.npz"))
+    dev = torch.device("cuda:0")
+    head = build_head(C.small_bevformer_head_cfg())
+    _load(head, fx)
+    head = head.to(dev).train()
+    for m in head.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    bs = 2
+    feats = [torch.from_numpy(fx["feat0"]).to(dev).requires_grad_(True), torch.from_numpy(fx["feat1"]).to(dev).requires_grad_(True)]
+    metas = _metas(fx, bs)
+    gtb, gtl = _gts(fx, bs, dev)
+    prev = torch.from_numpy(fx["prev_bev"]).to(dev)
+
+    def run():
+        head.zero_grad(set_to_none=True)
+        outs = head(feats, metas, prev.clone())
+        losses = head.loss(gtb, gtl, outs, img_metas=metas)
+        total = sum(losses.values())
+        g = torch.autograd.grad(total, [p for p in head.parameters() if p.requires_grad] + feats, allow_unused=True)
+        return losses, g
+    l1, g1 = run()
+    l2, g2 = run()
+    names = [n for n, p in head.named_parameters() if p.requires_grad] + ["feat0", "feat1"]
+    unused = [n for n, g in zip(names, g1) if g is None]
+    assert unused == [], unused
+    for k in l1:
+        assert torch.equal(l1[k], l2[k]), k
+        ref = float(fx["loss__" + k.replace(".", "_")])
+        assert abs(float(l1[k]) - ref) <= 1e-4 * abs(ref)                # dropout 0 in train mode == the eval fixture
+    for n, a, b in zip(names, g1, g2):
+        assert torch.equal(a, b), n
+        assert bool(torch.isfinite(a).all()), n
+
+
+def test_dgcnn3d_teacher_head_vs_reference_fixture():
+    import bevformer_cfgs as C
+    from distill_bev_amd import bevformer  # noqa: F401
+    from distill_bev_amd.registry import build_head
+    fx = np.load(os.path.join(GOLD, "dgcnn3d_head.npz"))
+    dev = torch.device("cuda:0")
+    head = build_head(C.small_dgcnn_head_cfg())
+    _load(head, fx)
+    head = head.to(dev).eval()
+    feats = [torch.from_numpy(fx[k]).to(dev) for k in ("f0", "f1", "f2")]
+    with torch.no_grad():
+        outs = head(feats)
+    for k in ("bev_embed", "hs", "all_cls_scores", "all_bbox_preds"):
+        _close(outs[k], fx[k], 1e-4, k)
+    bs = 2
+    gtb, gtl = _gts(fx, bs, dev)
+    from distill_bev_amd.center_head import LiDARBoxes
+    with torch.no_grad():
+        losses = head.loss(gtb, gtl, outs)
+        dec = head.get_bboxes({k: (v.clone() if torch.is_tensor(v) else v) for k, v in outs.items()},
+                              [dict(box_type_3d=lambda t, d=9: LiDARBoxes(t)) for _ in range(bs)])
+    for k, v in losses.items():
+        ref = float(fx["loss__" + k.replace(".", "_")])
+        assert abs(float(v) - ref) <= 1e-4 * abs(ref), (k, float(v), ref)
+    for b in range(bs):
+        _close(dec[b][1], fx[f"dec_scores{b}"], 1e-4, "scores")
+        _close(dec[b][0].tensor, fx[f"dec_boxes{b}"], 1e-4, "decoded boxes")
+
+
+def test_grid_mask_vs_reference_fixture():
+    from distill_bev_amd.bevformer import GridMask
+    fx = np.load(os.path.join(GOLD, "grid_mask.npz"))
+    dev = torch.device("cuda:0")
+    gm = GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=0.7).train()
+    x = torch.from_numpy(fx["x"]).to(dev)
+    changed = 0
+    for i, seed in enumerate((0, 1, 2, 3, 4, 5)):
+        np.random.seed(seed)
+        y = gm(x.clone())
+        assert torch.equal(y.cpu(), torch.from_numpy(fx["y"][i])), seed
+        changed += int(not torch.equal(y, x))
+    assert changed >= 3                                   # prob 0.7: most seeds apply a mask
+    assert torch.equal(gm.eval()(x), x)
