@@ -463,5 +463,63 @@ class MsdaOp(_Base):
                 "global_batch": self.B * world, "per_gpu_batch": self.B, "parallelism": f"dp{world}"}
 
 
+class BevformerDistillStep(_Base):
+    """BASELINE.json configs[4]: one full MVPFormer -> BEVFormer-R50 distillation training step at the shipped recipe's size
+    (configs/distillbev_mvpformer2bevformer_r50.py == the reference's mvpformer_to_bevformer_nus_1x1conv_r50.py): per sample a
+    queue of 4 frames x 6 cameras x 928 x 1600 (3 history frames through backbone + 6 encoder layers in eval / no_grad, the
+    current frame with gradients), 200 x 200 BEV queries, 900 object queries, Hungarian matching per decoder layer; teacher =
+    MVP virtual points (400 k x 17) -> SparseEncoder 41 x 1600 x 1600 -> SECOND -> FPN -> 6 deformable encoder layers ->
+    bev_embed; FGD loss on the BEV embedding through the fused adaptation + masked-MSE kernel; AdamW (backbone lr x 0.1),
+    grad clip 35.  samples_per_gpu = 1 as in the reference's config (BASELINE words it 'bs=4' over the node)."""
+    B = 1
+    units_per_step = 1
+    default_steps = 10
+    default_warmup = 3
+    metric = "MVP->BEVFormer-R50 distillation training samples/sec -- auxiliary workload (BASELINE configs[4])"
+
+    def __init__(self, dev, rank, world):
+        from distill_bev_amd import bevformer  # noqa: F401
+        from distill_bev_amd.bevformer import make_bevformer_batch
+        from distill_bev_amd.train_step import Trainer, build_model
+        self.dev = dev
+        self.B = int(os.environ.get("DBEV_BENCH_BS", self.B))
+        self.units_per_step = self.B
+        cfg_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "distillbev_mvpformer2bevformer_r50.py")
+        model, cfg = build_model(cfg_path, seed=0)
+        self.trainer = Trainer(model, cfg, dev, world_size=world, channels_last=os.environ.get("DBEV_BF_NCHW") != "1")
+        self.batch = make_bevformer_batch(self.B, np.random.default_rng(1234 + rank), dev, queue_length=cfg.queue_length)
+        self.n_params = sum(p.numel() for p in self.trainer.params)
+
+    def step(self):
+        self.trainer.step(self.batch)
+
+    def begin_timed(self):
+        L.kernel_timing_read()
+        L.kernel_timing(["msda_fwd", "msda_bwd_sample", "msda_gv_gather", "sp_conv_fwd", "adapt_mse_fwd"])
+
+    def roofline(self):
+        rec = L.kernel_timing_read()
+        L.kernel_timing(False)
+        f = rec.get("msda_fwd")
+        if not f:
+            return None
+        t = float(sum(r[0] for r in f)) * 1e-3
+        b = float(sum(r[1] for r in f))
+        other = {k: {"launches": len(v), "total_ms": float(sum(r[0] for r in v)), "avg_us": float(np.mean([r[0] for r in v])) * 1e3,
+                     "achieved_GBps": float(sum(r[1] for r in v)) / max(float(sum(r[0] for r in v)) * 1e-3, 1e-12) / 1e9}
+                 for k, v in rec.items()}
+        return {"bound": "hbm", "kernel": "msda_fwd (all deformable attentions of the step: 4 frames x 6 encoder layers x (temporal self "
+                "+ spatial cross attention), student + teacher decoders, teacher BEV encoder); algorithmic bytes = value + sampling "
+                "locations + weights read once + output, the corner gathers are served by L2 / MALL",
+                "achieved": b / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": t / len(f) * 1e6, "launches": len(f), "other_hot_kernels": other}
+
+    def config(self, world):
+        return {"workload": "MVPFormer -> BEVFormer-R50 full distillation step (BASELINE configs[4]; the reference ships the R50 "
+                            "recipe only): queue 4 x 6 cams x 928x1600, BEV 200x200, 900 queries, 400 k virtual points, fp32",
+                "global_batch": self.B * world, "per_gpu_batch": self.B, "parallelism": f"dp{world}", "params": self.n_params}
+
+
 WORKLOADS = {"bev_pool": BevPoolCfg1, "distill_step": DistillStep, "voxel_teacher": VoxelTeacher, "msda": MsdaOp,
+             "bevformer_distill": BevformerDistillStep,
              "default": "distill_step"}

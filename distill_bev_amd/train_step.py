@@ -269,9 +269,11 @@ class Trainer:
         self.detector = model.to(device)
         self.detector.train()
         if channels_last:
-            self.detector = self.detector.to(memory_format=torch.channels_last)
-            if getattr(self.detector, "teacher_model", None) is not None:
-                self.detector.teacher_model.to(memory_format=torch.channels_last)
+            # every 4-D parameter (2-D convolution weights); Module.to(memory_format=) would also try the 5-D sparse-conv weights
+            for root in (self.detector, getattr(self.detector, "teacher_model", None)):
+                for p in (root.parameters() if root is not None else ()):
+                    if p.dim() == 4:
+                        p.data = p.data.contiguous(memory_format=torch.channels_last)
             self.detector.channels_last = True
             self.fused_bn_relu, self.swapped_upsample = accelerate_modules(self.detector)
         self.wrapper = _TrainWrapper(self.detector)
