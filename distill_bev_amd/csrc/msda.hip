@@ -13,9 +13,10 @@
 // (4P gathers) is in flight per lane.  With NH*D/4 = 64 (8 heads x 32 channels, BEVFormer) a wave is exactly one query
 // and writes 1 KB of contiguous output.
 // Backward: d attn and d loc are per-sample reductions over the group's lanes (shuffle tree, no atomics);
-// d value is a DETERMINISTIC gather instead of mmcv's float atomicAdd scatter: the (sample, corner) entries are grouped
-// by target value row with the CSR primitive (integer histogram -> scan -> fill -> per-row sort by entry id) and one
-// lane group per value row adds coef * grad_out rows in ascending entry order -- bit-reproducible.
+// d value is a DETERMINISTIC gather instead of mmcv's float atomicAdd scatter: the samples are grouped by their anchor
+// cell (top-left corner, one integer atomic per sample) with the CSR primitive (integer histogram -> scan -> fill ->
+// per-bin sort by sample id); one lane group per value row walks the four anchor bins it is a corner of and adds
+// coef * grad_out rows in (corner, ascending sample) order -- bit-reproducible.
 #include "common.h"
 #include "prims.h"
 
@@ -26,6 +27,7 @@ constexpr int MSDA_MAX_LEVELS = 8;
 struct MsdaDims {
   int B, S, NH, D4, Q, L, P;
   int h[MSDA_MAX_LEVELS], w[MSDA_MAX_LEVELS], start[MSDA_MAX_LEVELS];
+  int astart[MSDA_MAX_LEVELS], A;     // anchor cells (h_low + 1, w_low + 1) of a level: (H + 1) x (W + 1), A = their total
 };
 
 struct Bil {
@@ -153,9 +155,12 @@ __global__ __launch_bounds__(256) void msda_bwd_sample(const float4* __restrict_
   }
 }
 
-// entries of the d value gather: id = sample << 2 | corner, grouped by value row (b * S + key) * NH + head
+// The d value gather groups the SAMPLES by their anchor cell (h_low, w_low) in [-1, H-1] x [-1, W-1] -- one integer atomic per
+// sample, not one per corner.  A value row (y, x) is corner k of exactly the samples anchored at
+//   k = 0: (y, x)   k = 1: (y, x - 1)   k = 2: (y - 1, x)   k = 3: (y - 1, x - 1)
+// so its gradient is the sum over those four anchor bins; bin index ((b * A + astart[l] + (h_low+1) * (W+1) + (w_low+1)) * NH + head.
 template <bool FILL>
-__global__ __launch_bounds__(256) void msda_corner_bin(const float* __restrict__ loc, MsdaDims d, long long nsamples,
+__global__ __launch_bounds__(256) void msda_anchor_bin(const float* __restrict__ loc, MsdaDims d, long long nsamples,
                                                        const int* __restrict__ start, int* __restrict__ count,
                                                        unsigned* __restrict__ list) {
   const long long s = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -165,15 +170,13 @@ __global__ __launch_bounds__(256) void msda_corner_bin(const float* __restrict__
   const int lp = static_cast<int>(s - gid * LP), l = lp / d.P;
   const int head = static_cast<int>(gid % d.NH);
   const int b = static_cast<int>(gid / (static_cast<long long>(d.NH) * d.Q));
-  const Bil t = bil_of(loc[2 * s], loc[2 * s + 1], d.h[l], d.w[l]);
-  const int o[4] = {t.o1, t.o2, t.o3, t.o4};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (o[k] < 0) continue;
-    const int row = (b * d.S + d.start[l] + o[k]) * d.NH + head;
-    if (FILL) list[start[row] + atomicSub(&count[row], 1) - 1] = (static_cast<unsigned>(s) << 2) | k;
-    else atomicAdd(&count[row], 1);
-  }
+  const int H = d.h[l], W = d.w[l];
+  const float h_im = loc[2 * s + 1] * static_cast<float>(H) - 0.5f, w_im = loc[2 * s] * static_cast<float>(W) - 0.5f;
+  if (!(h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(H) && w_im < static_cast<float>(W))) return;
+  const int ay = static_cast<int>(floorf(h_im)) + 1, ax = static_cast<int>(floorf(w_im)) + 1;
+  const int bin = (b * d.A + d.astart[l] + ay * (W + 1) + ax) * d.NH + head;
+  if (FILL) list[start[bin] + atomicSub(&count[bin], 1) - 1] = static_cast<unsigned>(s);
+  else atomicAdd(&count[bin], 1);
 }
 
 __global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__ gout, const float* __restrict__ loc,
@@ -187,34 +190,46 @@ __global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__
   const long long row = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   if (row >= vrows) return;
   const int LP = d.L * d.P;
-  const int st = start[row];
-  const int n = start[row + 1] - st;
+  const int head = static_cast<int>(row % d.NH);
+  const long long bk = row / d.NH;
+  const int b = static_cast<int>(bk / d.S), key = static_cast<int>(bk - static_cast<long long>(b) * d.S);
+  int l = 0;
+  while (l + 1 < d.L && key >= d.start[l + 1]) ++l;
+  const int H = d.h[l], W = d.w[l], cell = key - d.start[l];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j0 = 0; j0 < n; j0 += G) {
-    const int nb = min(G, n - j0);
-    unsigned mygid = 0u;
-    float mycoef = 0.f;
-    if (q4 < nb) {
-      const unsigned e = ents[st + j0 + q4];
-      const unsigned s = e >> 2;
-      const int k = e & 3;
-      mygid = s / static_cast<unsigned>(LP);
-      const int l = static_cast<int>(s - mygid * static_cast<unsigned>(LP)) / d.P;
-      const Bil t = bil_of(loc[2 * static_cast<size_t>(s)], loc[2 * static_cast<size_t>(s) + 1], d.h[l], d.w[l]);
-      const float w = k == 0 ? t.w1 : (k == 1 ? t.w2 : (k == 2 ? t.w3 : t.w4));
-      mycoef = attn[s] * w;
-    }
-    for (int h = 0; h < nb; h += DU) {                        // uniform inside the group
-      float4 v[DU];
+  if (cell < H * W) {                                          // (rows past the last level's cells get a zero gradient)
+    const int y = cell / W, x = cell - y * W;
+    const int base = b * d.A + d.astart[l];
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {                              // fixed order: corner, then ascending sample id
+      const int ay = y + 1 - (k >> 1), ax = x + 1 - (k & 1);
+      const int bin = (base + ay * (W + 1) + ax) * d.NH + head;
+      const int st = start[bin];
+      const int n = start[bin + 1] - st;
+      for (int j0 = 0; j0 < n; j0 += G) {
+        const int nb = min(G, n - j0);
+        unsigned mygid = 0u;
+        float mycoef = 0.f;
+        if (q4 < nb) {
+          const unsigned s = ents[st + j0 + q4];
+          mygid = s / static_cast<unsigned>(LP);
+          const Bil t = bil_of(loc[2 * static_cast<size_t>(s)], loc[2 * static_cast<size_t>(s) + 1], H, W);
+          const float w = k == 0 ? t.w1 : (k == 1 ? t.w2 : (k == 2 ? t.w3 : t.w4));
+          mycoef = attn[s] * w;
+        }
+        for (int h = 0; h < nb; h += DU) {                      // uniform inside the group
+          float4 v[DU];
 #pragma unroll
-      for (int u = 0; u < DU; ++u) {
-        const unsigned gi = __shfl(mygid, g0 | ((h + u) & (G - 1)));
-        v[u] = (h + u) < nb ? gout[static_cast<size_t>(gi) * G + q4] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+          for (int u = 0; u < DU; ++u) {
+            const unsigned gi = __shfl(mygid, g0 | ((h + u) & (G - 1)));
+            v[u] = (h + u) < nb ? gout[static_cast<size_t>(gi) * G + q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
 #pragma unroll
-      for (int u = 0; u < DU; ++u) {
-        const float c = __shfl(mycoef, g0 | ((h + u) & (G - 1)));
-        if ((h + u) < nb) fma4s(acc, c, v[u]);
+          for (int u = 0; u < DU; ++u) {
+            const float c = __shfl(mycoef, g0 | ((h + u) & (G - 1)));
+            if ((h + u) < nb) fma4s(acc, c, v[u]);
+          }
+        }
       }
     }
   }
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__
 size_t align_up256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 
 struct MsdaWs { size_t count, start, list, sorted, scanws, sortws, total; };
-MsdaWs msda_ws(long long vrows, long long nent) {
+MsdaWs msda_ws(long long vrows /* anchor bins */, long long nent) {
   MsdaWs L;
   size_t o = 0;
   L.count = o;  o += align_up256(sizeof(int) * vrows);
@@ -237,6 +252,9 @@ MsdaWs msda_ws(long long vrows, long long nent) {
   return L;
 }
 
+// (H + 1)(W + 1) <= 2 H W + 2 for H, W >= 1: bound of the anchor-bin count that needs no shapes (workspace query)
+long long msda_max_anchors(int S, int L) { return 2LL * S + 2LL * L; }
+
 bool msda_dims(int B, int S, int NH, int D, int Q, int L, int P, const int32_t* shapes_hw, const int32_t* level_start,
                MsdaDims* d) {
   if (B <= 0 || S <= 0 || NH <= 0 || D <= 0 || (D & 3) || Q <= 0 || L <= 0 || L > MSDA_MAX_LEVELS || P <= 0 ||
@@ -245,17 +263,23 @@ bool msda_dims(int B, int S, int NH, int D, int Q, int L, int P, const int32_t* 
   const int D4 = D >> 2;
   if (D4 > 64 || (D4 & (D4 - 1))) return false;              // lane groups are powers of two within a wave
   d->B = B; d->S = S; d->NH = NH; d->D4 = D4; d->Q = Q; d->L = L; d->P = P;
-  long long tot = 0;
+  long long tot = 0, anchors = 0;
   for (int l = 0; l < L; ++l) {
     d->h[l] = shapes_hw[2 * l];
     d->w[l] = shapes_hw[2 * l + 1];
     d->start[l] = level_start[l];
     if (d->h[l] <= 0 || d->w[l] <= 0 || d->start[l] < 0) return false;
+    if (l > 0 && d->start[l] < d->start[l - 1] + d->h[l - 1] * d->w[l - 1]) return false;   // levels in ascending, disjoint order
     tot = d->start[l] + static_cast<long long>(d->h[l]) * d->w[l];
     if (tot > S) return false;
+    d->astart[l] = static_cast<int>(anchors);
+    anchors += static_cast<long long>(d->h[l] + 1) * (d->w[l] + 1);
   }
+  if (anchors > msda_max_anchors(S, L)) return false;
+  d->A = static_cast<int>(anchors);
   const long long nsamples = static_cast<long long>(B) * Q * NH * L * P;
-  return nsamples < (1LL << 30) && static_cast<long long>(B) * S * NH < 0x7fffffffLL;
+  return nsamples < (1LL << 32) - 1 && static_cast<long long>(B) * anchors * NH < 0x7fffffffLL &&
+         static_cast<long long>(B) * S * NH < 0x7fffffffLL;
 }
 
 }  // namespace
@@ -263,8 +287,9 @@ bool msda_dims(int B, int S, int NH, int D, int Q, int L, int P, const int32_t* 
 extern "C" size_t dbev_msda_backward_workspace_bytes(int B, int S, int NH, int Q, int L, int P) {
   if (B <= 0 || S <= 0 || NH <= 0 || Q <= 0 || L <= 0 || P <= 0) return 0;
   const long long nsamples = static_cast<long long>(B) * Q * NH * L * P;
-  if (nsamples >= (1LL << 30)) return 0;
-  return msda_ws(static_cast<long long>(B) * S * NH, nsamples * 4).total;
+  const long long bins = static_cast<long long>(B) * msda_max_anchors(S, L) * NH;
+  if (nsamples >= (1LL << 32) - 1 || bins >= 0x7fffffffLL) return 0;
+  return msda_ws(bins, nsamples).total;
 }
 
 extern "C" int dbev_msda_forward(const float* value, const int32_t* spatial_shapes_hw_host,
@@ -300,7 +325,8 @@ extern "C" int dbev_msda_backward(const float* value, const int32_t* spatial_sha
     return DBEV_EINVAL;
   const long long rows = static_cast<long long>(B) * Q * NH, vrows = static_cast<long long>(B) * S * NH;
   const long long nsamples = rows * L * P;
-  const MsdaWs Lw = msda_ws(vrows, nsamples * 4);
+  const long long bins = static_cast<long long>(B) * d.A * NH;
+  const MsdaWs Lw = msda_ws(static_cast<long long>(B) * msda_max_anchors(S, L) * NH, nsamples);     // layout of the workspace query
   if (workspace_bytes < Lw.total) return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   char* ws = static_cast<char*>(workspace);
@@ -313,13 +339,13 @@ extern "C" int dbev_msda_backward(const float* value, const int32_t* spatial_sha
   { DbevKt kt(DBEV_K_MSDA_BWD_SAMPLE, 4LL * B * S * NH * D + 24LL * nsamples + 4LL * rows * D, s);
   hipLaunchKernelGGL(msda_bwd_sample, dim3(static_cast<unsigned>((rows * d.D4 + 255) / 256)), dim3(256), 0, s, v4,
                      sampling_loc, attn_weight, g4, grad_sampling_loc, grad_attn_weight, d, rows); }
-  DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * vrows, s));
+  DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * bins, s));
   const dim3 sgrid(static_cast<unsigned>((nsamples + 255) / 256));
-  hipLaunchKernelGGL((msda_corner_bin<false>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
-  int rc = dbev::exclusive_scan_i32(count, start, vrows, false, nullptr, reinterpret_cast<int*>(ws + Lw.scanws), s);
+  hipLaunchKernelGGL((msda_anchor_bin<false>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
+  int rc = dbev::exclusive_scan_i32(count, start, bins, false, nullptr, reinterpret_cast<int*>(ws + Lw.scanws), s);
   if (rc) return rc;
-  hipLaunchKernelGGL((msda_corner_bin<true>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
-  rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(vrows), reinterpret_cast<int*>(ws + Lw.sortws), s);
+  hipLaunchKernelGGL((msda_anchor_bin<true>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
+  rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(bins), reinterpret_cast<int*>(ws + Lw.sortws), s);
   if (rc) return rc;
   DbevKt kt(DBEV_K_MSDA_GV_GATHER, 4LL * B * S * NH * D + 16LL * nsamples + 4LL * rows * D, s);
   hipLaunchKernelGGL(msda_gv_gather, dim3(static_cast<unsigned>((vrows * d.D4 + 255) / 256)), dim3(256), 0, s, g4,

@@ -56,7 +56,7 @@ class MultiScaleDeformableAttnFunction_fp32(Function):
         with torch.cuda.device(dev):
             nbytes = int(L.call("dbev_msda_backward_workspace_bytes", B, S, NH, Q, Lv, P))
             if nbytes == 0:
-                raise L.DbevHipError("multi-scale deformable attention backward: batch too large for 30-bit sample ids")
+                raise L.DbevHipError("multi-scale deformable attention backward: batch too large for 32-bit sample ids / bin offsets")
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
             L.call("dbev_msda_backward", L.ptr(value), L.host_ints(hw), L.host_ints(st), L.ptr(loc), L.ptr(att), L.ptr(go),
                    B, S, NH, D, Q, Lv, P, L.ptr(gv), L.ptr(gl), L.ptr(ga), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
