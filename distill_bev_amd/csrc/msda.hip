@@ -113,12 +113,27 @@ __global__ __launch_bounds__(256) void msda_fwd(const float4* __restrict__ value
   out[static_cast<size_t>(gid) * G + q4] = acc;
 }
 
-// per-sample gradients wrt attention weight and sampling location
+// sum over the G lanes of a group (every lane gets the total), in a fixed order.  G = 8 (D = 32, BEVFormer): three DPP
+// row operations at VALU rate -- quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror -- instead of LDS-path permutes.
+template <int GT>
+__device__ __forceinline__ float group_sum(float v, int G) {
+  if (GT == 8) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    return v;
+  }
+  for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// per-sample gradients wrt attention weight and sampling location; PB samples (4 PB corner gathers) in flight per lane
+template <int GT, int PB>
 __global__ __launch_bounds__(256) void msda_bwd_sample(const float4* __restrict__ value, const float* __restrict__ loc,
                                                        const float* __restrict__ attn, const float4* __restrict__ gout,
                                                        float* __restrict__ gloc, float* __restrict__ gattn, MsdaDims d,
                                                        long long rows) {
-  const int G = d.D4;
+  const int G = GT ? GT : d.D4;
   const long long gid = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   if (gid >= rows) return;
   const int q4 = threadIdx.x & (G - 1);
@@ -126,30 +141,39 @@ __global__ __launch_bounds__(256) void msda_bwd_sample(const float4* __restrict_
   const int b = static_cast<int>(gid / (static_cast<long long>(d.NH) * d.Q));
   const float4 go = gout[static_cast<size_t>(gid) * G + q4];
   const size_t s0 = static_cast<size_t>(gid) * d.L * d.P;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int l = 0; l < d.L; ++l) {
     const int H = d.h[l], W = d.w[l], st = d.start[l];
-    for (int p = 0; p < d.P; ++p) {
-      const size_t si = s0 + static_cast<size_t>(l) * d.P + p;
-      const float a = attn[si];
-      const Bil t = bil_of(loc[2 * si], loc[2 * si + 1], H, W);
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 v1 = t.o1 >= 0 ? ld_row(value, d, b, st + t.o1, head, q4) : z;
-      const float4 v2 = t.o2 >= 0 ? ld_row(value, d, b, st + t.o2, head, q4) : z;
-      const float4 v3 = t.o3 >= 0 ? ld_row(value, d, b, st + t.o3, head, q4) : z;
-      const float4 v4 = t.o4 >= 0 ? ld_row(value, d, b, st + t.o4, head, q4) : z;
-      // per-lane partial dot products with grad_out over this lane's 4 channels
-      float ga = t.w1 * dot4(go, v1) + t.w2 * dot4(go, v2) + t.w3 * dot4(go, v3) + t.w4 * dot4(go, v4);
-      float gw = t.hh * (dot4(go, v2) - dot4(go, v1)) + t.lh * (dot4(go, v4) - dot4(go, v3));   // d/d w_im
-      float gh = t.hw * (dot4(go, v3) - dot4(go, v1)) + t.lw * (dot4(go, v4) - dot4(go, v2));   // d/d h_im
-      for (int m = 1; m < G; m <<= 1) {                       // fixed-order tree over the group's lanes
-        ga += __shfl_xor(ga, m);
-        gw += __shfl_xor(gw, m);
-        gh += __shfl_xor(gh, m);
+    for (int p0 = 0; p0 < d.P; p0 += PB) {
+      Bil t[PB];
+      float4 v[PB][4];
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        const size_t si = s0 + static_cast<size_t>(l) * d.P + min(p0 + u, d.P - 1);
+        t[u] = bil_of(loc[2 * si], loc[2 * si + 1], H, W);
+        v[u][0] = t[u].o1 >= 0 ? ld_row(value, d, b, st + t[u].o1, head, q4) : z;
+        v[u][1] = t[u].o2 >= 0 ? ld_row(value, d, b, st + t[u].o2, head, q4) : z;
+        v[u][2] = t[u].o3 >= 0 ? ld_row(value, d, b, st + t[u].o3, head, q4) : z;
+        v[u][3] = t[u].o4 >= 0 ? ld_row(value, d, b, st + t[u].o4, head, q4) : z;
       }
-      if (q4 == 0) {
-        gattn[si] = t.any ? ga : 0.f;
-        gloc[2 * si] = t.any ? static_cast<float>(W) * a * gw : 0.f;
-        gloc[2 * si + 1] = t.any ? static_cast<float>(H) * a * gh : 0.f;
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        if (p0 + u >= d.P) break;                              // uniform
+        const size_t si = s0 + static_cast<size_t>(l) * d.P + p0 + u;
+        // per-lane partial dot products with grad_out over this lane's 4 channels
+        const float d1 = dot4(go, v[u][0]), d2 = dot4(go, v[u][1]), d3 = dot4(go, v[u][2]), d4 = dot4(go, v[u][3]);
+        float ga = t[u].w1 * d1 + t[u].w2 * d2 + t[u].w3 * d3 + t[u].w4 * d4;
+        float gw = t[u].hh * (d2 - d1) + t[u].lh * (d4 - d3);   // d / d w_im
+        float gh = t[u].hw * (d3 - d1) + t[u].lw * (d4 - d2);   // d / d h_im
+        ga = group_sum<GT>(ga, G);
+        gw = group_sum<GT>(gw, G);
+        gh = group_sum<GT>(gh, G);
+        if (q4 == 0) {
+          const float a = attn[si];
+          gattn[si] = t[u].any ? ga : 0.f;
+          gloc[2 * si] = t[u].any ? static_cast<float>(W) * a * gw : 0.f;
+          gloc[2 * si + 1] = t[u].any ? static_cast<float>(H) * a * gh : 0.f;
+        }
       }
     }
   }
@@ -179,9 +203,28 @@ __global__ __launch_bounds__(256) void msda_anchor_bin(const float* __restrict__
   else atomicAdd(&count[bin], 1);
 }
 
-__global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__ gout, const float* __restrict__ loc,
-                                                      const float* __restrict__ attn, const int* __restrict__ start,
-                                                      const unsigned* __restrict__ ents, float4* __restrict__ gvalue,
+// After the sort: one record per binned sample, in bin order -- the (b, q, head) row of grad_out it reads and its four
+// corner coefficients attn * w_k.  The gather then streams its bins' records (coalesced) instead of chasing
+// entry -> location / weight -> bilinear weights once per corner.
+__global__ __launch_bounds__(256) void msda_expand(const unsigned* __restrict__ sorted, const int* __restrict__ start,
+                                                   long long bins, const float* __restrict__ loc,
+                                                   const float* __restrict__ attn, MsdaDims d, unsigned* __restrict__ rec_row,
+                                                   float4* __restrict__ rec_w) {
+  const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= start[bins]) return;
+  const unsigned s = sorted[e];
+  const unsigned LP = static_cast<unsigned>(d.L * d.P);
+  const unsigned gid = s / LP;
+  const int l = static_cast<int>(s - gid * LP) / d.P;
+  const Bil t = bil_of(loc[2 * static_cast<size_t>(s)], loc[2 * static_cast<size_t>(s) + 1], d.h[l], d.w[l]);
+  const float a = attn[s];
+  rec_row[e] = gid;
+  rec_w[e] = make_float4(a * t.w1, a * t.w2, a * t.w3, a * t.w4);
+}
+
+__global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__ gout, const int* __restrict__ start,
+                                                      const unsigned* __restrict__ rec_row,
+                                                      const float4* __restrict__ rec_w, float4* __restrict__ gvalue,
                                                       MsdaDims d, long long vrows) {
   constexpr int DU = 8;
   const int G = d.D4;
@@ -189,7 +232,6 @@ __global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__
   const int g0 = lane & ~(G - 1), q4 = lane & (G - 1);
   const long long row = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   if (row >= vrows) return;
-  const int LP = d.L * d.P;
   const int head = static_cast<int>(row % d.NH);
   const long long bk = row / d.NH;
   const int b = static_cast<int>(bk / d.S), key = static_cast<int>(bk - static_cast<long long>(b) * d.S);
@@ -211,11 +253,9 @@ __global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__
         unsigned mygid = 0u;
         float mycoef = 0.f;
         if (q4 < nb) {
-          const unsigned s = ents[st + j0 + q4];
-          mygid = s / static_cast<unsigned>(LP);
-          const Bil t = bil_of(loc[2 * static_cast<size_t>(s)], loc[2 * static_cast<size_t>(s) + 1], H, W);
-          const float w = k == 0 ? t.w1 : (k == 1 ? t.w2 : (k == 2 ? t.w3 : t.w4));
-          mycoef = attn[s] * w;
+          mygid = rec_row[st + j0 + q4];
+          const float4 w = rec_w[st + j0 + q4];
+          mycoef = k == 0 ? w.x : (k == 1 ? w.y : (k == 2 ? w.z : w.w));
         }
         for (int h = 0; h < nb; h += DU) {                      // uniform inside the group
           float4 v[DU];
@@ -238,7 +278,7 @@ __global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__
 
 size_t align_up256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 
-struct MsdaWs { size_t count, start, list, sorted, scanws, sortws, total; };
+struct MsdaWs { size_t count, start, list, sorted, recw, scanws, sortws, total; };
 MsdaWs msda_ws(long long vrows /* anchor bins */, long long nent) {
   MsdaWs L;
   size_t o = 0;
@@ -246,6 +286,7 @@ MsdaWs msda_ws(long long vrows /* anchor bins */, long long nent) {
   L.start = o;  o += align_up256(sizeof(int) * (vrows + 1));
   L.list = o;   o += align_up256(sizeof(int) * nent);
   L.sorted = o; o += align_up256(sizeof(int) * nent);
+  L.recw = o;   o += align_up256(sizeof(float) * 4 * nent);
   L.scanws = o; o += align_up256(sizeof(int) * dbev::scan_workspace_ints(vrows));
   L.sortws = o; o += align_up256(sizeof(int) * dbev::segment_sort_workspace_ints(nent));
   L.total = o;
@@ -337,8 +378,13 @@ extern "C" int dbev_msda_backward(const float* value, const int32_t* spatial_sha
   const float4* v4 = reinterpret_cast<const float4*>(value);
   const float4* g4 = reinterpret_cast<const float4*>(grad_out);
   { DbevKt kt(DBEV_K_MSDA_BWD_SAMPLE, 4LL * B * S * NH * D + 24LL * nsamples + 4LL * rows * D, s);
-  hipLaunchKernelGGL(msda_bwd_sample, dim3(static_cast<unsigned>((rows * d.D4 + 255) / 256)), dim3(256), 0, s, v4,
-                     sampling_loc, attn_weight, g4, grad_sampling_loc, grad_attn_weight, d, rows); }
+  const dim3 bgrid(static_cast<unsigned>((rows * d.D4 + 255) / 256));
+  if (d.D4 == 8)
+    hipLaunchKernelGGL((msda_bwd_sample<8, 4>), bgrid, dim3(256), 0, s, v4, sampling_loc, attn_weight, g4, grad_sampling_loc,
+                       grad_attn_weight, d, rows);
+  else
+    hipLaunchKernelGGL((msda_bwd_sample<0, 4>), bgrid, dim3(256), 0, s, v4, sampling_loc, attn_weight, g4, grad_sampling_loc,
+                       grad_attn_weight, d, rows); }
   DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * bins, s));
   const dim3 sgrid(static_cast<unsigned>((nsamples + 255) / 256));
   hipLaunchKernelGGL((msda_anchor_bin<false>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
@@ -347,9 +393,12 @@ extern "C" int dbev_msda_backward(const float* value, const int32_t* spatial_sha
   hipLaunchKernelGGL((msda_anchor_bin<true>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
   rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(bins), reinterpret_cast<int*>(ws + Lw.sortws), s);
   if (rc) return rc;
-  DbevKt kt(DBEV_K_MSDA_GV_GATHER, 4LL * B * S * NH * D + 16LL * nsamples + 4LL * rows * D, s);
-  hipLaunchKernelGGL(msda_gv_gather, dim3(static_cast<unsigned>((vrows * d.D4 + 255) / 256)), dim3(256), 0, s, g4,
-                     sampling_loc, attn_weight, start, sorted, reinterpret_cast<float4*>(grad_value), d, vrows);
+  float4* rec_w = reinterpret_cast<float4*>(ws + Lw.recw);
+  hipLaunchKernelGGL(msda_expand, sgrid, dim3(256), 0, s, sorted, start, bins, sampling_loc, attn_weight, d, list /* reused */,
+                     rec_w);
+  DbevKt kt(DBEV_K_MSDA_GV_GATHER, 4LL * B * S * NH * D + 20LL * nsamples + 4LL * rows * D, s);
+  hipLaunchKernelGGL(msda_gv_gather, dim3(static_cast<unsigned>((vrows * d.D4 + 255) / 256)), dim3(256), 0, s, g4, start, list,
+                     rec_w, reinterpret_cast<float4*>(grad_value), d, vrows);
   DBEV_LAUNCH_CHECK();
   return 0;
 }
