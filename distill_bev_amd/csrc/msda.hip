@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void msda_bwd_sample(const float4* __restrict_
 template <bool FILL>
 __global__ __launch_bounds__(256) void msda_anchor_bin(const float* __restrict__ loc, MsdaDims d, long long nsamples,
                                                        const int* __restrict__ start, int* __restrict__ count,
-                                                       unsigned* __restrict__ list) {
+                                                       int* __restrict__ rank, unsigned* __restrict__ list) {
   const long long s = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (s >= nsamples) return;
   const int LP = d.L * d.P;
@@ -199,8 +199,10 @@ __global__ __launch_bounds__(256) void msda_anchor_bin(const float* __restrict__
   if (!(h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(H) && w_im < static_cast<float>(W))) return;
   const int ay = static_cast<int>(floorf(h_im)) + 1, ax = static_cast<int>(floorf(w_im)) + 1;
   const int bin = (b * d.A + d.astart[l] + ay * (W + 1) + ax) * d.NH + head;
-  if (FILL) list[start[bin] + atomicSub(&count[bin], 1) - 1] = static_cast<unsigned>(s);
-  else atomicAdd(&count[bin], 1);
+  // counting pass: the arrival rank inside the bin is kept per sample, so the fill pass needs no second atomic (the order
+  // inside a bin is arbitrary here and fixed by the sort that follows)
+  if (FILL) list[start[bin] + rank[s]] = static_cast<unsigned>(s);
+  else rank[s] = atomicAdd(&count[bin], 1);
 }
 
 // After the sort: one record per binned sample, in bin order -- the (b, q, head) row of grad_out it reads and its four
@@ -387,10 +389,11 @@ extern "C" int dbev_msda_backward(const float* value, const int32_t* spatial_sha
                        grad_attn_weight, d, rows); }
   DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * bins, s));
   const dim3 sgrid(static_cast<unsigned>((nsamples + 255) / 256));
-  hipLaunchKernelGGL((msda_anchor_bin<false>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
+  int* rank = reinterpret_cast<int*>(sorted);                 // dead before the sort writes `sorted`
+  hipLaunchKernelGGL((msda_anchor_bin<false>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, rank, list);
   int rc = dbev::exclusive_scan_i32(count, start, bins, false, nullptr, reinterpret_cast<int*>(ws + Lw.scanws), s);
   if (rc) return rc;
-  hipLaunchKernelGGL((msda_anchor_bin<true>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, list);
+  hipLaunchKernelGGL((msda_anchor_bin<true>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, rank, list);
   rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(bins), reinterpret_cast<int*>(ws + Lw.sortws), s);
   if (rc) return rc;
   float4* rec_w = reinterpret_cast<float4*>(ws + Lw.recw);
