@@ -162,3 +162,61 @@ def test_grad_reducer_unused_parameters_and_mixed_gradient_layouts(tmp_path):
         assert torch.equal(r["p0"], g0 * 1.5) and torch.equal(r["p3"], g3 * 1.5) and r["p3_stride"]
         assert torch.equal(r["p1"], torch.full((7,), 1.0))
         assert r["p2"] is None
+
+
+# ---- the set-prediction heads' one collective: the averaging factors of the losses (configs[4]) ---------------------------
+def _head_loss_worker(rank, world, port, out):
+    """BEVFormerHead.loss on two ranks with different ground truth: `sync_cls_avg_factor` / `num_total_pos` go through
+    reduce_mean (bevformer_head.py:353-364), so each rank's losses use the MEAN number of matched queries over the ranks."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import bevformer_cfgs as C
+    from distill_bev_amd import bevformer  # noqa: F401
+    from distill_bev_amd.center_head import LiDARBoxes
+    from distill_bev_amd.registry import build_head
+    from distill_bev_amd import synthetic as syn
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    head = build_head(C.small_bevformer_head_cfg())
+    head.init_weights()
+    g = torch.Generator().manual_seed(100 + rank)
+    outs = dict(all_cls_scores=torch.randn((2, 1, 12, 10), generator=g), all_bbox_preds=torch.randn((2, 1, 12, 10), generator=g),
+                enc_cls_scores=None, enc_bbox_preds=None)
+    n_gt = (2, 7)[rank]
+    bx, lb = syn.gt_boxes(n_gt, np.random.default_rng(rank))
+    losses = head.loss([LiDARBoxes(bx)], [torch.from_numpy(lb)], outs)
+    out.put((rank, {k: float(v) for k, v in losses.items()}, n_gt))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_set_prediction_loss_averages_its_factors_over_the_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = [ctx.Process(target=_head_loss_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, l, n = q.get(timeout=300)
+        got[r] = (l, n)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process values of the same two shards (factor = own matched count) rescale to the two-rank ones by n_r / mean(n)
+    solo = dict()
+    for r in range(2):
+        qq = ctx.Queue()
+        _head_loss_worker(r, 1, 0, qq)
+        solo[r] = qq.get()[1]
+    mean_n = (got[0][1] + got[1][1]) / 2
+    for r in range(2):
+        for k, v in got[r][0].items():
+            want = solo[r][k] * got[r][1] / mean_n
+            assert abs(v - want) <= 1e-5 * abs(want), (r, k, v, want)
