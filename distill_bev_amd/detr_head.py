@@ -143,6 +143,10 @@ class HungarianAssigner3D(object):
         self.cls_cost, self.reg_cost, self.iou_cost = MODELS.build(cls_cost), MODELS.build(reg_cost), MODELS.build(iou_cost)
         self.pc_range = pc_range
 
+    def cost_matrix(self, bbox_pred, cls_pred, gt_bboxes, gt_labels):
+        """[num_query, num_gt] matching cost on the device (:95-103)"""
+        return self.cls_cost(cls_pred, gt_labels) + self.reg_cost(bbox_pred[:, :8], normalize_bbox(gt_bboxes, self.pc_range)[:, :8])
+
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_bboxes_ignore=None, eps=1e-7):
         from scipy.optimize import linear_sum_assignment
         assert gt_bboxes_ignore is None
@@ -153,8 +157,7 @@ class HungarianAssigner3D(object):
             if num_gts == 0:
                 gt_inds[:] = 0
             return AssignResult(num_gts, gt_inds, None, labels=labels)
-        cost = self.cls_cost(cls_pred, gt_labels) + self.reg_cost(bbox_pred[:, :8], normalize_bbox(gt_bboxes, self.pc_range)[:, :8])
-        rows, cols = linear_sum_assignment(cost.detach().cpu())
+        rows, cols = linear_sum_assignment(self.cost_matrix(bbox_pred, cls_pred, gt_bboxes, gt_labels).detach().cpu())
         rows = torch.from_numpy(rows).to(bbox_pred.device)
         cols = torch.from_numpy(cols).to(bbox_pred.device)
         gt_inds[:] = 0
@@ -345,13 +348,79 @@ class _SetPredictionHead(nn.Module):
         bbox_preds = bbox_preds.reshape(-1, bbox_preds.size(-1))
         targets = normalize_bbox(box_t, self.pc_range)
         ok = torch.isfinite(targets).all(dim=-1)
-        return self._box_loss(loss_cls, bbox_preds, targets, box_w, ok, num_pos)
+        return self._box_loss(loss_cls, bbox_preds[ok], targets[ok], box_w[ok], num_pos)
 
     def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None, img_metas=None):
-        """bevformer_head.py:389-470: one (cls, bbox) loss pair per decoder layer, the last one under the plain names"""
+        """bevformer_head.py:389-470: one (cls, bbox) loss pair per decoder layer, the last one under the plain names.
+
+        Same values as ``multi_apply(self.loss_single, ...)`` (the reference; kept above, and tested equal), organised for the
+        device: the matching costs of ALL decoder layers and samples are computed first and read back in ONE transfer, the
+        assignments are solved on the host, and targets / losses are then built from the host-side matches without a single
+        further read-back (the reference syncs ~8 times per layer and sample: cost matrix, nonzero / unique of the sampler,
+        boolean-mask indexing, .item() of the normaliser)."""
+        import numpy as np
+        from scipy.optimize import linear_sum_assignment
         assert gt_bboxes_ignore is None
         all_cls, all_box = preds_dicts["all_cls_scores"], preds_dicts["all_bbox_preds"]
         assert preds_dicts.get("enc_cls_scores") is None
+        n_layers, bs, nq = all_cls.shape[0], all_cls.shape[1], all_cls.shape[2]
+        device = all_cls.device
+        gt_boxes = [torch.cat((b.gravity_center, b.tensor[:, 3:]), dim=1).to(device) for b in gt_bboxes_list]
+        gt_labels = [l.to(device) for l in gt_labels_list]
+        with torch.no_grad():
+            blocks = [self.assigner.cost_matrix(all_box[lv, i], all_cls[lv, i], gt_boxes[i], gt_labels[i]).reshape(-1)
+                      for lv in range(n_layers) for i in range(bs) if gt_boxes[i].size(0) > 0]
+            host = torch.cat(blocks).cpu().numpy() if blocks else np.zeros((0,), np.float32)      # the one read-back
+        out, off = {}, 0
+        distributed = dist.is_available() and dist.is_initialized()
+        tdims = None
+        for lv in range(n_layers):
+            q_idx, g_idx, g_smp = [], [], []
+            for i in range(bs):
+                m = gt_boxes[i].size(0)
+                if m == 0:
+                    continue
+                rows, cols = linear_sum_assignment(host[off:off + nq * m].reshape(nq, m))
+                off += nq * m
+                q_idx.append(rows + i * nq)
+                g_idx.append(cols)
+                g_smp.append(i)
+            num_pos = int(sum(len(r) for r in q_idx))
+            num_neg = bs * nq - num_pos
+            cls_scores = all_cls[lv].reshape(-1, self.cls_out_channels)
+            bbox_preds = all_box[lv].reshape(-1, all_box.size(-1))
+            labels = torch.full((bs * nq,), self.num_classes, dtype=torch.long, device=device)
+            if num_pos:
+                pos = torch.from_numpy(np.concatenate(q_idx)).to(device)
+                sel = [torch.from_numpy(c).to(device) for c in g_idx]
+                labels[pos] = torch.cat([gt_labels[i][c] for i, c in zip(g_smp, sel)])
+                pos_boxes = torch.cat([gt_boxes[i][c] for i, c in zip(g_smp, sel)])
+            cls_avg_factor = num_pos * 1.0 + num_neg * self.bg_cls_weight
+            if self.sync_cls_avg_factor and distributed:
+                cls_avg_factor = reduce_mean(cls_scores.new_tensor([cls_avg_factor]))
+            cls_avg_factor = max(cls_avg_factor, 1)
+            loss_cls = self.loss_cls(cls_scores, labels, cls_scores.new_ones(bs * nq), avg_factor=cls_avg_factor)
+            npos = torch.clamp(reduce_mean(loss_cls.new_tensor([num_pos])), min=1).item() if distributed else max(float(num_pos), 1.0)
+            if num_pos:
+                preds = bbox_preds[pos]
+                tdims = self._target_dims(pos_boxes)
+                targets = normalize_bbox(pos_boxes[:, :tdims], self.pc_range)
+                finite = torch.isfinite(targets).all(dim=-1, keepdim=True)           # (a degenerate box has log(0) sizes)
+                targets = torch.where(finite, targets, preds.detach()[:, :targets.size(-1)])
+                weights = finite.to(preds.dtype).expand_as(preds)
+            else:
+                preds = targets = weights = bbox_preds[:0]
+            lc, lb = self._box_loss(loss_cls, preds, targets, weights, npos)
+            if lv == n_layers - 1:
+                out["loss_cls"], out["loss_bbox"] = lc, lb
+            else:
+                out[f"d{lv}.loss_cls"], out[f"d{lv}.loss_bbox"] = lc, lb
+        return {k: out[k] for k in ["loss_cls", "loss_bbox"] + [f"d{i}.{n}" for i in range(n_layers - 1) for n in ("loss_cls", "loss_bbox")]}
+
+    def loss_reference_order(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None, img_metas=None):
+        """The reference's own organisation (multi_apply over loss_single): the definition ``loss`` is tested against."""
+        assert gt_bboxes_ignore is None
+        all_cls, all_box = preds_dicts["all_cls_scores"], preds_dicts["all_bbox_preds"]
         n = len(all_cls)
         device = gt_labels_list[0].device
         gt_bboxes_list = [torch.cat((b.gravity_center, b.tensor[:, 3:]), dim=1).to(device) for b in gt_bboxes_list]
@@ -410,9 +479,10 @@ class BEVFormerHead(_SetPredictionHead):
     def _box_dims(self, bboxes):
         return bboxes.shape[-1]
 
-    def _box_loss(self, loss_cls, bbox_preds, targets, box_w, ok, num_pos):
+    def _box_loss(self, loss_cls, bbox_preds, targets, box_w, num_pos):
+        """:375-386 on the rows with finite targets"""
         box_w = box_w * self.code_weights
-        loss_bbox = self.loss_bbox(bbox_preds[ok, :10], targets[ok, :10], box_w[ok, :10], avg_factor=num_pos)
+        loss_bbox = self.loss_bbox(bbox_preds[:, :10], targets[:, :10], box_w[:, :10], avg_factor=num_pos)
         return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox)
 
 
@@ -461,8 +531,9 @@ class DGCNN3DHead(_SetPredictionHead):
     def _box_dims(self, bboxes):
         return 9 if bboxes.size(-1) == 9 else 7
 
-    def _box_loss(self, loss_cls, bbox_preds, targets, box_w, ok, num_pos):
-        loss_bbox = self.loss_bbox(bbox_preds[ok, :8], targets[ok, :8], box_w[ok, :8], avg_factor=num_pos)
+    def _box_loss(self, loss_cls, bbox_preds, targets, box_w, num_pos):
+        """:247-254 on the rows with finite targets"""
+        loss_bbox = self.loss_bbox(bbox_preds[:, :8], targets[:, :8], box_w[:, :8], avg_factor=num_pos)
         if self.code_size > 8:
-            loss_bbox = loss_bbox + 0.2 * self.loss_bbox(bbox_preds[ok, 8:], targets[ok, 8:], box_w[ok, 8:], avg_factor=num_pos)
+            loss_bbox = loss_bbox + 0.2 * self.loss_bbox(bbox_preds[:, 8:], targets[:, 8:], box_w[:, 8:], avg_factor=num_pos)
         return loss_cls, loss_bbox

@@ -15,9 +15,35 @@ from torch.autograd.function import once_differentiable
 from . import _lib as L
 
 
+_LEVELS = {}
+
+
+def level_tensors(shapes, device):
+    """(spatial_shapes [L, 2] int64, level_start_index [L] int64) on `device` for the host list ``shapes`` = [(h, w), ...],
+    built once per geometry and device.  The tensors carry their host values, so the op never reads them back: the
+    reference's modules rebuild both tensors in every layer call and mmcv's op reads them on the device."""
+    key = (tuple((int(h), int(w)) for h, w in shapes), str(device))
+    hit = _LEVELS.get(key)
+    if hit is None:
+        hw = [v for pair in key[0] for v in pair]
+        st, acc = [], 0
+        for h, w in key[0]:
+            st.append(acc)
+            acc += h * w
+        ss = torch.tensor(key[0], dtype=torch.long, device=device)
+        ls = torch.tensor(st, dtype=torch.long, device=device)
+        ss._dbev_host, ls._dbev_host = hw, st
+        hit = _LEVELS[key] = (ss, ls)
+    return hit
+
+
 def _levels(spatial_shapes, level_start_index):
-    hw = [int(v) for v in spatial_shapes.reshape(-1).tolist()]
-    st = [int(v) for v in level_start_index.reshape(-1).tolist()]
+    hw = getattr(spatial_shapes, "_dbev_host", None)
+    st = getattr(level_start_index, "_dbev_host", None)
+    if hw is None:
+        hw = [int(v) for v in spatial_shapes.reshape(-1).tolist()]       # one small device read-back per call
+    if st is None:
+        st = [int(v) for v in level_start_index.reshape(-1).tolist()]
     return hw, st
 
 

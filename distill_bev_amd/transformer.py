@@ -27,7 +27,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .msda import multi_scale_deformable_attn
+from .msda import level_tensors, multi_scale_deformable_attn
 from .registry import MODELS, build_activation_layer, build_norm_layer
 
 build_attention = build_feedforward_network = build_positional_encoding = MODELS.build
@@ -311,6 +311,14 @@ def _ring_offsets(num_heads, groups, num_points):
     return grid.view(-1)
 
 
+def _num_keys(spatial_shapes):
+    """sum of H * W over the levels -- from the host copy the level tensors of `level_tensors` carry (no device read-back)"""
+    hw = getattr(spatial_shapes, "_dbev_host", None)
+    if hw is None:
+        return int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum())
+    return sum(hw[i] * hw[i + 1] for i in range(0, len(hw), 2))
+
+
 class _DeformableAttention(nn.Module):
     """Shared construction of the four deformable attentions: value / offset / weight projections and their init."""
 
@@ -371,7 +379,7 @@ class MultiScaleDeformableAttention(_DeformableAttention):
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         bs, nq, _ = query.shape
         _, nv, _ = value.shape
-        assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == nv
+        assert _num_keys(spatial_shapes) == nv
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
@@ -412,7 +420,7 @@ class MSDeformableAttention3D(_DeformableAttention):
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         bs, nq, _ = query.shape
         _, nv, _ = value.shape
-        assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == nv
+        assert _num_keys(spatial_shapes) == nv
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
@@ -523,7 +531,7 @@ class TemporalSelfAttention(_DeformableAttention):
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         bs, nq, dims = query.shape
         _, nv, _ = value.shape
-        assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == nv
+        assert _num_keys(spatial_shapes) == nv
         assert self.num_bev_queue == 2
         NQ, NH, NL, NP = self.num_bev_queue, self.num_heads, self.num_levels, self.num_points
         query = torch.cat([value[:bs], query], -1)
@@ -561,13 +569,13 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         attn_masks = self._masks(attn_masks)
         ni = ai = fi = 0
         identity = query
+        bev_level = level_tensors([(bev_h, bev_w)], query.device)
         for op in self.operation_order:
             if op == "self_attn":
                 query = self.attentions[ai](query, prev_bev, prev_bev, identity if self.pre_norm else None, query_pos=bev_pos,
                                             key_pos=bev_pos, attn_mask=attn_masks[ai], key_padding_mask=query_key_padding_mask,
-                                            reference_points=ref_2d,
-                                            spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
-                                            level_start_index=torch.tensor([0], device=query.device), **kwargs)
+                                            reference_points=ref_2d, spatial_shapes=bev_level[0], level_start_index=bev_level[1],
+                                            **kwargs)
                 ai += 1
                 identity = query
             elif op == "norm":
@@ -772,8 +780,7 @@ class PerceptionTransformer(nn.Module):
             spatial_shapes.append((h, w))
             feat_flatten.append(feat)
         feat_flatten = torch.cat(feat_flatten, 2).permute(0, 2, 1, 3)           # [num_cam, sum(H*W), bs, C]
-        spatial_shapes = torch.as_tensor(spatial_shapes, dtype=torch.long, device=bev_pos.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = level_tensors(spatial_shapes, bev_pos.device)
         return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
                             spatial_shapes=spatial_shapes, level_start_index=level_start_index, prev_bev=prev_bev,
                             shift=shift, **kwargs)
@@ -789,11 +796,11 @@ class PerceptionTransformer(nn.Module):
         query = query.unsqueeze(0).expand(bs, -1, -1)
         reference_points = self.reference_points(query_pos).sigmoid()
         bev_embed = bev_embed.permute(1, 0, 2)
+        bev_level = level_tensors([(bev_h, bev_w)], query.device)
         inter_states, inter_references = self.decoder(
             query=query.permute(1, 0, 2), key=None, value=bev_embed, query_pos=query_pos.permute(1, 0, 2),
             reference_points=reference_points, reg_branches=reg_branches, cls_branches=cls_branches,
-            spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
-            level_start_index=torch.tensor([0], device=query.device), **kwargs)
+            spatial_shapes=bev_level[0], level_start_index=bev_level[1], **kwargs)
         return bev_embed, inter_states, reference_points, inter_references
 
 
@@ -843,8 +850,7 @@ class DeformableDetrTransformerDistill(nn.Module):
             spatial_shapes.append((h, w))
             feat_flatten.append(feat.flatten(2).transpose(1, 2))
         feat_flatten = torch.cat(feat_flatten, 1)
-        spatial_shapes = torch.as_tensor(spatial_shapes, dtype=torch.long, device=feat_flatten.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = level_tensors(spatial_shapes, feat_flatten.device)
         reference_points = self.get_reference_points(bs, spatial_shapes, self.bev_size, device=feat_flatten.device)
         feat_flatten = feat_flatten.permute(1, 0, 2)
         memory = self.encoder(query=bev_queries.unsqueeze(1).repeat(1, bs, 1), key=feat_flatten, value=feat_flatten,
@@ -857,9 +863,9 @@ class DeformableDetrTransformerDistill(nn.Module):
         query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
         query = query.unsqueeze(0).expand(bs, -1, -1)
         reference_points = self.reference_points(query_pos).sigmoid()
+        bev_level = level_tensors([(self.bev_size, self.bev_size)], query.device)
         inter_states, inter_references = self.decoder(
             query=query.permute(1, 0, 2), key=None, value=memory, query_pos=query_pos.permute(1, 0, 2),
             reference_points=reference_points, reg_branches=reg_branches, cls_branches=cls_branches,
-            spatial_shapes=torch.tensor([[self.bev_size, self.bev_size]], device=query.device),
-            level_start_index=torch.tensor([0], device=query.device), **kwargs)
+            spatial_shapes=bev_level[0], level_start_index=bev_level[1], **kwargs)
         return inter_states, reference_points, inter_references, bev_embed, None, None

@@ -39,6 +39,11 @@ def test_set_prediction_losses_and_decoding_from_the_reference_outputs():
         for k, v in losses.items():
             ref = float(fx["loss__" + k.replace(".", "_")])
             assert abs(float(v) - ref) <= 1e-5 * abs(ref), (name, k, float(v), ref)
+        # `loss` (one read-back for all layers) == the reference's per-layer organisation, value for value
+        per_layer = head.loss_reference_order(gtb, gtl, outs)
+        assert list(per_layer) == list(losses)
+        for k in losses:
+            assert abs(float(losses[k]) - float(per_layer[k])) <= 1e-6 * abs(float(per_layer[k])), (name, k)
         dec = head.get_bboxes({k: (v.clone() if torch.is_tensor(v) else v) for k, v in outs.items()},
                               [dict(box_type_3d=lambda t, d=9: LiDARBoxes(t)) for _ in range(2)])
         for b in range(2):
