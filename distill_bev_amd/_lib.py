@@ -94,6 +94,10 @@ _SIGNATURES = {
     "dbev_bn_act_train_forward": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_dual_workspace_bytes": [_ll, _i],
+    "dbev_bn_dual_train_forward": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p,
+                                   _ll, _i, _p, _sz, _p],
+    "dbev_bn_dual_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_kernel_name": ctypes.c_char_p,
@@ -108,6 +112,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_hard_voxelize_workspace_bytes": ctypes.c_size_t,
              "dbev_dynamic_scatter_workspace_bytes": ctypes.c_size_t,
              "dbev_bn_act_workspace_bytes": ctypes.c_size_t,
+             "dbev_bn_dual_workspace_bytes": ctypes.c_size_t,
              "dbev_skinny_conv3x3_workspace_bytes": ctypes.c_size_t,
              "dbev_centerhead_loss_workspace_bytes": ctypes.c_size_t,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,

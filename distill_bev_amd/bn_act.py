@@ -105,6 +105,64 @@ class _BNActTrain(Function):
         return dx, (dres if relu else dy) if has_res else None, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _BNDualTrain(Function):
+    """relu(bn(x) + bn_d(xd)): dbev_bn_dual_train_forward / dbev_bn_dual_backward"""
+
+    @staticmethod
+    def forward(ctx, x, xd, w, b, rm, rv, nbt, mom, eps, wd, bd, rmd, rvd, nbtd, momd, epsd, relu):
+        dev = x.device
+        N, C, H, W = x.shape
+        M = N * H * W
+        y = torch.empty_like(x)
+        stats = torch.empty((8, C), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift of both norms
+        nbytes = L.lib().dbev_bn_dual_workspace_bytes(M, C)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.call("dbev_bn_dual_train_forward", L.ptr(x), L.ptr(xd), L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
+                   float(mom or 0.0), float(eps), L.ptr(wd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), L.ptr(nbtd), float(momd or 0.0),
+                   float(epsd), int(relu), L.ptr(y), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2:4]), L.ptr(stats[4]),
+                   L.ptr(stats[5]), L.ptr(stats[6:8]), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev), alg_bytes=4 * M * C * 5)
+        ctx.save_for_backward(x, xd, y if relu else None, w, wd, stats)
+        ctx.cfg = (M, C, bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xd, y, w, wd, stats = ctx.saved_tensors
+        M, C, relu = ctx.cfg
+        dev = dy.device
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx, dxd = torch.empty_like(x), torch.empty_like(xd)
+        g = torch.empty((4, C), dtype=torch.float32, device=dev)
+        nbytes = L.lib().dbev_bn_dual_workspace_bytes(M, C)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.call("dbev_bn_dual_backward", L.ptr(dy), L.ptr(x), L.ptr(xd), L.ptr(y), L.ptr(w), L.ptr(stats[0]), L.ptr(stats[1]),
+                   L.ptr(wd), L.ptr(stats[4]), L.ptr(stats[5]), int(relu), L.ptr(dx), L.ptr(dxd), L.ptr(g[0]), L.ptr(g[1]),
+                   L.ptr(g[2]), L.ptr(g[3]), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev), alg_bytes=4 * M * C * 10)
+        return (dx, dxd, g[0], g[1], None, None, None, None, None, g[2], g[3], None, None, None, None, None, None)
+
+
+def bn_act_dual(x, bn, xd, bn_d, relu=True):
+    """relu(bn(x) + bn_d(xd)) -- the tail of a residual block whose identity branch ends in its own BatchNorm (`downsample`).
+    Training mode on channels-last tensors: one fused forward / backward that never writes bn_d(xd) or the gated gradient;
+    otherwise the same value through bn_act(x, bn, residual=bn_d(xd))."""
+    if (eligible(x, bn, xd) and eligible(xd, bn_d) and bn.training and bn_d.training and bn.running_mean is not None
+            and bn_d.running_mean is not None and torch.is_grad_enabled()):
+        return _BNDualTrain.apply(x, xd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                                  bn.eps, bn_d.weight, bn_d.bias, bn_d.running_mean, bn_d.running_var, bn_d.num_batches_tracked,
+                                  bn_d.momentum, bn_d.eps, relu)
+    return bn_act(x, bn, bn_act(xd, bn_d, None, False), relu)
+
+
+def split_downsample(downsample):
+    """(conv, norm) if `downsample` is the conv -> BatchNorm2d pair mmdet's ResLayer builds, else None"""
+    if isinstance(downsample, nn.Sequential) and len(downsample) == 2 and isinstance(downsample[0], nn.Conv2d) \
+            and type(downsample[1]) in _BN_TYPES and not isinstance(downsample[1], BatchNormAct2d):
+        return downsample[0], downsample[1]
+    return None
+
+
 def _infer(x, residual, bn, relu):
     dev = x.device
     N, C, H, W = x.shape

@@ -205,13 +205,21 @@ __global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ par
   }
 }
 
-template <bool RES, bool RELU>
+// RAFF: the residual is itself a normalised tensor, res * rsc + rsh with the scale / shift of a second BatchNorm
+// (`rcoef`): the `downsample` branch of a stage-first residual block, whose normalised copy is then never written
+template <bool RES, bool RELU, bool RAFF = false>
 __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, const float4* __restrict__ res,
-                                                const float* __restrict__ coef, float4* __restrict__ y, BnGeom g) {
+                                                const float* __restrict__ coef, float4* __restrict__ y, BnGeom g,
+                                                const float* __restrict__ rcoef = nullptr) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 sc = reinterpret_cast<const float4*>(coef)[q];
-  const float4 sh = reinterpret_cast<const float4*>(coef + g.C)[q];
+  float4 sh = reinterpret_cast<const float4*>(coef + g.C)[q];
+  float4 rsc = f4(1.f);
+  if (RAFF) {
+    rsc = reinterpret_cast<const float4*>(rcoef)[q];
+    add4(sh, reinterpret_cast<const float4*>(rcoef + g.C)[q]);       // both shifts in one constant
+  }
   const int stride = g.RP;
   int r_end;
   for (int r0 = block_rows(g, &r_end, g.RP) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
@@ -231,7 +239,8 @@ __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, co
         float4 o;
         o.x = fmaf(v[u].x, sc.x, sh.x); o.y = fmaf(v[u].y, sc.y, sh.y);
         o.z = fmaf(v[u].z, sc.z, sh.z); o.w = fmaf(v[u].w, sc.w, sh.w);
-        if (RES) add4(o, w[u]);
+        if (RES && !RAFF) add4(o, w[u]);
+        if (RAFF) fma4v(o, w[u], rsc);
         if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         st_nt(y + static_cast<size_t>(r) * g.C4 + q, o);
       }
@@ -385,6 +394,161 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, 
         d.w = fmaf(A.w, dz.w, fmaf(Bc.w, v[u].w, Cc.w));
         st_nt(dx + static_cast<size_t>(r) * g.C4 + q, d);
         if (DRES) st_nt(dres + static_cast<size_t>(r) * g.C4 + q, dz);
+      }
+    }
+  }
+}
+
+// ---- two BatchNorms feeding one add (+ ReLU): out = relu(bn(x) + bn_d(xd)) -- the main and the `downsample` branch of a
+// stage-first residual block.  dz = dout * [out > 0] is shared, so one reduction pass gives sum dz, sum dz * xhat and
+// sum dz * xhat_d (partial rows of THREE values per channel) and one pass writes both input gradients: 4 reads + 2 writes
+// and 4 reads, where two chained single-BatchNorm backwards take 8 reads + 3 writes (the gated gradient written and re-read).
+template <int TPB>
+__device__ __forceinline__ void block_merge_store3(float4 a, float4 b, float4 c, float* __restrict__ partial, int C, int CH,
+                                                   int RP, int q, int ql, int rp) {
+  __shared__ float4 sa[TPB], sb[TPB], sc[TPB];
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int st = RP >> 1; st > 0; st >>= 1) {
+    if (rp < st) {
+      add4(sa[threadIdx.x], sa[threadIdx.x + st * CH]);
+      add4(sb[threadIdx.x], sb[threadIdx.x + st * CH]);
+      add4(sc[threadIdx.x], sc[threadIdx.x + st * CH]);
+    }
+    __syncthreads();
+  }
+  if (rp == 0) {
+    reinterpret_cast<float4*>(partial + (static_cast<size_t>(blockIdx.x) * 3 + 0) * C)[q] = sa[ql];
+    reinterpret_cast<float4*>(partial + (static_cast<size_t>(blockIdx.x) * 3 + 1) * C)[q] = sb[ql];
+    reinterpret_cast<float4*>(partial + (static_cast<size_t>(blockIdx.x) * 3 + 2) * C)[q] = sc[ql];
+  }
+}
+
+template <bool RELU, int TPB, int UNR>
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                          const float4* __restrict__ xd, const float4* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ mean_d,
+                                                          const float* __restrict__ invstd_d, float* __restrict__ partial,
+                                                          BnGeom g) {
+  const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
+  const int q = blockIdx.y * g.CH + ql;
+  const float4 mu = reinterpret_cast<const float4*>(mean)[q], is = reinterpret_cast<const float4*>(invstd)[q];
+  const float4 mud = reinterpret_cast<const float4*>(mean_d)[q], isd = reinterpret_cast<const float4*>(invstd_d)[q];
+  float4 db = f4(0.f), dg = f4(0.f), dgd = f4(0.f);
+  const int stride = g.RRP;
+  int r_end;
+  for (int r0 = block_rows<true>(g, &r_end, g.RRP) + rp; r0 < r_end; r0 += UNR * stride) {
+    float4 a[UNR], v[UNR], vd[UNR], o[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int r = r0 + u * stride;
+      a[u] = f4(0.f); v[u] = f4(0.f); vd[u] = f4(0.f); o[u] = f4(0.f);
+      if (r < r_end) {
+        a[u] = dy[static_cast<size_t>(r) * g.C4 + q];
+        v[u] = x[static_cast<size_t>(r) * g.C4 + q];
+        vd[u] = xd[static_cast<size_t>(r) * g.C4 + q];
+        if (RELU) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const float4 dz = gate<RELU ? 2 : 0>(a[u], v[u], o[u], mu, mu);
+      float4 xh, xhd;
+      xh.x = (v[u].x - mu.x) * is.x; xh.y = (v[u].y - mu.y) * is.y; xh.z = (v[u].z - mu.z) * is.z; xh.w = (v[u].w - mu.w) * is.w;
+      xhd.x = (vd[u].x - mud.x) * isd.x; xhd.y = (vd[u].y - mud.y) * isd.y;
+      xhd.z = (vd[u].z - mud.z) * isd.z; xhd.w = (vd[u].w - mud.w) * isd.w;
+      add4(db, dz);
+      fma4v(dg, dz, xh);
+      fma4v(dgd, dz, xhd);
+    }
+  }
+  block_merge_store3<TPB>(db, dg, dgd, partial, g.C, g.CH, g.RRP, q, ql, rp);
+}
+
+// dgamma / dbeta of both norms (dbeta is the same sum for both) and their dx coefficients: bcoef [0..2] main, [3..5] branch
+__global__ __launch_bounds__(256) void bn_bwd_finalize_dual(const float* __restrict__ partial, int nbx, int M, int C,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma_d,
+                                                            const float* __restrict__ mean_d,
+                                                            const float* __restrict__ invstd_d, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dgamma_d,
+                                                            float* __restrict__ dbeta_d, float* __restrict__ bcoef) {
+  __shared__ double l0[4][BN_FIN_CH], l1[4][BN_FIN_CH], l2[4][BN_FIN_CH];
+  const int cl = threadIdx.x % BN_FIN_CH, ph = threadIdx.x / BN_FIN_CH;
+  const int c = blockIdx.x * BN_FIN_CH + cl;
+  double s = 0.0, sq = 0.0, sd = 0.0;
+  if (c < C) {
+    for (int b = ph; b < nbx; b += BN_FIN_PH) {
+      s += static_cast<double>(partial[(static_cast<size_t>(b) * 3 + 0) * C + c]);
+      sq += static_cast<double>(partial[(static_cast<size_t>(b) * 3 + 1) * C + c]);
+      sd += static_cast<double>(partial[(static_cast<size_t>(b) * 3 + 2) * C + c]);
+    }
+  }
+#pragma unroll
+  for (int m = BN_FIN_CH; m < 64; m <<= 1) { s += __shfl_xor(s, m); sq += __shfl_xor(sq, m); sd += __shfl_xor(sd, m); }
+  if ((threadIdx.x & 63) < BN_FIN_CH) { l0[threadIdx.x >> 6][cl] = s; l1[threadIdx.x >> 6][cl] = sq; l2[threadIdx.x >> 6][cl] = sd; }
+  __syncthreads();
+  if (ph == 0 && c < C) {
+    s = ((l0[0][cl] + l0[1][cl]) + l0[2][cl]) + l0[3][cl];
+    sq = ((l1[0][cl] + l1[1][cl]) + l1[2][cl]) + l1[3][cl];
+    sd = ((l2[0][cl] + l2[1][cl]) + l2[2][cl]) + l2[3][cl];
+    dbeta[c] = static_cast<float>(s);
+    dbeta_d[c] = static_cast<float>(s);
+    dgamma[c] = static_cast<float>(sq);
+    dgamma_d[c] = static_cast<float>(sd);
+    double is = invstd[c], mu = mean[c], A = static_cast<double>(gamma[c]) * is;
+    bcoef[c] = static_cast<float>(A);
+    bcoef[C + c] = static_cast<float>(-A * is * sq / M);
+    bcoef[2 * C + c] = static_cast<float>(A * (mu * is * sq - s) / M);
+    is = invstd_d[c]; mu = mean_d[c]; A = static_cast<double>(gamma_d[c]) * is;
+    bcoef[3 * C + c] = static_cast<float>(A);
+    bcoef[4 * C + c] = static_cast<float>(-A * is * sd / M);
+    bcoef[5 * C + c] = static_cast<float>(A * (mu * is * sd - s) / M);
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_dx_dual(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                      const float4* __restrict__ xd, const float4* __restrict__ y,
+                                                      const float* __restrict__ bcoef, float4* __restrict__ dx,
+                                                      float4* __restrict__ dxd, BnGeom g) {
+  const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
+  const int q = blockIdx.y * g.CH + ql;
+  const float4 A = reinterpret_cast<const float4*>(bcoef)[q], Bc = reinterpret_cast<const float4*>(bcoef + g.C)[q];
+  const float4 Cc = reinterpret_cast<const float4*>(bcoef + 2 * g.C)[q];
+  const float4 Ad = reinterpret_cast<const float4*>(bcoef + 3 * g.C)[q], Bd = reinterpret_cast<const float4*>(bcoef + 4 * g.C)[q];
+  const float4 Cd = reinterpret_cast<const float4*>(bcoef + 5 * g.C)[q];
+  const int stride = g.RP;
+  int r_end;
+  for (int r0 = block_rows(g, &r_end, g.RP) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
+    float4 a[BN_ROWS_UNROLL], v[BN_ROWS_UNROLL], vd[BN_ROWS_UNROLL], o[BN_ROWS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      a[u] = f4(0.f); v[u] = f4(0.f); vd[u] = f4(0.f); o[u] = f4(0.f);
+      if (r < r_end) {
+        a[u] = dy[static_cast<size_t>(r) * g.C4 + q];
+        v[u] = x[static_cast<size_t>(r) * g.C4 + q];
+        vd[u] = xd[static_cast<size_t>(r) * g.C4 + q];
+        if (RELU) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+      const int r = r0 + u * stride;
+      if (r < r_end) {
+        const float4 dz = gate<RELU ? 2 : 0>(a[u], v[u], o[u], A, A);
+        float4 d, e;
+        d.x = fmaf(A.x, dz.x, fmaf(Bc.x, v[u].x, Cc.x)); d.y = fmaf(A.y, dz.y, fmaf(Bc.y, v[u].y, Cc.y));
+        d.z = fmaf(A.z, dz.z, fmaf(Bc.z, v[u].z, Cc.z)); d.w = fmaf(A.w, dz.w, fmaf(Bc.w, v[u].w, Cc.w));
+        e.x = fmaf(Ad.x, dz.x, fmaf(Bd.x, vd[u].x, Cd.x)); e.y = fmaf(Ad.y, dz.y, fmaf(Bd.y, vd[u].y, Cd.y));
+        e.z = fmaf(Ad.z, dz.z, fmaf(Bd.z, vd[u].z, Cd.z)); e.w = fmaf(Ad.w, dz.w, fmaf(Bd.w, vd[u].w, Cd.w));
+        st_nt(dx + static_cast<size_t>(r) * g.C4 + q, d);
+        st_nt(dxd + static_cast<size_t>(r) * g.C4 + q, e);
       }
     }
   }
@@ -554,6 +718,108 @@ extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const f
     if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx<1, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
     else hipLaunchKernelGGL((bn_bwd_dx<0, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
   }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- dual BatchNorm: y = [relu](bn(x) + bn_d(xd)) ------------------------------------------------------------------------
+extern "C" size_t dbev_bn_dual_workspace_bytes(long long M, int C) {
+  BnGeom g;
+  if (!bn_geom(M, C, &g)) return 0;
+  return sizeof(float) * static_cast<size_t>(g.NBX) * 3 * C + sizeof(float) * 6 * static_cast<size_t>(C);
+}
+
+extern "C" int dbev_bn_dual_train_forward(const float* x, const float* xd, const float* gamma, const float* beta,
+                                          float* running_mean, float* running_var, long long* num_batches_tracked,
+                                          float momentum, float eps, const float* gamma_d, const float* beta_d,
+                                          float* running_mean_d, float* running_var_d, long long* num_batches_tracked_d,
+                                          float momentum_d, float eps_d, int relu, float* y, float* save_mean,
+                                          float* save_invstd, float* save_scale_shift, float* save_mean_d,
+                                          float* save_invstd_d, float* save_scale_shift_d, long long M, int C,
+                                          void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  BnGeom g;
+  if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
+  if (x == nullptr || xd == nullptr || gamma == nullptr || beta == nullptr || gamma_d == nullptr || beta_d == nullptr ||
+      y == nullptr || save_mean == nullptr || save_invstd == nullptr || save_scale_shift == nullptr ||
+      save_mean_d == nullptr || save_invstd_d == nullptr || save_scale_shift_d == nullptr || workspace == nullptr ||
+      workspace_bytes < dbev_bn_dual_workspace_bytes(M, C) || (running_mean == nullptr) != (running_var == nullptr) ||
+      (running_mean_d == nullptr) != (running_var_d == nullptr))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  float* partial = static_cast<float*>(workspace);
+  const dim3 grid(g.NBX, g.GY);
+  const long long T = 4LL * g.M * C;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* d4 = reinterpret_cast<const float4*>(xd);
+  // statistics of the branch first, then of the main input: the same partial buffer serves both (stream order)
+  { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, d4, partial); }
+  { DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * g.NBX * g.GY * C, s);
+    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma_d, beta_d,
+                       running_mean_d, running_var_d, momentum_d, eps_d, save_mean_d, save_invstd_d, save_scale_shift_d,
+                       num_batches_tracked_d); }
+  { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, x4, partial); }
+  { DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * g.NBX * g.GY * C, s);
+    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
+                       num_batches_tracked); }
+  const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
+  const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
+  const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
+  DbevKt kt(DBEV_K_BN_APPLY_RES, T * 3, s);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  if (relu) hipLaunchKernelGGL((bn_apply<true, true, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d);
+  else hipLaunchKernelGGL((bn_apply<true, false, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_bn_dual_backward(const float* grad_y, const float* x, const float* xd, const float* y,
+                                     const float* gamma, const float* save_mean, const float* save_invstd,
+                                     const float* gamma_d, const float* save_mean_d, const float* save_invstd_d, int relu,
+                                     float* grad_x, float* grad_xd, float* grad_gamma, float* grad_beta,
+                                     float* grad_gamma_d, float* grad_beta_d, long long M, int C, void* workspace,
+                                     size_t workspace_bytes, dbevStream_t stream) {
+  BnGeom g;
+  if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
+  if (grad_y == nullptr || x == nullptr || xd == nullptr || (relu && y == nullptr) || gamma == nullptr ||
+      save_mean == nullptr || save_invstd == nullptr || gamma_d == nullptr || save_mean_d == nullptr ||
+      save_invstd_d == nullptr || grad_x == nullptr || grad_xd == nullptr || grad_gamma == nullptr ||
+      grad_beta == nullptr || grad_gamma_d == nullptr || grad_beta_d == nullptr || workspace == nullptr ||
+      workspace_bytes < dbev_bn_dual_workspace_bytes(M, C))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  float* partial = static_cast<float*>(workspace);
+  float* bcoef = partial + static_cast<size_t>(g.NBX) * 3 * C;
+  const dim3 grid(g.NBX, g.GY);
+  const float4* dy4 = reinterpret_cast<const float4*>(grad_y);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* d4 = reinterpret_cast<const float4*>(xd);
+  const float4* y4 = reinterpret_cast<const float4*>(y);
+  const long long T = 4LL * g.M * C;
+  {
+    DbevKt kt(DBEV_K_BN_BWD_REDUCE_Y, T * (relu ? 4 : 3), s);
+#define BN_CALL(TP, U)                                                                                                        \
+  do {                                                                                                                        \
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_dual<true, TP, U>), grid, dim3(TP), 0, s, dy4, x4, d4, y4, save_mean,         \
+                                 save_invstd, save_mean_d, save_invstd_d, partial, g);                                        \
+    else hipLaunchKernelGGL((bn_bwd_reduce_dual<false, TP, U>), grid, dim3(TP), 0, s, dy4, x4, d4, y4, save_mean, save_invstd, \
+                            save_mean_d, save_invstd_d, partial, g);                                                          \
+  } while (0)
+    BN_DISPATCH_TPB_UNR(BN_CALL);
+#undef BN_CALL
+  }
+  { DbevKt kt(DBEV_K_BN_BWD_FINALIZE, 12LL * g.NBX * g.GY * C, s);
+    hipLaunchKernelGGL(bn_bwd_finalize_dual, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma,
+                       save_mean, save_invstd, gamma_d, save_mean_d, save_invstd_d, grad_gamma, grad_beta, grad_gamma_d,
+                       grad_beta_d, bcoef); }
+  const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
+  const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
+  const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
+  DbevKt kt(DBEV_K_BN_BWD_DX_RES, T * (relu ? 6 : 5), s);
+  if (relu) hipLaunchKernelGGL((bn_bwd_dx_dual<true>), agrid, dim3(256), 0, s, dy4, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
+                               reinterpret_cast<float4*>(grad_xd), g);
+  else hipLaunchKernelGGL((bn_bwd_dx_dual<false>), agrid, dim3(256), 0, s, dy4, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
+                          reinterpret_cast<float4*>(grad_xd), g);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

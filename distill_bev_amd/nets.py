@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 
-from .bn_act import bn_act
+from .bn_act import bn_act, bn_act_dual, split_downsample
 from .registry import (MODELS, ConvModule, build_activation_layer, build_conv_layer, build_norm_layer,
                        build_upsample_layer, register_conv)
 
@@ -57,6 +57,9 @@ class BasicBlock(nn.Module):
     def _fused(self, x):
         """same op sequence with norm -> (+identity) -> relu on the fused kernels (bn_act falls back by itself)"""
         out = bn_act(self.conv1(x), getattr(self, self.norm1_name), None, True)
+        ds = split_downsample(self.downsample)
+        if ds is not None:         # norm of the main path and norm of the identity branch, add and ReLU in one pass
+            return bn_act_dual(self.conv2(out), getattr(self, self.norm2_name), ds[0](x), ds[1], True)
         identity = x if self.downsample is None else self.downsample(x)
         return bn_act(self.conv2(out), getattr(self, self.norm2_name), identity, True)
 
@@ -106,6 +109,9 @@ class Bottleneck(nn.Module):
         """same op sequence with norm -> (+identity) -> relu on the fused kernels (bn_act falls back by itself)"""
         out = bn_act(self.conv1(x), getattr(self, self.norm1_name), None, True)
         out = bn_act(self.conv2(out), getattr(self, self.norm2_name), None, True)
+        ds = split_downsample(self.downsample)
+        if ds is not None:
+            return bn_act_dual(self.conv3(out), getattr(self, self.norm3_name), ds[0](x), ds[1], True)
         identity = x if self.downsample is None else self.downsample(x)
         return bn_act(self.conv3(out), getattr(self, self.norm3_name), identity, True)
 

@@ -444,6 +444,26 @@ int dbev_bn_act_backward(const float* grad_y, const float* x, const float* y, co
                          int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                          long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
+/* Two training-mode BatchNorm2d layers feeding one add (+ ReLU):  y = [relu]( bn(x) + bn_d(xd) )  -- the main and the
+ * `downsample` branch of a stage-first residual block (mmdet ResNet Bottleneck / BasicBlock: `identity = self.downsample(x)`,
+ * `out += identity`, `relu`).  Same semantics, layouts and constraints as dbev_bn_act_*; the normalised copy of the branch and the
+ * gated gradient dy * [y > 0] are never materialised (forward 4 reads + 1 write of [M, C], backward 8 reads + 2 writes; the two
+ * chained single-norm calls take 5 + 2 and 11 + 3).  grad_beta_d == grad_beta (both are sum dz).
+ * workspace: dbev_bn_dual_workspace_bytes(M, C) for either direction. */
+size_t dbev_bn_dual_workspace_bytes(long long M, int C);
+int dbev_bn_dual_train_forward(const float* x, const float* xd, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                               const float* gamma_d, const float* beta_d, float* running_mean_d, float* running_var_d,
+                               long long* num_batches_tracked_d, float momentum_d, float eps_d, int relu, float* y,
+                               float* save_mean, float* save_invstd, float* save_scale_shift, float* save_mean_d,
+                               float* save_invstd_d, float* save_scale_shift_d, long long M, int C, void* workspace,
+                               size_t workspace_bytes, dbevStream_t stream);
+int dbev_bn_dual_backward(const float* grad_y, const float* x, const float* xd, const float* y, const float* gamma,
+                          const float* save_mean, const float* save_invstd, const float* gamma_d, const float* save_mean_d,
+                          const float* save_invstd_d, int relu, float* grad_x, float* grad_xd, float* grad_gamma,
+                          float* grad_beta, float* grad_gamma_d, float* grad_beta_d, long long M, int C, void* workspace,
+                          size_t workspace_bytes, dbevStream_t stream);
+
 /* bev_pool helpers of the Python surface (mmdet3d/ops/bev_pool/bev_pool.py:64-97): the cell lists straight from the
  * int64 coordinates the reference's callers pass (no int32 conversion pass), and the [B, C, S] -> [B, S, C] transpose
  * for an out_grad that arrives in the reference's contiguous [B, C, D, H, W] layout (S = D*H*W). */

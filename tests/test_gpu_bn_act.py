@@ -163,3 +163,51 @@ def test_edge_cases_single_value_per_channel_and_tiny_tensors():
     bn3 = nn.BatchNorm2d(64).to(DEV).train(); ref3 = nn.BatchNorm2d(64).to(DEV).train()
     x3 = torch.randn((1, 64, 7, 13), device=DEV).contiguous(memory_format=torch.channels_last)
     assert torch.allclose(BA.bn_act(x3, bn3, None, True), torch.relu(ref3(x3)), atol=2e-6)
+
+
+@pytest.mark.parametrize("N,C,H,W,relu", [(2, 256, 16, 11, True), (3, 64, 9, 7, True), (1, 2048, 4, 3, True), (2, 512, 7, 5, False)])
+def test_dual_norm_add_relu_of_a_stage_first_residual_block(N, C, H, W, relu):
+    """bn_act_dual = relu(bn(x) + bn_d(xd)) (dbev_bn_dual_*): output, the two input gradients, the four parameter gradients
+    and both sets of running statistics against the fp64 torch sequence; bit-identical when repeated; eval / no-grad calls
+    take the two-step path and give the same values."""
+    from distill_bev_amd.bn_act import bn_act_dual
+    g = torch.Generator().manual_seed(C + W)
+    x = torch.randn((N, C, H, W), generator=g) * 1.5 + 0.3
+    xd = torch.randn((N, C, H, W), generator=g) * 0.7 - 0.2
+    bns = [nn.BatchNorm2d(C, eps=1e-5, momentum=0.1), nn.BatchNorm2d(C, eps=1e-3, momentum=0.05)]
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g))
+            bn.running_mean.copy_(torch.randn(C, generator=g)); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    r1, (rx, _, rw, rb), (rm1, rv1) = _ref(x, None, bns[0], False, True)
+    r2, (rxd, _, rwd, rbd), (rm2, rv2) = _ref(xd, None, bns[1], False, True)
+    ref = F.relu(r1 + r2) if relu else r1 + r2
+    gout = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(gout)
+    bns = [bn.to(DEV).train() for bn in bns]
+    init = [{k: v.clone() for k, v in bn.state_dict().items()} for bn in bns]
+    a = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = xd.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+    def run():
+        for bn, st in zip(bns, init):
+            bn.load_state_dict(st)
+        y = bn_act_dual(a, bns[0], b, bns[1], relu)
+        grads = torch.autograd.grad(y, [a, b, bns[0].weight, bns[0].bias, bns[1].weight, bns[1].bias], gout.float().to(DEV))
+        return y, grads
+    y, grads = run()
+    assert type(y.grad_fn).__name__ == "_BNDualTrainBackward"
+    _close(y, ref, 2e-6, "dual forward")
+    for got, want, tol, what in zip(grads, (rx.grad, rxd.grad, rw.grad, rb.grad, rwd.grad, rbd.grad),
+                                    (2e-5, 2e-5, 1e-5, 1e-5, 1e-5, 1e-5), ("dx", "dxd", "dgamma", "dbeta", "dgamma_d", "dbeta_d")):
+        _close(got, want, tol, what)
+    _close(bns[0].running_mean, rm1, 1e-6, "running_mean"); _close(bns[0].running_var, rv1, 1e-6, "running_var")
+    _close(bns[1].running_mean, rm2, 1e-6, "running_mean_d"); _close(bns[1].running_var, rv2, 1e-6, "running_var_d")
+    assert int(bns[0].num_batches_tracked) == 1 and int(bns[1].num_batches_tracked) == 1
+    y2, grads2 = run()
+    assert torch.equal(y, y2) and all(torch.equal(p, q) for p, q in zip(grads, grads2))
+    with torch.no_grad():                         # statistics path of the two-step fallback (no autograd): same numbers
+        for bn, st in zip(bns, init):
+            bn.load_state_dict(st)
+        y3 = bn_act_dual(a, bns[0], b, bns[1], relu)
+    _close(y3, ref, 2e-6, "two-step forward")
