@@ -280,7 +280,9 @@ class BEVFormerDistill(BEVFormer):
         B, _, H, W = fg_mask.shape
         boxes = [b.tensor[(s > thres).cpu()] if len(s) else b.tensor[:0] for b, s, _ in teacher_preds]
         inside, _, _ = self._fg_raster(H, W, [b.cpu() for b in boxes], fg_mask.device)
-        fp = ((inside > 0) & (fg_mask == 0)).float()
+        # the reference lays this mask out [x, y] -- it reshapes the x-major cell list without the transpose that
+        # foreground_scale_mask applies (:486-489 vs :621) -- and multiplies it with the [y, x] attention map as is: kept
+        fp = ((inside > 0) & (fg_mask == 0)).float().transpose(2, 3).contiguous()
         n_fp = fp.sum(dim=(1, 2, 3))
         return fp, fp / n_fp.clamp(min=1).view(-1, 1, 1, 1), n_fp
 

@@ -232,6 +232,9 @@ class LiDARBoxesStub:
     def __init__(self, tensor):
         self.tensor = torch.as_tensor(tensor, dtype=torch.float32)
 
+    def __getitem__(self, item):                      # lidar_box3d / base_box3d: indexing returns boxes of the same type
+        return LiDARBoxesStub(self.tensor[item].reshape(-1, self.tensor.shape[-1]))
+
     @property
     def gravity_center(self):
         bottom_center = self.tensor[:, :3]

@@ -796,7 +796,27 @@ def make_bevformer_fgd():
     losses = self.fgd_distill_loss(teacher, student, gtb, None, None, None, None, None, 0)
     total = sum(losses.values())
     grads = torch.autograd.grad(total, [student] + list(self.parameters()))
-    _save("bevformer_fgd.npz", teacher=teacher.numpy(), student=student.detach().numpy(), fg=fg.numpy(), fg_scale=fgs.numpy(),
+    # add_fp_as_fg_bbox (:555-631): cells inside confident teacher boxes and outside every ground-truth box
+    tboxes, tscores = [], []
+    for b in range(B):
+        tb, _ = syn.gt_boxes(12, rng)
+        tb[:, 3:5] *= 3.0
+        if len(boxes[b]):
+            tb[:2] = boxes[b][:2]                    # two predictions coincide with ground truth: not false positives
+        tboxes.append(tb)
+        tscores.append(torch.from_numpy(rng.uniform(0.0, 0.3, 12).astype(np.float32)))
+    preds = [(R.LiDARBoxesStub(tb), sc, None) for tb, sc in zip(tboxes, tscores)]
+    fp, fps, nfp = self.add_fp_as_fg_bbox(HW, HW, "teacher", fg, preds, gtb)
+    self.distill_params = dict(dp, fp_as_foreground=["teacher"], fp_weight=6e-2)
+    with torch.no_grad():
+        losses_fp = self.fgd_distill_loss(teacher, student, gtb, None, None, None, preds, None, 0)
+    self.distill_params = dp
+    print("with false positives:", {k: float(v) for k, v in losses_fp.items()})
+    extra = dict(fp=fp.numpy(), fp_scale=fps.numpy(), n_fp=nfp.numpy(), **_flat_losses("lossfp__", losses_fp),
+                 **{f"t_boxes{b}": tboxes[b] for b in range(B)},
+                 **{f"t_scores{b}": tscores[b].numpy() for b in range(B)})
+    print("fp cells per sample", nfp.tolist())
+    _save("bevformer_fgd.npz", **extra, teacher=teacher.numpy(), student=student.detach().numpy(), fg=fg.numpy(), fg_scale=fgs.numpy(),
           bg_scale=bgs.numpy(), g_student=grads[0].numpy(), **{f"gt_boxes{b}": boxes[b] for b in range(B)},
           **_flat_losses("loss__", losses), **_sd("cwa__", self.channel_wise_adaptations), **_sd("swa__", self.spatial_wise_adaptations),
           **{f"g__{i}": gr.numpy() for i, gr in enumerate(grads[1:])})

@@ -75,6 +75,44 @@ def test_bevformer_fgd_terms_vs_reference_fixture(fused):
         assert float((g.cpu() - r).abs().max()) <= 1e-4 * max(float(r.abs().max()), 1e-8)
 
 
+def test_bevformer_false_positive_mask_vs_reference_fixture():
+    """add_fp_as_fg_bbox (bevformer_distill.py:555-631): cells inside teacher boxes scored above output_threshold and outside
+    every ground-truth box, 1 / count scale, counts -- bit-equal to the reference's own function (including its [x, y]
+    layout), and the FGD loss with fp_as_foreground='teacher' builds the extra term from it."""
+    import copy
+    from distill_bev_amd.bevformer import BEVFormerDistill
+    from distill_bev_amd.center_head import LiDARBoxes
+    from distill_bev_amd.detectors import install_fgd_modules
+    from distill_bev_amd.distill_loss import ForegroundMaskRasterizer
+    fx = np.load(os.path.join(GOLD, "bevformer_fgd.npz"))
+    dev = torch.device("cuda:0")
+    d = BEVFormerDistill.__new__(BEVFormerDistill)
+    torch.nn.Module.__init__(d)
+    d.teacher_model = torch.nn.Identity()
+    d.distill_params = dict(copy.deepcopy(DP), fp_as_foreground="teacher", fp_weight=6e-2)
+    install_fgd_modules(d, d.distill_params)
+    d._fg_raster = ForegroundMaskRasterizer([512, 512, 1], PCR, [0.2, 0.2, 8], cell_center=True)
+    d._epoch, d.no_bg, d.fused_adapt_mse = 0, False, False
+    d.channel_wise_adaptations.load_state_dict({k[5:].replace("__", "."): torch.from_numpy(fx[k]) for k in fx.files if k.startswith("cwa__")})
+    d.spatial_wise_adaptations.load_state_dict({k[5:].replace("__", "."): torch.from_numpy(fx[k]) for k in fx.files if k.startswith("swa__")})
+    d.to(dev)
+    B = 3
+    gtb = [LiDARBoxes(fx[f"gt_boxes{b}"]) for b in range(B)]
+    preds = [(LiDARBoxes(fx[f"t_boxes{b}"]), torch.from_numpy(fx[f"t_scores{b}"]).to(dev), None) for b in range(B)]
+    fg, _, _ = d._fg_raster(20, 20, [b.tensor for b in gtb], dev)
+    fp, fps, nfp = d.add_fp_as_fg("teacher", fg, None, preds, None)
+    assert torch.equal(fp.cpu(), torch.from_numpy(fx["fp"]).float())
+    assert torch.equal(nfp.cpu(), torch.from_numpy(fx["n_fp"]).float())
+    assert float((fps.cpu() - torch.from_numpy(fx["fp_scale"]).float()).abs().max()) <= 1e-9
+    t = torch.from_numpy(fx["teacher"]).to(dev)
+    s = torch.from_numpy(fx["student"]).to(dev).requires_grad_(True)
+    losses = d.fgd_distill_loss(t, s, gtb, None, None, None, preds, None, 0)
+    assert set(losses) == {"kd_fg_feat_loss", "kd_bg_feat_loss", "kd_spatial_loss", "kd_fp_bg_feat_loss"}
+    for k, v in losses.items():                     # the four terms of the reference's own fgd_distill_loss in this mode
+        ref = float(fx["lossfp__" + k])
+        assert abs(float(v) - ref) <= 1e-4 * abs(ref), (k, float(v), ref)
+
+
 def small_distill_cfg(bev=20, dim=32, queue=3, cams=6):
     import bevformer_cfgs as C
     head = C.small_bevformer_head_cfg(dim=dim, bev=bev, levels=4, cams=cams, queries=40)
