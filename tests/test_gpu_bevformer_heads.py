@@ -175,3 +175,47 @@ def test_grid_mask_vs_reference_fixture():
         changed += int(not torch.equal(y, x))
     assert changed >= 3                                   # prob 0.7: most seeds apply a mask
     assert torch.equal(gm.eval()(x), x)
+
+
+def test_edge_cases_no_visible_query_no_ground_truth_no_history():
+    """(a) a calibration under which NO camera sees any BEV query (all pillar points behind the cameras): the spatial cross
+    attention contributes only its output-projection bias, the head still runs; (b) a batch without a single ground-truth box:
+    classification loss only, box loss exactly 0, gradients finite; (c) only_bev without history == with prev_bev=None."""
+    import bevformer_cfgs as C
+    from distill_bev_amd import bevformer  # noqa: F401
+    from distill_bev_amd.center_head import LiDARBoxes
+    from distill_bev_amd.registry import build_head
+    from distill_bev_amd.transformer import CameraPlan
+    fx = np.load(os.path.join(GOLD, "bevformer_head.npz"))
+    dev = torch.device("cuda:0")
+    head = build_head(C.small_bevformer_head_cfg())
+    _load(head, fx)
+    head = head.to(dev).eval()
+    bs = 2
+    feats = [torch.from_numpy(fx["feat0"]).to(dev).requires_grad_(True), torch.from_numpy(fx["feat1"]).to(dev)]
+    metas = _metas(fx, bs)
+    behind = np.eye(4)
+    behind[2, 3] = -1000.0                       # camera-frame depth = z - 1000 < 0 for every point of the grid
+    blind = [dict(m, lidar2img=[behind.copy() for _ in m["lidar2img"]]) for m in metas]
+    enc = head.transformer.encoder
+    ref3d = enc.get_reference_points(10, 10, 8.0, 4, dim="3d", bs=bs, device=dev, dtype=torch.float32)
+    _, mask = enc.point_sampling(ref3d, C.PCR, blind)
+    assert not bool(mask.any()) and CameraPlan(mask).max_len == 0
+    outs = head(feats, blind, None)
+    assert all(bool(torch.isfinite(outs[k]).all()) for k in ("bev_embed", "all_cls_scores", "all_bbox_preds"))
+    # (b) no ground truth at all
+    gtb = [LiDARBoxes(np.zeros((0, 9), np.float32)) for _ in range(bs)]
+    gtl = [torch.zeros((0,), dtype=torch.long, device=dev) for _ in range(bs)]
+    outs = head(feats, metas, torch.from_numpy(fx["prev_bev"]).to(dev))
+    losses = head.loss(gtb, gtl, outs, img_metas=metas)
+    assert float(losses["loss_bbox"]) == 0.0 and float(losses["d0.loss_bbox"]) == 0.0 and float(losses["loss_cls"]) > 0
+    g, = torch.autograd.grad(sum(losses.values()), feats[0])
+    assert bool(torch.isfinite(g).all())
+    ref = head.loss_reference_order(gtb, gtl, outs)
+    for k in losses:
+        assert abs(float(losses[k]) - float(ref[k])) <= 1e-6 * max(abs(float(ref[k])), 1e-6), k
+    # (c)
+    with torch.no_grad():
+        a = head(feats, metas, None, only_bev=True)
+        b = head(feats, [dict(m, prev_bev_exists=False) for m in metas], None, only_bev=True)
+    assert torch.equal(a, b)

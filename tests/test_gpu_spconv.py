@@ -249,3 +249,28 @@ def test_dynamic_voxel_encoder_plain_and_virtual():
     rv[mix, 6:] = rv[mix, 6:] / (1 - ind[mix].unsqueeze(-1))
     assert vv.shape == (rc.shape[0], 23) and np.array_equal(cv[:, 1:].cpu().numpy(), rc.numpy())
     assert float((vv.cpu() - rv).abs().max()) < 1e-4 and int(mix.sum()) > 5
+
+
+def test_edge_cases_empty_and_single_site_tensors():
+    """No active site at all, and one active site: every sparse layer type returns the right (possibly empty) site set; the
+    encoder of an empty sample is the zero canvas."""
+    from distill_bev_amd import spconv
+    dev = torch.device("cuda:0")
+    shape, B = [9, 12, 10], 2
+    for n in (0, 1):
+        idx = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        if n:
+            idx[0] = torch.tensor([1, 4, 5, 6], dtype=torch.int32)
+        x = spconv.SparseConvTensor(torch.randn((n, 16), device=dev), idx, shape, B)
+        with torch.no_grad():
+            y = spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="a").to(dev)(x)
+            z = spconv.SparseConv3d(32, 16, 3, stride=2, padding=1, bias=True, indice_key="b").to(dev)(y)
+            w = spconv.SparseInverseConv3d(16, 8, 3, indice_key="b", bias=False).to(dev)(z)
+        assert y.features.shape == (n, 32) and w.features.shape == (n, 8)
+        # site (4, 5, 6) under a stride-2 / pad-1 / 3-tap convolution: outputs o with 2 o - 1 + k = coordinate -> z {2}, y {2, 3}, x {3}
+        assert z.features.shape[0] == (0 if n == 0 else 2) and list(z.spatial_shape) == [5, 6, 5]
+        if n:
+            assert z.indices.cpu().tolist() == [[1, 2, 2, 3], [1, 2, 3, 3]]
+        d = z.dense()
+        assert d.shape == (B, 16, 5, 6, 5) and int((d != 0).any(dim=1).sum()) == z.features.shape[0]
+        assert bool(torch.isfinite(d).all())
