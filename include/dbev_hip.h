@@ -464,6 +464,18 @@ int dbev_bn_dual_backward(const float* grad_y, const float* x, const float* xd, 
                           float* grad_beta, float* grad_gamma_d, float* grad_beta_d, long long M, int C, void* workspace,
                           size_t workspace_bytes, dbevStream_t stream);
 
+/* LiDAR sweep -> per-camera sparse depth maps, the depth supervision BEVDepth's img_inputs carry as their last element.
+ * Replaces the loader transform PointToMultiViewDepth.__call__ / points2depthmap (mmdet3d/datasets/pipelines/loading.py:18-61).
+ *   points f32[n_points, n_feats] (x, y, z first, lidar frame);
+ *   cam_mats f32[n_cams, 24] per camera: inverse(rots @ inverse(intrins)) row-major [9], post_rots [9], trans [3], post_trans [3];
+ *   depth_maps f32[n_cams, height / downsample, width / downsample] (every element written: 0 where no point lands).
+ * A pixel takes the smallest depth in [depth_min, depth_max) of the points rounding onto it (integer atomicMin on the
+ * bit pattern: exact, order-independent); the reference reaches the same pixel value through argsort(pixel + depth / 100)
+ * in float32, whose ties below ~0.006 m it resolves arbitrarily. */
+int dbev_points_to_depth_maps(const float* points, int n_points, int n_feats, const float* cam_mats, int n_cams, int height,
+                              int width, int downsample, float depth_min, float depth_max, float* depth_maps,
+                              dbevStream_t stream);
+
 /* bev_pool helpers of the Python surface (mmdet3d/ops/bev_pool/bev_pool.py:64-97): the cell lists straight from the
  * int64 coordinates the reference's callers pass (no int32 conversion pass), and the [B, C, S] -> [B, S, C] transpose
  * for an out_grad that arrives in the reference's contiguous [B, C, D, H, W] layout (S = D*H*W). */

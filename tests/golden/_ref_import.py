@@ -900,3 +900,19 @@ def bevformer_distill():
     if "torch.utils.tensorboard" not in sys.modules:
         _mod("torch.utils.tensorboard", SummaryWriter=lambda *a, **k: None)
     return load("mmdet3d/models/detectors/bevformer_distill.py", "refpkg.models.detectors.bevformer_distill")
+
+
+def loading():
+    """datasets/pipelines/loading.py (PointToMultiViewDepth is plain torch; the other loaders of the file are only defined)"""
+    install_full_stubs()
+    for name in ("torchvision", "pyquaternion"):
+        if name not in sys.modules:
+            m = _mod(name)
+            m.__path__ = []
+    sys.modules["pyquaternion"].Quaternion = object
+    _mod("mmdet.datasets").__path__ = []
+    _mod("mmdet.datasets.builder", PIPELINES=_Registry())
+    _mod("mmdet.datasets.pipelines", LoadAnnotations=object, LoadImageFromFile=object)
+    pts = sys.modules["mmdet3d.core.points"]
+    pts.BasePoints, pts.get_points_type = object, (lambda *a, **k: None)
+    return load("mmdet3d/datasets/pipelines/loading.py", "refpkg_loading")

@@ -823,9 +823,27 @@ def make_bevformer_fgd():
     print({k: float(v) for k, v in losses.items()}, "fg cells per sample", fg.sum(dim=(1, 2, 3)).tolist())
 
 
+def make_depth_map():
+    """PointToMultiViewDepth (datasets/pipelines/loading.py:18-61) executed by the reference's file on a synthetic sweep and
+    the six-camera rig at the benchmark's image size (256 x 704, downsample 16, dbound [1, 60))."""
+    L = R.loading()
+    rng = np.random.default_rng(51)
+    rig = syn.camera_rig(1, rng, n_cams=6, input_size=(256, 704))
+    pts = syn.lidar_points(60000, rng)
+    pts[:, :2] *= 0.6                                     # denser near the ego vehicle: several points per pixel
+    t = lambda k: torch.from_numpy(rig[k][0])
+    tf = L.PointToMultiViewDepth(grid_config=dict(dbound=[1.0, 60.0, 1.0]), downsample=16)
+    import types
+    res = dict(points=types.SimpleNamespace(tensor=torch.from_numpy(pts)),
+               img_inputs=(torch.zeros((6, 3, 256, 704)), t("rots"), t("trans"), t("intrins"), t("post_rots"), t("post_trans")))
+    out = tf(res)["img_inputs"][-1]
+    _save("depth_map.npz", points=pts, depth=out.numpy(), **{k: rig[k][0] for k in ("rots", "trans", "intrins", "post_rots", "post_trans")})
+    print("pixels with a point per camera:", (out > 0).sum(dim=(1, 2)).tolist())
+
+
 SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center,
             "fgd": make_fgd, "shift_depth": make_shift_depth, "centerloss": make_centerloss, "pfn": make_pfn,
-            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd}
+            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)
