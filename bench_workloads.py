@@ -301,6 +301,9 @@ class DistillStep(_Base):
                 # GEMM-shaped work of one step at per_gpu_batch 8 (tools/flops_count.py: forward hooks on every conv, x2/x1 for
                 # the data/weight gradients that actually run): context for ms_per_step, executed by MIOpen fp32 MFMA kernels
                 "dense_tflop_per_gpu_step": 12.92 * self.B / 8.0,
+                # the frozen teacher's head runs the heat-map branches only -- the one output the step reads (add_fp_as_fg);
+                # DBEV_TEACHER_FULL_HEAD=1 runs all 36 branch stacks as the reference does (same losses, +4.5 ms)
+                "teacher_head_branches": "all" if os.environ.get("DBEV_TEACHER_FULL_HEAD") == "1" else "heatmap (the only ones read)",
                 "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py"}
 
 

@@ -292,9 +292,10 @@ class BEVFormerDistill(BEVFormer):
         dp = self.distill_params
         with torch.no_grad():
             _, teacher_x = self.teacher_model.extract_feat(points, None, img_metas)
-            teacher_outs = self.teacher_model.pts_bbox_head(teacher_x)
-            teacher_bev = teacher_outs["bev_embed"]
+            # the teacher's decoder and box decoding only feed the false-positive term: skipped when no position uses it
             needs_boxes = any(m != "none" for m in dp["fp_as_foreground"]) and self._epoch >= dp["fp_epoch"]
+            teacher_outs = self.teacher_model.pts_bbox_head(teacher_x, only_bev=not needs_boxes)
+            teacher_bev = teacher_outs["bev_embed"]
             teacher_preds = self.teacher_model.pts_bbox_head.get_bboxes(teacher_outs, img_metas, rescale=False) if needs_boxes else None
         assert len(set(dp["student_feat_pos"])) == len(dp["student_feat_pos"]) == len(dp["teacher_feat_pos"])
         out = {}

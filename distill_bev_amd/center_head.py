@@ -144,8 +144,9 @@ class SeparateHead(nn.Module):
         if "heatmap" in heads:
             getattr(self, "heatmap")[-1].bias.data.fill_(init_bias)
 
-    def forward(self, x):
-        return {head: getattr(self, head)(x) for head in self.heads}
+    def forward(self, x, only=None):
+        """``only``: names of the branches to evaluate (default all) -- the distillation reads nothing but the teacher's heat maps"""
+        return {head: getattr(self, head)(x) for head in self.heads if only is None or head in only}
 
 
 
@@ -246,13 +247,13 @@ class CenterHead(nn.Module):
             self.task_heads.append(build_head(sh))
         self.task_specific, self.loss_prefix = task_specific, loss_prefix
 
-    def forward_single(self, x):
+    def forward_single(self, x, only=None):
         x = self.shared_conv(x)
-        return [task(x) for task in self.task_heads]
+        return [task(x) if only is None else task(x, only) for task in self.task_heads]
 
-    def forward(self, feats):
+    def forward(self, feats, only=None):
         """-> tuple over tasks of [dict] (multi_apply transposition, centerpoint_head.py:352-363)."""
-        per_level = [self.forward_single(f) for f in feats]
+        per_level = [self.forward_single(f, only) for f in feats]
         return tuple([lvl[t] for lvl in per_level] for t in range(len(self.task_heads)))
 
     # ---- targets -------------------------------------------------------------------------

@@ -525,7 +525,15 @@ class BEVDepth4DDistill(CenterPoint):
                 points, img_feats=None, img_metas=img_metas, return_canvas=True, return_backbone_feature=True)
             if not isinstance(t_neck, (list, tuple)):
                 t_neck = [t_neck]
-            teacher_preds = self.teacher_model.pts_bbox_head(t_neck)
+            # the teacher's predictions are read in ONE place: the heat maps of add_fp_as_fg (bevdet_distill.py:846-870).  The
+            # other five branches of each task head (30 of its 36 branch stacks) and, when no position uses the false-positive
+            # term in this epoch, the whole head are skipped: unused values, identical losses.
+            # DBEV_TEACHER_FULL_HEAD=1 evaluates all 36 branch stacks as the reference does (same losses; for A/B timing).
+            need = any(m != "none" for m in dp["fp_as_foreground"]) and self._epoch >= dp["fp_epoch"]
+            if os.environ.get("DBEV_TEACHER_FULL_HEAD") == "1":
+                teacher_preds = self.teacher_model.pts_bbox_head(t_neck)
+            else:
+                teacher_preds = self.teacher_model.pts_bbox_head(t_neck, only=("heatmap",)) if need else None
         out = {}
         for index, (spos, tpos) in enumerate(zip(dp["student_feat_pos"], dp["teacher_feat_pos"])):
             if spos == "head":

@@ -496,8 +496,8 @@ class DGCNN3DHead(_SetPredictionHead):
         self.bev_shape = (int((self.pc_range[3] - self.pc_range[0]) / self.voxel_size[0]),
                           int((self.pc_range[4] - self.pc_range[1]) / self.voxel_size[1]))
 
-    def forward(self, mlvl_feats):
-        """:87-169  mlvl_feats: per level [bs, C, H, W]"""
+    def forward(self, mlvl_feats, only_bev=False):
+        """:87-169  mlvl_feats: per level [bs, C, H, W]; only_bev: stop after the BEV encoder -> {'bev_embed': ...}"""
         bs = mlvl_feats[0].size(0)
         img_masks = mlvl_feats[0].new_zeros((bs,) + self.bev_shape)
         mlvl_masks = [F.interpolate(img_masks[None], size=f.shape[-2:]).to(torch.bool).squeeze(0) for f in mlvl_feats]
@@ -508,7 +508,9 @@ class DGCNN3DHead(_SetPredictionHead):
         bev_pos = self.positional_encoding(bev_mask)
         hs, init_reference, inter_references, bev_embed, _, _ = self.transformer(
             mlvl_feats, bev_queries, mlvl_masks, bev_mask, bev_pos, query_embeds, mlvl_pos,
-            reg_branches=self.reg_branches if self.with_box_refine else None, cls_branches=None)
+            reg_branches=self.reg_branches if self.with_box_refine else None, cls_branches=None, only_bev=only_bev)
+        if only_bev:
+            return {"bev_embed": bev_embed}
         hs = hs.permute(0, 2, 1, 3)
         classes, coords = self._decode_layers(hs, init_reference, inter_references)
         return {"all_cls_scores": classes, "all_bbox_preds": coords, "enc_cls_scores": None, "enc_bbox_preds": None,

@@ -841,7 +841,7 @@ class DeformableDetrTransformerDistill(nn.Module):
         return ref.repeat(bs, 1, 1).unsqueeze(2)
 
     def forward(self, mlvl_feats, bev_queries, mlvl_masks, bev_mask, bev_pos, query_embed, mlvl_pos_embeds, reg_branches=None,
-                cls_branches=None, **kwargs):
+                cls_branches=None, only_bev=False, **kwargs):
         """:181-355 -> (decoder states, init reference, inter references, bev_embed [bs, bev_size**2, C], None, None)"""
         assert query_embed is not None
         feat_flatten, spatial_shapes = [], []
@@ -858,6 +858,8 @@ class DeformableDetrTransformerDistill(nn.Module):
                               spatial_shapes=spatial_shapes, reference_points=reference_points,
                               level_start_index=level_start_index, **kwargs)
         bev_embed = memory.permute(1, 0, 2)
+        if only_bev:                   # the distillation reads the BEV embedding only: the decoder is skipped
+            return None, None, None, bev_embed, None, None
         c = bev_embed.shape[-1]
         query_pos, query = torch.split(query_embed, c, dim=1)
         query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)

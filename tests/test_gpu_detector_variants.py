@@ -96,3 +96,17 @@ def test_distillation_variants_train_one_step(name):
     assert sum(k.startswith("kd_") for k in losses) == 10         # 3 positions x (fg, bg, spatial) + fp term at the head
     assert len(losses) == 36 + 10 + int(has_depth)
     _finite_backward(det, losses)
+
+
+def test_skipping_the_unread_teacher_branches_changes_no_loss(monkeypatch):
+    """forward_distill evaluates only the teacher's heat-map branches (the one thing add_fp_as_fg reads); with
+    DBEV_TEACHER_FULL_HEAD=1 all 36 branch stacks run as in the reference -- the same losses."""
+    model = _build(_cfg()).eval()                 # eval: BatchNorm on running statistics -> two forwards see the same state
+    batch = _batch(False)
+    with torch.no_grad():
+        a = model.forward_train(**batch)
+        monkeypatch.setenv("DBEV_TEACHER_FULL_HEAD", "1")
+        b = model.forward_train(**batch)
+    assert set(a) == set(b) and any("kd_fp_bg_feat_loss" in k for k in a)
+    for k in a:        # (two forwards of the image branch are not bit-identical by themselves: MIOpen's split-K convolutions)
+        assert abs(float(a[k]) - float(b[k])) <= 1e-5 * max(abs(float(b[k])), 1e-6), k
