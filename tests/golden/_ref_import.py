@@ -916,3 +916,37 @@ def loading():
     pts = sys.modules["mmdet3d.core.points"]
     pts.BasePoints, pts.get_points_type = object, (lambda *a, **k: None)
     return load("mmdet3d/datasets/pipelines/loading.py", "refpkg_loading")
+
+
+def bevformer_detectors():
+    """detectors/{base,mvx_two_stage,bevformer,bevformer_distill}.py for real (the BEVFormer classes with their own base
+    classes), on: mmcv.parallel.DataContainer, mmdet BaseDetector, mmdet3d.ops.Voxelization (never instantiated), tensorboard."""
+    _install_transformer_stubs()
+    mmcv = sys.modules["mmcv"]
+    runner = sys.modules["mmcv.runner"]
+    _mod("mmcv.parallel", DataContainer=object)
+    core = sys.modules["mmdet3d.core"]
+    for n in ("Box3DMode", "Coord3DMode", "bbox3d2result", "merge_aug_bboxes_3d", "show_result"):
+        setattr(core, n, None)
+    sys.modules["mmdet3d.ops"].Voxelization = object
+
+    class BaseDetector(runner.BaseModule):
+        def __init__(self, init_cfg=None):
+            super().__init__(init_cfg)
+            self.fp16_enabled = False
+
+    _mod("mmdet.models.detectors", BaseDetector=BaseDetector)
+    gm = grid_mask()
+    mu = sys.modules["mmdet3d.models.utils"]
+    mu.__path__ = []
+    sys.modules["mmdet3d.models.utils.grid_mask"] = gm
+    mu.grid_mask = gm
+    if "torch.utils.tensorboard" not in sys.modules:
+        _mod("torch.utils.tensorboard", SummaryWriter=lambda *a, **k: None)
+    shell = type("Shell", (nn.Module,), {})
+    _mod("refpkg.models.detectors.lidarformer", LidarFormer=type("LidarFormer", (shell,), {}))
+    _mod("refpkg.models.detectors.mvpformer", MVPFormer=type("MVPFormer", (shell,), {}))
+    load("mmdet3d/models/detectors/base.py", "refpkg.models.detectors.base")
+    load("mmdet3d/models/detectors/mvx_two_stage.py", "refpkg.models.detectors.mvx_two_stage")
+    load("mmdet3d/models/detectors/bevformer.py", "refpkg.models.detectors.bevformer")
+    return load("mmdet3d/models/detectors/bevformer_distill.py", "refpkg.models.detectors.bevformer_distill")

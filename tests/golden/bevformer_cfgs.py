@@ -76,3 +76,50 @@ def small_dgcnn_head_cfg(dim=32, bev=10, levels=3, queries=12, enc_layers=2, dec
                                      reg_cost=dict(type="BBox3DL1Cost", weight=0.25), iou_cost=dict(type="IoUCost", weight=0.0),
                                      pc_range=PCR)),
         test_cfg=None)
+
+
+# ---- detector-level fixture (make_golden.py bevformer_step): stand-ins for the un-vendored image branch -----------------
+# mmdet's ResNet / FPN are not in the reference tree; the detector-level fixture only needs SOME image branch that both sides
+# share, so these two plain-torch modules are registered on the reference's stub registries by make_golden.py and on the
+# product's registry by the test.  (Data module: no reference dependency.)
+import torch.nn as _nn
+
+
+class TinyBackbone(_nn.Module):
+    """3 -> 16 channels at stride 8 and stride 16 (no normalisation: nothing changes between train() and eval())"""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.c1 = _nn.Conv2d(3, 16, 8, stride=8)
+        self.c2 = _nn.Conv2d(16, 16, 2, stride=2)
+
+    def forward(self, x):
+        a = _nn.functional.relu(self.c1(x))
+        return a, _nn.functional.relu(self.c2(a))
+
+
+class TinyNeck(_nn.Module):
+    def __init__(self, out_channels=32, **kwargs):
+        super().__init__()
+        self.l1 = _nn.Conv2d(16, out_channels, 1)
+        self.l2 = _nn.Conv2d(16, out_channels, 1)
+
+    def forward(self, feats):
+        return [self.l1(feats[0]), self.l2(feats[1])]
+
+
+_DROPOUT_BY_DEFAULT = ("TemporalSelfAttention", "SpatialCrossAttention", "CustomMSDeformableAttention", "MultiScaleDeformableAttention",
+                       "MSDeformableAttention3D")
+
+
+def no_dropout(cfg):
+    """the same config with every dropout probability at 0 (train-mode fixtures must not depend on the RNG stream); the
+    attention types whose constructors default to dropout 0.1 get the key spelled out"""
+    if isinstance(cfg, dict):
+        out = {k: (0.0 if k in ("dropout", "ffn_dropout", "ffn_drop", "attn_drop", "proj_drop") else no_dropout(v)) for k, v in cfg.items()}
+        if out.get("type") in _DROPOUT_BY_DEFAULT:
+            out["dropout"] = 0.0
+        return out
+    if isinstance(cfg, (list, tuple)):
+        return type(cfg)(no_dropout(v) for v in cfg)
+    return cfg

@@ -841,9 +841,97 @@ def make_depth_map():
     print("pixels with a point per camera:", (out > 0).sum(dim=(1, 2)).tolist())
 
 
+def make_bevformer_step():
+    """BEVFormerDistill.forward_train of the reference (detectors/bevformer_distill.py:923-987 on bevformer.py / mvx_two_stage.py /
+    base.py, all loaded for real): GridMask -> image branch -> history BEV over the queue (eval, no_grad) -> current frame ->
+    BEVFormerHead + losses -> teacher head (reference DGCNN3DHead on fixed LiDAR features) -> FGD terms.  The un-vendored image
+    branch (mmdet ResNet / FPN) is the shared two-conv stand-in of bevformer_cfgs.py; the teacher's sparse feature extractor
+    (CUDA-only spconv) is replaced by fixed pyramid features stored in the fixture.  Train mode, every dropout at 0."""
+    import types
+    import bevformer_cfgs as C
+    D = R.bevformer_detectors()
+    regs = R.transformer_registries()
+    rng = np.random.default_rng(61)
+    g = torch.Generator().manual_seed(61)
+    dim, bev, cams, bs, queue = 32, 10, 3, 2, 3
+    img_hw = (48, 80)
+    head = regs["HEADS"].build(C.no_dropout(C.small_bevformer_head_cfg(dim, bev, 2, cams)))
+    thead = regs["HEADS"].build(C.small_dgcnn_head_cfg(dim, bev, 3))
+    assert all(mod.p == 0.0 for mod in head.modules() if isinstance(mod, torch.nn.Dropout))
+    head.init_weights(); thead.init_weights()
+    teacher = R.bare(D.MVPFormer)
+    teacher.pts_bbox_head = thead
+    tfeats = [torch.randn((bs, dim, 10, 10), generator=g), torch.randn((bs, dim, 5, 5), generator=g), torch.randn((bs, dim, 3, 3), generator=g)]
+    object.__setattr__(teacher, "extract_feat", lambda points, img, img_metas: (None, tfeats))
+    dp = dict(student_channels=[dim], teacher_channels=[dim], spatial_t=0.5, spatial_student_ratio=1.0, channel_t=0.5,
+              fg_feat_loss_weights=[3e-3], bg_feat_loss_weights=[4e-2], spatial_loss_weights=[1e-3], adaptation_type=["1x1conv"],
+              teacher_adaptation_type=["identity"], spatial_attentions=["teacher"],
+              feat_criterion=dict(type="MSELoss", reduction="none"), spatial_criterion=dict(type="L1Loss", reduction="none"),
+              channel_criterion=dict(type="L1Loss", reduction="none"), transpose_mask=False, foreground_mask="gt",
+              background_mask="logical_not", scale_mask="combine_gt", spatial_mask=True, channel_mask=False,
+              student_feat_pos=["head"], teacher_feat_pos=["head"], affinity_mode=["none"], fp_as_foreground=["none"], fp_weight=0,
+              fp_epoch=0, multi_scale_epoch=-1, context_length=0, context_weight=0, output_threshold=0.1, groundtruth_threshold=None,
+              fp_scale_mode="average")
+    m = R.bare(D.BEVFormerDistill, distill_type="fgd", distill_params=dp, _epoch=0, no_bg=False, eval_teacher=True, use_grid_mask=True,
+               video_test_mode=True, fp16_enabled=False, iter=0, train_cfg=None, test_cfg=None,
+               writter=types.SimpleNamespace(add_scalar=lambda *a, **k: None))
+    m.img_backbone, m.img_neck, m.pts_bbox_head = C.TinyBackbone(), C.TinyNeck(dim), head
+    m.grid_mask = R.grid_mask().GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=0.7)
+    m.channel_wise_adaptations = torch.nn.ModuleList([torch.nn.Conv2d(dim, dim, 1)])
+    m.teacher_adaptations = torch.nn.ModuleList([torch.nn.Identity()])
+    m.spatial_wise_adaptations = torch.nn.ModuleList([torch.nn.Conv2d(1, 1, 3, padding=1)])
+    object.__setattr__(m, "teacher_model", teacher)
+    _randomize(m, g)
+    _randomize(thead, g)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    m.train()
+    assert m.training and not thead.training
+    img = torch.randn((bs, queue, cams, 3, *img_hw), generator=g)
+    metas = []
+    for b in range(bs):
+        frames = {}
+        for q in range(queue):
+            one = small_camera_metas(1, cams, img_hw, rng)[0]
+            one["prev_bev_exists"] = q > 0
+            one["box_type_3d"] = lambda t, d: t
+            frames[q] = one
+        metas.append(frames)
+    boxes, labels = _gt(bs, rng, n=(6, 3))
+    for b in boxes:
+        b[:, 3:5] *= 6.0                            # 10.24 m BEV cells: boxes large enough to own a few of them
+    gtb = [R.LiDARBoxesStub(b) for b in boxes]
+    gtl = [torch.from_numpy(l) for l in labels]
+    trace = {"gm": [], "bev": []}
+    m.grid_mask.register_forward_hook(lambda mod, inp, out: trace["gm"].append(out.detach().clone()))
+    m.pts_bbox_head.register_forward_hook(
+        lambda mod, inp, out: trace["bev"].append((out["bev_embed"] if isinstance(out, dict) else out).detach().clone()))
+    np.random.seed(7)
+    torch.manual_seed(7)
+    losses = m.forward_train(points=None, img_metas=metas, gt_bboxes_3d=gtb, gt_labels_3d=gtl, img=img)
+    total = sum(losses.values())
+    inter = {f"trace_bev{i}": t.numpy() for i, t in enumerate(trace["bev"])}          # BEV of history frame 0, 1 and of the current frame
+    inter["masked_fraction"] = np.array([float((t == 0).float().mean()) for t in trace["gm"]])
+    print("grid-mask calls", len(trace["gm"]), "head calls", len(trace["bev"]),
+          "masked fraction of the current frame", float((trace["gm"][-1] == 0).float().mean()))
+    names = ["img_backbone.c1.weight", "img_neck.l2.bias", "pts_bbox_head.bev_embedding.weight", "channel_wise_adaptations.0.weight",
+             "pts_bbox_head.transformer.encoder.layers.0.attentions.0.value_proj.weight", "pts_bbox_head.reg_branches.1.4.weight"]
+    params = dict(m.named_parameters())
+    grads = torch.autograd.grad(total, [params[n] for n in names])
+    flat = {}
+    for b in range(bs):
+        for q in range(queue):
+            flat[f"can_bus_{b}_{q}"] = metas[b][q]["can_bus"]
+            flat[f"lidar2img_{b}_{q}"] = np.stack(metas[b][q]["lidar2img"])
+    _save("bevformer_step.npz", img=img.numpy(), img_hw=np.array(img_hw), tf0=tfeats[0].numpy(), tf1=tfeats[1].numpy(), tf2=tfeats[2].numpy(),
+          **flat, **{f"gt_boxes{b}": boxes[b] for b in range(bs)}, **{f"gt_labels{b}": labels[b] for b in range(bs)},
+          **_flat_losses("loss__", losses), **{"grad__" + n.replace(".", "__"): gr.numpy() for n, gr in zip(names, grads)},
+          **inter, **_sd("model__", m), **_sd("thead__", thead))
+    print({k: float(v) for k, v in losses.items()})
+
+
 SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center,
             "fgd": make_fgd, "shift_depth": make_shift_depth, "centerloss": make_centerloss, "pfn": make_pfn,
-            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map}
+            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map, "bevformer_step": make_bevformer_step}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)
