@@ -950,3 +950,96 @@ def bevformer_detectors():
     load("mmdet3d/models/detectors/mvx_two_stage.py", "refpkg.models.detectors.mvx_two_stage")
     load("mmdet3d/models/detectors/bevformer.py", "refpkg.models.detectors.bevformer")
     return load("mmdet3d/models/detectors/bevformer_distill.py", "refpkg.models.detectors.bevformer_distill")
+
+
+def bevdepth_detectors():
+    """The BEVDepth4DDistill class hierarchy of the reference for real -- detectors/{base,mvx_two_stage,centerpoint,
+    dynamic_centerpoint,bevdet,bevdet_distill,bevdet_distill_more}.py -- with a working builder registry that holds the
+    reference's own ViewTransformerLSSBEVDepth, CenterHead / SeparateHead, DynamicPillarFeatureNet, PointPillarsScatter,
+    SECOND, SECONDFPN and the shared stand-ins of tests/golden/standins.py.  -> (module bevdet_distill_more, registry)"""
+    install_full_stubs()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import dcn as ODCN
+    import standins
+    runner = sys.modules["mmcv.runner"]
+    REG = _RealRegistry("models")
+    for cls in standins.STANDINS.values():
+        REG.register_module(module=cls)
+    build = lambda cfg, *a, **k: None if cfg is None else REG.build(cfg)
+
+    class DCNv2(nn.Module):
+        """mmcv ModulatedDeformConv2dPack (un-vendored CUDA op): same parameters, forward through oracle/dcn.py"""
+
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, deform_groups=1, bias=True):
+            super().__init__()
+            k = kernel_size
+            self.stride, self.padding, self.dilation = stride, padding, dilation
+            self.weight = nn.Parameter(torch.randn(out_channels, in_channels, k, k) * 0.05)
+            self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+            self.conv_offset = nn.Conv2d(in_channels, 3 * k * k, kernel_size=k, stride=stride, padding=padding, dilation=dilation)
+
+        def forward(self, x):
+            return ODCN.pack_forward(self, x)
+
+    cnn = sys.modules["mmcv.cnn"]
+    plain_conv = cnn.build_conv_layer
+
+    def build_conv_layer(cfg, *a, **k):
+        if cfg is not None and cfg.get("type") == "DCNv2":
+            return DCNv2(*a, **k, **{kk: vv for kk, vv in cfg.items() if kk != "type"})
+        return plain_conv(cfg, *a, **k)
+
+    cnn.build_conv_layer = build_conv_layer
+    _mod("mmcv.parallel", DataContainer=object)
+    core = sys.modules["mmdet3d.core"]
+    for n in ("Box3DMode", "Coord3DMode", "bbox3d2result", "merge_aug_bboxes_3d", "show_result"):
+        setattr(core, n, None)
+    from oracle import voxel as OV
+
+    class Voxelization(nn.Module):
+        """ops/voxel Voxelization with max_num_points = -1 (dynamic): per point the (z, y, x) cell or -1 -- through
+        oracle/voxel.c, which tests/test_oracle_voxel.py pins bit-exact against the reference's voxelization_cpu.cpp"""
+
+        def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000, deterministic=True):
+            super().__init__()
+            assert max_num_points == -1
+            self.voxel_size, self.point_cloud_range = voxel_size, point_cloud_range
+
+        def forward(self, pts):
+            return torch.from_numpy(OV.dynamic_voxelize(pts.detach().numpy(), self.voxel_size, self.point_cloud_range)).to(torch.int32)
+
+    sys.modules["mmdet3d.ops"].Voxelization = Voxelization
+
+    class BaseDetector(runner.BaseModule):
+        def __init__(self, init_cfg=None):
+            super().__init__(init_cfg)
+            self.fp16_enabled = False
+
+    _mod("mmdet.models.detectors", BaseDetector=BaseDetector)
+    mm = sys.modules["mmdet.models"]
+    mm.HEADS = mm.DETECTORS = mm.NECKS = mm.BACKBONES = REG
+    mm.build_detector = lambda cfg, train_cfg=None, test_cfg=None: REG.build(cfg)
+    sys.modules["mmdet.utils"].get_root_logger = lambda *a, **k: types.SimpleNamespace(info=lambda *x, **y: None)
+    for name in ("refpkg.models.builder", "mmdet3d.models.builder"):
+        b = sys.modules[name]
+        b.HEADS = b.NECKS = b.BACKBONES = b.MIDDLE_ENCODERS = b.VOXEL_ENCODERS = b.DETECTORS = REG
+        b.build_backbone = b.build_neck = b.build_head = b.build_voxel_encoder = b.build_middle_encoder = b.build_fusion_layer = build
+        b.build_loss = build_loss
+    sys.modules["mmdet.core"].build_bbox_coder = lambda cfg: None
+    # the reference's own modules of the path, registered under their class names
+    for path, modname in (("mmdet3d/models/necks/view_transformer_mine.py", "refpkg.models.necks.view_transformer_mine"),
+                          ("mmdet3d/models/dense_heads/centerpoint_head.py", "refpkg.models.dense_heads.centerpoint_head_full"),
+                          ("mmdet3d/models/voxel_encoders/utils.py", "refpkg.models.voxel_encoders.utils"),
+                          ("mmdet3d/models/voxel_encoders/pillar_encoder.py", "refpkg.models.voxel_encoders.pillar_encoder"),
+                          ("mmdet3d/models/middle_encoders/pillar_scatter.py", "refpkg.models.middle_encoders.pillar_scatter"),
+                          ("mmdet3d/models/backbones/second.py", "refpkg.models.backbones.second"),
+                          ("mmdet3d/models/necks/second_fpn.py", "refpkg.models.necks.second_fpn")):
+        m = load(path, modname)
+        for k, v in vars(m).items():
+            if isinstance(v, type) and issubclass(v, nn.Module) and v.__module__ == modname and k not in REG.table:
+                REG.register_module(module=v)
+    sys.modules["refpkg.models.necks"].ViewTransformerLSSBEVDepthReproduce = None
+    for f in ("base", "mvx_two_stage", "centerpoint", "dynamic_centerpoint", "bevdet", "bevdet_distill"):
+        load(f"mmdet3d/models/detectors/{f}.py", f"refpkg.models.detectors.{f}")
+    more = load("mmdet3d/models/detectors/bevdet_distill_more.py", "refpkg.models.detectors.bevdet_distill_more")
+    return more, REG

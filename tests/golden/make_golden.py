@@ -929,9 +929,124 @@ def make_bevformer_step():
     print({k: float(v) for k, v in losses.items()})
 
 
+def make_bevdepth_step():
+    """BEVDepth4DDistill.forward_train of the reference -- the north-star step -- with the reference's OWN class hierarchy
+    (bevdet_distill_more.py:334-522 on bevdet_distill.py / bevdet.py / centerpoint.py / dynamic_centerpoint.py / mvx_two_stage.py),
+    built through its own constructors from the small recipe of standins.py: two-frame image encoding, SE + DCN depth net,
+    lift, voxel_pooling (cumsum trick), shift_feature, depth loss, CenterHead targets + losses, the DynamicCenterPoint teacher
+    (dynamic voxelization -> DynamicPillarFeatureNet -> PointPillarsScatter -> SECOND -> SECONDFPN -> CenterHead), and the FGD
+    terms at a backbone and the head position incl. the false-positive term.  Stand-ins (shared with the product test): the
+    un-vendored image backbone and the mmdet BasicBlock stacks of the depth net / BEV encoder; the two CUDA-only ops are the
+    oracle's pinned restatements (dynamic voxelization: oracle/voxel.c == the reference's C++; DCNv2: oracle/dcn.py)."""
+    import types
+    import standins as S
+    more, REG = R.bevdepth_detectors()
+    rng = np.random.default_rng(71)
+    g = torch.Generator().manual_seed(71)
+    cfg = S.distill_cfg(S.teacher_cfg())
+    cfg = R._ConfigDict({k: (R._ConfigDict(v) if isinstance(v, dict) else v) for k, v in cfg.items()})
+    cfg["train_cfg"] = R._ConfigDict(pts=R._ConfigDict(cfg["train_cfg"]["pts"]))
+    t = cfg["teacher_config"]["model"]
+    t["train_cfg"] = R._ConfigDict(pts=R._ConfigDict(t["train_cfg"]["pts"]))
+    torch.manual_seed(71)                        # the constructors draw their initial weights from the global generator
+    model = REG.build(dict(cfg))
+    teacher = model.teacher_model
+
+    _randomize_bevdepth(model, g)
+    _randomize_bevdepth(teacher, g)
+    model.train()
+    assert not teacher.training
+    B, N = 2, 6
+    H, W = S.INPUT_SIZE
+    batch = _bevdepth_batch(B, N, H, W, rng, g)
+    # the two BEV maps as the reference pooled them (its cumulative-sum trick carries ~1e-4 of fp32 cancellation noise): the
+    # product test re-runs the step with its own maps shifted onto these values, which removes the one noisy operator from the
+    # comparison and lets every other forward / backward stage be held to a tight tolerance
+    pooled = []
+    vt = model.img_view_transformer
+    pool = vt.voxel_pooling
+    vt.voxel_pooling = lambda *a, **k: (pooled.append(pool(*a, **k)), pooled[-1])[1]
+    torch.manual_seed(5)
+    losses = model.forward_train(points=batch["points"], img_metas=None, gt_bboxes_3d=[R.LiDARBoxesStub(b) for b in batch["boxes"]],
+                                 gt_labels_3d=[torch.from_numpy(l) for l in batch["labels"]], img_inputs=batch["img_inputs"])
+    assert len(pooled) == 2
+    total = sum(v for v in losses.values())
+    names = ["img_backbone.conv.weight", "img_view_transformer.dcn.0.weight", "img_view_transformer.depthnet.bias",
+             "img_bev_encoder_backbone.layers.0.weight", "pts_bbox_head.task_heads.2.heatmap.1.bias", "channel_wise_adaptations.1.weight"]
+    params = dict(model.named_parameters())
+    grads = torch.autograd.grad(total, [params[n] for n in names], retain_graph=True)
+    # the same BEV-encoder weight gradient split by loss group: localises a backward difference to one branch of the step
+    groups = {"det": [k for k in losses if k.startswith("task")], "kd_backbone": [k for k in losses if k.endswith("backbone0_backbone2")],
+              "kd_head": [k for k in losses if k.endswith("head_head")]}
+    gg = {}
+    for gname, keys in groups.items():
+        gg["gradgroup__" + gname] = torch.autograd.grad(sum(losses[k] for k in keys), params["img_bev_encoder_backbone.layers.0.weight"],
+                                                        retain_graph=True)[0].numpy()
+    # every loss term's own gradient at two small BEV-encoder parameters (48 numbers per term).  A ReLU gate or an L1 sign
+    # that sits within fp32 rounding of its kink flips between two implementations and moves that ONE term's gradient by
+    # percents; the per-term view lets the test demand tight agreement from (nearly) all terms instead of a loose bound on the sum
+    tb = [params["img_bev_encoder_backbone.layers.0.bias"], params["img_bev_encoder_neck.conv.bias"]]
+    for k, v in losses.items():
+        gr = torch.autograd.grad(v, tb, retain_graph=True, allow_unused=True)
+        if gr[0] is not None:                     # (the depth loss never reaches the BEV encoder; backbone-position terms skip the neck)
+            gg["term__" + k.replace(".", "_")] = torch.cat([(t if t is not None else torch.zeros_like(p)).reshape(-1)
+                                                           for t, p in zip(gr, tb)]).numpy()
+    gg["grad_depth__depthnet_bias"] = torch.autograd.grad(losses["loss_depth"], params["img_view_transformer.depthnet.bias"],
+                                                          retain_graph=True)[0].numpy()
+    imgs, rots, trans, intrins, post_rots, post_trans, dgt = batch["img_inputs"]
+    _save("bevdepth_step.npz", imgs=imgs.numpy().astype(np.float16), rots=rots.numpy(), trans=trans.numpy(), intrins=intrins.numpy(), post_rots=post_rots.numpy(),
+          post_trans=post_trans.numpy(), depth_gt=dgt.numpy(), **{f"points{b}": batch["points"][b].numpy() for b in range(B)},
+          **{f"gt_boxes{b}": batch["boxes"][b] for b in range(B)}, **{f"gt_labels{b}": batch["labels"][b] for b in range(B)},
+          **_flat_losses("loss__", losses), **{"grad__" + n.replace(".", "__"): gr.numpy() for n, gr in zip(names, grads)},
+          **gg, pooled0=pooled[0].detach().numpy(), pooled1=pooled[1].detach().numpy(), **_sd("model__", model), **_sd("teacher__", teacher))
+    print({k: len(v) for k, v in groups.items()})
+    print(len(losses), {k: round(float(v), 5) for k, v in losses.items()})
+
+
+def _randomize_bevdepth(module, gen):
+    for name, p in module.named_parameters():
+        if not p.requires_grad:                   # dx / bx / nx / frustum of the view transformer are frozen Parameters
+            continue
+        if p.dim() == 1 and ("bn" in name or "norm" in name or name.split(".")[-2].isdigit() and name.endswith(("weight", "bias")) and p.numel() <= 64 and "conv" not in name):
+            continue
+        p.data = p.data + torch.randn(p.shape, generator=gen) * 0.05
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.weight.data.uniform_(0.6, 1.4); m.bias.data.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.6, 1.6)
+
+
+def _bevdepth_batch(B, N, H, W, rng, g):
+    cur = syn.camera_rig(B, rng, n_cams=N, input_size=(H, W))
+    # per-camera calibration and resize / crop augmentation (the recipe draws them per image): the SE layer of the depth net
+    # batch-normalises these 33 numbers over the B*N cameras in train mode, and a column that is constant but non-zero turns
+    # into rounding noise times 1 / sqrt(eps) there
+    jit = np.random.default_rng(72)
+    cur["intrins"][:, :, 0, 0] *= jit.uniform(0.97, 1.03, (B, N)).astype(np.float32)
+    cur["intrins"][:, :, 1, 1] *= jit.uniform(0.97, 1.03, (B, N)).astype(np.float32)
+    cur["intrins"][:, :, :2, 2] += jit.uniform(-20.0, 20.0, (B, N, 2)).astype(np.float32)
+    scale = jit.uniform(0.94, 1.06, (B, N)).astype(np.float32)
+    cur["post_rots"][:, :, 0, 0] *= scale
+    cur["post_rots"][:, :, 1, 1] *= scale
+    cur["post_trans"][:, :, :2] += jit.uniform(-4.0, 4.0, (B, N, 2)).astype(np.float32)
+    adj = {k: v.copy() for k, v in cur.items()}
+    adj["trans"] = adj["trans"] + np.concatenate([rng.uniform(0.0, 2.0, (B, 1, 1)), rng.uniform(-0.2, 0.2, (B, 1, 1)), np.zeros((B, 1, 1))], 2).astype(np.float32)
+    mats = {k: torch.from_numpy(np.concatenate([cur[k], adj[k]], 1)) for k in cur}
+    imgs = torch.randn((B, 2 * N, 3, H, W), generator=g).half().float()          # stored as float16 in the fixture: exact round trip
+    dgt = torch.from_numpy(syn.depth_gt(B, 2 * N, H // 16, W // 16, rng))
+    points, boxes, labels = [], [], []
+    for b in range(B):
+        points.append(torch.from_numpy(syn.lidar_points(6000, rng)))
+        bx, lb = syn.gt_boxes(10, rng)
+        bx[:, 3:5] *= 2.5                         # 3.2 m BEV cells
+        boxes.append(bx); labels.append(lb)
+    return dict(points=points, boxes=boxes, labels=labels,
+                img_inputs=(imgs, mats["rots"], mats["trans"], mats["intrins"], mats["post_rots"], mats["post_trans"], dgt))
+
+
 SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center,
             "fgd": make_fgd, "shift_depth": make_shift_depth, "centerloss": make_centerloss, "pfn": make_pfn,
-            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map, "bevformer_step": make_bevformer_step}
+            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map, "bevformer_step": make_bevformer_step, "bevdepth_step": make_bevdepth_step}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)
