@@ -249,6 +249,10 @@ class CenterHead(nn.Module):
 
     def forward_single(self, x, only=None):
         x = self.shared_conv(x)
+        if only is None:
+            from . import head_batch
+            if head_batch.applies(self, x):          # the 36 branch stacks as a few wide convolution / norm calls
+                return head_batch.forward(self, x)
         return [task(x) if only is None else task(x, only) for task in self.task_heads]
 
     def forward(self, feats, only=None):

@@ -17,7 +17,8 @@ namespace {
 
 constexpr int SK_MAX_CO = 3;
 
-struct SkDims { int N, H, W, C4; };
+struct SkDims { int N, H, W, C4; int XP4, DP4; };   // XP4 / DP4: pixel pitch of x / dx in float4 (= C4 for a dense map; larger for a
+                                                       // channel slice of a wider NHWC tensor: the batched head branches)
 
 __device__ __forceinline__ float dot4f(const float4& a, const float4& b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void sk_fwd(const float4* __restrict__ x, cons
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
-      v[tap] = (live && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) ? x[((n * d.H + hh) * d.W + ww) * G + q]
+      v[tap] = (live && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) ? x[((n * d.H + hh) * d.W + ww) * d.XP4 + q]
                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void sk_bwd_data(const float* __restrict__ dy,
         acc.x = fmaf(gv[tap][co], wv.x, acc.x); acc.y = fmaf(gv[tap][co], wv.y, acc.y);
         acc.z = fmaf(gv[tap][co], wv.z, acc.z); acc.w = fmaf(gv[tap][co], wv.w, acc.w);
       }
-    st_nt(dx + p * G + q, acc);
+    st_nt(dx + p * d.DP4 + q, acc);
   }
 }
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void sk_bwd_weight(const float4* __restrict__ 
       const int w = static_cast<int>(pu - rowi * d.W);
       const long long n = rowi / static_cast<unsigned>(d.H);
       const int h = static_cast<int>(rowi - static_cast<unsigned>(n) * d.H);
-      v[u] = live ? x[pp * G + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[u] = live ? x[pp * d.XP4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int co = 0; co < CO; ++co) gc[u][co] = live ? dy[pp * CO + co] : 0.f;
 #pragma unroll
@@ -216,12 +217,13 @@ __global__ __launch_bounds__(256) void sk_final(const float* __restrict__ part, 
 
 constexpr int SK_WG_BLOCKS = 512;    // swept 256..1024: fewer, longer workgroups amortise the 9*Cout LDS merge rounds
 
-bool sk_ok(int N, int Cin, int H, int W, int Cout, SkDims* d) {
+bool sk_ok(int N, int Cin, int H, int W, int Cout, long long x_pitch, long long dx_pitch, SkDims* d) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout < 1 || Cout > SK_MAX_CO) return false;
   const int C4 = Cin >> 2;
   if (C4 < 8 || C4 > 64 || (C4 & (C4 - 1))) return false;
+  if (x_pitch < Cin || dx_pitch < Cin || (x_pitch & 3) || (dx_pitch & 3) || x_pitch > (1 << 20) || dx_pitch > (1 << 20)) return false;
   if (static_cast<long long>(N) * H * W > 0x7fffffffLL) return false;
-  *d = SkDims{N, H, W, C4};
+  *d = SkDims{N, H, W, C4, static_cast<int>(x_pitch >> 2), static_cast<int>(dx_pitch >> 2)};
   return true;
 }
 
@@ -239,10 +241,13 @@ extern "C" size_t dbev_skinny_conv3x3_workspace_bytes(int Cin, int Cout) {
   return sizeof(float) * static_cast<size_t>(SK_WG_BLOCKS) * (static_cast<size_t>(Cout) * 9 * Cin + Cout) + 256;
 }
 
-extern "C" int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* weight_ohwi, const float* bias, float* y_nhwc,
-                                           int N, int Cin, int H, int W, int Cout, dbevStream_t stream) {
+extern "C" int dbev_skinny_conv3x3_forward_pitched(const float* x_nhwc, long long x_pitch, const float* weight_ohwi,
+                                                   const float* bias, float* y_nhwc, int N, int Cin, int H, int W, int Cout,
+                                                   dbevStream_t stream) {
   SkDims d;
-  if (!sk_ok(N, Cin, H, W, Cout, &d) || x_nhwc == nullptr || weight_ohwi == nullptr || y_nhwc == nullptr) return DBEV_EINVAL;
+  if (!sk_ok(N, Cin, H, W, Cout, x_pitch, Cin, &d) || x_nhwc == nullptr || weight_ohwi == nullptr || y_nhwc == nullptr ||
+      (reinterpret_cast<uintptr_t>(x_nhwc) & 15))
+    return DBEV_EINVAL;
   const long long threads = static_cast<long long>(N) * H * W * d.C4;
   long long blocks = (threads + 255) / 256;
   if (blocks > SK_PERSIST_BLOCKS) blocks = SK_PERSIST_BLOCKS;
@@ -252,12 +257,19 @@ extern "C" int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* wei
   return 0;
 }
 
-extern "C" int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const float* x_nhwc, const float* weight_ohwi,
-                                            float* grad_x_nhwc, float* grad_weight_ohwi, float* grad_bias, int N, int Cin,
-                                            int H, int W, int Cout, void* workspace, size_t workspace_bytes,
-                                            dbevStream_t stream) {
+extern "C" int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* weight_ohwi, const float* bias, float* y_nhwc,
+                                           int N, int Cin, int H, int W, int Cout, dbevStream_t stream) {
+  return dbev_skinny_conv3x3_forward_pitched(x_nhwc, Cin, weight_ohwi, bias, y_nhwc, N, Cin, H, W, Cout, stream);
+}
+
+extern "C" int dbev_skinny_conv3x3_backward_pitched(const float* grad_y_nhwc, const float* x_nhwc, long long x_pitch,
+                                                    const float* weight_ohwi, float* grad_x_nhwc, long long grad_x_pitch,
+                                                    float* grad_weight_ohwi, float* grad_bias, int N, int Cin, int H, int W,
+                                                    int Cout, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
   SkDims d;
-  if (!sk_ok(N, Cin, H, W, Cout, &d) || grad_y_nhwc == nullptr || x_nhwc == nullptr || weight_ohwi == nullptr)
+  if (!sk_ok(N, Cin, H, W, Cout, x_pitch, grad_x_nhwc != nullptr ? grad_x_pitch : Cin, &d) || grad_y_nhwc == nullptr ||
+      x_nhwc == nullptr || weight_ohwi == nullptr || (reinterpret_cast<uintptr_t>(x_nhwc) & 15) ||
+      (reinterpret_cast<uintptr_t>(grad_x_nhwc) & 15))
     return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   const long long threads = static_cast<long long>(N) * H * W * d.C4;
@@ -285,4 +297,12 @@ extern "C" int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const floa
   }
   DBEV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const float* x_nhwc, const float* weight_ohwi,
+                                            float* grad_x_nhwc, float* grad_weight_ohwi, float* grad_bias, int N, int Cin,
+                                            int H, int W, int Cout, void* workspace, size_t workspace_bytes,
+                                            dbevStream_t stream) {
+  return dbev_skinny_conv3x3_backward_pitched(grad_y_nhwc, x_nhwc, Cin, weight_ohwi, grad_x_nhwc, Cin, grad_weight_ohwi, grad_bias,
+                                              N, Cin, H, W, Cout, workspace, workspace_bytes, stream);
 }

@@ -123,6 +123,11 @@ def accelerate_modules(detector):
     roots = [detector] + ([detector.teacher_model] if getattr(detector, "teacher_model", None) is not None else [])
     n_bn = sum(fuse_bn_relu_modules(r) for r in roots)
     detector.skinny_convs = sum(use_skinny_convs(r) for r in roots)    # final 64 -> 1..3 convs of the CenterHead branches
+    from .center_head import CenterHead
+    from .head_batch import plan_branches
+    detector.batched_branches = 0
+    if os.environ.get("DBEV_HEAD_BATCH", "1") != "0":
+        detector.batched_branches = sum(plan_branches(m) for r in roots for m in r.modules() if isinstance(m, CenterHead))
     n_up = 0
     for r in roots:
         for mod in r.modules():

@@ -417,6 +417,16 @@ int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* weight_ohwi, c
 int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const float* x_nhwc, const float* weight_ohwi,
                                  float* grad_x_nhwc, float* grad_weight_ohwi, float* grad_bias, int N, int Cin, int H, int W,
                                  int Cout, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+/* The same two calls on a CHANNEL SLICE of a wider NHWC tensor: x_nhwc points at the slice's first channel and x_pitch /
+ * grad_x_pitch are the widths of the enclosing tensors in floats (multiples of 4, >= Cin; pointers 16-byte aligned).  Used by
+ * the batched CenterHead branches: the 36 hidden maps of SeparateHead (centerpoint_head.py:83-101) live in a few wide tensors,
+ * each final convolution reads its 64 channels in place and writes its slice of the shared gradient in place. */
+int dbev_skinny_conv3x3_forward_pitched(const float* x_nhwc, long long x_pitch, const float* weight_ohwi, const float* bias,
+                                        float* y_nhwc, int N, int Cin, int H, int W, int Cout, dbevStream_t stream);
+int dbev_skinny_conv3x3_backward_pitched(const float* grad_y_nhwc, const float* x_nhwc, long long x_pitch,
+                                         const float* weight_ohwi, float* grad_x_nhwc, long long grad_x_pitch,
+                                         float* grad_weight_ohwi, float* grad_bias, int N, int Cin, int H, int W, int Cout,
+                                         void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* Training-mode BatchNorm2d fused with the residual add and ReLU that follow it (channels-last fp32):
  *   y = relu( (x - mean_batch) / sqrt(var_batch + eps) * gamma + beta  [+ residual] )
