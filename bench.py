@@ -82,6 +82,10 @@ def main():
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     n_gpus = dist.get_world_size() if dist.is_initialized() else 1
 
+    if os.environ.get("DBEV_MIOPEN_FIND", "0") == "1":     # exhaustive MIOpen search (tools/tune_miopen.sh regenerates the shipped tables)
+        torch.backends.cudnn.benchmark = True
+    from distill_bev_amd.miopen_tuning import use_shipped_db
+    miopen_db = use_shipped_db()               # before the first convolution of the process
     W = _workloads()
     name = args.workload or W["default"]
     wl = W[name](dev, rank, world)
@@ -133,7 +137,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": dict(wl.config(world), world_size=n_gpus,
-                           collective_backend=(dist.get_backend() + " (RCCL)") if dist.is_initialized() else None),
+                           collective_backend=(dist.get_backend() + " (RCCL)") if dist.is_initialized() else None,
+                           miopen_solver_tables=("distill_bev_amd/miopen_db (exhaustive search on MI355X, shipped)" if miopen_db
+                                                 else "library default / MIOPEN_USER_DB_PATH of the environment")),
             "roofline": roof,
             "cpu_baseline": cpu,
         }

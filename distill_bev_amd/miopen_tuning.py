@@ -1,0 +1,40 @@
+"""MIOpen solver tables tuned on MI355X for the convolutions of the shipped recipes.
+
+ROCm 7.2's MIOpen carries no find database for gfx950 (share/miopen/db holds gfx942 and older): on a fresh machine every
+convolution falls back to the immediate-mode heuristic plus a short hybrid search (~100 s at first touch), which picks
+e.g. 16x64x32 tiles for the 58 x 100 maps of the BEVFormer recipe (45 TFLOP/s where the library's best kernel reaches 124).
+`miopen_db/` holds the result of one exhaustive search (`torch.backends.cudnn.benchmark = True`, 9 + 7 minutes on one MI355X,
+`tools/tune_miopen.sh`) over the shapes of the three convolution-bearing bench workloads at their shipped batch sizes: 281
+problems -> ranked solvers (`*.ufdb.txt`) and tuned implicit-GEMM tile configurations (`*.udb.txt`), 190 KB of text.  With it the
+library starts on its best kernels immediately: BEVDepth4D distillation step 157 -> 148 ms, BEVFormer step 351 -> 306 ms, first
+step after 6-9 s instead of 100 s.  Shapes that are not in the table (another batch size, another image size) behave as before.
+
+`use_shipped_db()` points MIOPEN_USER_DB_PATH at a private copy (the library appends to the files; ranks must not share them)
+and has to run before the process's first convolution.  A user-set MIOPEN_USER_DB_PATH wins; DBEV_MIOPEN_DB=0 disables it.
+"""
+import atexit
+import glob
+import os
+import shutil
+import tempfile
+
+_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+_state = {"path": None}
+
+
+def use_shipped_db():
+    """-> the directory MIOpen will use as its user database (None: left alone)."""
+    if _state["path"] is not None:
+        return _state["path"]
+    if os.environ.get("DBEV_MIOPEN_DB", "1") == "0" or os.environ.get("MIOPEN_USER_DB_PATH"):
+        return None
+    files = glob.glob(os.path.join(_DB, "*.txt"))
+    if not files:
+        return None
+    dst = tempfile.mkdtemp(prefix="dbev_miopen_")
+    for f in files:
+        shutil.copy(f, dst)
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    _state["path"] = dst
+    atexit.register(shutil.rmtree, dst, ignore_errors=True)
+    return dst

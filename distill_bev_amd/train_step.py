@@ -270,6 +270,8 @@ def param_groups(detector, opt):
 
 class Trainer:
     def __init__(self, model, cfg, device, world_size=1, channels_last=False):
+        from .miopen_tuning import use_shipped_db
+        use_shipped_db()                     # MIOpen solver tables tuned on MI355X; before the process's first convolution
         self.device = device
         self.detector = model.to(device)
         self.detector.train()
