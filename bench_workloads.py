@@ -489,6 +489,8 @@ class BevformerDistillStep(_Base):
         self.units_per_step = self.B
         cfg_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "distillbev_mvpformer2bevformer_r50.py")
         model, cfg = build_model(cfg_path, seed=0)
+        from distill_bev_amd.miopen_tuning import use_shipped_gemm_table
+        self.gemm_table = use_shipped_gemm_table()        # ranked rocBLAS / hipBLASLt solutions for the attention / FFN linears
         self.trainer = Trainer(model, cfg, dev, world_size=world, channels_last=os.environ.get("DBEV_BF_NCHW") != "1")
         self.batch = make_bevformer_batch(self.B, np.random.default_rng(1234 + rank), dev, queue_length=cfg.queue_length)
         self.n_params = sum(p.numel() for p in self.trainer.params)

@@ -9,6 +9,10 @@ problems -> ranked solvers (`*.ufdb.txt`) and tuned implicit-GEMM tile configura
 library starts on its best kernels immediately: BEVDepth4D distillation step 157 -> 148 ms, BEVFormer step 351 -> 306 ms, first
 step after 6-9 s instead of 100 s.  Shapes that are not in the table (another batch size, another image size) behave as before.
 
+`tunableop_gemm.csv` is the same idea for the fp32 GEMMs of the BEVFormer recipe's 48 attention / FFN linears (40 000 x 256 queries):
+PyTorch's TunableOp ranks the rocBLAS / hipBLASLt solutions per GEMM shape (67 s on one MI355X); `use_shipped_gemm_table()` loads the
+69 results with tuning switched off (BEVFormer step 304 -> 293 ms).  Only the BEVFormer workload / recipe calls it.
+
 `use_shipped_db()` points MIOPEN_USER_DB_PATH at a private copy (the library appends to the files; ranks must not share them)
 and has to run before the process's first convolution.  A user-set MIOPEN_USER_DB_PATH wins; DBEV_MIOPEN_DB=0 disables it.
 """
@@ -28,7 +32,7 @@ def use_shipped_db():
         return _state["path"]
     if os.environ.get("DBEV_MIOPEN_DB", "1") == "0" or os.environ.get("MIOPEN_USER_DB_PATH"):
         return None
-    files = glob.glob(os.path.join(_DB, "*.txt"))
+    files = glob.glob(os.path.join(_DB, "*db.txt"))
     if not files:
         return None
     dst = tempfile.mkdtemp(prefix="dbev_miopen_")
@@ -37,4 +41,26 @@ def use_shipped_db():
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     _state["path"] = dst
     atexit.register(shutil.rmtree, dst, ignore_errors=True)
+    return dst
+
+
+def use_shipped_gemm_table():
+    """Load the shipped TunableOp results (no tuning at run time).  -> the file prefix in use, or None."""
+    import torch
+    if os.environ.get("DBEV_MIOPEN_DB", "1") == "0" or os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is not None:
+        return None                                   # the environment decides
+    src = os.path.join(_DB, "tunableop_gemm.csv")
+    if not (os.path.exists(src) and torch.cuda.is_available() and hasattr(torch.cuda, "tunable")):
+        return None
+    dst = _state.get("gemm")
+    if dst is None:
+        d = tempfile.mkdtemp(prefix="dbev_gemm_")
+        atexit.register(shutil.rmtree, d, ignore_errors=True)
+        for i in range(torch.cuda.device_count()):     # TunableOp reads <name><device ordinal>.csv
+            shutil.copy(src, os.path.join(d, f"tunableop_gemm{i}.csv"))
+        dst = os.path.join(d, "tunableop_gemm.csv")
+        _state["gemm"] = dst
+    torch.cuda.tunable.enable(True)
+    torch.cuda.tunable.tuning_enable(False)
+    torch.cuda.tunable.set_filename(dst, insert_device_ordinal=True)
     return dst
