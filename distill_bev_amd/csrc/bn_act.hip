@@ -32,18 +32,21 @@ constexpr int BN_FIN_CH = 4, BN_FIN_PH = 64;   // finalize kernels: channels x p
 struct BnGeom {
   int M, C, C4, CH, RP, GY, NBX;
   int RTPB, RRP, RUNR;     // reduction passes (bn_stats, bn_bwd_reduce): threads per block, row phases, row unroll
+  int STRIPE;              // reduction passes: 1 = workgroups interleaved over row stripes, walked back to front (see stripe_rows)
 };
 
 // Tunables of the reduction passes, overridable from the environment for A/B runs (tools/kbench_bn2.py):
 //   DBEV_BN_RTPB  threads per workgroup (256 / 512 / 1024)      DBEV_BN_RUNR  rows in flight per thread (4 / 8)
 //   DBEV_BN_RNBX  cap on workgroups (= partial rows the finalize kernel merges) per column chunk
-struct BnTune { int rtpb, runr, rnbx; };
+//   DBEV_BN_STRIPE  1 (default): stripe walk, back to front; 0: one contiguous row range per workgroup (round-1 layout)
+struct BnTune { int rtpb, runr, rnbx, stripe; };
 const BnTune& bn_tune() {
   static const BnTune t = [] {
-    BnTune v{512, 4, 256};   // swept on MI355X (tools/sweep_bn.sh): 512-thread workgroups, 4 rows in flight, <= 256 partial rows
+    BnTune v{512, 4, 256, 1};   // swept on MI355X (tools/sweep_bn.sh): 512-thread workgroups, 4 rows in flight, <= 256 partial rows
     if (const char* e = getenv("DBEV_BN_RTPB")) v.rtpb = atoi(e);
     if (const char* e = getenv("DBEV_BN_RUNR")) v.runr = atoi(e);
     if (const char* e = getenv("DBEV_BN_RNBX")) v.rnbx = atoi(e);
+    if (const char* e = getenv("DBEV_BN_STRIPE")) v.stripe = atoi(e) != 0;
     if (v.rtpb != 256 && v.rtpb != 512 && v.rtpb != 1024) v.rtpb = 512;
     if (v.runr != 4 && v.runr != 8) v.runr = 4;
     if (v.rnbx < 1 || v.rnbx > BN_MAX_BLOCKS_X) v.rnbx = 256;
@@ -73,6 +76,7 @@ bool bn_geom(long long M, int C, BnGeom* g) {
   g->RTPB = t.rtpb;
   g->RRP = t.rtpb / CH;
   g->RUNR = t.runr;
+  g->STRIPE = t.stripe;
   // every reduction workgroup gets at least 4 unrolled trips over its rows; at most `rnbx` partial rows
   const long long per = static_cast<long long>(g->RRP) * g->RUNR * 4;
   const long long tiles = (M + per - 1) / per;
@@ -104,6 +108,19 @@ __device__ __forceinline__ int block_rows(const BnGeom& g, int* r_end, int rp_co
   return static_cast<int>(b < g.M ? b : g.M);
 }
 
+// Stripe walk of the reduction passes: a stripe = gridDim.x consecutive pieces of R = RRP * UNR rows, workgroup b takes piece b of every
+// stripe, stripes are walked from the LAST to the first.  Against one contiguous range per workgroup: the tensor a reduction pass reads
+// was just written front to back by the convolution before it, so its tail sits in the 256 MB memory-side cache and its head in HBM;
+// with contiguous ranges the workgroups on the tail finish early and the ones on the head pull from HBM with half the machine idle,
+// with stripes every workgroup sees the same mix, the cached tail first (before this pass's own reads evict it).  Inside the step
+// (alternating A/B runs on one box): the bn_* family 24.3 -> 23.7 ms, the apply pass that follows finds the head of the tensor
+// hot (0.70 -> 0.72 of HBM peak); in isolation unchanged.
+__device__ __forceinline__ int stripe_count(const BnGeom& g, int R) {
+  const long long per = static_cast<long long>(gridDim.x) * R;
+  return static_cast<int>((g.M + per - 1) / per);
+}
+__device__ __forceinline__ int stripe_row0(int s, int R) { return (s * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x)) * R; }
+
 // block-level merge of two float4 accumulators over the row phases, result written by phase 0:
 // partial[(blockIdx.x * 2 + which) * C + 4*q .. +4]
 template <int TPB>
@@ -132,6 +149,22 @@ __global__ __launch_bounds__(TPB) void bn_stats(const float4* __restrict__ x, fl
   const int q = blockIdx.y * g.CH + ql;
   float4 s = f4(0.f), ss = f4(0.f);
   const int stride = g.RRP;
+  if (g.STRIPE) {
+    const int R = stride * UNR;
+    for (int st = stripe_count(g, R) - 1; st >= 0; --st) {
+      const int r0 = stripe_row0(st, R) + rp;
+      float4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int r = r0 + u * stride;
+        v[u] = r < g.M ? x[static_cast<size_t>(r) * g.C4 + q] : f4(0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) { add4(s, v[u]); fma4v(ss, v[u], v[u]); }
+    }
+    block_merge_store<TPB>(s, ss, partial, g.C, g.CH, g.RRP, q, ql, rp);
+    return;
+  }
   int r_end;
   int r = block_rows<true>(g, &r_end, g.RRP) + rp;
   for (; r + (UNR - 1) * stride < r_end; r += UNR * stride) {
@@ -284,7 +317,13 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ 
   float4 db = f4(0.f), dg = f4(0.f);
   const int stride = g.RRP;
   int r_end;
-  for (int r0 = block_rows<true>(g, &r_end, g.RRP) + rp; r0 < r_end; r0 += UNR * stride) {
+  int r0 = block_rows<true>(g, &r_end, g.RRP) + rp, step = UNR * stride, st = 0;
+  if (g.STRIPE) {                      // same loop body, rows from the stripe walk (back to front)
+    st = stripe_count(g, step) - 1;
+    r0 = stripe_row0(st, step) + rp;
+    r_end = g.M;
+  }
+  for (; g.STRIPE ? st >= 0 : r0 < r_end; g.STRIPE ? (--st, r0 = stripe_row0(st, step) + rp) : (r0 += step)) {
     float4 a[UNR], v[UNR], o[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -440,7 +479,13 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restri
   float4 db = f4(0.f), dg = f4(0.f), dgd = f4(0.f);
   const int stride = g.RRP;
   int r_end;
-  for (int r0 = block_rows<true>(g, &r_end, g.RRP) + rp; r0 < r_end; r0 += UNR * stride) {
+  int r0 = block_rows<true>(g, &r_end, g.RRP) + rp, step = UNR * stride, st = 0;
+  if (g.STRIPE) {
+    st = stripe_count(g, step) - 1;
+    r0 = stripe_row0(st, step) + rp;
+    r_end = g.M;
+  }
+  for (; g.STRIPE ? st >= 0 : r0 < r_end; g.STRIPE ? (--st, r0 = stripe_row0(st, step) + rp) : (r0 += step)) {
     float4 a[UNR], v[UNR], vd[UNR], o[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
