@@ -76,6 +76,9 @@ _SIGNATURES = {
     "dbev_skinny_conv3x3_workspace_bytes": [_i, _i],
     "dbev_skinny_conv3x3_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_skinny_conv3x3_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
+    "dbev_skinny_conv3x3_multi_workspace_bytes": [_i, _i],
+    "dbev_skinny_conv3x3_multi_forward": [_p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dbev_skinny_conv3x3_multi_backward": [_p, _p, _ll, _p, _p, _ll, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
     "dbev_skinny_conv3x3_forward_pitched": [_p, _ll, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_skinny_conv3x3_backward_pitched": [_p, _p, _ll, _p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
     "dbev_spconv_build_workspace_bytes": [_i, _i, _p, _i, _i],
@@ -117,6 +120,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_bn_act_workspace_bytes": ctypes.c_size_t,
              "dbev_bn_dual_workspace_bytes": ctypes.c_size_t,
              "dbev_skinny_conv3x3_workspace_bytes": ctypes.c_size_t,
+             "dbev_skinny_conv3x3_multi_workspace_bytes": ctypes.c_size_t,
              "dbev_centerhead_loss_workspace_bytes": ctypes.c_size_t,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,

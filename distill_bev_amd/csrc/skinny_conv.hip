@@ -227,6 +227,198 @@ bool sk_ok(int N, int Cin, int H, int W, int Cout, long long x_pitch, long long 
   return true;
 }
 
+// ---- all branches of a group in ONE launch ---------------------------------------------------------------------------------
+// The 36 final convolutions of the batched CenterHead read 64-channel slices of the same wide map; launched one by one each is a
+// 33 MB pass that lasts 10-25 us (1.3 TB/s: ramp-up and tail, not bandwidth).  grid.y = branch: every branch is padded to 3 output
+// channels in a packed weight buffer (zero rows cost nothing on an HBM-bound kernel), only its real channels are stored.
+constexpr int SK_MAX_BR = 48;
+struct SkMulti {
+  float* y[SK_MAX_BR];            // forward: outputs f32[N,H,W,co[b]];  backward: unused
+  const float* gy[SK_MAX_BR];     // backward: output gradients f32[N,H,W,co[b]]
+  int co[SK_MAX_BR];
+};
+
+__global__ __launch_bounds__(256) void sk_fwd_multi(const float4* __restrict__ xbase, const float4* __restrict__ wpk,
+                                                    const float* __restrict__ bpk, SkMulti m, SkDims d) {
+  constexpr int CO = 3;
+  const int br = blockIdx.y, con = m.co[br];
+  const int G = d.C4;
+  const int q = threadIdx.x & (G - 1);
+  const float4* __restrict__ x = xbase + static_cast<size_t>(br) * G;
+  const float4* __restrict__ wp = wpk + static_cast<size_t>(br) * CO * 9 * G;
+  float* __restrict__ y = m.y[br];
+  float4 wr[CO * 9];
+#pragma unroll
+  for (int i = 0; i < CO * 9; ++i) wr[i] = wp[i * G + q];
+  float br_[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) br_[co] = bpk[br * CO + co];
+  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
+  const long long ngrp = static_cast<long long>(gridDim.x) * blockDim.x / G;
+  const long long g0 = (static_cast<long long>(blockIdx.x) * blockDim.x + (threadIdx.x & ~63)) / G;
+  const long long gme = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
+  for (long long pb = g0; pb < npix; pb += ngrp) {
+    const long long p = pb + (gme - g0);
+    const bool live = p < npix;
+    const long long pp = live ? p : 0;
+    const unsigned pu = static_cast<unsigned>(pp);
+    const unsigned rowi = pu / static_cast<unsigned>(d.W);
+    const int w = static_cast<int>(pu - rowi * d.W);
+    const long long n = rowi / static_cast<unsigned>(d.H);
+    const int h = static_cast<int>(rowi - static_cast<unsigned>(n) * d.H);
+    float4 v[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+      v[tap] = (live && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) ? x[((n * d.H + hh) * d.W + ww) * d.XP4 + q]
+                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float s = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) s += dot4f(v[tap], wr[co * 9 + tap]);
+      for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (live && q == 0 && co < con) y[p * con + co] = s + br_[co];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sk_bwd_data_multi(const float4* __restrict__ wpk, float4* __restrict__ dxbase, SkMulti m, SkDims d) {
+  constexpr int CO = 3;
+  const int br = blockIdx.y, con = m.co[br];
+  const int G = d.C4;
+  const int q = threadIdx.x & (G - 1);
+  const float4* __restrict__ wp = wpk + static_cast<size_t>(br) * CO * 9 * G;
+  const float* __restrict__ dy = m.gy[br];
+  float4* __restrict__ dx = dxbase + static_cast<size_t>(br) * G;
+  float4 wr[CO * 9];
+#pragma unroll
+  for (int i = 0; i < CO * 9; ++i) wr[i] = wp[i * G + q];
+  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
+  const long long ngrp = static_cast<long long>(gridDim.x) * blockDim.x / G;
+  for (long long p = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G; p < npix; p += ngrp) {
+    const unsigned pu = static_cast<unsigned>(p);
+    const unsigned rowi = pu / static_cast<unsigned>(d.W);
+    const int w = static_cast<int>(pu - rowi * d.W);
+    const long long n = rowi / static_cast<unsigned>(d.H);
+    const int h = static_cast<int>(rowi - static_cast<unsigned>(n) * d.H);
+    float gv[9][CO];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
+      const bool in = hh >= 0 && hh < d.H && ww >= 0 && ww < d.W;
+      const float* g = dy + ((n * d.H + hh) * d.W + ww) * con;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) gv[tap][co] = (in && co < con) ? g[co] : 0.f;
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        const float4 wv = wr[co * 9 + tap];
+        acc.x = fmaf(gv[tap][co], wv.x, acc.x); acc.y = fmaf(gv[tap][co], wv.y, acc.y);
+        acc.z = fmaf(gv[tap][co], wv.z, acc.z); acc.w = fmaf(gv[tap][co], wv.w, acc.w);
+      }
+    st_nt(dx + p * d.DP4 + q, acc);
+  }
+}
+
+// weight / bias gradient partials of every branch: part_w [branch][gridDim.x][27][C4], part_b [branch][gridDim.x][3]
+__global__ __launch_bounds__(256) void sk_bwd_weight_multi(const float4* __restrict__ xbase, float4* __restrict__ part_w,
+                                                           float* __restrict__ part_b, SkMulti m, SkDims d) {
+  constexpr int CO = 3;
+  __shared__ float4 red[256];
+  const int br = blockIdx.y, con = m.co[br];
+  const int G = d.C4;
+  const float4* __restrict__ x = xbase + static_cast<size_t>(br) * G;
+  const float* __restrict__ dy = m.gy[br];
+  const int grp = threadIdx.x / G, q = threadIdx.x & (G - 1), ngrp = blockDim.x / G;
+  const long long npix = static_cast<long long>(d.N) * d.H * d.W;
+  const long long per = (npix + gridDim.x - 1) / gridDim.x;
+  const long long p0 = static_cast<long long>(blockIdx.x) * per;
+  const long long p1 = p0 + per < npix ? p0 + per : npix;
+  float4 acc[CO * 9];
+#pragma unroll
+  for (int i = 0; i < CO * 9; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bsum[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) bsum[co] = 0.f;
+  for (long long p = p0 + grp; p < p1; p += ngrp) {
+    const unsigned pu = static_cast<unsigned>(p);
+    const unsigned rowi = pu / static_cast<unsigned>(d.W);
+    const int w = static_cast<int>(pu - rowi * d.W);
+    const long long n = rowi / static_cast<unsigned>(d.H);
+    const int h = static_cast<int>(rowi - static_cast<unsigned>(n) * d.H);
+    const float4 v = x[p * d.XP4 + q];
+    float gv[9][CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) bsum[co] += co < con ? dy[p * con + co] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
+      const bool in = hh >= 0 && hh < d.H && ww >= 0 && ww < d.W;
+      const float* g = dy + ((n * d.H + hh) * d.W + ww) * con;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) gv[tap][co] = (in && co < con) ? g[co] : 0.f;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        float4& a = acc[co * 9 + tap];
+        const float g1 = gv[tap][co];
+        a.x = fmaf(g1, v.x, a.x); a.y = fmaf(g1, v.y, a.y); a.z = fmaf(g1, v.z, a.z); a.w = fmaf(g1, v.w, a.w);
+      }
+  }
+  const size_t blk = static_cast<size_t>(br) * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < CO * 9; ++i) {
+    __syncthreads();
+    red[threadIdx.x] = acc[i];
+    __syncthreads();
+    if (grp == 0) {
+      float4 t = red[q];
+      for (int k = 1; k < ngrp; ++k) {
+        const float4 u = red[k * G + q];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      part_w[(blk * CO * 9 + i) * G + q] = t;
+    }
+  }
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) reinterpret_cast<float*>(red)[grp * CO + co] = bsum[co];
+  }
+  __syncthreads();
+  if (threadIdx.x < CO) {
+    float t = 0.f;
+    for (int k = 0; k < ngrp; ++k) t += reinterpret_cast<float*>(red)[k * CO + threadIdx.x];
+    part_b[blk * CO + threadIdx.x] = t;
+  }
+}
+
+// out[b][i] = fp64 sum over the workgroup partials part[b][blk][i]   (grid (ceil(n_out / 16), branches))
+__global__ __launch_bounds__(256) void sk_final_multi(const float* __restrict__ part, int nblk, int n_out, float* __restrict__ out) {
+  __shared__ double red[16][16];
+  const int ol = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + ol;
+  const float* __restrict__ pb = part + static_cast<size_t>(blockIdx.y) * nblk * n_out;
+  double s = 0.0;
+  if (i < n_out)
+    for (int b = ph; b < nblk; b += 16) s += static_cast<double>(pb[static_cast<size_t>(b) * n_out + i]);
+  red[ph][ol] = s;
+  __syncthreads();
+  if (ph == 0 && i < n_out) {
+    for (int p = 1; p < 16; ++p) s += red[p][ol];
+    out[static_cast<size_t>(blockIdx.y) * n_out + i] = static_cast<float>(s);
+  }
+}
+
+constexpr int SK_MULTI_WG_BLOCKS = 128;   // weight-gradient workgroups per branch (x up to 48 branches)
+
 #define SK_DISPATCH(CO, KERNEL, ...)                            \
   switch (CO) {                                                 \
     case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break; \
@@ -305,4 +497,82 @@ extern "C" int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const floa
                                             dbevStream_t stream) {
   return dbev_skinny_conv3x3_backward_pitched(grad_y_nhwc, x_nhwc, Cin, weight_ohwi, grad_x_nhwc, Cin, grad_weight_ohwi, grad_bias,
                                               N, Cin, H, W, Cout, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t dbev_skinny_conv3x3_multi_workspace_bytes(int Cin, int n_branch) {
+  if (Cin <= 0 || (Cin & 3) || n_branch < 1 || n_branch > SK_MAX_BR) return 0;
+  return sizeof(float) * static_cast<size_t>(n_branch) * SK_MULTI_WG_BLOCKS * (27 * static_cast<size_t>(Cin) + 3) + 256;
+}
+
+static bool sk_multi_args(SkMulti* m, float* const* y, const float* const* gy, const int32_t* cout, int n_branch) {
+  if (n_branch < 1 || n_branch > SK_MAX_BR || cout == nullptr) return false;
+  for (int b = 0; b < n_branch; ++b) {
+    if (cout[b] < 1 || cout[b] > SK_MAX_CO) return false;
+    m->co[b] = cout[b];
+    m->y[b] = y ? y[b] : nullptr;
+    m->gy[b] = gy ? gy[b] : nullptr;
+    if ((y && !y[b]) || (gy && !gy[b])) return false;
+  }
+  return true;
+}
+
+extern "C" int dbev_skinny_conv3x3_multi_forward(const float* x_nhwc, long long x_pitch, const float* weights_packed,
+                                                 const float* bias_packed, float* const* y_nhwc, const int32_t* cout,
+                                                 int n_branch, int N, int Cin, int H, int W, dbevStream_t stream) {
+  SkDims d;
+  SkMulti m;
+  if (!sk_ok(N, Cin, H, W, 3, x_pitch, Cin, &d) || x_nhwc == nullptr || weights_packed == nullptr || bias_packed == nullptr ||
+      (reinterpret_cast<uintptr_t>(x_nhwc) & 15) || !sk_multi_args(&m, y_nhwc, nullptr, cout, n_branch) ||
+      x_pitch < static_cast<long long>(n_branch) * Cin)
+    return DBEV_EINVAL;
+  const long long threads = static_cast<long long>(N) * H * W * d.C4;
+  long long blocks = (threads + 255) / 256;
+  const long long cap = SK_PERSIST_BLOCKS * 2 / n_branch > 64 ? SK_PERSIST_BLOCKS * 2 / n_branch : 64;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(sk_fwd_multi, dim3(static_cast<unsigned>(blocks), n_branch), dim3(256), 0, dbev_stream(stream),
+                     reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<const float4*>(weights_packed), bias_packed, m, d);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_skinny_conv3x3_multi_backward(const float* const* grad_y_nhwc, const float* x_nhwc, long long x_pitch,
+                                                  const float* weights_packed, float* grad_x_nhwc, long long grad_x_pitch,
+                                                  float* grad_weights_packed, float* grad_bias_packed, const int32_t* cout,
+                                                  int n_branch, int N, int Cin, int H, int W, void* workspace,
+                                                  size_t workspace_bytes, dbevStream_t stream) {
+  SkDims d;
+  SkMulti m;
+  if (!sk_ok(N, Cin, H, W, 3, x_pitch, grad_x_nhwc != nullptr ? grad_x_pitch : Cin, &d) || x_nhwc == nullptr ||
+      weights_packed == nullptr || (reinterpret_cast<uintptr_t>(x_nhwc) & 15) || (reinterpret_cast<uintptr_t>(grad_x_nhwc) & 15) ||
+      !sk_multi_args(&m, nullptr, grad_y_nhwc, cout, n_branch) || x_pitch < static_cast<long long>(n_branch) * Cin ||
+      (grad_x_nhwc != nullptr && grad_x_pitch < static_cast<long long>(n_branch) * Cin))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const long long threads = static_cast<long long>(N) * H * W * d.C4;
+  long long pblocks = (threads + 255) / 256;
+  const long long cap = SK_PERSIST_BLOCKS * 2 / n_branch > 64 ? SK_PERSIST_BLOCKS * 2 / n_branch : 64;
+  if (pblocks > cap) pblocks = cap;
+  if (grad_x_nhwc != nullptr)
+    hipLaunchKernelGGL(sk_bwd_data_multi, dim3(static_cast<unsigned>(pblocks), n_branch), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(weights_packed), reinterpret_cast<float4*>(grad_x_nhwc), m, d);
+  if (grad_weights_packed != nullptr) {
+    if (grad_bias_packed == nullptr || workspace == nullptr ||
+        workspace_bytes < dbev_skinny_conv3x3_multi_workspace_bytes(Cin, n_branch))
+      return DBEV_EINVAL;
+    const long long npix = static_cast<long long>(N) * H * W;
+    const int rows_per_iter = 256 / d.C4;
+    long long blocks = (npix + rows_per_iter * 8 - 1) / (rows_per_iter * 8);
+    if (blocks > SK_MULTI_WG_BLOCKS) blocks = SK_MULTI_WG_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    float* part_w = static_cast<float*>(workspace);
+    float* part_b = part_w + static_cast<size_t>(n_branch) * SK_MULTI_WG_BLOCKS * 27 * Cin;
+    hipLaunchKernelGGL(sk_bwd_weight_multi, dim3(static_cast<unsigned>(blocks), n_branch), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<float4*>(part_w), part_b, m, d);
+    const int nw = 27 * Cin;
+    hipLaunchKernelGGL(sk_final_multi, dim3(dbev_ceil_div(nw, 16), n_branch), dim3(256), 0, s, part_w, static_cast<int>(blocks), nw,
+                       grad_weights_packed);
+    hipLaunchKernelGGL(sk_final_multi, dim3(1, n_branch), dim3(256), 0, s, part_b, static_cast<int>(blocks), 3, grad_bias_packed);
+  }
+  DBEV_LAUNCH_CHECK();
+  return 0;
 }

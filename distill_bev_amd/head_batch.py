@@ -10,16 +10,14 @@ arithmetic of ONE convolution C -> 36*Ch and ONE BatchNorm over 36*Ch channels, 
   convolution; its data gradient IS the sum over the group's branches;
 * one fused BatchNorm + ReLU pass (bn_act kernels) normalises the whole group -- batch statistics are per channel, so every
   branch sees exactly its own; running statistics are written back to the 36 modules with two multi-tensor copies;
-* the final convolutions (skinny kernels) read their 64 channels in place from the wide map (pitched entry points) and write
-  their slice of the one shared gradient tensor in place.
+* the final convolutions (skinny kernels) read their 64 channels in place from the wide map and write their slice of the one shared
+  gradient tensor in place -- all branches of a group in one launch each way (`dbev_skinny_conv3x3_multi_*`, grid.y = branch).
 
 Groups: the fused norm kernels take C/4 = 2^k <= 256 or a multiple of 256 channels columns, so the 36 x 64 channels of the recipe
 split into a group of 32 branches (2048 channels) and one of 4 (256).  Parameters, buffers and state-dict keys are untouched;
 `plan_branches(head)` only records which modules belong together, and CenterHead falls back to the per-branch module calls
 whenever the plan does not apply (eval mode, no_grad, NCHW inputs, `only=` pruning of the frozen teacher, fused norms disabled).
 """
-import ctypes
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -30,13 +28,9 @@ from . import bn_act as BA
 from .skinny_conv import SkinnyConv2d
 
 
-def _slice_ptr(t, channel_offset):
-    return ctypes.c_void_p(t.data_ptr() + 4 * channel_offset)
-
-
 class _BranchFinalConvs(Function):
-    """y_i = conv3x3(A[:, i*Ch:(i+1)*Ch], w_i) + b_i for the branches of one group, reading the slices in place
-    (dbev_skinny_conv3x3_forward_pitched / _backward_pitched)."""
+    """y_i = conv3x3(A[:, i*Ch:(i+1)*Ch], w_i) + b_i for the branches of one group: ONE launch forward, data gradient and weight
+    gradient each (dbev_skinny_conv3x3_multi_*, grid.y = branch), reading / writing the channel slices of the wide tensors in place."""
 
     @staticmethod
     def forward(ctx, A, Ch, *wb):
@@ -44,46 +38,46 @@ class _BranchFinalConvs(Function):
         N, Ct, H, W = A.shape
         n = len(wb) // 2
         assert n * Ch == Ct
-        wps, ys = [], []
+        couts = [int(w.shape[0]) for w in wb[0::2]]
+        pad = torch.zeros((2, 9 * Ch), dtype=torch.float32, device=dev)
+        wrows, brows = [], []
+        for i in range(n):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            wrows.append(w.permute(0, 2, 3, 1).reshape(couts[i], 9 * Ch))
+            brows.append(b if b is not None else pad[:couts[i], 0])
+            if couts[i] < 3:
+                wrows.append(pad[:3 - couts[i]]); brows.append(pad[:3 - couts[i], 0])
+        wpk = torch.cat(wrows)                          # [n * 3, 9 * Ch]: every branch padded to 3 output rows
+        bpk = torch.cat(brows)
+        ys = [torch.empty((N, co, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last) for co in couts]
         with torch.cuda.device(dev):
-            for i in range(n):
-                w, b = wb[2 * i], wb[2 * i + 1]
-                Co = w.shape[0]
-                wp = w.permute(0, 2, 3, 1).contiguous()
-                y = torch.empty((N, Co, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-                L.call("dbev_skinny_conv3x3_forward_pitched", _slice_ptr(A, i * Ch), Ct, L.ptr(wp), L.ptr(b), L.ptr(y), N, Ch, H, W,
-                       Co, L.stream_ptr(dev), alg_bytes=4 * N * H * W * (Ch + Co))
-                wps.append(wp); ys.append(y)
-        ctx.save_for_backward(A, *wps)
-        ctx.cfg = (Ch, [b is not None for b in wb[1::2]])
+            L.call("dbev_skinny_conv3x3_multi_forward", L.ptr(A), Ct, L.ptr(wpk), L.ptr(bpk), L.host_ptrs(ys), L.host_ints(couts), n,
+                   N, Ch, H, W, L.stream_ptr(dev), alg_bytes=4 * N * H * W * (Ct + sum(couts)))
+        ctx.save_for_backward(A, wpk)
+        ctx.cfg = (Ch, couts, [b is not None for b in wb[1::2]])
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *gys):
-        A, *wps = ctx.saved_tensors
-        Ch, has_bias = ctx.cfg
+        A, wpk = ctx.saved_tensors
+        Ch, couts, has_bias = ctx.cfg
         dev = A.device
         N, Ct, H, W = A.shape
+        n = len(couts)
+        gys = [(g if g is not None else torch.zeros((N, co, H, W), dtype=torch.float32, device=dev)).contiguous(memory_format=torch.channels_last)
+               for g, co in zip(gys, couts)]
         gA = torch.empty_like(A)                      # every channel slice is fully written by its branch
-        grads = []
+        gw = torch.empty((n, 3, 9, Ch), dtype=torch.float32, device=dev)
+        gb = torch.empty((n, 3), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            ws = None
-            for i, (gy, wp) in enumerate(zip(gys, wps)):
-                Co = wp.shape[0]
-                if gy is None:                        # a branch nothing consumed: zero gradient for its slice
-                    gA[:, i * Ch:(i + 1) * Ch].zero_()
-                    grads += [None, None]
-                    continue
-                gy = gy.contiguous(memory_format=torch.channels_last)
-                gwp = torch.empty_like(wp)
-                gb = torch.empty((Co,), dtype=torch.float32, device=dev)
-                nbytes = int(L.call("dbev_skinny_conv3x3_workspace_bytes", Ch, Co))
-                if ws is None or ws.numel() < nbytes:
-                    ws = torch.empty((int(L.call("dbev_skinny_conv3x3_workspace_bytes", Ch, 3)),), dtype=torch.uint8, device=dev)
-                L.call("dbev_skinny_conv3x3_backward_pitched", L.ptr(gy), _slice_ptr(A, i * Ch), Ct, L.ptr(wp), _slice_ptr(gA, i * Ch), Ct,
-                       L.ptr(gwp), L.ptr(gb), N, Ch, H, W, Co, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
-                       alg_bytes=4 * N * H * W * (2 * Ch + 2 * Co))
-                grads += [gwp.permute(0, 3, 1, 2), gb if has_bias[i] else None]
+            nbytes = int(L.call("dbev_skinny_conv3x3_multi_workspace_bytes", Ch, n))
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            L.call("dbev_skinny_conv3x3_multi_backward", L.host_ptrs(gys), L.ptr(A), Ct, L.ptr(wpk), L.ptr(gA), Ct, L.ptr(gw), L.ptr(gb),
+                   L.host_ints(couts), n, N, Ch, H, W, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+                   alg_bytes=4 * N * H * W * (2 * Ct + 2 * sum(couts)))
+        grads = []
+        for i, co in enumerate(couts):
+            grads += [gw[i, :co].view(co, 3, 3, Ch).permute(0, 3, 1, 2), gb[i, :co] if has_bias[i] else None]
         return (gA, None, *grads)
 
 

@@ -428,6 +428,21 @@ int dbev_skinny_conv3x3_backward_pitched(const float* grad_y_nhwc, const float* 
                                          float* grad_weight_ohwi, float* grad_bias, int N, int Cin, int H, int W, int Cout,
                                          void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
+/* All final convolutions of one branch group in one launch each way (grid.y = branch).  Branch b reads channels [b*Cin, (b+1)*Cin)
+ * of the wide map; weights_packed f32[n_branch,3,3,3,Cin] = every branch's weight.permute(0,2,3,1) padded with zero rows to 3 output
+ * channels, bias_packed f32[n_branch,3]; y_nhwc / grad_y_nhwc: HOST arrays of n_branch device pointers to f32[N,H,W,cout[b]];
+ * cout: HOST int32[n_branch] in 1..3; n_branch <= 48.  backward writes every slice of grad_x (pitch grad_x_pitch), the packed
+ * weight / bias gradients (rows >= cout[b] are zero) with fixed-order reductions; workspace from
+ * dbev_skinny_conv3x3_multi_workspace_bytes. */
+size_t dbev_skinny_conv3x3_multi_workspace_bytes(int Cin, int n_branch);
+int dbev_skinny_conv3x3_multi_forward(const float* x_nhwc, long long x_pitch, const float* weights_packed,
+                                      const float* bias_packed, float* const* y_nhwc, const int32_t* cout, int n_branch, int N,
+                                      int Cin, int H, int W, dbevStream_t stream);
+int dbev_skinny_conv3x3_multi_backward(const float* const* grad_y_nhwc, const float* x_nhwc, long long x_pitch,
+                                       const float* weights_packed, float* grad_x_nhwc, long long grad_x_pitch,
+                                       float* grad_weights_packed, float* grad_bias_packed, const int32_t* cout, int n_branch,
+                                       int N, int Cin, int H, int W, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
 /* Training-mode BatchNorm2d fused with the residual add and ReLU that follow it (channels-last fp32):
  *   y = relu( (x - mean_batch) / sqrt(var_batch + eps) * gamma + beta  [+ residual] )
  * = torch.nn.functional.batch_norm(training=True) [+ add] [+ relu] as the reference's dense blocks chain them
