@@ -79,8 +79,6 @@ _SIGNATURES = {
     "dbev_skinny_conv3x3_multi_workspace_bytes": [_i, _i],
     "dbev_skinny_conv3x3_multi_forward": [_p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_skinny_conv3x3_multi_backward": [_p, _p, _ll, _p, _p, _ll, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
-    "dbev_skinny_conv3x3_forward_pitched": [_p, _ll, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "dbev_skinny_conv3x3_backward_pitched": [_p, _p, _ll, _p, _p, _ll, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
     "dbev_spconv_build_workspace_bytes": [_i, _i, _p, _i, _i],
     "dbev_spconv_outputs": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _sz, _p],
     "dbev_spconv_neighbors": [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],

@@ -433,7 +433,7 @@ extern "C" size_t dbev_skinny_conv3x3_workspace_bytes(int Cin, int Cout) {
   return sizeof(float) * static_cast<size_t>(SK_WG_BLOCKS) * (static_cast<size_t>(Cout) * 9 * Cin + Cout) + 256;
 }
 
-extern "C" int dbev_skinny_conv3x3_forward_pitched(const float* x_nhwc, long long x_pitch, const float* weight_ohwi,
+static int sk_forward_pitched(const float* x_nhwc, long long x_pitch, const float* weight_ohwi,
                                                    const float* bias, float* y_nhwc, int N, int Cin, int H, int W, int Cout,
                                                    dbevStream_t stream) {
   SkDims d;
@@ -451,10 +451,10 @@ extern "C" int dbev_skinny_conv3x3_forward_pitched(const float* x_nhwc, long lon
 
 extern "C" int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* weight_ohwi, const float* bias, float* y_nhwc,
                                            int N, int Cin, int H, int W, int Cout, dbevStream_t stream) {
-  return dbev_skinny_conv3x3_forward_pitched(x_nhwc, Cin, weight_ohwi, bias, y_nhwc, N, Cin, H, W, Cout, stream);
+  return sk_forward_pitched(x_nhwc, Cin, weight_ohwi, bias, y_nhwc, N, Cin, H, W, Cout, stream);
 }
 
-extern "C" int dbev_skinny_conv3x3_backward_pitched(const float* grad_y_nhwc, const float* x_nhwc, long long x_pitch,
+static int sk_backward_pitched(const float* grad_y_nhwc, const float* x_nhwc, long long x_pitch,
                                                     const float* weight_ohwi, float* grad_x_nhwc, long long grad_x_pitch,
                                                     float* grad_weight_ohwi, float* grad_bias, int N, int Cin, int H, int W,
                                                     int Cout, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
@@ -495,7 +495,7 @@ extern "C" int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const floa
                                             float* grad_x_nhwc, float* grad_weight_ohwi, float* grad_bias, int N, int Cin,
                                             int H, int W, int Cout, void* workspace, size_t workspace_bytes,
                                             dbevStream_t stream) {
-  return dbev_skinny_conv3x3_backward_pitched(grad_y_nhwc, x_nhwc, Cin, weight_ohwi, grad_x_nhwc, Cin, grad_weight_ohwi, grad_bias,
+  return sk_backward_pitched(grad_y_nhwc, x_nhwc, Cin, weight_ohwi, grad_x_nhwc, Cin, grad_weight_ohwi, grad_bias,
                                               N, Cin, H, W, Cout, workspace, workspace_bytes, stream);
 }
 

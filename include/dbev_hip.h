@@ -417,19 +417,9 @@ int dbev_skinny_conv3x3_forward(const float* x_nhwc, const float* weight_ohwi, c
 int dbev_skinny_conv3x3_backward(const float* grad_y_nhwc, const float* x_nhwc, const float* weight_ohwi,
                                  float* grad_x_nhwc, float* grad_weight_ohwi, float* grad_bias, int N, int Cin, int H, int W,
                                  int Cout, void* workspace, size_t workspace_bytes, dbevStream_t stream);
-/* The same two calls on a CHANNEL SLICE of a wider NHWC tensor: x_nhwc points at the slice's first channel and x_pitch /
- * grad_x_pitch are the widths of the enclosing tensors in floats (multiples of 4, >= Cin; pointers 16-byte aligned).  Used by
- * the batched CenterHead branches: the 36 hidden maps of SeparateHead (centerpoint_head.py:83-101) live in a few wide tensors,
- * each final convolution reads its 64 channels in place and writes its slice of the shared gradient in place. */
-int dbev_skinny_conv3x3_forward_pitched(const float* x_nhwc, long long x_pitch, const float* weight_ohwi, const float* bias,
-                                        float* y_nhwc, int N, int Cin, int H, int W, int Cout, dbevStream_t stream);
-int dbev_skinny_conv3x3_backward_pitched(const float* grad_y_nhwc, const float* x_nhwc, long long x_pitch,
-                                         const float* weight_ohwi, float* grad_x_nhwc, long long grad_x_pitch,
-                                         float* grad_weight_ohwi, float* grad_bias, int N, int Cin, int H, int W, int Cout,
-                                         void* workspace, size_t workspace_bytes, dbevStream_t stream);
-
-/* All final convolutions of one branch group in one launch each way (grid.y = branch).  Branch b reads channels [b*Cin, (b+1)*Cin)
- * of the wide map; weights_packed f32[n_branch,3,3,3,Cin] = every branch's weight.permute(0,2,3,1) padded with zero rows to 3 output
+/* All final convolutions of one CenterHead branch group in one launch each way (grid.y = branch): the 36 hidden maps of SeparateHead
+ * (centerpoint_head.py:83-101) live in a few wide NHWC tensors (x_pitch / grad_x_pitch = their channel counts, multiples of 4, pointers
+ * 16-byte aligned).  Branch b reads channels [b*Cin, (b+1)*Cin) of the wide map in place and writes its slice of the shared gradient; weights_packed f32[n_branch,3,3,3,Cin] = every branch's weight.permute(0,2,3,1) padded with zero rows to 3 output
  * channels, bias_packed f32[n_branch,3]; y_nhwc / grad_y_nhwc: HOST arrays of n_branch device pointers to f32[N,H,W,cout[b]];
  * cout: HOST int32[n_branch] in 1..3; n_branch <= 48.  backward writes every slice of grad_x (pitch grad_x_pitch), the packed
  * weight / bias gradients (rows >= cout[b] are zero) with fixed-order reductions; workspace from
