@@ -48,6 +48,14 @@ def _self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +129,12 @@ def main():
     if world > 1:
         dist.barrier(device_ids=[local_rank])
 
+    # RCCL writes a banner through C stdio, which is block-buffered on a pipe and would otherwise be flushed at process exit, i.e.
+    # AFTER the JSON line (and, from the other ranks, after rank 0 has exited): push it out on every rank now, then synchronise,
+    # so that the JSON line is the last thing on stdout
+    _flush_c_stdio()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
     if rank == 0:
         units = wl.units_per_step * world * steps
         line = {
@@ -143,9 +157,11 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
