@@ -87,6 +87,8 @@ _SIGNATURES = {
     "dbev_spconv_pair_lists": [_p, _i, _i, _i, _p, _p, _p, _sz, _p],
     "dbev_spconv_forward_fused": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "dbev_sparse_to_dense": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "dbev_range_voxel_coords": [_p, _i, _i, _p, _p, _i, _p, _p],
+    "dbev_virtual_voxel_reduce": [_p, _p, _p, _p, _i, _p],
     "dbev_msda_backward_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "dbev_msda_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p],
     "dbev_msda_backward": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p],

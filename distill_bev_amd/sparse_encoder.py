@@ -10,9 +10,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as L
 from . import spconv
 from .registry import MODELS, build_conv_layer, build_norm_layer
-from .voxel import dynamic_scatter
+from .voxel import dynamic_scatter_prepare, dynamic_scatter_reduce
 
 
 class SparseBasicBlock(spconv.SparseModule):
@@ -147,54 +148,49 @@ class SparseEncoder(nn.Module):
 
 
 # ---- dynamic_voxel_encoder.py ---------------------------------------------------------------------------------------------
-def _voxel_mean(rows, points_xyz, pc_range, voxel_size):
-    """coords = trunc((xyz - min) / size) in (z, y, x) order; unique rows in lexicographic order + per-voxel mean of `rows`
-    (the reference: coords.unique(return_inverse, dim=0) + scatter_mean, :14-17) on the dynamic-scatter kernels."""
-    coords = ((points_xyz[:, [2, 1, 0]] - pc_range[[2, 1, 0]]) / voxel_size[[2, 1, 0]]).to(torch.int64)
-    voxels, unique_coords = dynamic_scatter(rows.contiguous(), coords.int().contiguous(), "mean")
-    return voxels, unique_coords.long()
+def _host3(t):
+    """range / size triple on the host (the ABI takes them by value; a device tensor costs one read-back)"""
+    return [float(v) for v in (t.tolist() if torch.is_tensor(t) else t)]
 
 
-def _keep(points, pc_range):
-    return ((points[:, 0] >= pc_range[0]) & (points[:, 0] <= pc_range[3]) & (points[:, 1] >= pc_range[1])
-            & (points[:, 1] <= pc_range[4]) & (points[:, 2] >= pc_range[2]) & (points[:, 2] <= pc_range[5]))
+def _group_by_voxel(points, pc_range, voxel_size, virtual):
+    """Range test + (z, y, x) voxel of every point (dbev_range_voxel_coords), then the dynamic-scatter grouping: voxels in the
+    lexicographic order of `coords.unique(dim=0)` (dynamic_voxel_encoder.py:14,58), the points of a voxel in ascending id.
+    Points on the upper range border fall into cell index `shape` (the reference keeps them): the grid has one more cell
+    per axis than the encoder's `shape`."""
+    dev = L.require_cuda(points)
+    points = points.contiguous()
+    assert points.dtype == torch.float32 and points.dim() == 2
+    rng, vs = _host3(pc_range), _host3(voxel_size)
+    n, F = points.shape
+    coors = torch.empty((n, 3), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dbev_range_voxel_coords", L.ptr(points), n, F, L.host_floats(rng), L.host_floats(vs), int(virtual),
+               L.ptr(coors), L.stream_ptr(dev))
+    # largest index = trunc(fp32((max - min) / size)): fp32 subtraction and division are monotonic
+    grid = tuple(int((np.float32(rng[3 + k]) - np.float32(rng[k])) / np.float32(vs[k])) + 1 for k in (2, 1, 0))
+    return points, dynamic_scatter_prepare(coors, grid)
 
 
 def voxelization(points, pc_range, voxel_size):
-    """dynamic_voxel_encoder.py:8-18"""
-    points = points[_keep(points, pc_range), :]
-    return _voxel_mean(points, points[:, :3], pc_range, voxel_size)
+    """dynamic_voxel_encoder.py:8-17: per-voxel mean of the rows inside the range -> (voxels [M, F], coords [M, 3] (z, y, x))"""
+    points, prep = _group_by_voxel(points, pc_range, voxel_size, False)
+    return dynamic_scatter_reduce(points, prep, "mean"), prep["out_coors"].long()
 
 
 def voxelization_virtual(points, pc_range, voxel_size):
-    """dynamic_voxel_encoder.py:19-68 (MVP virtual points; channel -2 = 1 real / 0 painted / -1 virtual)."""
-    points = points[_keep(points, pc_range), :]
-    real_points_mask = points[:, -2] == 1
-    painted_points_mask = points[:, -2] == 0
-    virtual_points_mask = points[:, -2] == -1
-    real_points = points[real_points_mask][:, [0, 1, 2, 3, 4, -1]]
-    painted_point = points[painted_points_mask]
-    virtual_point = points[virtual_points_mask]
-    nr, npnt = len(real_points), len(painted_point)
-    padded_points = torch.zeros(len(points), 24, device=points.device, dtype=points.dtype)
-    padded_points[:nr, :6] = real_points
-    padded_points[:nr, -1] = 1
-    padded_points[nr:nr + npnt, 6:21] = painted_point[:, :-2]
-    padded_points[nr:nr + npnt, 21] = painted_point[:, -2]
-    padded_points[nr:nr + npnt, 22] = 1
-    padded_points[nr:nr + npnt, 23] = 0
-    padded_points[nr + npnt:, 6:21] = virtual_point[:, :-2]
-    padded_points[nr + npnt:, 21] = virtual_point[:, -2]
-    padded_points[nr + npnt:, 22] = 0
-    padded_points[nr + npnt:, 23] = 0
-    points_xyz = torch.cat([real_points[:, :3], painted_point[:, :3], virtual_point[:, :3]], dim=0)
-    voxels, unique_coords = _voxel_mean(padded_points, points_xyz, pc_range, voxel_size)
-    indicator = voxels[:, -1]
-    mix_mask = (indicator > 0) * (indicator < 1)
-    voxels = voxels[:, :-1]
-    voxels[mix_mask, :6] = voxels[mix_mask, :6] / indicator[mix_mask].unsqueeze(-1)
-    voxels[mix_mask, 6:] = voxels[mix_mask, 6:] / (1 - indicator[mix_mask].unsqueeze(-1))
-    return voxels, unique_coords
+    """dynamic_voxel_encoder.py:19-68 (MVP virtual points; column -2 = 1 real / 0 painted / -1 virtual): 23 columns per
+    voxel -- real points' (x y z i t score) means in 0..5, painted / virtual points' 15 columns + tag + painted flag in 6..22,
+    voxels holding both kinds rescaled by the real fraction -- in one pass over the voxel's rows (dbev_virtual_voxel_reduce),
+    no padded copy of the cloud."""
+    points, prep = _group_by_voxel(points, pc_range, voxel_size, True)
+    dev, M = points.device, prep["M"]
+    voxels = torch.empty((M, 23), dtype=torch.float32, device=dev)
+    if M > 0:
+        with torch.cuda.device(dev):
+            L.call("dbev_virtual_voxel_reduce", L.ptr(points), L.ptr(prep["vstart"]), L.ptr(prep["vlist"]), L.ptr(voxels), M,
+                   L.stream_ptr(dev))
+    return voxels, prep["out_coors"].long()
 
 
 @MODELS.register_module()
@@ -214,7 +210,7 @@ class DynamicVoxelEncoder(nn.Module):
         coors, voxels = [], []
         for res in points:
             fn = voxelization_virtual if self.virtual else voxelization
-            voxel, coor = fn(res, self.pc_range.to(res.device), self.voxel_size.to(res.device))
+            voxel, coor = fn(res, self.pc_range, self.voxel_size)  # host triples: passed by value to the kernels
             voxels.append(voxel)
             coors.append(coor)
         coors_batch = torch.cat([F.pad(c, (1, 0), mode="constant", value=i) for i, c in enumerate(coors)], dim=0)

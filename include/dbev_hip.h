@@ -580,6 +580,22 @@ int dbev_spconv_forward_fused(const float* features, const float* weight, const 
 int dbev_sparse_to_dense(const float* features, const int32_t* indices, int n, int C, int B, int D, int H, int W,
                          float* canvas_ncdhw, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Dynamic voxel encoders of the voxel teachers (mmdet3d/models/voxel_encoders/dynamic_voxel_encoder.py; torch op sequences
+ * in the reference: boolean row selections, a zero-padded [N, 24] copy, `unique(dim=0)`, scatter_mean, masked divisions).
+ *  dbev_range_voxel_coords    `voxelization` :9-13 / `voxelization_virtual` :22-26,57: coors i32[N, 3] = (z, y, x) =
+ *                             trunc((p - range_min) / voxel_size) for the points inside the CLOSED range, (-1,-1,-1) for the
+ *                             others (and, with virtual_classes != 0, for rows whose tag column F-2 is none of 1 / 0 / -1:
+ *                             the reference cannot represent them).  Row convention of dbev_dynamic_scatter_prepare, which
+ *                             then yields the voxels in `unique`'s order.  pc_range_host f32[6], voxel_size_host f32[3]: HOST.
+ *  dbev_virtual_voxel_reduce  `voxelization_virtual` :27-67 on the point lists of dbev_dynamic_scatter_prepare:
+ *                             points f32[N, 17] -> voxels f32[M, 23] (real columns 0..5, painted / virtual columns 6..22,
+ *                             mixed voxels rescaled by the real fraction); per-column sums in the reference's order. */
+int dbev_range_voxel_coords(const float* points, int num_points, int num_feats, const float* pc_range_host,
+                            const float* voxel_size_host, int virtual_classes, int32_t* coors, dbevStream_t stream);
+int dbev_virtual_voxel_reduce(const float* points, const int32_t* voxel_point_start, const int32_t* voxel_point_list,
+                              float* voxels, int num_voxels, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -431,6 +431,15 @@ def second_fpn():
     return load("mmdet3d/models/necks/second_fpn.py", "refpkg.models.necks.second_fpn")
 
 
+def dynamic_voxel_encoder():
+    """voxel_encoders/dynamic_voxel_encoder.py on the reference's own core/utils/scatter.py (pure torch, TorchScript)."""
+    install_full_stubs()
+    if "mmdet3d.core.utils" not in sys.modules:
+        cu = _mod("mmdet3d.core.utils"); cu.__path__ = []
+        cu.scatter = load("mmdet3d/core/utils/scatter.py", "mmdet3d.core.utils.scatter")
+    return load("mmdet3d/models/voxel_encoders/dynamic_voxel_encoder.py", "refpkg.models.voxel_encoders.dynamic_voxel_encoder")
+
+
 def bare(cls, **attrs):
     """An instance of a reference class without running its __init__ (which would build the whole mmdet model zoo):
     nn.Module state only, then the attributes the called methods read."""

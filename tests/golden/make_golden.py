@@ -605,6 +605,49 @@ def make_pfn():
     print("pillars", vf.shape[0], "points", points.shape[0])
 
 
+def make_dynvoxel():
+    """voxelization / voxelization_virtual / DynamicVoxelEncoder.forward (dynamic_voxel_encoder.py:8-102) executed by the
+    imported file on seeded clouds: 5-column sweeps and 17-column MVP clouds (column -2: 1 real / 0 painted / -1 virtual)
+    with points outside the range, on its closed border, all-real / all-virtual / no-real clouds, voxels mixing the kinds."""
+    D = R.dynamic_voxel_encoder()
+    rng = np.random.default_rng(21)
+    pcr, vs = [-4.0, -4.0, -1.0, 4.0, 4.0, 1.0], [0.5, 0.5, 0.4]
+    out = dict(pc_range=np.array(pcr, np.float32), voxel_size=np.array(vs, np.float32))
+
+    def cloud(n, F, tags=None):
+        p = rng.normal(size=(n, F)).astype(np.float32)
+        p[:, :2] = rng.uniform(-4.4, 4.4, (n, 2))
+        p[:, 2] = rng.uniform(-1.15, 1.15, n)
+        # rows exactly on the closed range border (kept by the reference, cell index == shape) and just outside it
+        p[0, :3] = [4.0, 4.0, 1.0]; p[1, :3] = [-4.0, -4.0, -1.0]; p[2, :3] = [4.0, 0.1, 0.2]; p[3, :3] = [4.0000005, 0, 0]
+        p[4, :3] = [0.49999997, 0.5, 0.39999998]
+        if tags is not None:
+            p[:, -2] = rng.choice(np.array(tags, np.float32), n)
+            p[:, 5:15] = rng.uniform(0, 1, (n, 10))
+        return torch.from_numpy(p)
+
+    pr, v = torch.tensor(pcr), torch.tensor(vs)
+    plain = [cloud(1500, 5), cloud(700, 5)]
+    for i, p in enumerate(plain):
+        vox, co = D.voxelization(p, pr, v)
+        out.update({f"plain{i}_points": p.numpy(), f"plain{i}_voxels": vox.numpy(), f"plain{i}_coords": co.numpy()})
+    cases = dict(mixed=cloud(2500, 17, [1, 0, -1]), dense=cloud(4000, 17, [1, 0, -1, -1, -1]), all_real=cloud(600, 17, [1]),
+                 all_virtual=cloud(600, 17, [-1]), no_real=cloud(800, 17, [0, -1]), no_virtual=cloud(800, 17, [1, 0]))
+    # a cloud concentrated in few voxels: long per-voxel lists (> 64 points) with all three kinds
+    cases["dense"][:, :2] *= 0.12
+    for name, p in cases.items():
+        vox, co = D.voxelization_virtual(p.clone(), pr, v)
+        out.update({f"virt_{name}_points": p.numpy(), f"virt_{name}_voxels": vox.numpy(), f"virt_{name}_coords": co.numpy()})
+        print(name, tuple(vox.shape))
+    enc = D.DynamicVoxelEncoder(pcr, vs, virtual=True)
+    vb, cb, shp = enc([cases["mixed"], cases["no_real"]])
+    out.update(enc_voxels=vb.numpy(), enc_coords=cb.numpy(), enc_shape=np.asarray(shp))
+    encp = D.DynamicVoxelEncoder(pcr, vs)
+    vb, cb, shp = encp(plain)
+    out.update(encp_voxels=vb.numpy(), encp_coords=cb.numpy(), encp_shape=np.asarray(shp))
+    _save("dynvoxel.npz", **out)
+
+
 def make_second():
     """SECOND (second.py:80-93) + SECONDFPN (second_fpn.py:77-93) outputs of the imported modules on seeded weights,
     eval mode (the teacher runs under eval / no_grad), thin channels so that the state dict fits a fixture."""
@@ -1046,7 +1089,8 @@ def _bevdepth_batch(B, N, H, W, rng, g):
 
 SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center,
             "fgd": make_fgd, "shift_depth": make_shift_depth, "centerloss": make_centerloss, "pfn": make_pfn,
-            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map, "bevformer_step": make_bevformer_step, "bevdepth_step": make_bevdepth_step}
+            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map, "bevformer_step": make_bevformer_step, "bevdepth_step": make_bevdepth_step,
+            "dynvoxel": make_dynvoxel}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)

@@ -199,56 +199,56 @@ def test_sparse_encoder_of_the_mvp_teacher_vs_dense_reference_network():
     assert sd["conv_input.0.weight"].shape == (3, 3, 3, 23, 16)
 
 
-def test_dynamic_voxel_encoder_plain_and_virtual():
-    """voxelization / voxelization_virtual (dynamic_voxel_encoder.py:8-68) vs the reference's op sequence restated with
-    torch.unique + an fp64 index_add mean on the CPU."""
-    from distill_bev_amd.sparse_encoder import DynamicVoxelEncoder
+def test_dynamic_voxel_encoder_vs_reference_fixture():
+    """voxelization / voxelization_virtual / DynamicVoxelEncoder (dynamic_voxel_encoder.py:8-102) on the kernels
+    (dbev_range_voxel_coords, dbev_virtual_voxel_reduce, dynamic-scatter grouping) against tests/golden/dynvoxel.npz, the
+    outputs of the IMPORTED reference file: voxel coordinates and order exact, voxel rows BIT-equal (the kernels keep the
+    reference's per-column summation order and its fp32 divisions), incl. points on the closed range border, clouds
+    without real / without virtual points and voxels holding > 64 points of all three kinds."""
+    import os
+    from distill_bev_amd.sparse_encoder import DynamicVoxelEncoder, voxelization, voxelization_virtual
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "dynvoxel.npz"))
     dev = torch.device("cuda:0")
-    pcr, vs = [-4.0, -4.0, -1.0, 4.0, 4.0, 1.0], [0.5, 0.5, 0.5]
-    rng = np.random.default_rng(3)
+    pr, vs = torch.from_numpy(G["pc_range"]), torch.from_numpy(G["voxel_size"])
+    for i in range(2):
+        v, c = voxelization(torch.from_numpy(G[f"plain{i}_points"]).to(dev), pr, vs)
+        assert c.dtype == torch.int64 and np.array_equal(c.cpu().numpy(), G[f"plain{i}_coords"])
+        assert np.array_equal(v.cpu().numpy(), G[f"plain{i}_voxels"])
+    for name in ("mixed", "dense", "all_real", "all_virtual", "no_real", "no_virtual"):
+        v, c = voxelization_virtual(torch.from_numpy(G[f"virt_{name}_points"]).to(dev), pr.to(dev), vs.to(dev))  # device triples too
+        assert np.array_equal(c.cpu().numpy(), G[f"virt_{name}_coords"]), name
+        ref = G[f"virt_{name}_voxels"]
+        assert v.shape == ref.shape and np.array_equal(v.cpu().numpy(), ref), (name, float(np.abs(v.cpu().numpy() - ref).max()))
+    v, c, shp = DynamicVoxelEncoder(G["pc_range"].tolist(), G["voxel_size"].tolist(), virtual=True)(
+        [torch.from_numpy(G["virt_mixed_points"]).to(dev), torch.from_numpy(G["virt_no_real_points"]).to(dev)])
+    assert np.array_equal(c.cpu().numpy(), G["enc_coords"]) and np.array_equal(v.cpu().numpy(), G["enc_voxels"])
+    assert np.array_equal(shp, G["enc_shape"])
+    v, c, shp = DynamicVoxelEncoder(G["pc_range"].tolist(), G["voxel_size"].tolist())(
+        [torch.from_numpy(G["plain0_points"]).to(dev), torch.from_numpy(G["plain1_points"]).to(dev)])
+    assert np.array_equal(c.cpu().numpy(), G["encp_coords"]) and np.array_equal(v.cpu().numpy(), G["encp_voxels"])
+    # empty cloud / everything outside the range
+    far = torch.full((10, 17), 99.0, device=dev)
+    v, c = voxelization_virtual(far, pr, vs)
+    assert v.shape == (0, 23) and c.shape == (0, 3)
 
-    def ref_mean(rows, xyz):
-        pr, v = torch.tensor(pcr), torch.tensor(vs)
-        coords = ((xyz[:, [2, 1, 0]] - pr[[2, 1, 0]]) / v[[2, 1, 0]]).to(torch.int64)
-        uc, inv = coords.unique(return_inverse=True, dim=0)
-        s = torch.zeros((uc.shape[0], rows.shape[1]), dtype=torch.float64).index_add_(0, inv, rows.double())
-        cnt = torch.zeros(uc.shape[0], dtype=torch.float64).index_add_(0, inv, torch.ones(len(inv), dtype=torch.float64))
-        return (s / cnt[:, None]).float(), uc
 
-    def keep(p):
-        return p[(p[:, 0] >= pcr[0]) & (p[:, 0] <= pcr[3]) & (p[:, 1] >= pcr[1]) & (p[:, 1] <= pcr[4]) & (p[:, 2] >= pcr[2]) & (p[:, 2] <= pcr[5])]
-
-    pts = [torch.from_numpy(np.concatenate([rng.uniform(-4.5, 4.5, (900, 2)), rng.uniform(-1.2, 1.2, (900, 1)), rng.uniform(0, 1, (900, 2))], 1).astype(np.float32))
-           for _ in range(2)]
-    v, c, shp = DynamicVoxelEncoder(pcr, vs)( [p.to(dev) for p in pts])
-    assert list(shp) == [16, 16, 4]
-    off = 0
-    for b, p in enumerate(pts):
-        rv, rc = ref_mean(keep(p), keep(p)[:, :3])
-        n = rc.shape[0]
-        assert np.array_equal(c[off:off + n, 1:].cpu().numpy(), rc.numpy()) and bool((c[off:off + n, 0] == b).all())
-        assert float((v[off:off + n].cpu() - rv).abs().max()) < 1e-5
-        off += n
-    assert off == c.shape[0]
-    # virtual points: 17 columns (MVP), column -2 = 1 real / 0 painted / -1 virtual
-    p = torch.from_numpy(rng.uniform(-3.9, 3.9, (600, 17)).astype(np.float32))
-    p[:, 2] = torch.from_numpy(rng.uniform(-0.9, 0.9, 600).astype(np.float32))
-    p[:, -2] = torch.from_numpy(rng.choice([1.0, 0.0, -1.0], 600).astype(np.float32))
-    vv, cv, _ = DynamicVoxelEncoder(pcr, vs, virtual=True)([p.to(dev)])
-    real, paint, virt = p[p[:, -2] == 1][:, [0, 1, 2, 3, 4, -1]], p[p[:, -2] == 0], p[p[:, -2] == -1]
-    pad = torch.zeros(600, 24)
-    nr, npn = len(real), len(paint)
-    pad[:nr, :6] = real; pad[:nr, -1] = 1
-    pad[nr:nr + npn, 6:21] = paint[:, :-2]; pad[nr:nr + npn, 21] = paint[:, -2]; pad[nr:nr + npn, 22] = 1
-    pad[nr + npn:, 6:21] = virt[:, :-2]; pad[nr + npn:, 21] = virt[:, -2]
-    rv, rc = ref_mean(pad, torch.cat([real[:, :3], paint[:, :3], virt[:, :3]]))
-    ind = rv[:, -1]
-    mix = (ind > 0) & (ind < 1)
-    rv = rv[:, :-1]
-    rv[mix, :6] = rv[mix, :6] / ind[mix].unsqueeze(-1)
-    rv[mix, 6:] = rv[mix, 6:] / (1 - ind[mix].unsqueeze(-1))
-    assert vv.shape == (rc.shape[0], 23) and np.array_equal(cv[:, 1:].cpu().numpy(), rc.numpy())
-    assert float((vv.cpu() - rv).abs().max()) < 1e-4 and int(mix.sum()) > 5
+def test_dynamic_voxel_encoder_full_size_vs_oracle():
+    """400 k MVP points on the 1440 x 1440 x 40 grid of the shipped recipe (configs/teacher_transformer/mvpformer.py):
+    coordinates exact and voxel rows bit-equal to the pinned CPU oracle (oracle/dynvoxel.py), bit-identical when repeated."""
+    from distill_bev_amd.sparse_encoder import voxelization_virtual
+    from oracle import dynvoxel as O
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    n = 400_000
+    p = rng.normal(size=(n, 17)).astype(np.float32)
+    p[:, :2] = rng.normal(0, 18, (n, 2)); p[:, 2] = rng.uniform(-5.5, 3.5, n)
+    p[:, -2] = rng.choice(np.array([1, 0, -1, -1], np.float32), n)
+    pcr, vs = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], [0.075, 0.075, 0.2]
+    v, c = voxelization_virtual(torch.from_numpy(p).to(dev), pcr, vs)
+    rv, rc = O.voxelization_virtual(p, pcr, vs)
+    assert np.array_equal(c.cpu().numpy(), rc) and np.array_equal(v.cpu().numpy(), rv)
+    v2, c2 = voxelization_virtual(torch.from_numpy(p).to(dev), pcr, vs)
+    assert torch.equal(v, v2) and torch.equal(c, c2)
 
 
 def test_edge_cases_empty_and_single_site_tensors():
