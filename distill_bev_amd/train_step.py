@@ -276,11 +276,13 @@ class Trainer:
         self.detector = model.to(device)
         self.detector.train()
         if channels_last:
-            # every 4-D parameter (2-D convolution weights); Module.to(memory_format=) would also try the 5-D sparse-conv weights
+            # OIHW weights of the dense 2-D convolution modules only: Module.to(memory_format=) would also re-stride the sparse
+            # layers' [ky, kx, Cin, Cout] / 5-D weights, whose kernels view them in their own layout
+            from .dcn import ModulatedDeformConv2dPack
             for root in (self.detector, getattr(self.detector, "teacher_model", None)):
-                for p in (root.parameters() if root is not None else ()):
-                    if p.dim() == 4:
-                        p.data = p.data.contiguous(memory_format=torch.channels_last)
+                for m in (root.modules() if root is not None else ()):
+                    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, ModulatedDeformConv2dPack)) and m.weight.dim() == 4:
+                        m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
             self.detector.channels_last = True
             self.fused_bn_relu, self.swapped_upsample = accelerate_modules(self.detector)
         self.wrapper = _TrainWrapper(self.detector)

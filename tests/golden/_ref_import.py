@@ -58,7 +58,7 @@ def install_stubs():
         t = cfg.get("type", "BN")
         kw = {k: v for k, v in cfg.items() if k in ("eps", "momentum")}
         cls = nn.BatchNorm1d if t == "BN1d" else nn.BatchNorm2d
-        return "bn", cls(n, **kw)
+        return "bn" + str(postfix), cls(n, **kw)      # mmcv: abbreviation + postfix ("bn1", "bn2", ...)
 
     def build_upsample_layer(cfg, *a, **k):
         return nn.ConvTranspose2d(*a, **k, **_extras(cfg))
@@ -438,6 +438,24 @@ def dynamic_voxel_encoder():
         cu = _mod("mmdet3d.core.utils"); cu.__path__ = []
         cu.scatter = load("mmdet3d/core/utils/scatter.py", "mmdet3d.core.utils.scatter")
     return load("mmdet3d/models/voxel_encoders/dynamic_voxel_encoder.py", "refpkg.models.voxel_encoders.dynamic_voxel_encoder")
+
+
+def student_dense():
+    """The student's vendored dense stack for real: bricks/res_block.py (BasicBlock, Bottleneck), backbones/resnet.py
+    (ResNetForBEVDet), necks/lss_fpn.py (FPN_LSS), necks/fpn.py (FPNForBEVDet) -> namespace of the four modules"""
+    install_full_stubs()
+    cnn = sys.modules["mmcv.cnn"]
+    if not hasattr(cnn, "build_plugin_layer"):
+        cnn.build_plugin_layer = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("plugin layers: not on the path"))
+    rb = load("mmdet3d/models/bricks/res_block.py", "refpkg.models.bricks.res_block")
+    bricks = sys.modules["refpkg.models.bricks"]
+    bricks.__path__ = []
+    bricks.BasicBlock, bricks.Bottleneck = rb.BasicBlock, rb.Bottleneck
+    return types.SimpleNamespace(
+        res_block=rb,
+        resnet=load("mmdet3d/models/backbones/resnet.py", "refpkg.models.backbones.resnet"),
+        lss_fpn=load("mmdet3d/models/necks/lss_fpn.py", "refpkg.models.necks.lss_fpn"),
+        fpn=load("mmdet3d/models/necks/fpn.py", "refpkg.models.necks.fpn"))
 
 
 def bare(cls, **attrs):
@@ -965,8 +983,10 @@ def bevdepth_detectors():
     """The BEVDepth4DDistill class hierarchy of the reference for real -- detectors/{base,mvx_two_stage,centerpoint,
     dynamic_centerpoint,bevdet,bevdet_distill,bevdet_distill_more}.py -- with a working builder registry that holds the
     reference's own ViewTransformerLSSBEVDepth, CenterHead / SeparateHead, DynamicPillarFeatureNet, PointPillarsScatter,
-    SECOND, SECONDFPN and the shared stand-ins of tests/golden/standins.py.  -> (module bevdet_distill_more, registry)"""
+    SECOND, SECONDFPN, ResNetForBEVDet (on its BasicBlock), FPN_LSS, FPNForBEVDet and the one shared stand-in of
+    tests/golden/standins.py (the un-vendored image backbone).  -> (module bevdet_distill_more, registry)"""
     install_full_stubs()
+    student_dense()                       # bricks/res_block.py for real before backbones/resnet.py imports `..bricks`
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from oracle import dcn as ODCN
     import standins
@@ -1042,7 +1062,10 @@ def bevdepth_detectors():
                           ("mmdet3d/models/voxel_encoders/pillar_encoder.py", "refpkg.models.voxel_encoders.pillar_encoder"),
                           ("mmdet3d/models/middle_encoders/pillar_scatter.py", "refpkg.models.middle_encoders.pillar_scatter"),
                           ("mmdet3d/models/backbones/second.py", "refpkg.models.backbones.second"),
-                          ("mmdet3d/models/necks/second_fpn.py", "refpkg.models.necks.second_fpn")):
+                          ("mmdet3d/models/necks/second_fpn.py", "refpkg.models.necks.second_fpn"),
+                          ("mmdet3d/models/backbones/resnet.py", "refpkg.models.backbones.resnet"),
+                          ("mmdet3d/models/necks/lss_fpn.py", "refpkg.models.necks.lss_fpn"),
+                          ("mmdet3d/models/necks/fpn.py", "refpkg.models.necks.fpn")):
         m = load(path, modname)
         for k, v in vars(m).items():
             if isinstance(v, type) and issubclass(v, nn.Module) and v.__module__ == modname and k not in REG.table:

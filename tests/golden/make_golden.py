@@ -648,6 +648,82 @@ def make_dynvoxel():
     _save("dynvoxel.npz", **out)
 
 
+def _randomize_dense(module, gen):
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 1.0 + 0.3 * torch.randn(m.weight.shape, generator=gen)
+            m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=gen)
+            m.running_mean.copy_(0.3 * torch.randn(m.running_mean.shape, generator=gen))
+            m.running_var.copy_(0.5 + 1.5 * torch.rand(m.running_var.shape, generator=gen))
+        elif isinstance(m, torch.nn.Conv2d):
+            fan = m.weight[0].numel()
+            m.weight.data = torch.randn(m.weight.shape, generator=gen) * (1.4 / fan ** 0.5)
+            if m.bias is not None:
+                m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=gen)
+
+
+def _dense_case(out, tag, module, inputs, gen):
+    """training-mode forward + backward (outputs, input gradients, every parameter gradient, running statistics after the step)
+    and the eval-mode forward of `module` on `inputs` (a tensor or a list of tensors), weights stored BEFORE the step"""
+    _randomize_dense(module, gen)
+    out.update({k: v.copy() for k, v in _sd(f"{tag}__sd__", module).items()})      # before the step (numpy() shares memory)
+    xs = [x.clone().requires_grad_(True) for x in (inputs if isinstance(inputs, (list, tuple)) else [inputs])]
+    arg = xs if isinstance(inputs, (list, tuple)) else xs[0]
+    module.train()
+    ys = module(arg)
+    ys = list(ys) if isinstance(ys, (list, tuple)) else [ys]
+    ws = [torch.randn(y.shape, generator=gen) for y in ys]
+    loss = sum((y * w).sum() for y, w in zip(ys, ws))
+    params = dict(module.named_parameters())
+    grads = torch.autograd.grad(loss, xs + list(params.values()), allow_unused=True)
+    grads = [gr if gr is not None else torch.zeros_like(t) for gr, t in zip(grads, xs + list(params.values()))]
+    for i, (x, y, w) in enumerate(zip(xs + [None] * len(ys), ys, ws)):
+        out[f"{tag}__y{i}"] = y.detach().numpy()
+        out[f"{tag}__w{i}"] = w.numpy()
+    for i, x in enumerate(xs):
+        out[f"{tag}__x{i}"] = x.detach().numpy()
+        out[f"{tag}__gx{i}"] = grads[i].numpy()
+    for (n, _), g in zip(params.items(), grads[len(xs):]):
+        out[f"{tag}__gp__" + n.replace(".", "__")] = g.numpy()
+    for n, b in module.named_buffers():
+        if "running" in n:
+            out[f"{tag}__after__" + n.replace(".", "__")] = b.detach().numpy().copy()
+    module.eval()
+    with torch.no_grad():
+        ye = module(arg)
+    for i, y in enumerate(list(ye) if isinstance(ye, (list, tuple)) else [ye]):
+        out[f"{tag}__eval{i}"] = y.numpy()
+    print(tag, [tuple(y.shape) for y in ys], "params", len(params))
+
+
+def make_student_dense():
+    """The student's vendored dense stack executed by the reference's own files -- backbones/resnet.py:13-62
+    (ResNetForBEVDet), bricks/res_block.py:11-100,102-330 (BasicBlock, Bottleneck), necks/lss_fpn.py:10-72 (FPN_LSS),
+    necks/fpn.py:10-204 (FPNForBEVDet) -- at the structure of the shipped recipe (CFG_D:96-128: BEV encoder [2,2,2] basic
+    blocks at strides 2, depth net 3 basic blocks at stride 1, pre-process net 2 blocks, FPN_LSS on levels (0, 2), image neck
+    on two levels with out_ids [0]) with thin channels: training-mode outputs, input / parameter gradients and running
+    statistics, eval-mode outputs."""
+    D = R.student_dense()
+    g = torch.Generator().manual_seed(33)
+    out = {}
+    torch.manual_seed(33)
+    x = torch.randn((2, 16, 32, 32), generator=g)
+    _dense_case(out, "bev_backbone", D.resnet.ResNetForBEVDet(16, num_channels=[16, 32, 64]), x, g)
+    _dense_case(out, "depth_net", D.resnet.ResNetForBEVDet(16, num_layer=[3], num_channels=[16], stride=[1]), torch.randn((3, 16, 8, 22), generator=g), g)
+    _dense_case(out, "pre_process", D.resnet.ResNetForBEVDet(8, num_layer=[2], num_channels=[8], stride=[1], backbone_output_ids=[0]),
+                torch.randn((2, 8, 16, 16), generator=g), g)
+    _dense_case(out, "bottleneck", D.resnet.ResNetForBEVDet(16, num_layer=[2, 2], num_channels=[32, 64], stride=[2, 2], block_type="BottleNeck"), x, g)
+    feats = [torch.randn((2, 16, 16, 16), generator=g), torch.randn((2, 32, 8, 8), generator=g), torch.randn((2, 64, 4, 4), generator=g)]
+    _dense_case(out, "fpn_lss", D.lss_fpn.FPN_LSS(16 + 64, 32), feats, g)
+    _dense_case(out, "fpn_lss_lateral", D.lss_fpn.FPN_LSS(16 + 64, 24, lateral=16, extra_norm_act=True), feats, g)
+    _dense_case(out, "fpn_lss_noup", D.lss_fpn.FPN_LSS(32 + 64, 24, scale_factor=2, input_feature_index=(1, 2), extra_upsample=None), feats, g)
+    pyr = [torch.randn((3, 32, 8, 22), generator=g), torch.randn((3, 64, 4, 11), generator=g)]
+    _dense_case(out, "img_neck", D.fpn.FPNForBEVDet([32, 64], 24, 1, start_level=0, out_ids=[0]), pyr, g)
+    _dense_case(out, "img_neck_norm", D.fpn.FPNForBEVDet([32, 64], 24, 1, start_level=0, out_ids=[0], norm_cfg=dict(type="BN"),
+                                                         upsample_cfg=dict(mode="nearest", scale_factor=2)), pyr, g)
+    _save("student_dense.npz", **out)
+
+
 def make_second():
     """SECOND (second.py:80-93) + SECONDFPN (second_fpn.py:77-93) outputs of the imported modules on seeded weights,
     eval mode (the teacher runs under eval / no_grad), thin channels so that the state dict fits a fixture."""
@@ -1014,8 +1090,10 @@ def make_bevdepth_step():
                                  gt_labels_3d=[torch.from_numpy(l) for l in batch["labels"]], img_inputs=batch["img_inputs"])
     assert len(pooled) == 2
     total = sum(v for v in losses.values())
-    names = ["img_backbone.conv.weight", "img_view_transformer.dcn.0.weight", "img_view_transformer.depthnet.bias",
-             "img_bev_encoder_backbone.layers.0.weight", "pts_bbox_head.task_heads.2.heatmap.1.bias", "channel_wise_adaptations.1.weight"]
+    names = ["img_backbone.conv.weight", "img_neck.lateral_convs.1.conv.weight", "img_view_transformer.extra_depthnet.layers.0.0.conv1.weight",
+             "img_view_transformer.dcn.0.weight", "img_view_transformer.depthnet.bias", "pre_process_net.layers.0.0.conv2.weight",
+             "img_bev_encoder_backbone.layers.0.0.conv1.weight", "img_bev_encoder_backbone.layers.2.1.bn2.weight",
+             "img_bev_encoder_neck.up2.1.weight", "pts_bbox_head.task_heads.2.heatmap.1.bias", "channel_wise_adaptations.1.weight"]
     params = dict(model.named_parameters())
     grads = torch.autograd.grad(total, [params[n] for n in names], retain_graph=True)
     # the same BEV-encoder weight gradient split by loss group: localises a backward difference to one branch of the step
@@ -1023,12 +1101,12 @@ def make_bevdepth_step():
               "kd_head": [k for k in losses if k.endswith("head_head")]}
     gg = {}
     for gname, keys in groups.items():
-        gg["gradgroup__" + gname] = torch.autograd.grad(sum(losses[k] for k in keys), params["img_bev_encoder_backbone.layers.0.weight"],
+        gg["gradgroup__" + gname] = torch.autograd.grad(sum(losses[k] for k in keys), params["img_bev_encoder_backbone.layers.0.0.conv1.weight"],
                                                         retain_graph=True)[0].numpy()
     # every loss term's own gradient at two small BEV-encoder parameters (48 numbers per term).  A ReLU gate or an L1 sign
     # that sits within fp32 rounding of its kink flips between two implementations and moves that ONE term's gradient by
     # percents; the per-term view lets the test demand tight agreement from (nearly) all terms instead of a loose bound on the sum
-    tb = [params["img_bev_encoder_backbone.layers.0.bias"], params["img_bev_encoder_neck.conv.bias"]]
+    tb = [params["img_bev_encoder_backbone.layers.0.0.bn1.bias"], params["img_bev_encoder_neck.conv.1.bias"]]
     for k, v in losses.items():
         gr = torch.autograd.grad(v, tb, retain_graph=True, allow_unused=True)
         if gr[0] is not None:                     # (the depth loss never reaches the BEV encoder; backbone-position terms skip the neck)
@@ -1090,7 +1168,7 @@ def _bevdepth_batch(B, N, H, W, rng, g):
 SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center,
             "fgd": make_fgd, "shift_depth": make_shift_depth, "centerloss": make_centerloss, "pfn": make_pfn,
             "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map, "bevformer_step": make_bevformer_step, "bevdepth_step": make_bevdepth_step,
-            "dynvoxel": make_dynvoxel}
+            "dynvoxel": make_dynvoxel, "student_dense": make_student_dense}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)

@@ -1,67 +1,27 @@
-"""Plain-torch stand-ins shared by tests/golden/make_golden.py (registered on the REFERENCE's stub registries) and the GPU tests
-(registered on the product's registry) for the detector-level BEVDepth4DDistill fixture: the pieces of the recipe that live in
-un-vendored packages (mmdet ResNet / FPN image branch, the mmdet BasicBlock stacks of the depth net and of the BEV encoder).
-Everything the north-star path itself owns -- view transformer, lift-splat, shift, depth loss, CenterHead, the whole teacher,
-the distillation losses -- is the reference's own code on one side and the product's on the other.  No reference dependency."""
+"""The ONE plain-torch stand-in shared by tests/golden/make_golden.py (registered on the REFERENCE's stub registry) and the GPU
+test (registered on the product's registry) for the detector-level BEVDepth4DDistill fixture: the image backbone, mmdet's
+ResNet-50, which lives in the un-vendored mmdet package.  Everything else of the recipe is the reference's own code on one
+side and the product's on the other: image neck (necks/fpn.py FPNForBEVDet), view transformer with its SE + BasicBlock depth
+net + DCN, lift-splat, pre-process net / BEV encoder (backbones/resnet.py ResNetForBEVDet on bricks/res_block.py) and BEV neck
+(necks/lss_fpn.py FPN_LSS), shift, depth loss, CenterHead, the whole teacher, the distillation losses.  No reference dependency."""
 import torch.nn as nn
 import torch.nn.functional as F
 
 
 class TinyImageBackbone(nn.Module):
-    """3 -> C channels at stride 16 (one conv, no norm)"""
+    """3 -> (C4, C5) channels at strides 16 / 32 (two convs, no norm): the two levels `out_indices=(2, 3)` hands the image neck"""
 
-    def __init__(self, out_channels=32, **kwargs):
+    def __init__(self, out_channels=(32, 64), **kwargs):
         super().__init__()
-        self.conv = nn.Conv2d(3, out_channels, 16, stride=16)
+        self.conv = nn.Conv2d(3, out_channels[0], 16, stride=16)
+        self.conv2 = nn.Conv2d(out_channels[0], out_channels[1], 2, stride=2)
 
     def forward(self, x):
-        return F.relu(self.conv(x))
+        c4 = F.relu(self.conv(x))
+        return c4, F.relu(self.conv2(c4))
 
 
-class TinyDepthNet(nn.Module):
-    """the `extra_depth_net` slot of ViewTransformerLSSBEVDepth: returns a one-element list like ResNetForBEVDet"""
-
-    def __init__(self, numC_input, num_channels, **kwargs):
-        super().__init__()
-        self.conv = nn.Conv2d(numC_input, num_channels[0], 3, padding=1)
-
-    def forward(self, x):
-        return [F.relu(self.conv(x))]
-
-
-class TinyBEVBackbone(nn.Module):
-    """BEV encoder backbone slot: three maps at strides 2, 4, 8 (a list, as ResNetForBEVDet returns)"""
-
-    def __init__(self, numC_input, num_channels=(16, 32, 64), **kwargs):
-        super().__init__()
-        cin, layers = numC_input, []
-        for c in num_channels:
-            layers.append(nn.Conv2d(cin, c, 3, stride=2, padding=1))
-            cin = c
-        self.layers = nn.ModuleList(layers)
-
-    def forward(self, x):
-        outs = []
-        for l in self.layers:
-            x = F.relu(l(x))
-            outs.append(x)
-        return outs
-
-
-class TinyBEVNeck(nn.Module):
-    """BEV encoder neck slot: deepest map upsampled x4 + shallowest map -> out_channels at stride 1 (x2 up), like FPN_LSS"""
-
-    def __init__(self, in_channels, out_channels, **kwargs):
-        super().__init__()
-        self.conv = nn.Conv2d(in_channels, out_channels, 3, padding=1)
-
-    def forward(self, feats):
-        x = F.interpolate(feats[2], scale_factor=4, mode="bilinear", align_corners=True)
-        x = self.conv(__import__("torch").cat([feats[0], x], dim=1))
-        return F.interpolate(F.relu(x), scale_factor=2, mode="bilinear", align_corners=True)
-
-
-STANDINS = dict(TinyImageBackbone=TinyImageBackbone, TinyDepthNet=TinyDepthNet, TinyBEVBackbone=TinyBEVBackbone, TinyBEVNeck=TinyBEVNeck)
+STANDINS = dict(TinyImageBackbone=TinyImageBackbone)
 
 
 # ---- the small BEVDepth4DDistill recipe both sides build (same structure as configs/distillbev_centerpoint2bevdepth4d_r50.py) ----
@@ -110,7 +70,8 @@ def distill_cfg(teacher):
     """student: 2 frames x 6 cameras of 64 x 176 -> 32 x 32 BEV (24 channels per frame) -> BEV encoder -> 32 channels at 32 x 32"""
     return dict(
         type="BEVDepth4DDistill", teacher_config=teacher, teacher_ckpt=None, self_ckpt=None, inherit_head=False, distill_type="fgd",
-        aligned=True, detach=True, before=True, interpolation_mode="bilinear", pre_process=None,
+        aligned=True, detach=True, before=True, interpolation_mode="bilinear",
+        pre_process=dict(type="ResNetForBEVDet", numC_input=24, num_layer=[1], num_channels=[24], stride=[1], backbone_output_ids=[0]),
         distill_params=dict(
             student_channels=[16, 32], teacher_channels=[64, 48], spatial_t=0.5, spatial_student_ratio=1.0, channel_t=0.5,
             fg_feat_loss_weights=[3e-3, 2e-3], bg_feat_loss_weights=[4e-2, 3e-2], channel_loss_weights=[0.25], spatial_loss_weights=[1e-3, 1e-3],
@@ -123,10 +84,12 @@ def distill_cfg(teacher):
             affinity_weights=[0, 0], affinity_mode="none", affinity_criterion=dict(type="SmoothL1Loss"), affinity_split=1,
             non_empty_weight=0, output_threshold=0.1, groundtruth_threshold=None, fp_as_foreground=["none", "teacher"], fp_weight=6e-2,
             fp_epoch=0, multi_scale_epoch=-1, fp_scale_mode="average", gauss_fg_weight=-1e10, context_length=0, context_weight=0),
-        img_backbone=dict(type="TinyImageBackbone", out_channels=32), img_neck=None,
+        img_backbone=dict(type="TinyImageBackbone", out_channels=(32, 64)),
+        img_neck=dict(type="FPNForBEVDet", in_channels=[32, 64], out_channels=32, num_outs=1, start_level=0, out_ids=[0]),
         img_view_transformer=dict(type="ViewTransformerLSSBEVDepth", loss_depth_weight=100.0, grid_config=GRID,
                                   data_config=dict(input_size=INPUT_SIZE), numC_input=32, numC_Trans=24,
-                                  extra_depth_net=dict(type="TinyDepthNet", numC_input=16, num_channels=[16]), dcn_config=dict(bias=True)),
-        img_bev_encoder_backbone=dict(type="TinyBEVBackbone", numC_input=48, num_channels=(16, 32, 64)),
-        img_bev_encoder_neck=dict(type="TinyBEVNeck", in_channels=16 + 64, out_channels=32),
+                                  extra_depth_net=dict(type="ResNetForBEVDet", numC_input=16, num_layer=[2], num_channels=[16], stride=[1]),
+                                  dcn_config=dict(bias=True)),
+        img_bev_encoder_backbone=dict(type="ResNetForBEVDet", numC_input=48, num_channels=[16, 32, 64]),
+        img_bev_encoder_neck=dict(type="FPN_LSS", in_channels=16 + 64, out_channels=32),
         pts_bbox_head=head_cfg(32, [0.1, 0.1], 32), train_cfg=train_cfg(1024, [0.1, 0.1, 0.2], 32), test_cfg=None)

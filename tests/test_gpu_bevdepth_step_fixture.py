@@ -2,8 +2,10 @@
 
 tests/golden/bevdepth_step.npz (make_golden.py bevdepth_step) holds BEVDepth4DDistill.forward_train of the REFERENCE -- its own
 bevdet_distill_more.py / bevdet_distill.py / bevdet.py / centerpoint.py / dynamic_centerpoint.py / mvx_two_stage.py files, built
-through their own constructors from the small recipe of tests/golden/standins.py -- run on CPU: 44 losses, six gradients of the
-total loss and the BEV-encoder weight gradient split by loss group.  Here the product detector is built from the SAME recipe,
+through their own constructors from the small recipe of tests/golden/standins.py, with the reference's own FPNForBEVDet,
+ResNetForBEVDet / BasicBlock (depth net, pre-process net, BEV encoder) and FPN_LSS inside; the one stand-in is the un-vendored
+image backbone -- run on CPU: 44 losses, eleven gradients of the total loss along the step and the BEV-encoder weight gradient
+split by loss group.  Here the product detector is built from the SAME recipe,
 loads the reference's two state dicts strict, and runs the step on the HIP path (lift-splat, DCNv2, dynamic voxelization,
 pillar scatter, FG masks, CenterHead targets + loss, FGD terms).
 
@@ -91,7 +93,7 @@ def test_bevdepth4d_distill_forward_train_vs_reference_fixture(aligned):
     rel = lambda g, ref: float((g.cpu() - ref).norm() / ref.norm().clamp_min(1e-20))
 
     # every term's own gradient at two small BEV-encoder parameters
-    tb = [params["img_bev_encoder_backbone.layers.0.bias"], params["img_bev_encoder_neck.conv.bias"]]
+    tb = [params["img_bev_encoder_backbone.layers.0.0.bn1.bias"], params["img_bev_encoder_neck.conv.1.bias"]]
     errs = {}
     for k, v in losses.items():
         key = "term__" + k.replace(".", "_")
@@ -115,7 +117,7 @@ def test_bevdepth4d_distill_forward_train_vs_reference_fixture(aligned):
         print(n, e)
         if e > 5e-2:
             bad.append((n, e))
-    w0 = params["img_bev_encoder_backbone.layers.0.weight"]
+    w0 = params["img_bev_encoder_backbone.layers.0.0.conv1.weight"]
     for gname, keys in _groups(losses).items():
         g = torch.autograd.grad(sum(losses[k] for k in keys), w0, retain_graph=True)[0]
         e = rel(g, torch.from_numpy(fx["gradgroup__" + gname]))

@@ -1,0 +1,90 @@
+"""CPU: the student's dense modules (distill_bev_amd/nets.py: ResNetForBEVDet with BasicBlock / Bottleneck stacks, FPN_LSS,
+FPNForBEVDet) against tests/golden/student_dense.npz -- outputs, gradients and running statistics computed by the reference's
+OWN files (backbones/resnet.py, bricks/res_block.py, necks/lss_fpn.py, necks/fpn.py; make_golden.py student_dense).  The
+reference's state dicts load strict (same keys, same shapes).  tests/test_gpu_student_dense.py repeats this on the GPU in the
+bench configuration (channels-last, fused norm-act kernels)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def cases():
+    from distill_bev_amd import nets
+    return {
+        "bev_backbone": lambda: nets.ResNetForBEVDet(16, num_channels=[16, 32, 64]),
+        "depth_net": lambda: nets.ResNetForBEVDet(16, num_layer=[3], num_channels=[16], stride=[1]),
+        "pre_process": lambda: nets.ResNetForBEVDet(8, num_layer=[2], num_channels=[8], stride=[1], backbone_output_ids=[0]),
+        "bottleneck": lambda: nets.ResNetForBEVDet(16, num_layer=[2, 2], num_channels=[32, 64], stride=[2, 2], block_type="BottleNeck"),
+        "fpn_lss": lambda: nets.FPN_LSS(16 + 64, 32),
+        "fpn_lss_lateral": lambda: nets.FPN_LSS(16 + 64, 24, lateral=16, extra_norm_act=True),
+        "fpn_lss_noup": lambda: nets.FPN_LSS(32 + 64, 24, scale_factor=2, input_feature_index=(1, 2), extra_upsample=None),
+        "img_neck": lambda: nets.FPNForBEVDet([32, 64], 24, 1, start_level=0, out_ids=[0]),
+        "img_neck_norm": lambda: nets.FPNForBEVDet([32, 64], 24, 1, start_level=0, out_ids=[0], norm_cfg=dict(type="BN"),
+                                                   upsample_cfg=dict(mode="nearest", scale_factor=2)),
+    }
+
+
+LIST_INPUT = ("fpn_lss", "fpn_lss_lateral", "fpn_lss_noup", "img_neck", "img_neck_norm")
+
+
+def run_case(fx, tag, build, dev, channels_last=False, prepare=None):
+    """-> worst relative errors {outputs, input grads, param grads, running stats, eval outputs} of the product module `tag`
+    against the fixture, on device `dev`"""
+    m = build()
+    sd = {k[len(tag) + 6:].replace("__", "."): torch.from_numpy(fx[k]) for k in fx.files if k.startswith(tag + "__sd__")}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    m = m.to(dev)
+    if channels_last:
+        m = m.to(memory_format=torch.channels_last)
+    if prepare is not None:
+        prepare(m)
+    n_in = len([k for k in fx.files if k.startswith(tag + "__x")])
+    xs = [torch.from_numpy(fx[f"{tag}__x{i}"]).to(dev) for i in range(n_in)]
+    if channels_last:
+        xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+    xs = [x.requires_grad_(True) for x in xs]
+    arg = xs if tag in LIST_INPUT else xs[0]
+    rel = lambda a, b: float((a.detach().cpu() - b).norm() / b.norm().clamp_min(1e-12))
+    m.train()
+    ys = m(arg)
+    ys = list(ys) if isinstance(ys, (list, tuple)) else [ys]
+    err = {"y": 0.0, "gx": 0.0, "gp": 0.0, "stats": 0.0, "eval": 0.0}
+    loss = 0
+    for i, y in enumerate(ys):
+        err["y"] = max(err["y"], rel(y, torch.from_numpy(fx[f"{tag}__y{i}"])))
+        loss = loss + (y * torch.from_numpy(fx[f"{tag}__w{i}"]).to(dev)).sum()
+    params = dict(m.named_parameters())
+    grads = torch.autograd.grad(loss, xs + list(params.values()), allow_unused=True)
+    for i in range(n_in):
+        ref = torch.from_numpy(fx[f"{tag}__gx{i}"])
+        if grads[i] is None:
+            assert float(ref.abs().max()) == 0.0
+        else:
+            err["gx"] = max(err["gx"], rel(grads[i], ref))
+    for (n, p), g in zip(params.items(), grads[n_in:]):
+        ref = torch.from_numpy(fx[f"{tag}__gp__" + n.replace(".", "__")])
+        assert g is not None and g.shape == ref.shape, n
+        # a bias in front of a training-mode norm has an exactly-zero gradient in the reference and rounding noise anywhere
+        e = float((g.detach().cpu() - ref).norm() / max(float(ref.norm()), 1e-3 * float(torch.from_numpy(fx[f"{tag}__w0"]).norm())))
+        err["gp"] = max(err["gp"], e)
+    for n, b in m.named_buffers():
+        if "running" in n:
+            err["stats"] = max(err["stats"], rel(b, torch.from_numpy(fx[f"{tag}__after__" + n.replace(".", "__")])))
+    m.eval()
+    with torch.no_grad():
+        ye = m(arg)
+    for i, y in enumerate(list(ye) if isinstance(ye, (list, tuple)) else [ye]):
+        err["eval"] = max(err["eval"], rel(y, torch.from_numpy(fx[f"{tag}__eval{i}"])))
+    return err
+
+
+@pytest.mark.parametrize("tag", list(cases()))
+def test_student_dense_modules_match_the_reference_files_on_cpu(tag):
+    fx = np.load(os.path.join(GOLD, "student_dense.npz"))
+    err = run_case(fx, tag, cases()[tag], torch.device("cpu"))
+    assert max(err.values()) <= 2e-5, err
