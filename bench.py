@@ -110,6 +110,8 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     wl.begin_timed()
+    from distill_bev_amd import _lib as _L
+    _L.fallback_reset()                          # ledger of torch-path fallbacks of the fused ops, over the timed region
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step()
@@ -122,6 +124,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    fallbacks = _L.fallback_counts()
+    from distill_bev_amd.miopen_tuning import tables_status
+    tables = tables_status()                     # after the convolutions ran: "active" | "stale" (warns) | "off"
     roof = wl.roofline()          # live HIP-event timing of the dominant kernel (this rank)
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -152,8 +157,10 @@ def main():
             "data": "synthetic",
             "config": dict(wl.config(world), world_size=n_gpus,
                            collective_backend=(dist.get_backend() + " (RCCL)") if dist.is_initialized() else None,
-                           miopen_solver_tables=("distill_bev_amd/miopen_db (exhaustive search on MI355X, shipped)" if miopen_db
-                                                 else "library default / MIOPEN_USER_DB_PATH of the environment")),
+                           fallbacks=fallbacks,
+                           miopen_solver_tables={"active": "distill_bev_amd/miopen_db (exhaustive search on MI355X, shipped)",
+                                                 "stale": "stale: shipped tables keyed to another MIOpen build, ignored by this one",
+                                                 "off": "library default / MIOPEN_USER_DB_PATH of the environment"}[tables]),
             "roofline": roof,
             "cpu_baseline": cpu,
         }

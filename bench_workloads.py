@@ -158,7 +158,7 @@ class DistillStep(_Base):
         self.dev, self.rank, self.world = dev, rank, world
         self.B = int(os.environ.get("DBEV_BENCH_BS", self.B))
         self.units_per_step = self.B
-        model, cfg = build_model(seed=0)            # same init on every rank (DDP broadcasts anyway)
+        model, cfg = build_model(seed=0, allow_synthetic_teacher=True)            # same init on every rank (DDP broadcasts anyway)
         self.trainer = Trainer(model, cfg, dev, world_size=world, channels_last=True)
         self.batch = make_batch(self.B, np.random.default_rng(1234 + rank), dev, n_points=self.N_POINTS)
         self.n_params = sum(p.numel() for p in self.trainer.params)
@@ -203,6 +203,20 @@ class DistillStep(_Base):
         fam = L.kernel_timing_read()
         L.kernel_timing(False)
         n_extra = self.steps_timed
+        # the reference-shaped variant of the same step: all 36 branch stacks of the frozen teacher's head (the default prunes
+        # the 30 whose outputs nothing reads -- identical losses); 1 warm-up + 5 timed steps, outside the timed region
+        if os.environ.get("DBEV_TEACHER_FULL_HEAD") != "1":
+            os.environ["DBEV_TEACHER_FULL_HEAD"] = "1"
+            try:
+                self.step()
+                torch.cuda.synchronize(self.dev)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    self.step()
+                torch.cuda.synchronize(self.dev)
+                self.full_head_ms = (time.perf_counter() - t0) / 5 * 1e3
+            finally:
+                del os.environ["DBEV_TEACHER_FULL_HEAD"]
         rt, rb = self._fam(roof)
         ach = rb / rt / 1e9
         other = {}
@@ -258,7 +272,7 @@ class DistillStep(_Base):
         # socket's worth of physical cores at most and say so.
         ncores = min(64, os.cpu_count() or 1)
         torch.set_num_threads(ncores)
-        model, cfg = build_model(seed=0)
+        model, cfg = build_model(seed=0, allow_synthetic_teacher=True)
         model = to_cpu_reference(model)
         cpu = torch.device("cpu")
         batch = make_batch(1, np.random.default_rng(1234), cpu, n_points=self.N_POINTS)
@@ -304,6 +318,7 @@ class DistillStep(_Base):
                 # the frozen teacher's head runs the heat-map branches only -- the one output the step reads (add_fp_as_fg);
                 # DBEV_TEACHER_FULL_HEAD=1 runs all 36 branch stacks as the reference does (same losses, +4.5 ms)
                 "teacher_head_branches": "all" if os.environ.get("DBEV_TEACHER_FULL_HEAD") == "1" else "heatmap (the only ones read)",
+                "ms_per_step_full_teacher_head": getattr(self, "full_head_ms", None),
                 "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py"}
 
 
@@ -488,7 +503,7 @@ class BevformerDistillStep(_Base):
         self.B = int(os.environ.get("DBEV_BENCH_BS", self.B))
         self.units_per_step = self.B
         cfg_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "distillbev_mvpformer2bevformer_r50.py")
-        model, cfg = build_model(cfg_path, seed=0)
+        model, cfg = build_model(cfg_path, seed=0, allow_synthetic_teacher=True)
         from distill_bev_amd.miopen_tuning import use_shipped_gemm_table
         self.gemm_table = use_shipped_gemm_table()        # ranked rocBLAS / hipBLASLt solutions for the attention / FFN linears
         self.trainer = Trainer(model, cfg, dev, world_size=world, channels_last=os.environ.get("DBEV_BF_NCHW") != "1")

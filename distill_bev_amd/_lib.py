@@ -29,6 +29,9 @@ _SIGNATURES = {
     "dbev_kernel_timing_enable": [_i],
     "dbev_kernel_timing_read": [_p, _p, _p, _i],
     "dbev_kernel_name": [_i],
+    "dbev_fallback_note": [_i],
+    "dbev_fallback_count": [_i],
+    "dbev_fallback_reset": [],
     "dbev_bev_pool_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_bev_pool_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dbev_bev_pool_prepare": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
@@ -106,6 +109,7 @@ _SIGNATURES = {
     "dbev_bn_dual_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
+             "dbev_fallback_count": ctypes.c_longlong,
              "dbev_kernel_name": ctypes.c_char_p,
              "dbev_msda_backward_workspace_bytes": ctypes.c_size_t,
              "dbev_spconv_build_workspace_bytes": ctypes.c_size_t,
@@ -234,6 +238,33 @@ def kernel_timing_read():
     for i in range(n):
         out.setdefault(h.dbev_kernel_name(kid[i]).decode(), []).append((ms[i], by[i]))
     return out
+
+
+FALLBACK_SITES = {"bn_act": 0, "skinny_conv": 1, "adapt_mse": 2, "pillar_vfe": 3, "head_batch": 4}   # DBEV_FB_*
+_warned_fallbacks = set()
+
+
+def note_fallback(site, why=""):
+    """A device tensor took the stock torch path instead of the fused kernel of `site`: count it in the library's ledger
+    (dbev_fallback_note) and warn ONCE per (site, reason)."""
+    lib().dbev_fallback_note(FALLBACK_SITES[site])
+    if (site, why) not in _warned_fallbacks:
+        _warned_fallbacks.add((site, why))
+        import warnings
+        warnings.warn(f"distill_bev_amd: {site} took the stock torch path on a device tensor ({why or 'ineligible'}); "
+                      "further occurrences are only counted (fallback_counts())", RuntimeWarning, stacklevel=3)
+
+
+def fallback_counts():
+    """-> {site: notes since load / the last reset}, plus 'total'"""
+    h = lib()
+    out = {k: int(h.dbev_fallback_count(v)) for k, v in FALLBACK_SITES.items()}
+    out["total"] = int(h.dbev_fallback_count(-1))
+    return out
+
+
+def fallback_reset():
+    lib().dbev_fallback_reset()
 
 
 def host_ptrs(tensors):

@@ -131,9 +131,14 @@ class _BevPoolCSR(torch.autograd.Function):
         return x_grad, None, None, None, None, None
 
 
-def bev_pool(feats, coords, B, D, H, W):
+def bev_pool(feats, coords, B, D, H, W, contiguous=False):
     """bev_pool.py:83-97.  feats f32[n, C]; coords int[n, 4] = (x, y, z, b) with
     0<=x<H, 0<=y<W, 0<=z<D -> f32[B, C, D, H, W].
+
+    Layout contract: the LOGICAL shape is always the reference's [B, C, D, H, W]; the strides are channels-last-3d (the
+    cell-major rows [B, D, H, W, C] the kernels write, viewed without a copy) on BOTH paths below, so whether a caller's
+    `.view()` works never depends on the channel count.  `contiguous=True` returns the reference's physical layout
+    (`x.permute(0, 4, 1, 2, 3).contiguous()`, bev_pool.py:95) at the price of one transposing copy.
 
     The reference ranks the points, argsorts, gathers `feats[indices]` and sums rank intervals
     (QuickCumsumCuda, kept above for callers of that level).  Same result here without moving the feature rows:
@@ -143,11 +148,13 @@ def bev_pool(feats, coords, B, D, H, W):
     B, D, H, W = int(B), int(D), int(H), int(W)
     C = feats.shape[1]
     if feats.dtype == torch.float32 and C % 4 == 0 and C <= 256 and feats.shape[0] > 0:
-        return _BevPoolCSR.apply(feats, coords, B, D, H, W)
-    return bev_pool_sorted(feats, coords, B, D, H, W)
+        out = _BevPoolCSR.apply(feats, coords, B, D, H, W)
+    else:
+        out = bev_pool_sorted(feats, coords, B, D, H, W, contiguous=False)
+    return out.contiguous() if contiguous else out
 
 
-def bev_pool_sorted(feats, coords, B, D, H, W):
+def bev_pool_sorted(feats, coords, B, D, H, W, contiguous=True):
     """the reference's own sequence (rank, argsort, gather, interval sums) on the HIP interval kernels"""
     B, D, H, W = int(B), int(D), int(H), int(W)
     ranks = (coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B)
@@ -155,6 +162,6 @@ def bev_pool_sorted(feats, coords, B, D, H, W):
     # stable -> run-to-run deterministic summation order (the reference's argsort is not)
     indices = ranks.argsort(stable=True)
     feats, coords, ranks = feats[indices], coords[indices], ranks[indices]
-    x = QuickCumsumCuda.apply(feats, coords, ranks, B, D, H, W)
-    x = x.permute(0, 4, 1, 2, 3).contiguous()
-    return x
+    x = QuickCumsumCuda.apply(feats, coords, ranks, B, D, H, W)        # cell-major rows [B, D, H, W, C]
+    x = x.permute(0, 4, 1, 2, 3)
+    return x.contiguous() if contiguous else x

@@ -62,6 +62,21 @@ def eligible(x, bn, residual=None):
                                              or (residual is not None and residual.requires_grad)))
 
 
+def _why_not(x, bn, residual):
+    """one-line reason for the fallback ledger"""
+    if x.dtype != torch.float32:
+        return f"dtype {x.dtype}"
+    if not _nhwc(x) or (residual is not None and not _nhwc(residual)):
+        return "not channels-last"
+    if type(bn) not in _BN_TYPES or not bn.affine:
+        return f"norm type {type(bn).__name__}"
+    if not _channels_ok(x.shape[1]):
+        return f"{x.shape[1]} channels"
+    if bn.training or bn.running_mean is None:
+        return "one value per channel" if x.numel() // x.shape[1] <= 1 else "momentum=None"
+    return "eval-mode norm inside autograd"
+
+
 class _BNActTrain(Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu):
@@ -183,6 +198,8 @@ def bn_act(x, bn, residual=None, relu=True):
             return _BNActTrain.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      bn.num_batches_tracked, bn.momentum, bn.eps, relu)
         return _infer(x, residual, bn, relu)
+    if x.is_cuda and _state["enabled"] and x.numel() > 0:
+        L.note_fallback("bn_act", _why_not(x, bn, residual))
     out = nn.BatchNorm2d.forward(bn, x) if isinstance(bn, BatchNormAct2d) else bn(x)
     if residual is not None:
         out = out + residual

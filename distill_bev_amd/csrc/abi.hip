@@ -1,6 +1,7 @@
 // Library identity entry points of libdbev_hip.so and the per-kernel timing log (include/dbev_hip.h).
 #include "common.h"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -14,6 +15,28 @@ std::mutex g_mu;
 }  // namespace
 
 unsigned g_dbev_kt_mask = 0;   // bit k set: kernel id k is logged
+
+// ---- fallback ledger: the host-side mirrors (bn_act, SkinnyConv2d, fused adaptation, fused pillar path, batched head) note here whenever a DEVICE tensor they were built for takes the stock torch path instead of the kernels of this
+// library (ineligible layout / channel count / mode), so that a layout regression shows up as a number, not as a slower step.
+namespace {
+std::atomic<long long> g_fallbacks[DBEV_FB_SITES];
+}
+extern "C" int dbev_fallback_note(int site) {
+  if (site < 0 || site >= DBEV_FB_SITES) return DBEV_EINVAL;
+  g_fallbacks[site].fetch_add(1, std::memory_order_relaxed);
+  return 0;
+}
+extern "C" long long dbev_fallback_count(int site) {
+  if (site >= DBEV_FB_SITES) return -1;
+  if (site >= 0) return g_fallbacks[site].load(std::memory_order_relaxed);
+  long long t = 0;
+  for (int i = 0; i < DBEV_FB_SITES; ++i) t += g_fallbacks[i].load(std::memory_order_relaxed);
+  return t;
+}
+extern "C" int dbev_fallback_reset(void) {
+  for (int i = 0; i < DBEV_FB_SITES; ++i) g_fallbacks[i].store(0, std::memory_order_relaxed);
+  return 0;
+}
 
 void dbev_kt_push(hipEvent_t a, hipEvent_t b, int kid, long long bytes) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as L
 from .center_head import LiDARBoxes, clip_sigmoid  # noqa: F401
 from .config import Config
 from .bn_act import bn_act
@@ -130,6 +131,9 @@ class DynamicCenterPoint(CenterPoint):
             x = pillar_encoder.fused_pillar_canvas(pts, self.pts_voxel_layer, self.pts_voxel_encoder,
                                                    self.pts_middle_encoder)
             return self._backbone_neck(x, outputs, return_canvas, return_backbone_feature)
+        if (getattr(self, "use_fused_pillar_path", True) and not self.training and pts[0].is_cuda
+                and isinstance(self.pts_voxel_encoder, pillar_encoder.DynamicPillarFeatureNet)):
+            L.note_fallback("pillar_vfe", "frozen pillar teacher outside the fused kernel's recipe")
         voxels, coors = self.voxelize(pts)
         coors = coors.type(torch.int32)
         batch_size = len(pts)
@@ -485,10 +489,15 @@ class BEVDepth4DDistill(CenterPoint):
         assert dp["foreground_mask"] == "gt" and dp["background_mask"] == "logical_not"
         assert dp["scale_mask"] == "combine_gt" and dp["non_empty_weight"] == 0
         assert dp["affinity_mode"][index] == "none" and dp["context_length"] == 0
+        # the rasteriser emits the [y, x] mask layout of transpose_mask=False (every shipped recipe); bevdet_distill.py:1022-1027
+        assert not dp.get("transpose_mask", False), "transpose_mask=True is outside the hot-path recipe"
         teacher_feat = self.teacher_adaptations[index](teacher_feat)
         adapt = self.channel_wise_adaptations[index]
         # 'head' recipe (1x1-conv adaptation): GEMM + loss reductions in one MFMA kernel, no adapted tensor in memory
         fused = self.fused_adapt_mse and not dp["channel_mask"] and fused_adapt_eligible(adapt, student_feat, teacher_feat)
+        if (not fused and self.fused_adapt_mse and not dp["channel_mask"] and type(adapt) is nn.Conv2d and adapt.kernel_size == (1, 1)
+                and getattr(self, "channels_last", False) and student_feat.is_cuda):
+            L.note_fallback("adapt_mse", f"{adapt.in_channels}->{adapt.out_channels}, layouts {student_feat.stride()} / {teacher_feat.stride()}")
         if not fused:
             student_feat = adapt(student_feat)
             assert teacher_feat.shape == student_feat.shape

@@ -39,7 +39,7 @@ class _BranchFinalConvs(Function):
         n = len(wb) // 2
         assert n * Ch == Ct
         couts = [int(w.shape[0]) for w in wb[0::2]]
-        pad = torch.zeros((2, 9 * Ch), dtype=torch.float32, device=dev)
+        pad = torch.zeros((3, 9 * Ch), dtype=torch.float32, device=dev)     # zero rows: weight padding and the bias of a bias-free branch
         wrows, brows = [], []
         for i in range(n):
             w, b = wb[2 * i], wb[2 * i + 1]
@@ -127,8 +127,17 @@ def plan_branches(head):
 
 def applies(head, x):
     plan = getattr(head, "_branch_plan", None)
+    ok = _applies(head, x, plan)
+    if not ok and plan is not None and head.training and torch.is_grad_enabled() and BA._state["enabled"] and x.is_cuda:
+        L.note_fallback("head_batch", "not channels-last" if not BA._nhwc(x) else "branch norm in eval mode / shape")
+    return ok
+
+
+def _applies(head, x, plan):
     return (plan is not None and head.training and torch.is_grad_enabled() and BA._state["enabled"] and x.is_cuda
-            and x.dtype == torch.float32 and BA._nhwc(x) and x.numel() > 0 and x.shape[0] * x.shape[2] * x.shape[3] > 1)
+            and x.dtype == torch.float32 and BA._nhwc(x) and x.numel() > 0 and x.shape[0] * x.shape[2] * x.shape[3] > 1
+            # a branch norm put into eval mode on its own (frozen statistics) needs its own path: per-branch calls
+            and all(s[0].norm.training for group in plan["groups"] for _, _, s in group))
 
 
 def forward(head, x):
@@ -140,8 +149,6 @@ def forward(head, x):
     for group in plan["groups"]:
         mods = [s[0] for _, _, s in group]
         bns = [m.norm for m in mods]
-        if not all(bn.training for bn in bns):
-            raise RuntimeError("batched head branches: every branch norm must be in training mode")
         w = torch.cat([m.conv.weight for m in mods], 0)
         a = F.conv2d(x, w, None, 1, 1)
         gamma = torch.cat([bn.weight for bn in bns])

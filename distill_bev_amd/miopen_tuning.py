@@ -44,6 +44,43 @@ def use_shipped_db():
     return dst
 
 
+def shipped_keys():
+    """the MIOpen database keys (`<arch><cus>.HIP.<major>_<minor>_<patch>_<tweak>`) the shipped tables were tuned under"""
+    return sorted({os.path.basename(f).rsplit(".", 2)[0] for f in glob.glob(os.path.join(_DB, "*db.txt"))})
+
+
+def tables_status():
+    """-> "off" | "active" | "stale".  The tables are plain text keyed by the MIOpen BUILD string in their file names; another
+    ROCm / PyTorch build looks for other names and silently ignores them (the step is then ~7 % slower and the first one takes
+    ~100 s of solver search).  Two checks, no 1 GB library scan: (a) before the first convolution the library's
+    major.minor.patch (torch.backends.cudnn.version()) against the names; (b) afterwards, database files under another key in
+    the private directory = the library searched and recorded for itself.  "stale" warns once."""
+    dst = _state["path"]
+    if dst is None:
+        return "off"
+    keys = shipped_keys()
+    stale = None
+    try:
+        import torch
+        v = int(torch.backends.cudnn.version() or 0)
+        if v:
+            mmp = f"{v // 1000000}_{v // 1000 % 1000}_{v % 1000}_"
+            if not any(f".HIP.{mmp}" in k for k in keys):
+                stale = f"running MIOpen {mmp[:-1].replace('_', '.')} vs tables {keys}"
+    except Exception:                                     # torch without a MIOpen backend
+        pass
+    if stale is None:
+        others = sorted({os.path.basename(f).rsplit(".", 2)[0] for f in glob.glob(os.path.join(dst, "*db.txt"))} - set(keys))
+        if others:
+            stale = f"the library recorded under {others}, tables are keyed {keys}"
+    if stale and not _state.get("warned"):
+        _state["warned"] = True
+        import warnings
+        warnings.warn("distill_bev_amd: the shipped MIOpen solver tables do not match this MIOpen build and are being ignored ("
+                      + stale + "); re-tune with tools/tune_miopen.sh", RuntimeWarning)
+    return "stale" if stale else "active"
+
+
 def use_shipped_gemm_table():
     """Load the shipped TunableOp results (no tuning at run time).  -> the file prefix in use, or None."""
     import torch

@@ -71,6 +71,8 @@ class SkinnyConv2d(nn.Conv2d):
         if (self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1
                 and self.padding_mode == "zeros" and eligible(x, self.weight)):
             return skinny_conv3x3(x, self.weight, self.bias)
+        if x.is_cuda and x.numel() > 0:
+            L.note_fallback("skinny_conv", "not channels-last" if not _nhwc(x) else f"geometry {tuple(self.weight.shape)}")
         return super().forward(x)
 
 

@@ -83,14 +83,21 @@ def synthetic_teacher_checkpoint(model_cfg, seed=0, directory=None):
     return out
 
 
-def build_model(config=None, cfg_options=None, seed=0):
+def build_model(config=None, cfg_options=None, seed=0, allow_synthetic_teacher=False):
+    """Build the detector of `config`.  A recipe that inherits the teacher's head needs `teacher_ckpt`
+    (bevdet_distill.py:175-176 asserts it); `allow_synthetic_teacher=True` -- benchmarks and tests only -- substitutes a
+    seeded random-init checkpoint for a missing one and says so; without it the detector's own assert fires."""
     cfg = Config.fromfile(config or DEFAULT_CONFIG) if not isinstance(config, Config) else config
     if cfg_options:
         cfg.merge_from_args(cfg_options) if isinstance(cfg_options, (list, tuple)) else cfg.merge_from_dict(cfg_options)
     m = cfg.model
     ck = m.get("teacher_ckpt")
-    if m.get("teacher_config") is not None and m.get("inherit_head") and not (isinstance(ck, str) and ck.lower() != "none"):
+    if (allow_synthetic_teacher and m.get("teacher_config") is not None and m.get("inherit_head")
+            and not (isinstance(ck, str) and ck.lower() != "none")):
         m["teacher_ckpt"] = synthetic_teacher_checkpoint(m, seed)
+        import warnings
+        warnings.warn(f"build_model: no teacher_ckpt in the recipe -- distilling from a SYNTHETIC (seeded random-init) teacher, "
+                      f"{m['teacher_ckpt']}", RuntimeWarning)
     torch.manual_seed(seed)
     model = build_detector(cfg.model)
     model.init_weights()

@@ -59,6 +59,19 @@ int dbev_kernel_timing_read(int* kernel_id, float* ms, long long* algorithmic_by
 const char* dbev_kernel_name(int kernel_id);
 
 /* ------------------------------------------------------------------------------------
+ * Fallback ledger (no counterpart in the reference).  The host-side mirrors of the fused ops -- bn_act / BatchNormAct2d,
+ * SkinnyConv2d, the fused adaptation + masked-MSE op, the fused pillar path, the batched CenterHead branches -- call dbev_fallback_note(site) whenever a DEVICE tensor they were wired for takes the stock torch path
+ * (ineligible layout, channel count or mode).  dbev_fallback_count(site): notes since load / the last reset, site < 0 = all
+ * sites.  bench.py prints the count of its timed region (config.fallbacks), tests/test_gpu_full_size.py asserts 0 for the step.
+ * ---------------------------------------------------------------------------------- */
+enum {
+  DBEV_FB_BN_ACT = 0, DBEV_FB_SKINNY_CONV, DBEV_FB_ADAPT_MSE, DBEV_FB_PILLAR_VFE, DBEV_FB_HEAD_BATCH, DBEV_FB_SITES
+};
+int dbev_fallback_note(int site);
+long long dbev_fallback_count(int site);
+int dbev_fallback_reset(void);
+
+/* ------------------------------------------------------------------------------------
  * bev_pool  (replaces bev_pool_ext: mmdet3d/ops/bev_pool/src/bev_pool.cpp:22-47,60-87,
  *            kernels src/bev_pool_cuda.cu:20-42,61-84)
  * ---------------------------------------------------------------------------------- */

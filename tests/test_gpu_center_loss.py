@@ -13,7 +13,7 @@ def _setup(B, n_boxes, seed, dup=False):
     from distill_bev_amd import synthetic as syn
     from distill_bev_amd.center_head import LiDARBoxes
     from distill_bev_amd.train_step import build_model
-    m, _ = build_model()
+    m, _ = build_model(allow_synthetic_teacher=True)
     head = m.pts_bbox_head.to("cuda:0")
     rng = np.random.default_rng(seed)
     boxes, labels = [], []

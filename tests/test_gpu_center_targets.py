@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 def _head(**over):
     from distill_bev_amd.train_step import build_model
-    m, _ = build_model()
+    m, _ = build_model(allow_synthetic_teacher=True)
     h = m.pts_bbox_head
     h.train_cfg = dict(h.train_cfg); h.train_cfg.update(over)
     return h

@@ -33,7 +33,7 @@ def _worker(rank, world, port, out, backend, multi_scale_epoch):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     opts = dict(OPTS)
     opts["model.distill_params.multi_scale_epoch"] = multi_scale_epoch
-    model, cfg = build_model(cfg_options=opts, seed=3 + rank)                  # ranks start from DIFFERENT weights
+    model, cfg = build_model(cfg_options=opts, seed=3 + rank, allow_synthetic_teacher=True)                  # ranks start from DIFFERENT weights
     teacher_before = torch.cat([p.detach().reshape(-1) for p in model.teacher_model.parameters()]).clone()
     tr = Trainer(model, cfg, dev, world_size=world, channels_last=True)
     assert tr.reducer is not None and tr.reducer.world == world

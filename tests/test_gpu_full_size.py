@@ -23,7 +23,7 @@ B, N_POINTS = 8, 240000
 def full():
     from distill_bev_amd.train_step import Trainer, build_model, make_batch
     dev = torch.device("cuda:0")
-    model, cfg = build_model(seed=0)
+    model, cfg = build_model(seed=0, allow_synthetic_teacher=True)
     tr = Trainer(model, cfg, dev, world_size=1, channels_last=True)
     batch = make_batch(B, np.random.default_rng(1234), dev, n_points=N_POINTS)
     return tr, batch, dev
@@ -34,7 +34,9 @@ def test_full_size_forward_finite_and_stable_then_one_optimizer_step(full):
     for a few student convolutions at this size (first divergent module: img_backbone.layer4.0.conv2, found with
     tools/find_nondeterminism.py), so the passes agree to fp32 round-off, not bit for bit; every loss whose inputs are
     produced by hand-written kernels and deterministic convolutions only (the teacher branch) is bit-identical."""
+    from distill_bev_amd import _lib as L
     tr, batch, dev = full
+    L.fallback_reset()
     a = tr.detector.forward_train(**batch)
     b = tr.detector.forward_train(**batch)
     assert len(a) == 47 and set(a) == set(b)
@@ -44,6 +46,8 @@ def test_full_size_forward_finite_and_stable_then_one_optimizer_step(full):
         assert abs(x - y) <= 1e-4 * max(abs(x), 1e-3), (k, x, y)
     loss, _ = tr.step(batch)                      # backward + clip + fused AdamW at full size
     assert bool(torch.isfinite(loss))
+    # no fused op of the bench configuration took the stock torch path (a layout regression would show up here, not as a slower bench)
+    assert L.fallback_counts()["total"] == 0, L.fallback_counts()
     assert all(bool(torch.isfinite(p).all()) for p in tr.params[:8])
 
 

@@ -17,8 +17,8 @@ def test_distill_step_losses_and_grads_match_cpu_reference_sequence():
     from distill_bev_amd.train_step import build_model, make_batch, parse_losses
     from oracle.cpu_step import to_cpu_reference
     dev = torch.device("cuda:0")
-    cpu_model, _ = build_model(cfg_options=dict(OPTS), seed=3)
-    gpu_model, _ = build_model(cfg_options=dict(OPTS), seed=3)
+    cpu_model, _ = build_model(cfg_options=dict(OPTS), seed=3, allow_synthetic_teacher=True)
+    gpu_model, _ = build_model(cfg_options=dict(OPTS), seed=3, allow_synthetic_teacher=True)
     gpu_model.load_state_dict(cpu_model.state_dict())
     gpu_model.teacher_model.load_state_dict(cpu_model.teacher_model.state_dict())
     # reference op sequence (oracle ops on the host, dense modules on the SAME GPU as the product:
@@ -76,7 +76,7 @@ def test_channels_last_fused_norm_act_step_matches_unfused_op_sequence():
     from distill_bev_amd import bn_act as BA
     from distill_bev_amd.train_step import Trainer, build_model, make_batch
     dev = torch.device("cuda:0")
-    model, cfg = build_model(cfg_options=dict(OPTS), seed=5)
+    model, cfg = build_model(cfg_options=dict(OPTS), seed=5, allow_synthetic_teacher=True)
     tr = Trainer(model, cfg, dev, channels_last=True)
     assert tr.fused_bn_relu > 20                                  # Sequential / ConvModule pairs rewired
     batch = make_batch(2, np.random.default_rng(11), dev, n_points=20000, input_size=(64, 176))

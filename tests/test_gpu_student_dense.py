@@ -22,11 +22,9 @@ def _accelerate(m):
 @pytest.mark.parametrize("mode", ["nchw", "channels_last_fused"])
 @pytest.mark.parametrize("tag", list(cases()))
 def test_student_dense_modules_match_the_reference_files(tag, mode):
-    from distill_bev_amd import bn_act
     fx = np.load(os.path.join(GOLD, "student_dense.npz"))
     dev = torch.device("cuda:0")
     cl = mode != "nchw"
-    before = bn_act.fallback_count() if hasattr(bn_act, "fallback_count") else 0
     err = run_case(fx, tag, cases()[tag], dev, channels_last=cl, prepare=_accelerate if cl else None)
     print(tag, mode, err)
     # outputs / statistics 2e-5; gradients through 6-12 training-mode norms 1e-4 (CPU vs GPU convolution rounding)

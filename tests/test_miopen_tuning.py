@@ -49,3 +49,32 @@ def test_activation_respects_the_environment(monkeypatch):
     MT = _fresh(monkeypatch, DBEV_MIOPEN_DB="0")
     assert MT.use_shipped_db() is None and "MIOPEN_USER_DB_PATH" not in os.environ
     assert MT.use_shipped_gemm_table() is None              # no GPU here / switched off
+
+
+def test_stale_tables_are_detected_and_reported_once(monkeypatch, recwarn):
+    """tables keyed to another MIOpen build are silently ignored by the library: tables_status() says so (bench.py prints it)"""
+    import warnings
+    MT = _fresh(monkeypatch)
+    assert MT.tables_status() == "off"                       # not activated yet
+    path = MT.use_shipped_db()
+    assert len(MT.shipped_keys()) == 1 and MT.shipped_keys()[0].startswith("gfx950")
+    import torch
+    real = torch.backends.cudnn.version
+    try:
+        torch.backends.cudnn.version = lambda: 3005000       # the build the tables were tuned under (3.5.0)
+        assert MT.tables_status() == "active"
+        # the library found nothing under its own key, searched, and recorded under ANOTHER key: stale
+        open(os.path.join(path, "gfx950100.HIP.9_9_9_deadbeef.ufdb.txt"), "w").write("x=y\n")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert MT.tables_status() == "stale" and MT.tables_status() == "stale"
+        assert len([x for x in w if "solver tables" in str(x.message)]) == 1
+        os.remove(os.path.join(path, "gfx950100.HIP.9_9_9_deadbeef.ufdb.txt"))
+        MT._state["warned"] = False
+        torch.backends.cudnn.version = lambda: 3006001       # another library version: stale before the first convolution
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert MT.tables_status() == "stale"
+        assert any("3.6.1" in str(x.message) for x in w)
+    finally:
+        torch.backends.cudnn.version = real

@@ -69,7 +69,7 @@ def test_center_targets_restatement_matches_fixture_from_imported_gaussian_utils
     from distill_bev_amd.train_step import build_model
     from oracle import center_targets as OCT
     fx = load_golden("center_targets.npz")
-    head = build_model()[0].pts_bbox_head
+    head = build_model(allow_synthetic_teacher=True)[0].pts_bbox_head
     boxes, labels = [], []
     for b in range(2):
         g9 = fx[f"boxes{b}"].copy()

@@ -8,7 +8,7 @@ from distill_bev_amd.train_step import Trainer, build_model, make_batch
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", 8))
-model, cfg = build_model(seed=0)
+model, cfg = build_model(seed=0, allow_synthetic_teacher=True)
 tr = Trainer(model, cfg, dev, world_size=1, channels_last=True)
 batch = make_batch(B, np.random.default_rng(1234), dev, n_points=240000)
 det = tr.detector

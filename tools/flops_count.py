@@ -10,7 +10,7 @@ import torch.nn as nn
 from distill_bev_amd.train_step import Trainer, build_model, make_batch
 
 dev = torch.device("cuda:0")
-model, cfg = build_model()
+model, cfg = build_model(allow_synthetic_teacher=True)
 tr = Trainer(model, cfg, dev, channels_last=True)
 batch = make_batch(8, np.random.default_rng(0), dev, n_points=240000)
 tot = {"fwd": 0.0, "bwd": 0.0}

@@ -12,7 +12,7 @@ if os.environ.get("DBEV_FORCE_DDP") == "1":
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-model, cfg = build_model()
+model, cfg = build_model(allow_synthetic_teacher=True)
 tr = Trainer(model, cfg, dev, channels_last=True)
 batch = make_batch(8, np.random.default_rng(0), dev, n_points=240000)
 for _ in range(4):

@@ -8,7 +8,7 @@ from distill_bev_amd.train_step import Trainer, build_model, make_batch
 from distill_bev_amd import bn_act as BA
 
 dev = torch.device("cuda:0")
-model, cfg = build_model()
+model, cfg = build_model(allow_synthetic_teacher=True)
 tr = Trainer(model, cfg, dev, channels_last=True)
 head = tr.detector.pts_bbox_head
 x = torch.randn((8, 256, 128, 128), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)

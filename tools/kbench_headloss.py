@@ -10,7 +10,7 @@ from distill_bev_amd.center_head import LiDARBoxes
 from distill_bev_amd.train_step import build_model
 
 dev = torch.device("cuda:0")
-m, _ = build_model()
+m, _ = build_model(allow_synthetic_teacher=True)
 head = m.pts_bbox_head.to(dev)
 rng = np.random.default_rng(0)
 B = 8

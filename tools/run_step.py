@@ -21,7 +21,7 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = args.benchmark
 t0 = time.time()
-model, cfg = build_model()
+model, cfg = build_model(allow_synthetic_teacher=True)
 tr = Trainer(model, cfg, dev, channels_last=args.channels_last)
 print("build+to(device) %.1fs" % (time.time() - t0), flush=True)
 batch = make_batch(args.bs, np.random.default_rng(0), dev, n_points=args.points)
