@@ -90,6 +90,9 @@ _SIGNATURES = {
     "dbev_spconv_pair_lists": [_p, _i, _i, _i, _p, _p, _p, _sz, _p],
     "dbev_spconv_forward_fused": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "dbev_sparse_to_dense": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "dbev_spconv_backward_data": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p],
+    "dbev_spconv_backward_weight_workspace_bytes": [_i, _i, _i, _i],
+    "dbev_spconv_backward_weight": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p],
     "dbev_range_voxel_coords": [_p, _i, _i, _p, _p, _i, _p, _p],
     "dbev_virtual_voxel_reduce": [_p, _p, _p, _p, _i, _p],
     "dbev_msda_backward_workspace_bytes": [_i, _i, _i, _i, _i, _i],
@@ -114,6 +117,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_msda_backward_workspace_bytes": ctypes.c_size_t,
              "dbev_spconv_build_workspace_bytes": ctypes.c_size_t,
              "dbev_spconv_pair_lists_workspace_bytes": ctypes.c_size_t,
+             "dbev_spconv_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_kernel_timing_read": ctypes.c_int,
              "dbev_pillar_vfe_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_workspace_bytes": ctypes.c_size_t,

@@ -264,6 +264,132 @@ __global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in,
   }
 }
 
+// ---- backward (spconv_ops.h:352-420 indice_conv_backward: per offset k a gather, two GEMMs and a scatter-add with float atomics) ----
+// Data gradient: din[i, :] = sum_k dout[inv[i, k], :] @ W[k]^T is the FORWARD gather-GEMM on the inverse table with the per-offset
+// transposed weights (sp_transpose_w + sp_conv_fwd): input-stationary, written once, no atomics.
+// Weight gradient: dW[k] = sum over the offset's (in, out) pairs of in[i, :]^T (x) dout[o, :] -- a [Cin x Cout] GEMM per offset whose
+// reduction dimension is the COMPACTED pair list of that offset (the reference's indice_pairs[k], ascending output row), so the
+// matrix cores only see valid pairs.  Workgroup (part, k) walks its contiguous slice of the list in chunks of 64 pairs: both
+// gathered row sets are staged in LDS (float4 row gathers), every wave keeps TR x TC accumulator tiles of 16 x 16 in registers
+// (v_mfma_f32_16x16x4_f32: A = 4 pairs x 16 input channels, B = 4 pairs x 16 output channels) and writes one partial
+// matrix; sp_wgrad_reduce adds the partials of an offset in slice order -> bit-reproducible.
+__global__ __launch_bounds__(256) void sp_transpose_w(const float* __restrict__ W, float* __restrict__ Wt, int K, int Cin, int Cout) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<long long>(K) * Cin * Cout) return;
+  const int ci = static_cast<int>(t % Cin);
+  const long long r = t / Cin;
+  const int co = static_cast<int>(r % Cout), k = static_cast<int>(r / Cout);
+  Wt[t] = W[(static_cast<size_t>(k) * Cin + ci) * Cout + co];            // Wt [K, Cout, Cin]
+}
+
+constexpr int SPW_CHUNK = 64;          // pairs staged per trip
+constexpr int SPW_PADF = 16;           // row padding (floats): the four 16-float row segments a wave reads land on distinct banks
+
+template <int TR, int TC>
+__global__ __launch_bounds__(256) void sp_conv_wgrad(const float* __restrict__ in, const float* __restrict__ gout,
+                                                     const int* __restrict__ pairs, const int* __restrict__ pair_num,
+                                                     int pair_stride, int src, int slice, int Cin, int Cout, int WR, int WC,
+                                                     float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const int SA = Cin + SPW_PADF, SG = Cout + SPW_PADF;
+  float* As = lds;                                   // [SPW_CHUNK][SA]
+  float* Gs = lds + SPW_CHUNK * SA;                  // [SPW_CHUNK][SG]
+  int* rows = reinterpret_cast<int*>(Gs + SPW_CHUNK * SG);   // [2][SPW_CHUNK]: input row, output row (-1: past the list)
+  const int part = blockIdx.x, k = blockIdx.y, nparts = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const int wr = wv / WC, wc = wv - wr * WC;         // this wave's block of tiles: rows wr*TR.., columns wc*TC..
+  const bool active = wv < WR * WC;
+  floatx4 acc[TR][TC];
+#pragma unroll
+  for (int a = 0; a < TR; ++a)
+#pragma unroll
+    for (int b = 0; b < TC; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int nk = pair_num[k];
+  const int p0 = part * slice, p1 = min(nk, p0 + slice);
+  const int* pin = pairs + (static_cast<size_t>(k) * 2 + src) * pair_stride;
+  const int* pout = pairs + (static_cast<size_t>(k) * 2 + (1 - src)) * pair_stride;
+  const int A4 = Cin >> 2, G4 = Cout >> 2;
+  for (int c0 = p0; c0 < p1; c0 += SPW_CHUNK) {
+    __syncthreads();                                 // the previous trip's tiles are consumed
+    if (tid < SPW_CHUNK) {
+      const int p = c0 + tid;
+      rows[tid] = p < p1 ? pin[p] : -1;
+      rows[SPW_CHUNK + tid] = p < p1 ? pout[p] : -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < SPW_CHUNK * A4; i += 256) {
+      const int s = i / A4, c4 = i - s * A4, r = rows[s];
+      const float4 v = r >= 0 ? reinterpret_cast<const float4*>(in)[static_cast<size_t>(r) * A4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&As[s * SA + 4 * c4]) = v;
+    }
+    for (int i = tid; i < SPW_CHUNK * G4; i += 256) {
+      const int s = i / G4, c4 = i - s * G4, r = rows[SPW_CHUNK + s];
+      const float4 v = r >= 0 ? reinterpret_cast<const float4*>(gout)[static_cast<size_t>(r) * G4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&Gs[s * SG + 4 * c4]) = v;
+    }
+    __syncthreads();
+    if (active) {
+      const int ng = (min(p1 - c0, SPW_CHUNK) + 3) >> 2;       // groups of 4 pairs that hold any
+      for (int g = 0; g < ng; ++g) {
+        float a[TR], b[TC];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) a[t] = As[(4 * g + kk) * SA + 16 * (wr * TR + t) + j];
+#pragma unroll
+        for (int t = 0; t < TC; ++t) b[t] = Gs[(4 * g + kk) * SG + 16 * (wc * TC + t) + j];
+#pragma unroll
+        for (int ta = 0; ta < TR; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < TC; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+      }
+    }
+  }
+  if (active) {                                      // partial [K][nparts][Cin][Cout]; a lane holds rows 4 kk + (0..3), column j of a tile
+    float* P = partial + (static_cast<size_t>(k) * nparts + part) * Cin * Cout;
+#pragma unroll
+    for (int ta = 0; ta < TR; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < TC; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          P[static_cast<size_t>(16 * (wr * TR + ta) + 4 * kk + r) * Cout + 16 * (wc * TC + tb) + j] = acc[ta][tb][r];
+  }
+}
+
+__global__ __launch_bounds__(256) void sp_wgrad_reduce(const float* __restrict__ partial, int nparts, long long per_k, int K,
+                                                       float* __restrict__ gw) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= per_k * K) return;
+  const long long k = t / per_k, e = t - k * per_k;
+  const float* p = partial + k * nparts * per_k + e;
+  float s = 0.f;
+  for (int i = 0; i < nparts; ++i) s += p[static_cast<size_t>(i) * per_k];     // slice order: fixed
+  gw[t] = s;
+}
+
+struct SpwPlan { int WR, WC, TR, TC, nparts, slice; size_t lds; };
+
+bool spw_plan(int K, int Cin, int Cout, int n_pairs_max, SpwPlan* p) {
+  const int ci = Cin / 16, co = Cout / 16;
+  if (Cin <= 0 || Cout <= 0 || (Cin & 15) || (Cout & 15) || ci > 8 || co > 8 || (ci & (ci - 1)) || (co & (co - 1)) || K <= 0 || n_pairs_max < 0)
+    return false;
+  p->WR = ci >= 4 ? 4 : ci;
+  p->WC = 4 / p->WR < co ? 4 / p->WR : co;
+  p->TR = ci / p->WR;
+  p->TC = co / p->WC;
+  int nparts = 1024 / K;                             // ~4 workgroups per CU over all offsets
+  if (nparts < 1) nparts = 1;
+  if (nparts > 64) nparts = 64;
+  int slice = (n_pairs_max + nparts - 1) / nparts;
+  slice = (slice + SPW_CHUNK - 1) / SPW_CHUNK * SPW_CHUNK;
+  if (slice < SPW_CHUNK) slice = SPW_CHUNK;
+  p->nparts = (n_pairs_max + slice - 1) / slice;
+  if (p->nparts < 1) p->nparts = 1;
+  p->slice = slice;
+  p->lds = sizeof(float) * SPW_CHUNK * (static_cast<size_t>(Cin) + Cout + 2 * SPW_PADF) + sizeof(int) * 2 * SPW_CHUNK;
+  return true;
+}
+
 // dense() of a sparse tensor in the channels-first layout the encoders return: canvas [B, C, D, H, W] (pre-zeroed)
 __global__ __launch_bounds__(256) void sp_to_dense(const float* __restrict__ feats, const int* __restrict__ idx, int n, int C,
                                                    int D, int H, int Wd, float* __restrict__ canvas) {
@@ -479,6 +605,69 @@ extern "C" int dbev_sparse_to_dense(const float* features, const int32_t* indice
   if (n > 0)
     hipLaunchKernelGGL(sp_to_dense, dim3(dbev_ceil_div(static_cast<long long>(n) * C, 256)), dim3(256), 0, s, features,
                        indices, n, C, D, H, W, canvas_ncdhw);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------
+extern "C" int dbev_spconv_backward_data(const float* grad_out, const float* weight, const int32_t* inverse_table, int n_in,
+                                         int K, int Cin, int Cout, float* grad_features, void* workspace,
+                                         size_t workspace_bytes, dbevStream_t stream) {
+  if (n_in < 0 || K <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 15) || (Cout & 15) || Cin > 128 || Cout > 256) return DBEV_EINVAL;
+  if (n_in == 0) return 0;
+  const size_t need = sizeof(float) * static_cast<size_t>(K) * Cin * Cout;
+  if (grad_out == nullptr || weight == nullptr || inverse_table == nullptr || grad_features == nullptr || workspace == nullptr ||
+      workspace_bytes < need)
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  float* Wt = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(sp_transpose_w, dim3(dbev_ceil_div(static_cast<long long>(K) * Cin * Cout, 256)), dim3(256), 0, s, weight, Wt,
+                     K, Cin, Cout);
+  DBEV_LAUNCH_CHECK();
+  // the forward kernel with the roles exchanged: "input" rows = dout [*, Cout], "output" rows = din [n_in, Cin]
+  return dbev_spconv_forward_fused(grad_out, Wt, nullptr, nullptr, nullptr, 0, inverse_table, n_in, K, Cout, Cin, grad_features, stream);
+}
+
+extern "C" size_t dbev_spconv_backward_weight_workspace_bytes(int K, int Cin, int Cout, int n_pairs_max) {
+  SpwPlan p;
+  if (!spw_plan(K, Cin, Cout, n_pairs_max, &p)) return 0;
+  return sizeof(float) * static_cast<size_t>(K) * p.nparts * Cin * Cout + 256;
+}
+
+extern "C" int dbev_spconv_backward_weight(const float* features, const float* grad_out, const int32_t* indice_pairs,
+                                           const int32_t* indice_pair_num, int pair_stride, int n_pairs_max, int inverse, int K,
+                                           int Cin, int Cout, float* grad_weight, void* workspace, size_t workspace_bytes,
+                                           dbevStream_t stream) {
+  SpwPlan p;
+  if (!spw_plan(K, Cin, Cout, n_pairs_max, &p) || pair_stride < n_pairs_max) return DBEV_EINVAL;
+  if (grad_weight == nullptr || workspace == nullptr ||
+      workspace_bytes < dbev_spconv_backward_weight_workspace_bytes(K, Cin, Cout, n_pairs_max))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const long long per_k = static_cast<long long>(Cin) * Cout;
+  if (n_pairs_max == 0) {
+    DBEV_HIP_TRY(hipMemsetAsync(grad_weight, 0, sizeof(float) * per_k * K, s));
+    return 0;
+  }
+  if (features == nullptr || grad_out == nullptr || indice_pairs == nullptr || indice_pair_num == nullptr) return DBEV_EINVAL;
+  float* partial = static_cast<float*>(workspace);
+  const dim3 grid(p.nparts, K);
+  const int src = inverse ? 1 : 0;       // inverse convolution: the list's output rows are this layer's inputs
+#define SPW_LAUNCH(TRV, TCV)                                                                                               \
+  do {                                                                                                                     \
+    if (p.lds > 64 * 1024)                                                                                                 \
+      DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sp_conv_wgrad<TRV, TCV>),                             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p.lds)));             \
+    hipLaunchKernelGGL((sp_conv_wgrad<TRV, TCV>), grid, dim3(256), p.lds, s, features, grad_out, indice_pairs, indice_pair_num, \
+                       pair_stride, src, p.slice, Cin, Cout, p.WR, p.WC, partial);                                         \
+  } while (0)
+  if (p.TR == 1) {
+    if (p.TC == 1) SPW_LAUNCH(1, 1); else if (p.TC == 2) SPW_LAUNCH(1, 2); else if (p.TC == 4) SPW_LAUNCH(1, 4); else SPW_LAUNCH(1, 8);
+  } else {
+    if (p.TC == 1) SPW_LAUNCH(2, 1); else if (p.TC == 2) SPW_LAUNCH(2, 2); else if (p.TC == 4) SPW_LAUNCH(2, 4); else SPW_LAUNCH(2, 8);
+  }
+#undef SPW_LAUNCH
+  hipLaunchKernelGGL(sp_wgrad_reduce, dim3(dbev_ceil_div(per_k * K, 256)), dim3(256), 0, s, partial, p.nparts, per_k, K, grad_weight);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -166,13 +166,11 @@ def _pad16(n):
 
 
 class _PairsView(object):
-    """pair lists handed in by the caller (indice_conv): same two members the backward reads from a Rulebook"""
+    """pair lists handed in by the caller (indice_conv) with the two tables derived from them: the members the backward reads
+    from a Rulebook"""
 
-    def __init__(self, indice_pairs, nums):
-        self.indice_pairs, self._nums = indice_pairs, nums
-
-    def pair_num_host(self):
-        return self._nums
+    def __init__(self, indice_pairs, indice_pair_num, nbr, inv):
+        self.indice_pairs, self.indice_pair_num, self.nbr, self.inv = indice_pairs, indice_pair_num, nbr, inv
 
 
 def _conv_forward(features, weight, table, n_out, scale=None, shift=None, residual=None, relu=False):
@@ -198,8 +196,54 @@ def _conv_forward(features, weight, table, n_out, scale=None, shift=None, residu
     return out[:, :Cout] if co != Cout else out
 
 
+def _pad_pow2(n):
+    """channel count the weight-gradient kernel tiles: 16, 32, 64 or 128"""
+    c = 16
+    while c < n:
+        c *= 2
+    return c
+
+
+def _conv_backward(features, weight, grad_out, book, swap, need_input_grad, need_weight_grad):
+    """indice_conv_backward (spconv_ops.h:352-420) on the kernels: the data gradient is the forward gather-GEMM over the table of
+    the opposite direction with transposed weights, the weight gradient one MFMA GEMM per kernel offset over that offset's
+    compacted pair list.  No host read-back, no float atomics."""
+    dev = L.require_cuda(features, weight, grad_out)
+    K, Cin, Cout = weight.shape
+    ci, co = _pad_pow2(Cin), _pad_pow2(Cout)
+    assert ci <= 128 and co <= 128, "sparse convolution backward: up to 128 channels"
+    pad = torch.nn.functional.pad
+    f, g, w = features.float(), grad_out.float(), weight.float()
+    if ci != Cin:
+        f, w = pad(f, (0, ci - Cin)), pad(w, (0, 0, 0, ci - Cin))
+    if co != Cout:
+        g, w = pad(g, (0, co - Cout)), pad(w, (0, co - Cout))
+    f, g, w = f.contiguous(), g.contiguous(), w.contiguous()
+    n_in = f.shape[0]
+    gin = gw = None
+    with torch.cuda.device(dev):
+        if need_input_grad:
+            table = book.nbr if swap else book.inv          # rows of this layer's INPUT <- rows of its output, per offset
+            gin = torch.empty((n_in, ci), dtype=torch.float32, device=dev)
+            ws = torch.empty((K * ci * co,), dtype=torch.float32, device=dev)
+            L.call("dbev_spconv_backward_data", L.ptr(g), L.ptr(w), L.ptr(table), n_in, K, ci, co, L.ptr(gin), L.ptr(ws),
+                   ws.numel() * 4, L.stream_ptr(dev))
+            gin = gin[:, :Cin] if ci != Cin else gin
+        if need_weight_grad:
+            pairs, nums = book.indice_pairs, book.indice_pair_num
+            stride = pairs.shape[2]
+            nmax = min(stride, max(f.shape[0], g.shape[0]))
+            gw = torch.empty((K, ci, co), dtype=torch.float32, device=dev)
+            nbytes = int(L.call("dbev_spconv_backward_weight_workspace_bytes", K, ci, co, nmax))
+            ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
+            L.call("dbev_spconv_backward_weight", L.ptr(f), L.ptr(g), L.ptr(pairs), L.ptr(nums), stride, nmax, int(bool(swap)), K,
+                   ci, co, L.ptr(gw), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+            gw = gw[:, :Cin, :Cout] if (ci, co) != (Cin, Cout) else gw
+    return gin, gw
+
+
 class _SparseConvFn(Function):
-    """features [n_in, Cin] x weight [K, Cin, Cout] through table [n_out, K] -> [n_out, Cout] (dbev_spconv_forward)."""
+    """features [n_in, Cin] x weight [K, Cin, Cout] through table [n_out, K] -> [n_out, Cout] (dbev_spconv_forward / _backward_*)."""
 
     @staticmethod
     def forward(ctx, features, weight, table, n_out, book, swap):
@@ -210,37 +254,29 @@ class _SparseConvFn(Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        """indice_conv_backward (spconv_ops.h:352-420): per offset, dW[k] = in_k^T @ dout_k, din rows += dout_k @ W[k]^T."""
         features, weight = ctx.saved_tensors
         book, swap, n_out = ctx.meta
-        pairs, nums = book.indice_pairs, book.pair_num_host()
-        gin = torch.zeros_like(features)
-        gw = torch.zeros_like(weight)
-        src, dst = (1, 0) if swap else (0, 1)              # inverse convolution: the pair roles are exchanged
-        go = grad_out.contiguous()
-        for k, n in enumerate(nums):
-            if n == 0:
-                continue
-            i_in = pairs[k, src, :n].long()
-            i_out = pairs[k, dst, :n].long()
-            a, g = features[i_in], go[i_out]
-            gw[k] = a.t() @ g
-            gin.index_add_(0, i_in, g @ weight[k].t())
+        gin, gw = _conv_backward(features, weight, grad_out, book, swap, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gin, gw, None, None, None, None
 
 
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
-    """ops.py:107-126 with the reference's arguments (pair lists): converts the lists to a table and runs the kernel."""
+    """ops.py:107-126 with the reference's arguments (pair lists): converts the lists to the two tables and runs the kernels."""
     K = indice_pairs.shape[0]
     dev = features.device
-    table = torch.full((max(num_activate_out, 1), K), -1, dtype=torch.int32, device=dev)
+    n_src = features.shape[0]
+    nbr = torch.full((max(num_activate_out, 1), K), -1, dtype=torch.int32, device=dev)      # output row <- input row
+    inv = torch.full((max(n_src, 1), K), -1, dtype=torch.int32, device=dev)                 # input row <- output row
     nums = indice_pair_num.cpu().tolist()
     src, dst = (1, 0) if inverse else (0, 1)
     for k, n in enumerate(nums):
         if n:
-            table[indice_pairs[k, dst, :n].long(), k] = indice_pairs[k, src, :n]
+            nbr[indice_pairs[k, dst, :n].long(), k] = indice_pairs[k, src, :n]
+            inv[indice_pairs[k, src, :n].long(), k] = indice_pairs[k, dst, :n]
     w = filters.reshape(K, filters.shape[-2], filters.shape[-1])
-    return _SparseConvFn.apply(features, w, table, num_activate_out, _PairsView(indice_pairs, nums), inverse)
+    # _SparseConvFn's backward takes `book.nbr if swap else book.inv` for the data gradient: hand it the inverse table either way
+    book = _PairsView(indice_pairs.int().contiguous(), indice_pair_num.int().contiguous(), inv if inverse else None, None if inverse else inv)
+    return _SparseConvFn.apply(features, w, nbr, num_activate_out, book, inverse)
 
 
 # ---- structure.py ----------------------------------------------------------------------------------------------------

@@ -592,6 +592,21 @@ int dbev_spconv_forward_fused(const float* features, const float* weight, const 
                               float* out_features, dbevStream_t stream);
 int dbev_sparse_to_dense(const float* features, const int32_t* indices, int n, int C, int B, int D, int H, int W,
                          float* canvas_ncdhw, dbevStream_t stream);
+/* indice_conv_backward (spconv_ops.h:352-420; per offset a gather, two GEMMs and a float-atomic scatter-add in the reference):
+ *  dbev_spconv_backward_data    grad_features[i, :] = sum_k grad_out[inverse_table[i, k], :] @ weight[k]^T -- the forward
+ *                               gather-GEMM on the table of the opposite direction (dbev_spconv_neighbors' `inv` for a regular
+ *                               convolution, its `nbr` for an inverse convolution); weight [K, Cin, Cout] as in the forward,
+ *                               Cin <= 128, Cout <= 256, multiples of 16; workspace >= 4 * K * Cin * Cout bytes; no atomics.
+ *  dbev_spconv_backward_weight  grad_weight[k] = sum over the pairs p < indice_pair_num[k] of
+ *                               features[pairs[k, inverse ? 1 : 0, p], :]^T (x) grad_out[pairs[k, inverse ? 0 : 1, p], :]
+ *                               from the reference-format lists (dbev_spconv_pair_lists; row stride `pair_stride`, no list longer
+ *                               than n_pairs_max); Cin, Cout in {16, 32, 64, 128}; partial sums merged in a fixed order. */
+int dbev_spconv_backward_data(const float* grad_out, const float* weight, const int32_t* inverse_table, int n_in, int K, int Cin,
+                              int Cout, float* grad_features, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+size_t dbev_spconv_backward_weight_workspace_bytes(int K, int Cin, int Cout, int n_pairs_max);
+int dbev_spconv_backward_weight(const float* features, const float* grad_out, const int32_t* indice_pairs,
+                                const int32_t* indice_pair_num, int pair_stride, int n_pairs_max, int inverse, int K, int Cin,
+                                int Cout, float* grad_weight, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Dynamic voxel encoders of the voxel teachers (mmdet3d/models/voxel_encoders/dynamic_voxel_encoder.py; torch op sequences

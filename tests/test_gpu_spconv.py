@@ -274,3 +274,81 @@ def test_edge_cases_empty_and_single_site_tensors():
         d = z.dense()
         assert d.shape == (B, 16, 5, 6, 5) and int((d != 0).any(dim=1).sum()) == z.features.shape[0]
         assert bool(torch.isfinite(d).all())
+
+
+@pytest.mark.parametrize("n,Cin,Cout,kind", [(3000, 16, 16, "subm"), (3000, 32, 64, "down"), (2500, 64, 128, "down"), (1500, 128, 128, "subm"),
+                                               (2000, 23, 16, "subm"), (1200, 48, 24, "down"), (800, 32, 16, "inverse")])
+def test_sparse_conv_backward_kernels_vs_pair_list_definition(n, Cin, Cout, kind):
+    """indice_conv_backward (spconv_ops.h:352-420) on the kernels (dbev_spconv_backward_data / _weight): input and weight gradients
+    against the fp64 definition summed over the oracle's pair lists (oracle/spconv.py rulebook_pairs), 1e-5 of scale; bit-identical
+    when repeated (no float atomics); regular, submanifold and inverse layers, channel counts that need padding."""
+    from distill_bev_amd import spconv
+    from oracle import spconv as OS
+    dev = torch.device("cuda:0")
+    shape, B = (10, 18, 16), 2
+    idx, feats = _cloud(100 + n + Cin, B, shape, n, Cin if kind != "inverse" else 16)
+    rng = np.random.default_rng(n)
+    if kind == "inverse":
+        down = spconv.SparseConv3d(16, Cin, 3, stride=2, padding=1, bias=False, indice_key="d").to(dev)
+        conv = spconv.SparseInverseConv3d(Cin, Cout, 3, indice_key="d", bias=False).to(dev)
+        x0 = spconv.SparseConvTensor(torch.from_numpy(feats).to(dev), torch.from_numpy(idx).to(dev), list(shape), B)
+        with torch.no_grad():
+            mid = down(x0)
+        f = mid.features.detach().clone().requires_grad_(True)
+        x = spconv.SparseConvTensor(f, mid.indices, mid.spatial_shape, B)
+        x.indice_dict, x.rulebooks = mid.indice_dict, mid.rulebooks
+        _, pairs = OS.rulebook_pairs(idx, shape, B, 3, 2, 1, 1, False)
+        pairs = [pr[:, ::-1] for pr in pairs]                       # (row of this layer's input, row of its output)
+    else:
+        subm = kind == "subm"
+        kw = dict(kernel_size=3, padding=1) if subm else dict(kernel_size=3, stride=2, padding=1)
+        conv = getattr(spconv, "SubMConv3d" if subm else "SparseConv3d")(Cin, Cout, bias=False, **kw).to(dev)
+        f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+        x = spconv.SparseConvTensor(f, torch.from_numpy(idx).to(dev), list(shape), B)
+        _, pairs = OS.rulebook_pairs(idx, shape, B, 3, 1 if subm else 2, 1, 1, subm)
+    runs = []
+    for _ in range(2):
+        y = conv(x)
+        g = torch.from_numpy(np.random.default_rng(7).normal(size=tuple(y.features.shape)).astype(np.float32)).to(dev)
+        gf, gw = torch.autograd.grad(y.features, (f, conv.weight), g)
+        runs.append((gf, gw))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    f64, g64 = f.detach().cpu().double().numpy(), g.cpu().double().numpy()
+    w64 = conv.weight.detach().cpu().double().numpy().reshape(27, Cin, Cout)
+    rf, rw = np.zeros_like(f64), np.zeros_like(w64)
+    for k, pr in enumerate(pairs):
+        if len(pr):
+            rw[k] = f64[pr[:, 0]].T @ g64[pr[:, 1]]
+            np.add.at(rf, pr[:, 0], g64[pr[:, 1]] @ w64[k].T)
+    gf, gw = runs[0][0].cpu().double().numpy(), runs[0][1].cpu().double().numpy().reshape(27, Cin, Cout)
+    assert np.abs(gf - rf).max() <= 1e-5 * np.abs(rf).max(), np.abs(gf - rf).max() / np.abs(rf).max()
+    assert np.abs(gw - rw).max() <= 1e-5 * np.abs(rw).max(), np.abs(gw - rw).max() / np.abs(rw).max()
+
+
+def test_indice_conv_api_backward_and_empty_inputs():
+    """ops.indice_conv with the reference's arguments (pair lists) is differentiable through the same kernels; a layer without any
+    active site returns empty / zero gradients."""
+    from distill_bev_amd import spconv
+    dev = torch.device("cuda:0")
+    shape, B = (8, 12, 10), 1
+    idx, feats = _cloud(3, B, shape, 400, 32)
+    it = torch.from_numpy(idx).to(dev)
+    outids, pairs, nums = spconv.get_indice_pairs(it, B, list(shape), 3, 2, 1, 1)
+    w = torch.randn(3, 3, 3, 32, 64, device=dev, requires_grad=True)
+    f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    y = spconv.indice_conv(f, w, pairs, nums, outids.shape[0])
+    conv = spconv.SparseConv3d(32, 64, 3, stride=2, padding=1, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    f2 = f.detach().clone().requires_grad_(True)
+    y2 = conv(spconv.SparseConvTensor(f2, it, list(shape), B)).features
+    assert torch.equal(y, y2)
+    g = torch.randn_like(y)
+    a = torch.autograd.grad(y, (f, w), g)
+    b = torch.autograd.grad(y2, (f2, conv.weight), g)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    e = spconv.SparseConvTensor(torch.zeros((0, 32), device=dev, requires_grad=True), torch.zeros((0, 4), dtype=torch.int32, device=dev), list(shape), B)
+    ye = conv(e).features
+    assert ye.shape == (0, 64)
+    ge = torch.autograd.grad(ye.sum(), conv.weight, allow_unused=True)[0]
+    assert ge is None or float(ge.abs().max()) == 0.0
