@@ -182,7 +182,7 @@ class GradReducer:
     the same bucket offset whatever kernels produced its gradients.
     """
 
-    def __init__(self, params, buffers=(), bucket_mb=64):
+    def __init__(self, params, buffers=(), bucket_mb=64, overlap=None):
         self.params = list(params)
         self.world = dist.get_world_size()
         self.host_staged = dist.get_backend() == "gloo"      # gloo: device gradients travel through a host buffer
@@ -204,6 +204,16 @@ class GradReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
+        # Overlap with backward (mmcv's MMDistributedDataParallel does it per 25 MB bucket, tools/distributed.py:29-79): a
+        # post-accumulate-grad hook per parameter marks it ready; a bucket whose parameters are all ready is packed and its
+        # all-reduce started AT ONCE, from inside backward -- but strictly in bucket order, so every rank issues the same sequence
+        # of collectives whatever order (or subset) of gradients its own batch produced.  Buckets holding a parameter without a
+        # gradient on this rank simply wait for all_reduce_grads(), which flushes the rest in the same order.
+        self.overlap = (os.environ.get("DBEV_DDP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        self._bucket_of = {id(p): i for i, bucket in enumerate(self.buckets) for p in bucket}
+        self._seen = [set() for _ in self.buckets]
+        self._fired, self._pending, self.fired_in_backward = 0, [], 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.overlap else []
 
     @staticmethod
     def _in_param_layout(p, g):
@@ -213,41 +223,66 @@ class GradReducer:
         out.copy_(g)
         return out
 
+    def _on_grad(self, p):
+        i = self._bucket_of[id(p)]
+        self._seen[i].add(id(p))
+        if i == self._fired:
+            n0 = self._fired
+            self._fire(force=False)
+            self.fired_in_backward += self._fired - n0
+
+    @torch.no_grad()
+    def _fire(self, force):
+        while self._fired < len(self.buckets) and (force or len(self._seen[self._fired]) == len(self.buckets[self._fired])):
+            self._launch(self.buckets[self._fired])
+            self._fired += 1
+
+    def _launch(self, bucket):
+        """pack one bucket (ONE concat kernel over memory-order views + the per-parameter flags), pre-divide, start its all-reduce"""
+        grads, have = [], []
+        for p in bucket:
+            have.append(p.grad is not None)
+            g = self._in_param_layout(p, p.grad) if p.grad is not None else torch.zeros_like(p)
+            if p.grad is not None and g is not p.grad:
+                p.grad = g
+            grads.append(g)
+        flats = [_flat_view(g) for g in grads]          # memory-order 1-D views: no per-tensor copy kernels
+        flags = torch.tensor(have, dtype=flats[0].dtype).to(flats[0].device, non_blocking=True) * self.world
+        flat = torch.cat(flats + [flags])
+        flat.div_(self.world)
+        host = flat.cpu() if self.host_staged and flat.is_cuda else None
+        work = dist.all_reduce(host if host is not None else flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((work, flat, flats, grads, bucket, have, host))
+
     @torch.no_grad()
     def all_reduce_grads(self):
-        pending = []
-        for bucket in self.buckets:
-            grads, have = [], []
-            for p in bucket:
-                have.append(p.grad is not None)
-                g = self._in_param_layout(p, p.grad) if p.grad is not None else torch.zeros_like(p)
-                if p.grad is not None and g is not p.grad:
-                    p.grad = g
-                grads.append(g)
-            flats = [_flat_view(g) for g in grads]          # memory-order 1-D views: no per-tensor copy kernels
-            flags = torch.tensor(have, dtype=flats[0].dtype).to(flats[0].device, non_blocking=True) * self.world
-            flat = torch.cat(flats + [flags])
-            flat.div_(self.world)
-            if self.host_staged and flat.is_cuda:
-                host = flat.cpu()
-                pending.append((dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=True), flat, flats, grads, bucket, have, host))
-            else:
-                pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, flats, grads, bucket, have, None))
-        for work, flat, flats, grads, bucket, have, host in pending:
+        """after backward: start whatever has not been started, wait, hand the averaged gradients back"""
+        self._fire(force=True)
+        for work, flat, flats, grads, bucket, have, host in self._pending:
             work.wait()
             if host is not None:
                 flat.copy_(host)
             n = len(flats)
             parts = list(flat.split([f.numel() for f in flats] + [n]))
-            torch._foreach_copy_(flats, parts[:n])
-            for f, g in zip(flats, grads):                  # exotic strides: the flat tensor was a copy, write it back
-                if f.data_ptr() != g.data_ptr():
-                    g.copy_(f.view_as(g))
-            if not all(have):                               # rare path (one host read-back): adopt what other ranks produced
-                any_rank = parts[n].cpu() > 0
-                for p, g, mine, someone in zip(bucket, grads, have, any_rank.tolist()):
-                    if not mine and someone:
-                        p.grad = g
+            any_rank = None if all(have) else (parts[n].cpu() > 0).tolist()     # rare path: one host read-back
+            for j, (p, f, g, part) in enumerate(zip(bucket, flats, grads, parts[:n])):
+                if not have[j] and not any_rank[j]:
+                    continue                                # NO rank produced a gradient: stays None (the optimizer skips it)
+                if f.data_ptr() == g.data_ptr():
+                    # the averaged gradient stays where the collective left it: a view of the bucket with the parameter's
+                    # strides (no 217 MB copy-back); the inverse of _flat_view's two memory-order layouts
+                    if g.is_contiguous():
+                        p.grad = part.view(g.shape)
+                    else:
+                        N, C, H, W = g.shape
+                        p.grad = part.view(N, H, W, C).permute(0, 3, 1, 2)
+                else:                                       # exotic parameter strides: the flat piece was a logical-order copy
+                    g.copy_(part.view(g.shape))
+                    p.grad = g
+        self._pending = []
+        self._fired = 0
+        for s_ in self._seen:
+            s_.clear()
 
 
 def param_groups(detector, opt):
@@ -300,7 +335,7 @@ class Trainer:
             # default data-parallel path: bucketed flat gradient all-reduce right after backward (GradReducer)
             self.module = self.wrapper
             self.reducer = GradReducer([p for p in self.detector.parameters() if p.requires_grad],
-                                       list(self.detector.buffers()), bucket_mb=64)
+                                       list(self.detector.buffers()), bucket_mb=32)
         elif distributed:
             self.module = nn.parallel.DistributedDataParallel(
                 self.wrapper, device_ids=[device.index] if device.type == "cuda" else None, broadcast_buffers=False,
