@@ -1096,6 +1096,11 @@ def make_bevdepth_step():
              "img_bev_encoder_neck.up2.1.weight", "pts_bbox_head.task_heads.2.heatmap.1.bias", "channel_wise_adaptations.1.weight"]
     params = dict(model.named_parameters())
     grads = torch.autograd.grad(total, [params[n] for n in names], retain_graph=True)
+    # ... and of the 38 losses other than the six heat-map focal terms: those six are ~100x larger than the rest at a random
+    # initialisation and carry the step's sharpest gates (one flipped ReLU under a focal term moves it by a percent), so the
+    # sum without them is what can be compared tightly
+    smooth = sum(v for k, v in losses.items() if not k.endswith("loss_heatmap"))
+    grads_nh = torch.autograd.grad(smooth, [params[n] for n in names], retain_graph=True, allow_unused=True)
     # the same BEV-encoder weight gradient split by loss group: localises a backward difference to one branch of the step
     groups = {"det": [k for k in losses if k.startswith("task")], "kd_backbone": [k for k in losses if k.endswith("backbone0_backbone2")],
               "kd_head": [k for k in losses if k.endswith("head_head")]}
@@ -1119,6 +1124,7 @@ def make_bevdepth_step():
           post_trans=post_trans.numpy(), depth_gt=dgt.numpy(), **{f"points{b}": batch["points"][b].numpy() for b in range(B)},
           **{f"gt_boxes{b}": batch["boxes"][b] for b in range(B)}, **{f"gt_labels{b}": batch["labels"][b] for b in range(B)},
           **_flat_losses("loss__", losses), **{"grad__" + n.replace(".", "__"): gr.numpy() for n, gr in zip(names, grads)},
+          **{"gradnh__" + n.replace(".", "__"): gr.numpy() for n, gr in zip(names, grads_nh) if gr is not None},
           **gg, pooled0=pooled[0].detach().numpy(), pooled1=pooled[1].detach().numpy(), **_sd("model__", model), **_sd("teacher__", teacher))
     print({k: len(v) for k, v in groups.items()})
     print(len(losses), {k: round(float(v), 5) for k, v in losses.items()})

@@ -16,13 +16,18 @@ Two passes:
   gradient still flows into the product's lift-splat backward), which takes the one operator with a different summation
   order out of the comparison: losses to 1e-4.
 
-Gradients, both passes.  The step holds ~1.2 M ReLU gates and L1 signs in the head alone; a gate within fp32 rounding of its
-kink flips between any two implementations (here CPU vs GPU convolutions), and one flipped gate under a 3-object L1 term moves
-that term's gradient by percents (sqrt(1 / #active gates)).  So the fixture carries every loss term's own gradient at two
-small BEV-encoder parameters: at least 90 % of the 43 terms must agree to 1e-4 of their norm (measured: 41 of 43 at <= 2e-5,
-the other two with one flipped gate each), every term and every summed gradient -- image backbone, DCN, depth net (through the
-lift-splat backward), BEV encoder, head, adaptation -- to 5e-2, and the depth-loss path, which has no such gates after its last
-activation, to 1e-4."""
+Gradients.  The step holds ~1.2 M ReLU gates and L1 signs in the head alone, and (new in round 3) the reference's own training-
+mode BatchNorm stacks of depth net / pre-process net / BEV encoder / BEV neck, the deepest over 2 x 4 x 4 = 32 values per channel.
+A gate within fp32 rounding of its kink flips between any two implementations (here CPU vs GPU convolutions); under one of the six
+heat-map focal terms -- ~100x larger than every other loss at a random initialisation -- one flipped gate moves that term's
+gradient by a percent.  So the fixture carries every loss term's own gradient at two small BEV-encoder parameters, and the summed
+gradient at eleven parameters along the step both for all 44 losses and for the 38 other than the heat-map terms.
+* aligned pass (the comparison proper): >= 34 of the 43 terms agree to 1e-4 of their norm (measured 36; the loose ones: five heat-
+  map terms with flipped gates, the worst 1.1e-2), every term to 3e-2; the summed gradient WITHOUT the heat-map terms at image
+  backbone / image neck / depth net / DCN / depth head (through the lift-splat backward) / pre-process net / BEV encoder / BEV neck /
+  head / adaptation to 5e-4, with them to 2e-2 (measured 5e-3, the flipped gates); FGD groups to 1e-4 / 1e-3; depth-loss path 1e-4.
+* as-is pass: the reference's pooled maps carry 2e-5 of cumulative-sum noise, which the 32-value BatchNorms amplify ~100x in the
+  gradients: every term and every summed gradient to 5e-2 (measured <= 4.3e-2 / 1.1e-2), the FGD backbone group to 1e-3."""
 import os
 import sys
 
@@ -105,24 +110,30 @@ def test_bevdepth4d_distill_forward_train_vs_reference_fixture(aligned):
         errs[k] = rel(g, torch.from_numpy(fx[key]))
     tight = [k for k, e in errs.items() if e <= 1e-4]
     print("terms", len(errs), "tight", len(tight), "loose", {k: e for k, e in errs.items() if e > 1e-4})
-    assert len(errs) == 43 and len(tight) >= 39, errs
-    assert max(errs.values()) <= 5e-2, errs
+    term_report = (len(errs), len(tight), max(errs.values()))
 
-    # summed gradients at six parameters along the step, and the BEV-encoder weight gradient by loss group
+    # summed gradients at eleven parameters along the step (all losses / all but the heat-map terms), and the BEV-encoder weight
+    # gradient by loss group
     bad = []
     names = [k[6:].replace("__", ".") for k in fx.files if k.startswith("grad__")]
+    assert len(names) == 11
     grads = torch.autograd.grad(sum(losses.values()), [params[n] for n in names], retain_graph=True)
-    for n, g in zip(names, grads):
+    smooth = sum(v for k, v in losses.items() if not k.endswith("loss_heatmap"))
+    grads_nh = torch.autograd.grad(smooth, [params[n] for n in names], retain_graph=True, allow_unused=True)
+    for n, g, gn in zip(names, grads, grads_nh):
         e = rel(g, torch.from_numpy(fx["grad__" + n.replace(".", "__")]))
-        print(n, e)
-        if e > 5e-2:
-            bad.append((n, e))
+        key = "gradnh__" + n.replace(".", "__")
+        en = rel(gn, torch.from_numpy(fx[key])) if key in fx.files else 0.0
+        print(n, e, en)
+        if e > (2e-2 if aligned else 5e-2) or en > (5e-4 if aligned else 5e-2):
+            bad.append((n, e, en))
     w0 = params["img_bev_encoder_backbone.layers.0.0.conv1.weight"]
+    gbar = dict(det=2e-2, kd_backbone=1e-4, kd_head=1e-3) if aligned else dict(det=5e-2, kd_backbone=1e-3, kd_head=5e-2)
     for gname, keys in _groups(losses).items():
         g = torch.autograd.grad(sum(losses[k] for k in keys), w0, retain_graph=True)[0]
         e = rel(g, torch.from_numpy(fx["gradgroup__" + gname]))
         print("group", gname, len(keys), e)
-        if e > (5e-2 if gname == "det" else 1e-3):
+        if e > gbar[gname]:
             bad.append((gname, e))
     # the depth loss alone (sigmoid + BCE on the depth logits): its whole backward, image backbone included
     n = "img_view_transformer.depthnet.bias"
@@ -131,4 +142,9 @@ def test_bevdepth4d_distill_forward_train_vs_reference_fixture(aligned):
     print("depth", e)
     if e > 1e-4:
         bad.append(("depth", e))
+    print("REPORT", aligned, term_report, bad)
+    if aligned:
+        assert term_report[0] == 43 and term_report[1] >= 34 and term_report[2] <= 3e-2, (term_report, errs)
+    else:
+        assert term_report[0] == 43 and term_report[2] <= 5e-2, (term_report, errs)
     assert not bad, bad

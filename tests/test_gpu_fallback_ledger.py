@@ -15,6 +15,7 @@ def test_ineligible_device_calls_are_counted_eligible_ones_are_not():
     from distill_bev_amd.skinny_conv import SkinnyConv2d
     dev = torch.device("cuda:0")
     L.fallback_reset()
+    L._warned_fallbacks.clear()            # earlier tests of the same process may have used up the once-per-reason warnings
     bn = nn.BatchNorm2d(64).to(dev).train()
     x = torch.randn(4, 64, 8, 8, device=dev)
     xl = x.contiguous(memory_format=torch.channels_last)
