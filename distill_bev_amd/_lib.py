@@ -93,6 +93,8 @@ _SIGNATURES = {
     "dbev_spconv_backward_data": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p],
     "dbev_spconv_backward_weight_workspace_bytes": [_i, _i, _i, _i],
     "dbev_spconv_backward_weight": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p],
+    "dbev_conv1x1_stats_rows": [_ll, _i, _i],
+    "dbev_conv1x1_forward": [_p, _p, _p, _p, _ll, _i, _i, _i, _p],
     "dbev_range_voxel_coords": [_p, _i, _i, _p, _p, _i, _p, _p],
     "dbev_virtual_voxel_reduce": [_p, _p, _p, _p, _i, _p],
     "dbev_msda_backward_workspace_bytes": [_i, _i, _i, _i, _i, _i],
@@ -133,7 +135,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
-_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices"}
+_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows"}
 
 
 class DbevHipError(RuntimeError):
@@ -212,7 +214,7 @@ def call(name, *args, alg_bytes=0):
 
 KERNEL_IDS = {"bn_stats": 1, "bn_finalize": 2, "bn_apply": 3, "bn_apply_res": 4, "bn_bwd_reduce": 5, "bn_bwd_reduce_y": 6,
               "bn_bwd_finalize": 7, "bn_bwd_dx": 8, "bn_bwd_dx_res": 9, "sp_conv_fwd": 10, "msda_fwd": 11, "msda_bwd_sample": 12,
-              "msda_gv_gather": 13, "adapt_mse_fwd": 14}        # DBEV_K_* of include/dbev_hip.h
+              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15}        # DBEV_K_* of include/dbev_hip.h
 
 
 def kernel_timing(which):

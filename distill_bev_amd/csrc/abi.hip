@@ -83,6 +83,7 @@ extern "C" const char* dbev_kernel_name(int kid) {
     case DBEV_K_MSDA_BWD_SAMPLE: return "msda_bwd_sample";
     case DBEV_K_MSDA_GV_GATHER: return "msda_gv_gather";
     case DBEV_K_ADAPT_MSE_FWD: return "adapt_mse_fwd";
+    case DBEV_K_CONV1X1_FWD: return "c1x1_fwd";
     default: return "?";
   }
 }

@@ -46,7 +46,14 @@ __global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict_
   float (*sX)[AM_KC][AM_STR] = reinterpret_cast<float (*)[AM_KC][AM_STR]>(smem);
   float (*sW)[AM_KC][WSTR] = reinterpret_cast<float (*)[AM_KC][WSTR]>(smem + 2 * AM_KC * AM_STR);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int m0 = blockIdx.x * AM_PXB, n0 = blockIdx.y * NCH;
+  // XCD-aware order: the N / NCH channel slices of one pixel tile re-read the same 128 x K activation rows; logical block id L walks
+  // (tile, slice) with the slice fastest and xcd_block() keeps consecutive L on ONE XCD back to back, so the second and third read
+  // of a tile come out of that XCD's L2 instead of HBM (a (tiles, slices) grid put them ~1000 workgroups apart: 1.78x the bytes)
+  const int nsl = N / NCH;
+  const int L = xcd_block();
+  const int tile_id = L / nsl, slice_id = L - tile_id * nsl;
+  if (tile_id * AM_PXB >= M) return;                          // grid rounded up to a multiple of 8 XCDs
+  const int m0 = tile_id * AM_PXB, n0 = slice_id * NCH;
   const int half = lane >> 5, l31 = lane & 31;
 
   // loader: 8 consecutive lanes read one row's 128-byte chunk (whole cache lines per wave instruction)
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict_
   // the other half-wave holds the other 16 rows of every tile for the same pixel
   e += __shfl_xor(e, 32); efp += __shfl_xor(efp, 32); sa += __shfl_xor(sa, 32); sp += __shfl_xor(sp, 32);
   if (live && half == 0) {
-    float* mp = maps + static_cast<size_t>(blockIdx.y) * 4 * M;
+    float* mp = maps + static_cast<size_t>(slice_id) * 4 * M;
     mp[p] = e; mp[static_cast<size_t>(M) + p] = efp; mp[2 * static_cast<size_t>(M) + p] = sa; mp[3 * static_cast<size_t>(M) + p] = sp;
   }
   __syncthreads();
@@ -219,7 +226,7 @@ extern "C" int dbev_adapt_mse_forward(const float* x_nhwc, const float* weight, 
   const long long M = static_cast<long long>(B) * HW;
   if (M > 0x3fffffffLL) return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
-  const dim3 grid(dbev_ceil_div(M, AM_PXB), Ct / (32 * nt));
+  const dim3 grid(dbev_round_xcd(dbev_ceil_div(M, AM_PXB) * (Ct / (32 * nt))));
 #define AM_LAUNCH(NTV) hipLaunchKernelGGL((adapt_mse_fwd<NTV>), grid, dim3(256), 0, s, x_nhwc, weight, bias, teacher_nhwc, \
                                          channel_weight, diff_nhwc, maps, static_cast<int>(M), Cs, Ct, HW)
   DbevKt kt(DBEV_K_ADAPT_MSE_FWD, 4LL * M * (Cs + 2LL * Ct), s);      // x + teacher read, difference written

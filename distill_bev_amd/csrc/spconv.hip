@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void sp_transpose_w(const float* __restrict__ 
 }
 
 constexpr int SPW_CHUNK = 64;          // pairs staged per trip
-constexpr int SPW_PADF = 16;           // row padding (floats): the four 16-float row segments a wave reads land on distinct banks
+// row padding (floats) of the two LDS stages: ds_read_b32 banks = (dword address) mod 32 inside each 32-lane half, and lanes l / l + 16
+// read consecutive rows -> the row stride must be 16 mod 32 (C = 16: none, C a multiple of 32: 16)
+__host__ __device__ constexpr int spw_pad(int C) { return (C & 31) == 0 ? 16 : 0; }
 
 template <int TR, int TC>
 __global__ __launch_bounds__(256) void sp_conv_wgrad(const float* __restrict__ in, const float* __restrict__ gout,
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void sp_conv_wgrad(const float* __restrict__ i
                                                      int pair_stride, int src, int slice, int Cin, int Cout, int WR, int WC,
                                                      float* __restrict__ partial) {
   extern __shared__ float lds[];
-  const int SA = Cin + SPW_PADF, SG = Cout + SPW_PADF;
+  const int SA = Cin + spw_pad(Cin), SG = Cout + spw_pad(Cout);
   float* As = lds;                                   // [SPW_CHUNK][SA]
   float* Gs = lds + SPW_CHUNK * SA;                  // [SPW_CHUNK][SG]
   int* rows = reinterpret_cast<int*>(Gs + SPW_CHUNK * SG);   // [2][SPW_CHUNK]: input row, output row (-1: past the list)
@@ -386,7 +388,7 @@ bool spw_plan(int K, int Cin, int Cout, int n_pairs_max, SpwPlan* p) {
   p->nparts = (n_pairs_max + slice - 1) / slice;
   if (p->nparts < 1) p->nparts = 1;
   p->slice = slice;
-  p->lds = sizeof(float) * SPW_CHUNK * (static_cast<size_t>(Cin) + Cout + 2 * SPW_PADF) + sizeof(int) * 2 * SPW_CHUNK;
+  p->lds = sizeof(float) * SPW_CHUNK * (static_cast<size_t>(Cin) + Cout + spw_pad(Cin) + spw_pad(Cout)) + sizeof(int) * 2 * SPW_CHUNK;
   return true;
 }
 

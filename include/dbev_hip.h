@@ -52,7 +52,7 @@ const char* dbev_target_arch(void);
 enum {
   DBEV_K_BN_STATS = 1, DBEV_K_BN_FINALIZE, DBEV_K_BN_APPLY, DBEV_K_BN_APPLY_RES, DBEV_K_BN_BWD_REDUCE,
   DBEV_K_BN_BWD_REDUCE_Y, DBEV_K_BN_BWD_FINALIZE, DBEV_K_BN_BWD_DX, DBEV_K_BN_BWD_DX_RES, DBEV_K_SPCONV_FWD,
-  DBEV_K_MSDA_FWD, DBEV_K_MSDA_BWD_SAMPLE, DBEV_K_MSDA_GV_GATHER, DBEV_K_ADAPT_MSE_FWD, DBEV_K_COUNT
+  DBEV_K_MSDA_FWD, DBEV_K_MSDA_BWD_SAMPLE, DBEV_K_MSDA_GV_GATHER, DBEV_K_ADAPT_MSE_FWD, DBEV_K_CONV1X1_FWD, DBEV_K_COUNT
 };
 int dbev_kernel_timing_enable(int mask);
 int dbev_kernel_timing_read(int* kernel_id, float* ms, long long* algorithmic_bytes, int cap);
@@ -623,6 +623,19 @@ int dbev_range_voxel_coords(const float* points, int num_points, int num_feats, 
                             const float* voxel_size_host, int virtual_classes, int32_t* coors, dbevStream_t stream);
 int dbev_virtual_voxel_reduce(const float* points, const int32_t* voxel_point_start, const int32_t* voxel_point_list,
                               float* voxels, int num_voxels, dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 1x1 convolution of the bottleneck blocks with the batch statistics of the BatchNorm that follows it in the epilogue
+ * (mmdet3d/models/bricks/res_block.py:102-230 conv1 / conv3 -> norm; mmdet ResNet `downsample`: nn.Conv2d(k=1) -> BatchNorm2d; the
+ * reference runs cuDNN's convolution, then the norm layer re-reads the whole output for mean / variance).
+ *   x_nhwc f32[M, x_row_stride >= Cin] (M = N*H*W pixels, channels-last), weight f32[Cout, Cin] (OIHW with a 1x1 kernel, no bias),
+ *   y_nhwc f32[M, Cout]; Cin % 32 == 0, Cout % 32 == 0.
+ *   stats_partial (may be NULL) f32[rows, 2, Cout], rows = dbev_conv1x1_stats_rows(M, Cin, Cout): per persistent workgroup the sums
+ *   of y and y^2 over the pixels it computed -- the partial-row layout dbev_bn_act_from_partials merges (fixed order, no atomics).
+ * ---------------------------------------------------------------------------------- */
+int dbev_conv1x1_stats_rows(long long M, int Cin, int Cout);
+int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, float* y_nhwc, float* stats_partial, long long M, int Cin,
+                         int Cout, int x_row_stride, dbevStream_t stream);
 
 #ifdef __cplusplus
 }
