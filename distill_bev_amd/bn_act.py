@@ -79,7 +79,8 @@ def _why_not(x, bn, residual):
 
 class _BNActTrain(Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, pre=None):
+        """pre: f32[rows, 2, C] partial (sum, sum of squares) rows the producer of x already took (conv1x1_stats): no statistics pass"""
         dev = x.device
         N, C, H, W = x.shape
         M = N * H * W
@@ -90,10 +91,11 @@ class _BNActTrain(Function):
         nbytes = L.lib().dbev_bn_act_workspace_bytes(M, C)
         ws = torch.empty((nbytes + 12 * C,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.call("dbev_bn_act_train_forward", L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
+            L.call("dbev_bn_act_train_forward_pre", L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
                    L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), float(momentum or 0.0), float(eps), int(relu), L.ptr(y),
-                   L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
-                   alg_bytes=4 * M * C * (3 + (residual is not None)))     # x twice (stats, apply) [+ res] + y
+                   L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), M, C, L.ptr(pre), 0 if pre is None else pre.shape[0],
+                   L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+                   alg_bytes=4 * M * C * (3 + (residual is not None) - (pre is not None)))     # x (stats), x (apply) [+ res] + y
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, weight, save_mean, save_invstd, coef)
         ctx.cfg = (M, C, bool(relu), residual is not None)
@@ -117,14 +119,14 @@ class _BNActTrain(Function):
                    L.ptr(save_invstd), L.ptr(coef), int(relu), L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), M, C,
                    L.ptr(ws), ws.numel(), L.stream_ptr(dev),
                    alg_bytes=4 * M * C * (5 + 3 * (dres is not None)))     # dy, x twice each + dx [+ y twice + dres]
-        return dx, (dres if relu else dy) if has_res else None, dgamma, dbeta, None, None, None, None, None, None
+        return dx, (dres if relu else dy) if has_res else None, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class _BNDualTrain(Function):
     """relu(bn(x) + bn_d(xd)): dbev_bn_dual_train_forward / dbev_bn_dual_backward"""
 
     @staticmethod
-    def forward(ctx, x, xd, w, b, rm, rv, nbt, mom, eps, wd, bd, rmd, rvd, nbtd, momd, epsd, relu):
+    def forward(ctx, x, xd, w, b, rm, rv, nbt, mom, eps, wd, bd, rmd, rvd, nbtd, momd, epsd, relu, pre=None, pre_d=None):
         dev = x.device
         N, C, H, W = x.shape
         M = N * H * W
@@ -133,10 +135,12 @@ class _BNDualTrain(Function):
         nbytes = L.lib().dbev_bn_dual_workspace_bytes(M, C)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.call("dbev_bn_dual_train_forward", L.ptr(x), L.ptr(xd), L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
+            L.call("dbev_bn_dual_train_forward_pre", L.ptr(x), L.ptr(xd), L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
                    float(mom or 0.0), float(eps), L.ptr(wd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), L.ptr(nbtd), float(momd or 0.0),
                    float(epsd), int(relu), L.ptr(y), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2:4]), L.ptr(stats[4]),
-                   L.ptr(stats[5]), L.ptr(stats[6:8]), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev), alg_bytes=4 * M * C * 5)
+                   L.ptr(stats[5]), L.ptr(stats[6:8]), M, C, L.ptr(pre), 0 if pre is None else pre.shape[0], L.ptr(pre_d),
+                   0 if pre_d is None else pre_d.shape[0], L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+                   alg_bytes=4 * M * C * (5 - (pre is not None) - (pre_d is not None)))
         ctx.save_for_backward(x, xd, y if relu else None, w, wd, stats)
         ctx.cfg = (M, C, bool(relu))
         return y
@@ -155,10 +159,10 @@ class _BNDualTrain(Function):
             L.call("dbev_bn_dual_backward", L.ptr(dy), L.ptr(x), L.ptr(xd), L.ptr(y), L.ptr(w), L.ptr(stats[0]), L.ptr(stats[1]),
                    L.ptr(wd), L.ptr(stats[4]), L.ptr(stats[5]), int(relu), L.ptr(dx), L.ptr(dxd), L.ptr(g[0]), L.ptr(g[1]),
                    L.ptr(g[2]), L.ptr(g[3]), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev), alg_bytes=4 * M * C * 10)
-        return (dx, dxd, g[0], g[1], None, None, None, None, None, g[2], g[3], None, None, None, None, None, None)
+        return (dx, dxd, g[0], g[1], None, None, None, None, None, g[2], g[3], None, None, None, None, None, None, None, None)
 
 
-def bn_act_dual(x, bn, xd, bn_d, relu=True):
+def bn_act_dual(x, bn, xd, bn_d, relu=True, pre=None, pre_d=None):
     """relu(bn(x) + bn_d(xd)) -- the tail of a residual block whose identity branch ends in its own BatchNorm (`downsample`).
     Training mode on channels-last tensors: one fused forward / backward that never writes bn_d(xd) or the gated gradient;
     otherwise the same value through bn_act(x, bn, residual=bn_d(xd))."""
@@ -166,8 +170,63 @@ def bn_act_dual(x, bn, xd, bn_d, relu=True):
             and bn_d.running_mean is not None and torch.is_grad_enabled()):
         return _BNDualTrain.apply(x, xd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                   bn.eps, bn_d.weight, bn_d.bias, bn_d.running_mean, bn_d.running_var, bn_d.num_batches_tracked,
-                                  bn_d.momentum, bn_d.eps, relu)
-    return bn_act(x, bn, bn_act(xd, bn_d, None, False), relu)
+                                  bn_d.momentum, bn_d.eps, relu, pre, pre_d)
+    return bn_act(x, bn, bn_act(xd, bn_d, None, False, pre=pre_d), relu, pre=pre)
+
+
+class _Conv1x1Stats(Function):
+    """z = conv1x1(x, w) on the fp32 matrix cores with the BatchNorm partial statistics of z in the epilogue
+    (dbev_conv1x1_forward); backward = the library convolution's data / weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        dev = x.device
+        N, Ci, H, W = x.shape
+        Co = w.shape[0]
+        M = N * H * W
+        z = torch.empty((N, Co, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        rows = int(L.call("dbev_conv1x1_stats_rows", M, Ci, Co))
+        part = torch.empty((rows, 2, Co), dtype=torch.float32, device=dev)
+        w2 = w.reshape(Co, Ci)
+        w2 = w2 if w2.is_contiguous() else w2.contiguous()
+        with torch.cuda.device(dev):
+            L.call("dbev_conv1x1_forward", L.ptr(x), L.ptr(w2), L.ptr(z), L.ptr(part), M, Ci, Co, Ci, L.stream_ptr(dev),
+                   alg_bytes=4 * M * (Ci + Co))
+        ctx.save_for_backward(x, w)
+        ctx.mark_non_differentiable(part)
+        return z, part
+
+    @staticmethod
+    def backward(ctx, gz, _gpart):
+        x, w = ctx.saved_tensors
+        gx, gw, _ = torch.ops.aten.convolution_backward(gz.contiguous(memory_format=torch.channels_last), x, w, None, [1, 1], [0, 0],
+                                                        [1, 1], False, [0, 0], 1, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw
+
+
+_C1 = {"enabled": os.environ.get("DBEV_CONV1X1", "1") != "0", "max_cin": int(os.environ.get("DBEV_CONV1X1_MAX_CIN", "512")),
+       "min_rows": int(os.environ.get("DBEV_CONV1X1_MIN_ROWS", "100000"))}
+
+
+def conv1x1_bn_ready(conv, bn, x):
+    """The 1x1 convolution + training-mode BatchNorm pairs the fused GEMM serves: where `conv + statistics pass` is slower in the
+    library than the hand-written kernel with the statistics in its epilogue -- measured (tools/kbench_c1x1.py): the large-map
+    layers, Cin <= 512 with >= 100 k pixels (stages 1 and 2 of the image backbone); elsewhere the library's kernels win."""
+    if not (_C1["enabled"] and _state["enabled"] and type(conv) is nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and _nhwc(x) and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
+            and conv.in_channels <= _C1["max_cin"] and x.shape[0] * x.shape[2] * x.shape[3] >= _C1["min_rows"]):
+        return False
+    if not (type(bn) in _BN_TYPES and bn.affine and bn.training and bn.momentum is not None and bn.running_mean is not None
+            and _channels_ok(conv.out_channels)):
+        return False
+    return int(L.call("dbev_conv1x1_stats_rows", x.shape[0] * x.shape[2] * x.shape[3], conv.in_channels, conv.out_channels)) > 0
+
+
+def conv1x1_stats(conv, x):
+    """-> (conv(x), partial statistics rows) for a pair accepted by conv1x1_bn_ready"""
+    return _Conv1x1Stats.apply(x, conv.weight)
 
 
 def split_downsample(downsample):
@@ -190,13 +249,14 @@ def _infer(x, residual, bn, relu):
     return y
 
 
-def bn_act(x, bn, residual=None, relu=True):
-    """relu(bn(x) + residual) with the module `bn`'s parameters, statistics and mode."""
+def bn_act(x, bn, residual=None, relu=True, pre=None):
+    """relu(bn(x) + residual) with the module `bn`'s parameters, statistics and mode.  `pre`: partial statistics rows of x taken by
+    its producer (conv1x1_stats) -- only handed over when the training-mode kernel path applies (conv1x1_bn_ready)."""
     if eligible(x, bn, residual):
         if bn.training or bn.running_mean is None:
             # num_batches_tracked += 1 happens inside the finalize kernel (no extra launch)
             return _BNActTrain.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     bn.num_batches_tracked, bn.momentum, bn.eps, relu)
+                                     bn.num_batches_tracked, bn.momentum, bn.eps, relu, pre)
         return _infer(x, residual, bn, relu)
     if x.is_cuda and _state["enabled"] and x.numel() > 0:
         L.note_fallback("bn_act", _why_not(x, bn, residual))

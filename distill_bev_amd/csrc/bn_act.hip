@@ -653,8 +653,22 @@ extern "C" int dbev_bn_act_train_forward(const float* x, const float* residual, 
                                          float momentum, float eps, int relu, float* y, float* save_mean,
                                          float* save_invstd, float* save_scale_shift, long long M, int C,
                                          void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  return dbev_bn_act_train_forward_pre(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu,
+                                       y, save_mean, save_invstd, save_scale_shift, M, C, nullptr, 0, workspace, workspace_bytes,
+                                       stream);
+}
+
+// ... with the per-channel partial sums (sum x, sum x^2) already taken by the kernel that PRODUCED x (dbev_conv1x1_forward's
+// epilogue: `stats_partial` f32[partial_rows, 2, C]): the statistics pass over x does not run.  stats_partial == NULL: as above.
+extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residual, const float* gamma, const float* beta,
+                                             float* running_mean, float* running_var, long long* num_batches_tracked,
+                                             float momentum, float eps, int relu, float* y, float* save_mean,
+                                             float* save_invstd, float* save_scale_shift, long long M, int C,
+                                             const float* stats_partial, int partial_rows, void* workspace,
+                                             size_t workspace_bytes, dbevStream_t stream) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
+  if (stats_partial != nullptr && partial_rows <= 0) return DBEV_EINVAL;
   if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || save_mean == nullptr ||
       save_invstd == nullptr || save_scale_shift == nullptr || workspace == nullptr ||
       workspace_bytes < bn_ws(g).total || (running_mean == nullptr) != (running_var == nullptr))
@@ -663,9 +677,17 @@ extern "C" int dbev_bn_act_train_forward(const float* x, const float* residual, 
   float* partial = static_cast<float*>(workspace);
   const dim3 grid(g.NBX, g.GY);
   const long long T = 4LL * g.M * C;                       // bytes of one full-tensor pass
-  { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, reinterpret_cast<const float4*>(x), partial); }
-  { DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * g.NBX * g.GY * C, s);
-    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma, beta,
+  int nrows = g.NBX;
+  const float* rows = partial;
+  if (stats_partial != nullptr) {
+    nrows = partial_rows;
+    rows = stats_partial;
+  } else {
+    DbevKt kt(DBEV_K_BN_STATS, T, s);
+    launch_stats(g, grid, s, reinterpret_cast<const float4*>(x), partial);
+  }
+  { DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nrows * C, s);
+    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, rows, nrows, g.M, C, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
                        num_batches_tracked); }
   const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -782,6 +804,22 @@ extern "C" int dbev_bn_dual_train_forward(const float* x, const float* xd, const
                                           float* save_invstd, float* save_scale_shift, float* save_mean_d,
                                           float* save_invstd_d, float* save_scale_shift_d, long long M, int C,
                                           void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  return dbev_bn_dual_train_forward_pre(x, xd, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, gamma_d,
+                                        beta_d, running_mean_d, running_var_d, num_batches_tracked_d, momentum_d, eps_d, relu, y,
+                                        save_mean, save_invstd, save_scale_shift, save_mean_d, save_invstd_d, save_scale_shift_d, M,
+                                        C, nullptr, 0, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+// ... with the partial sums of either input already taken by its producer (see dbev_bn_act_train_forward_pre)
+extern "C" int dbev_bn_dual_train_forward_pre(const float* x, const float* xd, const float* gamma, const float* beta,
+                                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                                              float momentum, float eps, const float* gamma_d, const float* beta_d,
+                                              float* running_mean_d, float* running_var_d, long long* num_batches_tracked_d,
+                                              float momentum_d, float eps_d, int relu, float* y, float* save_mean,
+                                              float* save_invstd, float* save_scale_shift, float* save_mean_d,
+                                              float* save_invstd_d, float* save_scale_shift_d, long long M, int C,
+                                              const float* stats_partial, int partial_rows, const float* stats_partial_d,
+                                              int partial_rows_d, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
   if (x == nullptr || xd == nullptr || gamma == nullptr || beta == nullptr || gamma_d == nullptr || beta_d == nullptr ||
@@ -797,15 +835,18 @@ extern "C" int dbev_bn_dual_train_forward(const float* x, const float* xd, const
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* d4 = reinterpret_cast<const float4*>(xd);
   // statistics of the branch first, then of the main input: the same partial buffer serves both (stream order)
-  { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, d4, partial); }
-  { DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * g.NBX * g.GY * C, s);
-    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma_d, beta_d,
-                       running_mean_d, running_var_d, momentum_d, eps_d, save_mean_d, save_invstd_d, save_scale_shift_d,
-                       num_batches_tracked_d); }
-  { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, x4, partial); }
-  { DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * g.NBX * g.GY * C, s);
-    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma, beta,
-                       running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
+  if ((stats_partial != nullptr && partial_rows <= 0) || (stats_partial_d != nullptr && partial_rows_d <= 0)) return DBEV_EINVAL;
+  if (stats_partial_d == nullptr) { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, d4, partial); }
+  { const int nr = stats_partial_d != nullptr ? partial_rows_d : g.NBX;
+    DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nr * C, s);
+    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, stats_partial_d != nullptr ? stats_partial_d : partial,
+                       nr, g.M, C, gamma_d, beta_d, running_mean_d, running_var_d, momentum_d, eps_d, save_mean_d, save_invstd_d,
+                       save_scale_shift_d, num_batches_tracked_d); }
+  if (stats_partial == nullptr) { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, x4, partial); }
+  { const int nr = stats_partial != nullptr ? partial_rows : g.NBX;
+    DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nr * C, s);
+    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, stats_partial != nullptr ? stats_partial : partial,
+                       nr, g.M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
                        num_batches_tracked); }
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;

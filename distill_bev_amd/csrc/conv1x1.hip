@@ -13,12 +13,19 @@
 // (persistent: <= 2 workgroups per CU, the batch statistics of everything a workgroup computed stay in registers -> a few hundred
 // partial rows however large M is).  MFMA rows = pixels (A operand = activation), columns = channels (B operand = weight): a lane
 // holds ONE output channel and 16 pixel rows per 32x32 tile, so the per-channel sums are in-register adds and the output leaves the
-// accumulators directly as 128-byte row segments (32 consecutive channels of a pixel per half-wave store).  K is walked in chunks
-// of 32 through a double-buffered k-major LDS stage (conflict-free ds_read_b32 for both operands); the global loads of chunk c+1 --
-// and of the next work item's first chunk during the epilogue -- are in flight while chunk c is multiplied.  Work items are ordered
+// accumulators directly as 128-byte row segments (32 consecutive channels of a pixel per half-wave store).
+// Operand staging: both tiles sit in LDS ROW-major ([pixel][k], [channel][k], row stride KC + 4 floats) exactly as the 16-byte global
+// loads deliver them (one ds_write_b128 per load, no transposing scalar writes).  The reduction index is consumed in a permuted
+// order -- MFMA step 4j + e takes k = 8j + 4*half + e -- so that the four steps' operand values of a lane are ONE ds_read_b128
+// (the stride's 36 = 4 * 9 puts the 16 lanes of every b128 service group on 16 distinct bank quads: conflict-free); A and B use
+// the same permutation, the sum is unchanged.  K is walked in chunks of 32, double-buffered; the global loads of chunk c+1 -- and
+// of the next work item's first chunk during the epilogue -- are in flight while chunk c is multiplied.  With WRES (K <= 64) the
+// workgroup's weight slice stays resident in LDS for its whole life and only activations are staged.  Work items are ordered
 // (pixel tile, channel slice) with the slice fastest and XCD-aware, so the slices of a tile re-read its activation rows from ONE
 // XCD's L2, back to back.
 #include "common.h"
+
+#include <stdlib.h>
 
 namespace {
 
@@ -26,16 +33,36 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int C1_PXB = 128;           // pixels per work item (4 waves x 32)
 constexpr int C1_KC = 32;             // K chunk
-constexpr int C1_XSTR = C1_PXB + 1;   // k-major stage rows, pad 1: the transposing scalar writes of the loader spread over the banks
+constexpr int C1_STR = C1_KC + 4;     // LDS row stride (floats) of a chunk tile
 
-template <int NT, bool STATS>
+// V float4 per thread = a [32 * V rows][32 floats] chunk tile: 8 consecutive lanes take one row's 128 bytes
+template <int V>
+__device__ __forceinline__ void c1_load_rows(float4 (&r)[V], const float* __restrict__ base, int row0, int row_end, int row_stride,
+                                             int kc, int tid) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int f = tid + 256 * i, row = row0 + (f >> 3), kq = f & 7;
+    r[i] = row < row_end ? *reinterpret_cast<const float4*>(base + static_cast<size_t>(row) * row_stride + kc * C1_KC + 4 * kq)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int V>
+__device__ __forceinline__ void c1_store_rows(const float4 (&r)[V], float* __restrict__ tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int f = tid + 256 * i;
+    *reinterpret_cast<float4*>(tile + (f >> 3) * C1_STR + 4 * (f & 7)) = r[i];
+  }
+}
+
+template <int NT, bool STATS, bool WRES>
 __global__ __launch_bounds__(256, 2) void c1x1_fwd(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y,
-                                                   float* __restrict__ partial, int M, int K, int N, int x_row_stride) {
+                                                   float* __restrict__ partial, int M, int K, int N, int x_row_stride, int dbg) {
   constexpr int NCH = NT * 32;
-  constexpr int WSTR = NCH + 1;
-  __shared__ float smem[2 * C1_KC * (C1_XSTR + WSTR)];
-  float (*sX)[C1_KC][C1_XSTR] = reinterpret_cast<float (*)[C1_KC][C1_XSTR]>(smem);
-  float (*sW)[C1_KC][WSTR] = reinterpret_cast<float (*)[C1_KC][WSTR]>(smem + 2 * C1_KC * C1_XSTR);
+  constexpr int WBUF = WRES ? 2 : 2;                          // WRES: the two K chunks of the resident slice (K <= 64)
+  __shared__ __attribute__((aligned(16))) float smem[2 * C1_PXB * C1_STR + WBUF * NCH * C1_STR];
+  float (*sX)[C1_PXB][C1_STR] = reinterpret_cast<float (*)[C1_PXB][C1_STR]>(smem);
+  float (*sW)[NCH][C1_STR] = reinterpret_cast<float (*)[NCH][C1_STR]>(smem + 2 * C1_PXB * C1_STR);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int nsl = N / NCH;                                    // channel slices per pixel tile
@@ -49,42 +76,44 @@ __global__ __launch_bounds__(256, 2) void c1x1_fwd(const float* __restrict__ X, 
   constexpr int XV = C1_PXB * C1_KC / 4 / 256;                // float4 loads per thread per chunk (8 lanes = one row's 128 bytes)
   constexpr int WV = NCH * C1_KC / 4 / 256;
   float4 rx[XV], rw[WV];
-  auto load_chunk = [&](int m0, int kc) {
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int f = tid + 256 * i, px = f >> 3, kq = f & 7;
-      const int m = m0 + px;
-      rx[i] = m < M ? *reinterpret_cast<const float4*>(X + static_cast<size_t>(m) * x_row_stride + kc * C1_KC + 4 * kq)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < WV; ++i) {
-      const int f = tid + 256 * i, ch = f >> 3, kq = f & 7;
-      rw[i] = *reinterpret_cast<const float4*>(Wt + static_cast<size_t>(n0 + ch) * K + kc * C1_KC + 4 * kq);
-    }
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int f = tid + 256 * i, px = f >> 3, kq = f & 7;
-      sX[buf][4 * kq + 0][px] = rx[i].x; sX[buf][4 * kq + 1][px] = rx[i].y;
-      sX[buf][4 * kq + 2][px] = rx[i].z; sX[buf][4 * kq + 3][px] = rx[i].w;
-    }
-#pragma unroll
-    for (int i = 0; i < WV; ++i) {
-      const int f = tid + 256 * i, ch = f >> 3, kq = f & 7;
-      sW[buf][4 * kq + 0][ch] = rw[i].x; sW[buf][4 * kq + 1][ch] = rw[i].y;
-      sW[buf][4 * kq + 2][ch] = rw[i].z; sW[buf][4 * kq + 3][ch] = rw[i].w;
-    }
-  };
+#define load_x(m0_, kc_) c1_load_rows<XV>(rx, X, (m0_), M, x_row_stride, (kc_), tid)
+#define load_w(kc_) c1_load_rows<WV>(rw, Wt, n0, N, K, (kc_), tid)
+#define store_x(buf_) c1_store_rows<XV>(rx, &sX[(buf_)][0][0], tid)
+#define store_w(buf_) c1_store_rows<WV>(rw, &sW[(buf_)][0][0], tid)
 
   float s1[NT], s2[NT];                                        // this lane's channel (32 t + l31): sum y, sum y^2 over its pixel rows
 #pragma unroll
   for (int t = 0; t < NT; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
 
+  if (WRES) {                                                  // the whole weight slice, once (K <= 64: at most two chunks)
+    load_w(0); store_w(0);
+    if (nchunk > 1) { load_w(1); store_w(1); }
+  }
   int item = L;
-  if (item < nitem) load_chunk((item / nsl) * C1_PXB, 0);
   int buf = 0;
+  if (item < nitem) {                                          // chunk 0 of the first item
+    load_x((item / nsl) * C1_PXB, 0);
+    if (!WRES) load_w(0);
+    store_x(0);
+    if (!WRES) store_w(0);
+  }
+  // Software pipeline over the work items: the OUTPUT of item i (16 * NT values per lane, kept in `prev`) is stored -- and its
+  // statistics taken -- between the MFMAs of item i+1's first chunk, one store per MFMA, instead of as a burst after its last chunk:
+  // the memory pipeline sees a steady stream while the matrix cores stay busy, and no wave sits in a store-queue stall with idle MFMAs.
+  floatx16 prev[NT];
+  int prev_m0 = -1;                                            // < 0: nothing pending
+  // register 4q + r of tile t = pixel row0 + 8 q + r (row0 = m0 + 32 w + 4 half), channel n0 + 32 t + l31
+#define C1_EMIT(qv)                                                                                          \
+  do {                                                                                                       \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                         \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
+        const float v = prev[t][4 * (qv) + r];                                                               \
+        const int m = prev_m0 + 32 * w + 8 * (qv) + 4 * half + r;                                            \
+        if (m < M && !(dbg & 1)) Y[static_cast<size_t>(m) * N + n0 + 32 * t + l31] = v;                       \
+        if (STATS) { s1[t] += v; s2[t] = fmaf(v, v, s2[t]); }   /* rows past M hold exact zeros */             \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
   for (; item < nitem; item += G) {
     const int m0 = (item / nsl) * C1_PXB;
     floatx16 acc[NT];
@@ -92,46 +121,51 @@ __global__ __launch_bounds__(256, 2) void c1x1_fwd(const float* __restrict__ X, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    store_chunk(buf);                                          // chunk 0 of this item (its loads were issued one stage earlier)
-    __syncthreads();
+    __syncthreads();                                           // chunk 0 of this item is in sX[buf] (staged one stage earlier)
     for (int c = 0; c < nchunk; ++c) {
-      if (c + 1 < nchunk) load_chunk(m0, c + 1);               // in flight during the MFMAs below
-      else if (item + G < nitem) load_chunk(((item + G) / nsl) * C1_PXB, 0);   // next item's first chunk: under the last MFMAs + epilogue
-#pragma unroll
-      for (int kk = 0; kk < C1_KC / 2; ++kk) {
-        const int k = 2 * kk + half;
-        const float a = sX[buf][k][32 * w + l31];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float b = sW[buf][k][32 * t + l31];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-        }
+      // prefetch (in flight during the MFMAs below): the next chunk of this item, or the first chunk of the next item
+      const bool last = c + 1 >= nchunk;
+      const bool pf = !last || item + G < nitem;
+      const int pm0 = last ? ((item + G) / nsl) * C1_PXB : m0, pkc = last ? 0 : c + 1;
+      if (pf && !(dbg & 2)) {
+        load_x(pm0, pkc);
+        if (!WRES) load_w(pkc);
       }
-      if (c + 1 < nchunk) {
-        store_chunk(buf ^ 1);                                  // the other buffer: its readers passed the previous barrier
-        __syncthreads();
+      const int wb = WRES ? c : buf;
+      const bool emit = c == 0 && prev_m0 >= 0;
+      if (!(dbg & 4))
+#pragma unroll
+      for (int j = 0; j < C1_KC / 8; ++j) {
+        const float4 av = *reinterpret_cast<const float4*>(&sX[buf][32 * w + l31][8 * j + 4 * half]);
+        float4 bv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const float4*>(&sW[wb][32 * t + l31][8 * j + 4 * half]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
+        if (emit) C1_EMIT(j);                                  // rows 8 j .. 8 j + 3 (+ 4 half) of the previous item's tile
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
       }
+      // stage the prefetched chunk in the OTHER buffer (its last readers passed an earlier barrier)
+      if (pf) {
+        store_x(buf ^ 1);
+        if (!WRES) store_w(buf ^ 1);
+      }
+      if (!last) __syncthreads();
       buf ^= 1;
     }
-    // epilogue: accumulator register 4q + r of tile t = pixel m0 + 32 w + 8 q + 4 half + r, channel n0 + 32 t + l31
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[t][4 * q + r];
-          const int m = m0 + 32 * w + 8 * q + 4 * half + r;
-          if (m < M) Y[static_cast<size_t>(m) * N + n0 + 32 * t + l31] = v;
-          if (STATS) { a1 += v; a2 = fmaf(v, v, a2); }          // rows past M hold exact zeros (zero-filled activations)
-        }
-      }
-      if (STATS) { s1[t] += a1; s2[t] += a2; }
-    }
-    // no barrier here: the next item's store_chunk(buf) goes to the buffer the LAST chunk did not read (its last readers passed an
-    // earlier barrier), so a wave may start staging the next item while the others finish this one
+    for (int t = 0; t < NT; ++t) prev[t] = acc[t];
+    prev_m0 = m0;
   }
+  if (prev_m0 >= 0) {                                          // the last item's output
+    C1_EMIT(0); C1_EMIT(1); C1_EMIT(2); C1_EMIT(3);
+  }
+#undef C1_EMIT
   if (STATS) {
     // 2 halves x 4 waves -> one value per channel, fixed order; row g = L / nsl of the slice's partial table
     float* red = smem;                                         // [2][4][NCH]
@@ -153,6 +187,8 @@ __global__ __launch_bounds__(256, 2) void c1x1_fwd(const float* __restrict__ X, 
     }
   }
 }
+
+int c1_dbg() { static const int v = getenv("DBEV_C1_DBG") ? atoi(getenv("DBEV_C1_DBG")) : 0; return v; }
 
 int c1_pick_nt(int N) {
   if (N % 32) return 0;
@@ -182,6 +218,11 @@ bool c1_plan(long long M, int K, int N, C1Plan* p) {
   return true;
 }
 
+#undef load_x
+#undef load_w
+#undef store_x
+#undef store_w
+
 }  // namespace
 
 extern "C" int dbev_conv1x1_stats_rows(long long M, int Cin, int Cout) {
@@ -197,14 +238,14 @@ extern "C" int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, fl
     return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   const int m = static_cast<int>(M);
+  const bool wres = Cin <= 2 * C1_KC;       // the weight slice fits the two chunk buffers: staged once per workgroup
+#define C1_GO(NTV, ST, WR)                                                                                                      \
+  hipLaunchKernelGGL((c1x1_fwd<NTV, ST, WR>), dim3(p.grid), dim3(256), 0, s, x_nhwc, weight, y_nhwc, stats_partial, m, Cin, Cout, \
+                     x_row_stride, c1_dbg())
 #define C1_LAUNCH(NTV)                                                                                                          \
   do {                                                                                                                          \
-    if (stats_partial != nullptr)                                                                                               \
-      hipLaunchKernelGGL((c1x1_fwd<NTV, true>), dim3(p.grid), dim3(256), 0, s, x_nhwc, weight, y_nhwc, stats_partial, m, Cin, Cout, \
-                         x_row_stride);                                                                                         \
-    else                                                                                                                        \
-      hipLaunchKernelGGL((c1x1_fwd<NTV, false>), dim3(p.grid), dim3(256), 0, s, x_nhwc, weight, y_nhwc, stats_partial, m, Cin, Cout, \
-                         x_row_stride);                                                                                         \
+    if (stats_partial != nullptr) { if (wres) C1_GO(NTV, true, true); else C1_GO(NTV, true, false); }                           \
+    else { if (wres) C1_GO(NTV, false, true); else C1_GO(NTV, false, false); }                                                  \
   } while (0)
   DbevKt kt(DBEV_K_CONV1X1_FWD, 4LL * M * (Cin + Cout), s);
   switch (p.nt) {
@@ -212,6 +253,7 @@ extern "C" int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, fl
     case 2: C1_LAUNCH(2); break;
     default: C1_LAUNCH(1); break;
   }
+#undef C1_GO
 #undef C1_LAUNCH
   DBEV_LAUNCH_CHECK();
   return 0;

@@ -463,6 +463,13 @@ int dbev_bn_act_train_forward(const float* x, const float* residual, const float
                               float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd,
                               float* save_scale_shift, long long M, int C, void* workspace, size_t workspace_bytes,
                               dbevStream_t stream);
+/* the same with the statistics pass replaced by partial sums the PRODUCER of x already took (dbev_conv1x1_forward's epilogue):
+ * stats_partial f32[partial_rows, 2, C] = per row (sum x, sum x^2) per channel over a disjoint share of the M rows; NULL = as above */
+int dbev_bn_act_train_forward_pre(const float* x, const float* residual, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                                  float eps, int relu, float* y, float* save_mean, float* save_invstd, float* save_scale_shift,
+                                  long long M, int C, const float* stats_partial, int partial_rows, void* workspace,
+                                  size_t workspace_bytes, dbevStream_t stream);
 /* eval mode (running statistics, no gradient): y = relu(x * scale + shift [+ residual]); workspace >= 8*C bytes */
 int dbev_bn_act_infer(const float* x, const float* residual, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, float eps, int relu, float* y,
@@ -486,6 +493,14 @@ int dbev_bn_dual_train_forward(const float* x, const float* xd, const float* gam
                                float* save_mean, float* save_invstd, float* save_scale_shift, float* save_mean_d,
                                float* save_invstd_d, float* save_scale_shift_d, long long M, int C, void* workspace,
                                size_t workspace_bytes, dbevStream_t stream);
+int dbev_bn_dual_train_forward_pre(const float* x, const float* xd, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                   const float* gamma_d, const float* beta_d, float* running_mean_d, float* running_var_d,
+                                   long long* num_batches_tracked_d, float momentum_d, float eps_d, int relu, float* y,
+                                   float* save_mean, float* save_invstd, float* save_scale_shift, float* save_mean_d,
+                                   float* save_invstd_d, float* save_scale_shift_d, long long M, int C,
+                                   const float* stats_partial, int partial_rows, const float* stats_partial_d, int partial_rows_d,
+                                   void* workspace, size_t workspace_bytes, dbevStream_t stream);
 int dbev_bn_dual_backward(const float* grad_y, const float* x, const float* xd, const float* y, const float* gamma,
                           const float* save_mean, const float* save_invstd, const float* gamma_d, const float* save_mean_d,
                           const float* save_invstd_d, int relu, float* grad_x, float* grad_xd, float* grad_gamma,
