@@ -205,13 +205,14 @@ class _Conv1x1Stats(Function):
 
 
 _C1 = {"enabled": os.environ.get("DBEV_CONV1X1", "1") != "0", "max_cin": int(os.environ.get("DBEV_CONV1X1_MAX_CIN", "512")),
-       "min_rows": int(os.environ.get("DBEV_CONV1X1_MIN_ROWS", "100000"))}
+       "min_rows": int(os.environ.get("DBEV_CONV1X1_MIN_ROWS", "300000"))}
 
 
 def conv1x1_bn_ready(conv, bn, x):
     """The 1x1 convolution + training-mode BatchNorm pairs the fused GEMM serves: where `conv + statistics pass` is slower in the
-    library than the hand-written kernel with the statistics in its epilogue -- measured (tools/kbench_c1x1.py): the large-map
-    layers, Cin <= 512 with >= 100 k pixels (stages 1 and 2 of the image backbone); elsewhere the library's kernels win."""
+    library than the hand-written kernel with the statistics in its epilogue -- measured (tools/kbench_c1x1.py,
+    profiles/r03_conv1x1_vs_miopen.txt): the >= 300 k-pixel maps of the image backbone's first stage (64 <-> 256 channels, HBM-bound:
+    conv + statistics 0.21 vs 0.30 ms); at stage 2 the two are even, from stage 3 on the library's kernels win."""
     if not (_C1["enabled"] and _state["enabled"] and type(conv) is nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None):
         return False

@@ -99,10 +99,10 @@ __device__ __forceinline__ void fma4v(float4& a, const float4& b, const float4& 
 // 256 MB memory-side cache is the END for the first pass and the START for the pass after it: measured -6 % / -12 %
 // on the forward+backward of 277 MB / 138 MB activations, neutral above 500 MB.
 template <bool REV = false>
-__device__ __forceinline__ int block_rows(const BnGeom& g, int* r_end, int rp_count) {
+__device__ __forceinline__ int block_rows(const BnGeom& g, int* r_end, int rp_count, bool rev = false) {
   int per = (g.M + gridDim.x - 1) / gridDim.x;
   per = (per + rp_count - 1) / rp_count * rp_count;
-  const long long b = static_cast<long long>(REV ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * per;
+  const long long b = static_cast<long long>((REV || rev) ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * per;
   const long long e = b + per;
   *r_end = static_cast<int>(e < g.M ? e : g.M);
   return static_cast<int>(b < g.M ? b : g.M);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ par
 template <bool RES, bool RELU, bool RAFF = false>
 __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, const float4* __restrict__ res,
                                                 const float* __restrict__ coef, float4* __restrict__ y, BnGeom g,
-                                                const float* __restrict__ rcoef = nullptr) {
+                                                const float* __restrict__ rcoef = nullptr, int rev = 0) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 sc = reinterpret_cast<const float4*>(coef)[q];
@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, co
   }
   const int stride = g.RP;
   int r_end;
-  for (int r0 = block_rows(g, &r_end, g.RP) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
+  // rev: x was just written front to back by its producer and no statistics pass has touched it since (the 1x1-convolution GEMM
+  // took the statistics itself): its TAIL is what the memory-side cache still holds, so the first workgroups start there
+  for (int r0 = block_rows(g, &r_end, g.RP, rev != 0) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
     float4 v[BN_ROWS_UNROLL], w[BN_ROWS_UNROLL];
 #pragma unroll
     for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
@@ -699,12 +701,14 @@ extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residu
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
   {
     DbevKt kt(residual != nullptr ? DBEV_K_BN_APPLY_RES : DBEV_K_BN_APPLY, T * (residual != nullptr ? 3 : 2), s);
+    const float* none = nullptr;
+    const int rev = stats_partial != nullptr ? 1 : 0;
     if (residual != nullptr) {
-      if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
-      else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+      if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev);
+      else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev);
     } else {
-      if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
-      else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g);
+      if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev);
+      else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev);
     }
   }
   DBEV_LAUNCH_CHECK();
@@ -853,8 +857,9 @@ extern "C" int dbev_bn_dual_train_forward_pre(const float* x, const float* xd, c
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
   DbevKt kt(DBEV_K_BN_APPLY_RES, T * 3, s);
   float4* y4 = reinterpret_cast<float4*>(y);
-  if (relu) hipLaunchKernelGGL((bn_apply<true, true, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d);
-  else hipLaunchKernelGGL((bn_apply<true, false, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d);
+  const int rev = (stats_partial != nullptr && stats_partial_d != nullptr) ? 1 : 0;
+  if (relu) hipLaunchKernelGGL((bn_apply<true, true, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev);
+  else hipLaunchKernelGGL((bn_apply<true, false, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -133,13 +133,29 @@ __global__ __launch_bounds__(256, 2) void c1x1_fwd(const float* __restrict__ X, 
       }
       const int wb = WRES ? c : buf;
       const bool emit = c == 0 && prev_m0 >= 0;
+      // operands of step group j + 1 are read from LDS before the 16 * NT / 4 ... MFMAs of group j are issued (register double
+      // buffer); the prefetched global chunk goes to the other LDS buffer before the LAST group, so that its write latency and
+      // the barrier that follows sit under that group's MFMAs instead of after them
+      const float* xrow = &sX[buf][32 * w + l31][4 * half];
+      const float* wrow = &sW[wb][l31][4 * half];
+      float4 av = *reinterpret_cast<const float4*>(xrow);
+      float4 bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const float4*>(wrow + 32 * t * C1_STR);
       if (!(dbg & 4))
 #pragma unroll
       for (int j = 0; j < C1_KC / 8; ++j) {
-        const float4 av = *reinterpret_cast<const float4*>(&sX[buf][32 * w + l31][8 * j + 4 * half]);
-        float4 bv[NT];
+        float4 an = av, bn[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const float4*>(&sW[wb][32 * t + l31][8 * j + 4 * half]);
+        for (int t = 0; t < NT; ++t) bn[t] = bv[t];
+        if (j + 1 < C1_KC / 8) {
+          an = *reinterpret_cast<const float4*>(xrow + 8 * (j + 1));
+#pragma unroll
+          for (int t = 0; t < NT; ++t) bn[t] = *reinterpret_cast<const float4*>(wrow + 32 * t * C1_STR + 8 * (j + 1));
+        } else if (pf) {
+          store_x(buf ^ 1);                                    // the other buffer: its last readers passed an earlier barrier
+          if (!WRES) store_w(buf ^ 1);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -149,9 +165,11 @@ __global__ __launch_bounds__(256, 2) void c1x1_fwd(const float* __restrict__ X, 
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
+        av = an;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = bn[t];
       }
-      // stage the prefetched chunk in the OTHER buffer (its last readers passed an earlier barrier)
-      if (pf) {
+      if ((dbg & 4) && pf) {
         store_x(buf ^ 1);
         if (!WRES) store_w(buf ^ 1);
       }
