@@ -20,6 +20,8 @@
 #include "common.h"
 #include "prims.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int SP_EMPTY = -1;
@@ -261,6 +263,131 @@ __global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in,
         *reinterpret_cast<float4*>(out + static_cast<size_t>(o[s]) * COUT + 16 * ct + 4 * kk) = v;
       }
     }
+  }
+}
+
+// The same convolution for the SPARSE early stages (16 / 32 channels, 1 ... 6 of 27 neighbours per site -- the output-stationary kernel
+// above multiplies an offset for all 16 sites of a tile when any of them has that neighbour: 4 ... 25 x the valid pairs there).
+// Here a wave owns 64 output sites and, per kernel offset, COMPACTS its valid (site, input row) pairs (ballot + prefix count into a
+// wave-private LDS list), multiplies them 16 pairs per MFMA tile and adds the 16 x Cout results into a wave-private LDS
+// accumulator [64 sites][Cout] (read-modify-write, no atomics: a site appears once per offset, offsets are walked in order and a
+// wave's LDS operations execute in order -> the reference's accumulation order per site, bit-reproducible).  One tile per offset
+// holds ~15 of 16 valid pairs at 6 neighbours per site instead of 4 of 16.
+constexpr int SPC_SITES = 256;          // output sites per workgroup (64 per wave)
+constexpr int SPC_MAXK = 27;
+
+// The wave's 64 x K slice of the neighbour table is one contiguous block of memory and comes in with coalesced loads once (the
+// per-offset strided read of one int per lane cost more than the gathers).  Weights: WLDS = the workgroup stages W[k] in LDS per
+// offset (two barriers per offset, every A operand an LDS read); !WLDS (16 -> 16 channels: 4 values per lane) = each lane loads
+// its A operands of W[k] straight into registers (L2 hits) and the four waves never synchronise.
+template <int CT, int G16, bool WLDS>
+__global__ __launch_bounds__(256) void sp_conv_fwd_cmp(const float* __restrict__ in, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const int* __restrict__ nbr,
+                                                       float* __restrict__ out, int M, int K,
+                                                       const float* __restrict__ scale, const float* __restrict__ residual, int relu) {
+  extern __shared__ float lds[];
+  constexpr int COUT = 16 * CT, CIN = 16 * G16, STR = COUT + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  float* wacc = lds + 64 * wv * STR;                                        // [64 sites][STR]   (wave-private)
+  int2* wl = reinterpret_cast<int2*>(lds + SPC_SITES * STR) + 64 * wv;      // [64] (site in wave, input row)
+  float* sW = lds + SPC_SITES * STR + 2 * SPC_SITES;                        // WLDS: [CIN][STR]
+  int* wnb = reinterpret_cast<int*>(lds + SPC_SITES * STR + 2 * SPC_SITES) + 64 * K * wv;   // !WLDS: [64 sites][K]
+  const int base = blockIdx.x * SPC_SITES + 64 * wv;
+  if (!WLDS && base >= M) return;
+  for (int i = lane; i < 64 * STR / 4; i += 64) reinterpret_cast<float4*>(wacc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int o = base + lane;
+  int nb_next = -1;
+  if (WLDS) {                                          // (staging the table costs the third resident workgroup here: strided reads, one offset ahead)
+    nb_next = o < M ? nbr[static_cast<size_t>(o) * K] : -1;
+  } else {
+    const long long nbr_end = static_cast<long long>(M) * K;
+    for (int i = lane; i < 64 * K; i += 64) {
+      const long long gi = static_cast<long long>(base) * K + i;
+      wnb[i] = gi < nbr_end ? nbr[gi] : -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const float4* W4 = reinterpret_cast<const float4*>(W);
+  for (int k = 0; k < K; ++k) {
+    int nb;
+    if (WLDS) {
+      nb = nb_next;
+      if (k + 1 < K) nb_next = o < M ? nbr[static_cast<size_t>(o) * K + k + 1] : -1;
+    } else {
+      nb = wnb[lane * K + k];
+    }
+    const unsigned long long mask = __ballot(nb >= 0);
+    const int n = __popcll(mask);
+    float a[G16][4][CT];                                                     // !WLDS: W[k] in the A-operand layout of this lane
+    if (WLDS) {
+      if (!__syncthreads_or(n > 0)) continue;                                // also the barrier that lets sW be overwritten
+      for (int i = tid; i < CIN * (COUT / 4); i += 256) {
+        const int row = i / (COUT / 4), c4 = i - row * (COUT / 4);
+        *reinterpret_cast<float4*>(&sW[row * STR + 4 * c4]) = W4[(static_cast<size_t>(k) * CIN + row) * (COUT / 4) + c4];
+      }
+    } else {
+      if (n == 0) continue;
+#pragma unroll
+      for (int g = 0; g < G16; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) a[g][t][ct] = W[(static_cast<size_t>(k) * CIN + 16 * g + 4 * kk + t) * COUT + 16 * ct + j];
+    }
+    if (nb >= 0) wl[__popcll(mask & ((1ull << lane) - 1ull))] = make_int2(lane, nb);
+    if (WLDS) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    for (int t0 = 0; t0 < n; t0 += 16) {
+      const int p = t0 + j;
+      const bool valid = p < n;
+      const int2 e = valid ? wl[p] : make_int2(0, 0);
+      const float* row = in + static_cast<size_t>(e.y) * CIN + 4 * kk;
+      float4 bv[G16];
+#pragma unroll
+      for (int g = 0; g < G16; ++g) bv[g] = valid ? *reinterpret_cast<const float4*>(row + 16 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      floatx4 acc[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G16; ++g) {
+        const float b[4] = {bv[g].x, bv[g].y, bv[g].z, bv[g].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(WLDS ? sW[(16 * g + 4 * kk + t) * STR + 16 * ct + j] : a[g][t][ct], b[t], acc[ct], 0, 0, 0);
+      }
+      if (valid) {                                     // accumulator rows = output channels 16 ct + 4 kk + (0..3) of pair j
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          float4* d = reinterpret_cast<float4*>(wacc + e.x * STR + 16 * ct + 4 * kk);
+          float4 v = *d;
+          v.x += acc[ct][0]; v.y += acc[ct][1]; v.z += acc[ct][2]; v.w += acc[ct][3];
+          *d = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                   // the list is rewritten by the next offset
+  }
+  for (int i = lane; i < 64 * (COUT / 4); i += 64) {
+    const int site = i / (COUT / 4), c4 = i - site * (COUT / 4);
+    const int o2 = base + site;
+    if (o2 >= M) continue;
+    float4 v = *reinterpret_cast<const float4*>(wacc + site * STR + 4 * c4);
+    if (scale != nullptr) {
+      const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * c4);
+      v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+    }
+    if (bias != nullptr) {
+      const float4 bi = *reinterpret_cast<const float4*>(bias + 4 * c4);
+      v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+    }
+    if (residual != nullptr) {
+      const float4 rs = *reinterpret_cast<const float4*>(residual + static_cast<size_t>(o2) * COUT + 4 * c4);
+      v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(out + static_cast<size_t>(o2) * COUT + 4 * c4) = v;
   }
 }
 
@@ -571,9 +698,43 @@ extern "C" int dbev_spconv_forward_fused(const float* features, const float* wei
   if (n_out < 0 || K <= 0 || Cin <= 0 || (Cin & 15) || Cout <= 0 || (Cout & 15) || Cout > 128 || Cin > 256) return DBEV_EINVAL;
   if (n_out == 0) return 0;
   if (features == nullptr || weight == nullptr || nbr == nullptr || out_features == nullptr) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  // the sparse early stages (<= 32 input channels: 1 ... 6 of 27 neighbours per site in the voxel teachers) run on the pair-compacting
+  // kernel, the dense ones on the output-stationary kernel; DBEV_SPCONV_COMPACT=0 / 1 forces one of them (A/B runs)
+  static const int force_cmp = getenv("DBEV_SPCONV_COMPACT") ? atoi(getenv("DBEV_SPCONV_COMPACT")) : -1;
+  if ((force_cmp == 1 || force_cmp < 0) && Cin <= 32 && Cout <= 64 && K <= SPC_MAXK) {
+    const bool wlds = !(Cin == 16 && Cout == 16);
+    const size_t ldc = sizeof(float) * SPC_SITES * (Cout + 4) + sizeof(int2) * SPC_SITES +
+                       (wlds ? sizeof(float) * Cin * (Cout + 4) : sizeof(int) * SPC_SITES * K);
+    const dim3 gridc(dbev_ceil_div(n_out, SPC_SITES));
+#define SPC_GO(CTV, GV, WL)                                                                                          \
+  do {                                                                                                               \
+    if (ldc > 64 * 1024)                                                                                             \
+      DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sp_conv_fwd_cmp<CTV, GV, WL>),                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldc)));          \
+    hipLaunchKernelGGL((sp_conv_fwd_cmp<CTV, GV, WL>), gridc, dim3(256), ldc, s, features, weight, bias, nbr, out_features, n_out, \
+                       K, scale, residual, relu);                                                                    \
+  } while (0)
+#define SPC_LAUNCH(CTV)                                                        \
+  do {                                                                         \
+    if (!wlds) SPC_GO(1, 1, false);                                            \
+    else if (Cin == 16) SPC_GO(CTV, 1, true);                                  \
+    else SPC_GO(CTV, 2, true);                                                 \
+  } while (0)
+    DbevKt kt(DBEV_K_SPCONV_FWD, 4LL * n_out * (Cout + K) + 4LL * K * Cin * Cout, s);
+    switch (Cout / 16) {
+      case 1: SPC_LAUNCH(1); break;
+      case 2: SPC_LAUNCH(2); break;
+      case 3: SPC_LAUNCH(3); break;
+      default: SPC_LAUNCH(4); break;
+    }
+#undef SPC_LAUNCH
+#undef SPC_GO
+    DBEV_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = sizeof(float) * static_cast<size_t>(Cin) * (Cout + 4);
   const dim3 grid(dbev_ceil_div(n_out, SP_SITES));
-  hipStream_t s = dbev_stream(stream);
 #define SP_LAUNCH(CTV)                                                                                              \
   do {                                                                                                              \
     if (lds > 64 * 1024)                                                                                            \
