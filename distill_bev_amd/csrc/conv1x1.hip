@@ -97,93 +97,94 @@ __global__ __launch_bounds__(256, 2) void c1x1_fwd(const float* __restrict__ X, 
     store_x(0);
     if (!WRES) store_w(0);
   }
-  // Software pipeline over the work items: the OUTPUT of item i (16 * NT values per lane, kept in `prev`) is stored -- and its
-  // statistics taken -- between the MFMAs of item i+1's first chunk, one store per MFMA, instead of as a burst after its last chunk:
-  // the memory pipeline sees a steady stream while the matrix cores stay busy, and no wave sits in a store-queue stall with idle MFMAs.
-  floatx16 prev[NT];
-  int prev_m0 = -1;                                            // < 0: nothing pending
+  // Software pipeline over the work items: the OUTPUT of item i (16 * NT values per lane) is stored -- and its statistics taken --
+  // under the MFMAs of item i+1's first chunk, ONE value behind each MFMA (a store, two statistics FMAs and an address add fit in
+  // the 64-cycle shadow of a v_mfma_f32_32x32x2; a burst of them between MFMA groups left the matrix pipe idle a fifth of the
+  // time).  Two accumulator sets alternate (item loop unrolled by two): no copy between them.
   // register 4q + r of tile t = pixel row0 + 8 q + r (row0 = m0 + 32 w + 4 half), channel n0 + 32 t + l31
-#define C1_EMIT(qv)                                                                                          \
-  do {                                                                                                       \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                         \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
-        const float v = prev[t][4 * (qv) + r];                                                               \
-        const int m = prev_m0 + 32 * w + 8 * (qv) + 4 * half + r;                                            \
-        if (m < M && !(dbg & 1)) Y[static_cast<size_t>(m) * N + n0 + 32 * t + l31] = v;                       \
-        if (STATS) { s1[t] += v; s2[t] = fmaf(v, v, s2[t]); }   /* rows past M hold exact zeros */             \
-      }                                                                                                      \
-    }                                                                                                        \
+#define C1_EMIT1(PRV, pm0_, full_, q_, t_, r_)                                                                 \
+  do {                                                                                                         \
+    const float v_ = PRV[t_][4 * (q_) + (r_)];                                                                 \
+    const int m_ = (pm0_) + 32 * w + 8 * (q_) + 4 * half + (r_);                                               \
+    if (((full_) || m_ < M) && !(dbg & 1)) Y[static_cast<size_t>(m_) * N + n0 + 32 * (t_) + l31] = v_;         \
+    if (STATS) { s1[t_] += v_; s2[t_] = fmaf(v_, v_, s2[t_]); }   /* rows past M hold exact zeros */            \
   } while (0)
-  for (; item < nitem; item += G) {
-    const int m0 = (item / nsl) * C1_PXB;
-    floatx16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    __syncthreads();                                           // chunk 0 of this item is in sX[buf] (staged one stage earlier)
-    for (int c = 0; c < nchunk; ++c) {
-      // prefetch (in flight during the MFMAs below): the next chunk of this item, or the first chunk of the next item
-      const bool last = c + 1 >= nchunk;
-      const bool pf = !last || item + G < nitem;
-      const int pm0 = last ? ((item + G) / nsl) * C1_PXB : m0, pkc = last ? 0 : c + 1;
-      if (pf && !(dbg & 2)) {
-        load_x(pm0, pkc);
-        if (!WRES) load_w(pkc);
-      }
-      const int wb = WRES ? c : buf;
-      const bool emit = c == 0 && prev_m0 >= 0;
-      // operands of step group j + 1 are read from LDS before the 16 * NT / 4 ... MFMAs of group j are issued (register double
-      // buffer); the prefetched global chunk goes to the other LDS buffer before the LAST group, so that its write latency and
-      // the barrier that follows sit under that group's MFMAs instead of after them
-      const float* xrow = &sX[buf][32 * w + l31][4 * half];
-      const float* wrow = &sW[wb][l31][4 * half];
-      float4 av = *reinterpret_cast<const float4*>(xrow);
-      float4 bv[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const float4*>(wrow + 32 * t * C1_STR);
-      if (!(dbg & 4))
-#pragma unroll
-      for (int j = 0; j < C1_KC / 8; ++j) {
-        float4 an = av, bn[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bn[t] = bv[t];
-        if (j + 1 < C1_KC / 8) {
-          an = *reinterpret_cast<const float4*>(xrow + 8 * (j + 1));
-#pragma unroll
-          for (int t = 0; t < NT; ++t) bn[t] = *reinterpret_cast<const float4*>(wrow + 32 * t * C1_STR + 8 * (j + 1));
-        } else if (pf) {
-          store_x(buf ^ 1);                                    // the other buffer: its last readers passed an earlier barrier
-          if (!WRES) store_w(buf ^ 1);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
-        if (emit) C1_EMIT(j);                                  // rows 8 j .. 8 j + 3 (+ 4 half) of the previous item's tile
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
-        av = an;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bv[t] = bn[t];
-      }
-      if ((dbg & 4) && pf) {
-        store_x(buf ^ 1);
-        if (!WRES) store_w(buf ^ 1);
-      }
-      if (!last) __syncthreads();
-      buf ^= 1;
+#define C1_STEP(ACC, PRV, comp, r_)                                                                            \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                             \
+    ACC[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.comp, bv[t].comp, ACC[t], 0, 0, 0);                       \
+    if (emit) C1_EMIT1(PRV, prev_m0, prev_full, j, t, r_);                                                     \
+  }
+#define C1_ITEM(ACC, PRV, item_)                                                                               \
+  do {                                                                                                         \
+    const int it_ = (item_);                                                                                   \
+    const int m0 = (it_ / nsl) * C1_PXB;                                                                       \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) ACC[t][r] = 0.f;                                          \
+    __syncthreads();               /* chunk 0 of this item is in sX[buf] (staged one stage earlier) */          \
+    for (int c = 0; c < nchunk; ++c) {                                                                         \
+      /* prefetch (in flight during the MFMAs below): the next chunk of this item, or the first chunk of the next item */ \
+      const bool last = c + 1 >= nchunk;                                                                       \
+      const bool pf = !last || it_ + G < nitem;                                                                \
+      const int pm0 = last ? ((it_ + G) / nsl) * C1_PXB : m0, pkc = last ? 0 : c + 1;                          \
+      if (pf && !(dbg & 2)) {                                                                                  \
+        load_x(pm0, pkc);                                                                                      \
+        if (!WRES) load_w(pkc);                                                                                \
+      }                                                                                                        \
+      const int wb = WRES ? c : buf;                                                                           \
+      const bool emit = c == 0 && prev_m0 >= 0 && !(dbg & 16);                                                 \
+      const float* xrow = &sX[buf][32 * w + l31][4 * half];                                                    \
+      const float* wrow = &sW[wb][l31][4 * half];                                                              \
+      if (!(dbg & 4)) {                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < C1_KC / 8; ++j) {                                                \
+          /* the prefetched global chunk goes to the other LDS buffer before the LAST step group: its write latency and the  \
+             barrier that follows sit under that group's MFMAs */                                               \
+          if (j + 1 == C1_KC / 8 && pf && !(dbg & 8)) {                                                        \
+            store_x(buf ^ 1);      /* the other buffer: its last readers passed an earlier barrier */          \
+            if (!WRES) store_w(buf ^ 1);                                                                       \
+          }                                                                                                    \
+          const float4 av = *reinterpret_cast<const float4*>(xrow + 8 * j);                                    \
+          float4 bv[NT];                                                                                       \
+          _Pragma("unroll") for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const float4*>(wrow + 32 * t * C1_STR + 8 * j); \
+          C1_STEP(ACC, PRV, x, 0)                                                                              \
+          C1_STEP(ACC, PRV, y, 1)                                                                              \
+          C1_STEP(ACC, PRV, z, 2)                                                                              \
+          C1_STEP(ACC, PRV, w, 3)                                                                              \
+        }                                                                                                      \
+      } else if (pf) {                                                                                         \
+        store_x(buf ^ 1);                                                                                      \
+        if (!WRES) store_w(buf ^ 1);                                                                           \
+      }                                                                                                        \
+      if (!last) __syncthreads();                                                                              \
+      buf ^= 1;                                                                                                \
+    }                                                                                                          \
+    prev_m0 = m0;                                                                                              \
+    prev_full = m0 + C1_PXB <= M;                                                                              \
+  } while (0)
+
+  floatx16 accA[NT], accB[NT];
+  int prev_m0 = -1;                                            // < 0: nothing pending
+  bool prev_full = false, last_in_a = false;
+  for (; item < nitem; item += 2 * G) {
+    C1_ITEM(accA, accB, item);
+    last_in_a = true;
+    if (item + G < nitem) {
+      C1_ITEM(accB, accA, item + G);
+      last_in_a = false;
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) prev[t] = acc[t];
-    prev_m0 = m0;
   }
   if (prev_m0 >= 0) {                                          // the last item's output
-    C1_EMIT(0); C1_EMIT(1); C1_EMIT(2); C1_EMIT(3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (last_in_a) C1_EMIT1(accA, prev_m0, prev_full, q, t, r); else C1_EMIT1(accB, prev_m0, prev_full, q, t, r);
+        }
   }
-#undef C1_EMIT
+#undef C1_ITEM
+#undef C1_STEP
+#undef C1_EMIT1
   if (STATS) {
     // 2 halves x 4 waves -> one value per channel, fixed order; row g = L / nsl of the slice's partial table
     float* red = smem;                                         // [2][4][NCH]
