@@ -6,6 +6,8 @@ The bilinear sampling + modulation (im2col) and its backward (col2im, offset/mas
 ``libdbev_hip.so`` (``csrc/dcn.hip``); the (k, c) contraction with the weight is a 1x1 convolution of the
 channels-last column tensor, i.e. an MFMA GEMM in MIOpen -- the same split as mmcv's im2col + GEMM.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -58,6 +60,10 @@ def modulated_deform_conv2d_raw(x, offset_mask, weight, bias, stride=1, padding=
     Co, C, kh, kw = weight.shape
     cols = _DCNv2Columns.apply(x, offset_mask, kh, kw, stride, padding, dilation)
     w = weight.permute(0, 2, 3, 1).reshape(Co, kh * kw * C, 1, 1)       # (k, c) order of the columns
+    if os.environ.get("DBEV_DCN_GEMM") == "1":                           # the same contraction as a plain GEMM (debugging / A-B aid)
+        N, KC, Ho, Wo = cols.shape
+        y = F.linear(cols.permute(0, 2, 3, 1).reshape(-1, KC), w.view(Co, KC), bias)
+        return y.view(N, Ho, Wo, Co).permute(0, 3, 1, 2)
     return F.conv2d(cols, w, bias)
 
 

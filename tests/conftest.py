@@ -9,6 +9,16 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# MIOpen on a machine without a find database for gfx950 (every fresh GPU box: ROCm 7.2 ships none) answers the FIRST convolution of
+# every new shape with a hybrid search that launches each applicable solver -- naive / debug kernels included -- and keeps the
+# fastest by a one-shot timing.  On the odd, tiny shapes of these tests that search is not reliable: observed in round 3 on fresh
+# boxes (tools/abort_shim.c gave the native side of it): a GPU memory access fault inside the backward of a 32 -> 4 channel 1x1
+# convolution (test_gpu_dcn), and first-call input gradients off by 3e-3 for a 256 -> 64 bottleneck (test_gpu_conv1x1), both only
+# in the process that ran the search and depending on which candidate happened to win.  The tests are about THIS library's kernels:
+# they run MIOpen in its immediate ("FAST") mode -- find-db hit or heuristic pick, no search -- which is also what the product path
+# amounts to, since it ships tuned tables for its recipes' shapes (distill_bev_amd/miopen_db, tests/test_gpu_miopen_tables.py).
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -22,3 +32,4 @@ def golden_dir():
 def load_golden(name):
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, name)))
+

@@ -75,6 +75,14 @@ for _ in range(3):
     o = multi_scale_deformable_attn(val, shapes, starts, loc, att)
     o.backward(torch.ones_like(o))
     val.grad = None; loc.grad = None; att.grad = None
+# round 3: 1x1 convolution + BatchNorm statistics GEMM at the first-stage shape (48 x 64 -> 256 x 64 x 176; 692 MB algorithmic)
+from distill_bev_amd import _lib as L
+Mc, Kc, Nc = 48 * 64 * 176, 64, 256
+xc = torch.randn((Mc, Kc), device=dev); wc = torch.randn((Nc, Kc), device=dev) * 0.1
+yc = torch.empty((Mc, Nc), device=dev)
+pc = torch.empty((int(L.call("dbev_conv1x1_stats_rows", Mc, Kc, Nc)), 2, Nc), device=dev)
+for _ in range(5):
+    L.call("dbev_conv1x1_forward", L.ptr(xc), L.ptr(wc), L.ptr(yc), L.ptr(pc), Mc, Kc, Nc, Kc, L.stream_ptr(dev))
 # calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (MI355X_MICROARCH.md, HBM section)
 buf = torch.empty((128 * 1024 * 1024,), device=dev); src = torch.randn_like(buf)   # 512 MiB each
 for _ in range(3):
