@@ -185,3 +185,42 @@ def test_full_size_lift_splat_vs_fp64_oracle_on_one_sample_frame(full):
     err = np.abs(bev1[s].cpu().numpy() - ref[0]).max()
     print("full-size lift-splat sample-frame L-inf vs fp64 oracle", err, "max |bev|", np.abs(ref).max())
     assert err < 1e-4
+
+
+def test_full_size_bevformer_distillation_step():
+    """BASELINE configs[4] at the size `bench.py --workload bevformer_distill` times (queue of 4 frames x 6 cameras x 928 x 1600,
+    200 x 200 BEV queries, 900 object queries, 400 k virtual points through the sparse encoder): the losses of two forward passes
+    on the same weights and batch agree to 1e-4 (the deformable attentions and sparse convolutions are bit-reproducible; MIOpen's
+    split-K convolutions are not), every loss is finite, one optimizer step runs and moves the weights, and no fused op of the
+    step takes the stock torch path."""
+    import os
+    from distill_bev_amd import _lib as L
+    from distill_bev_amd import bevformer  # noqa: F401
+    from distill_bev_amd.bevformer import make_bevformer_batch
+    from distill_bev_amd.train_step import Trainer, build_model
+    dev = torch.device("cuda:0")
+    cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "distillbev_mvpformer2bevformer_r50.py")
+    model, cfg = build_model(cfg_path, seed=0, allow_synthetic_teacher=True)
+    tr = Trainer(model, cfg, dev, world_size=1, channels_last=True)
+    batch = make_bevformer_batch(1, np.random.default_rng(1234), dev, queue_length=cfg.queue_length)
+    # the history frames run in eval mode on the running statistics the training-mode pass over the current frame updates:
+    # the second pass starts from the same buffers as the first
+    bufs = {k: v.clone() for k, v in tr.detector.state_dict().items() if "running_" in k or "num_batches" in k}
+    np.random.seed(0); torch.manual_seed(0)                    # GridMask draws, dropout
+    a = tr.detector.forward_train(**batch)
+    tr.detector.load_state_dict(bufs, strict=False)
+    np.random.seed(0); torch.manual_seed(0)
+    b = tr.detector.forward_train(**batch)
+    assert set(a) == set(b) and len(a) >= 7
+    for k in a:
+        x, y = float(a[k].detach()), float(b[k].detach())
+        assert np.isfinite(x) and np.isfinite(y), k
+        assert abs(x - y) <= 1e-4 * max(abs(x), 1e-3), (k, x, y)
+    L.fallback_reset()
+    w0 = [p.detach().clone() for p in tr.params[:4]]
+    loss, _ = tr.step(batch)
+    assert bool(torch.isfinite(loss))
+    assert any(not torch.equal(p, q) for p, q in zip(tr.params[:4], w0))
+    counts = L.fallback_counts()
+    assert counts["adapt_mse"] == 0 and counts["skinny_conv"] == 0 and counts["head_batch"] == 0 and counts["pillar_vfe"] == 0, counts
+    print("bevformer full-size fallbacks:", counts)
