@@ -23,6 +23,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 namespace {
 
 constexpr int BN_MAX_BLOCKS_X = 2048;   // partial sums per channel merged by the finalize kernels
@@ -143,8 +145,144 @@ __device__ __forceinline__ void block_merge_store(float4 a, float4 b, float* __r
   }
 }
 
+
+// ---- finalize without a launch (round 3) -------------------------------------------------------------------------------------
+// The merge of the per-workgroup partial rows used to be its own 16..64-workgroup kernel between the reduction pass and the
+// streaming pass that needs its result (bn_finalize / bn_bwd_finalize*: 235 launches, 1.6 ms per training step).  Now:
+//  * producers (bn_stats, bn_bwd_reduce*): the 16 workgroups of a GROUP of consecutive blockIdx.x take a ticket after writing their
+//    rows; the last arriver merges the group's rows (fixed order) into the group's first row -- groups finish at different times, so
+//    these merges overlap the pass itself;
+//  * consumers (bn_apply, bn_bwd_dx*): every thread merges the <= 16 group rows of its own four channels in fp64 in its prologue
+//    (<= 32 float4 loads out of L2, the same addresses for every workgroup) and derives its coefficients in registers; workgroup 0 of
+//    a column chunk also writes what later kernels read (saved mean / invstd / scale / shift, running statistics, dgamma / dbeta).
+// Tickets live in a small device array, self-resetting (the last arriver zeroes its slot); the host hands every call its own slots.
+constexpr int BN_GROUP = 16;            // workgroups per group
+constexpr int BN_MAX_GROUPS = 16;       // groups per column chunk (NBX <= 256)
+constexpr int BN_TICKET_SLOTS = 8192;
+__device__ unsigned g_bn_tickets[BN_TICKET_SLOTS];
+
+template <int TPB, int V>
+__device__ __forceinline__ void group_merge(float* __restrict__ partial, int C, int CH, int RRP, int q, int ql, int rp, int nbx,
+                                            unsigned* __restrict__ tickets) {
+  __shared__ int s_last;
+  __shared__ float4 sm[V][TPB];
+  const int g = blockIdx.x / BN_GROUP;
+  const int cnt = min(BN_GROUP, nbx - g * BN_GROUP);
+  __syncthreads();                                   // the row's stores are issued ...
+  if (threadIdx.x == 0) {
+    __threadfence();                                 // ... and visible device-wide before the ticket (ONE release per workgroup: the
+                                                     // fence writes the XCD's L2 back; per thread it cost 40 us per launch)
+    unsigned* tk = tickets + blockIdx.y * BN_MAX_GROUPS + g;
+    const unsigned t = atomicAdd(tk, 1u);
+    s_last = (t == static_cast<unsigned>(cnt - 1));
+    if (s_last) *tk = 0u;                            // every member has arrived: the slot is free for its next user
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();                                   // the other members' rows
+  float4 acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = rp; r < cnt; r += RRP) {
+    const size_t row = static_cast<size_t>(g) * BN_GROUP + r;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const float4 x = reinterpret_cast<const float4*>(partial + (row * V + v) * C)[q];
+      acc[v].x += x.x; acc[v].y += x.y; acc[v].z += x.z; acc[v].w += x.w;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) sm[v][threadIdx.x] = acc[v];
+  __syncthreads();
+  for (int st = RRP >> 1; st > 0; st >>= 1) {
+    if (rp < st) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float4 a = sm[v][threadIdx.x];
+        const float4 b = sm[v][threadIdx.x + st * CH];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        sm[v][threadIdx.x] = a;
+      }
+    }
+    __syncthreads();
+  }
+  if (rp == 0) {
+    const size_t row = static_cast<size_t>(g) * BN_GROUP;
+#pragma unroll
+    for (int v = 0; v < V; ++v) reinterpret_cast<float4*>(partial + (row * V + v) * C)[q] = sm[v][ql];
+  }
+}
+
+struct d4 { double x, y, z, w; };
+// fp64 sum of the group rows (first row of every group) of value v for this thread's four channels
+template <int V>
+__device__ __forceinline__ void merged_rows(const float* __restrict__ partial, int C, int q, int nbx, d4 (&out)[V]) {
+#pragma unroll
+  for (int v = 0; v < V; ++v) out[v] = d4{0.0, 0.0, 0.0, 0.0};
+  const int ng = (nbx + BN_GROUP - 1) / BN_GROUP;
+  for (int g = 0; g < ng; ++g) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const float4 x = reinterpret_cast<const float4*>(partial + (static_cast<size_t>(g) * BN_GROUP * V + v) * C)[q];
+      out[v].x += x.x; out[v].y += x.y; out[v].z += x.z; out[v].w += x.w;
+    }
+  }
+}
+
+// forward finalize in a consumer's prologue: scale / shift of this thread's four channels; `write`: also store what later kernels read
+struct BnFin {
+  const float* partial;           // nullptr: coefficients come from memory (bn_finalize ran, or eval mode)
+  int nbx, M;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  float momentum, eps;
+  float *save_mean, *save_invstd, *coef;
+  long long* nbt;
+};
+
+__device__ __forceinline__ void fin_forward(const BnFin& f, int C, int q, bool write, float4* sc_out, float4* sh_out) {
+  d4 m[2];
+  merged_rows<2>(f.partial, C, q, f.nbx, m);
+  const double s[4] = {m[0].x, m[0].y, m[0].z, m[0].w}, sq[4] = {m[1].x, m[1].y, m[1].z, m[1].w};
+  float sc[4], sh[4], mf[4], is[4];
+  const float4 ga = reinterpret_cast<const float4*>(f.gamma)[q], be = reinterpret_cast<const float4*>(f.beta)[q];
+  const float gv[4] = {ga.x, ga.y, ga.z, ga.w}, bv[4] = {be.x, be.y, be.z, be.w};
+  double mean[4], var[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mean[i] = s[i] / f.M;
+    var[i] = sq[i] / f.M - mean[i] * mean[i];
+    if (var[i] < 0.0) var[i] = 0.0;
+    is[i] = static_cast<float>(1.0 / sqrt(var[i] + static_cast<double>(f.eps)));
+    mf[i] = static_cast<float>(mean[i]);
+    sc[i] = gv[i] * is[i];
+    sh[i] = fmaf(-mf[i], sc[i], bv[i]);
+  }
+  *sc_out = make_float4(sc[0], sc[1], sc[2], sc[3]);
+  *sh_out = make_float4(sh[0], sh[1], sh[2], sh[3]);
+  if (write) {
+    reinterpret_cast<float4*>(f.save_mean)[q] = make_float4(mf[0], mf[1], mf[2], mf[3]);
+    reinterpret_cast<float4*>(f.save_invstd)[q] = make_float4(is[0], is[1], is[2], is[3]);
+    reinterpret_cast<float4*>(f.coef)[q] = *sc_out;
+    reinterpret_cast<float4*>(f.coef + C)[q] = *sh_out;
+    if (f.running_mean != nullptr) {
+      float4 rm = reinterpret_cast<float4*>(f.running_mean)[q], rv = reinterpret_cast<float4*>(f.running_var)[q];
+      float r1[4] = {rm.x, rm.y, rm.z, rm.w}, r2[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double unbiased = f.M > 1 ? var[i] * (static_cast<double>(f.M) / (f.M - 1)) : var[i];
+        r1[i] = static_cast<float>((1.0 - f.momentum) * r1[i] + f.momentum * mean[i]);
+        r2[i] = static_cast<float>((1.0 - f.momentum) * r2[i] + f.momentum * unbiased);
+      }
+      reinterpret_cast<float4*>(f.running_mean)[q] = make_float4(r1[0], r1[1], r1[2], r1[3]);
+      reinterpret_cast<float4*>(f.running_var)[q] = make_float4(r2[0], r2[1], r2[2], r2[3]);
+    }
+  }
+}
+
 template <int TPB, int UNR>
-__global__ __launch_bounds__(TPB) void bn_stats(const float4* __restrict__ x, float* __restrict__ partial, BnGeom g) {
+__global__ __launch_bounds__(TPB) void bn_stats(const float4* __restrict__ x, float* __restrict__ partial, BnGeom g,
+                                                 unsigned* __restrict__ tickets = nullptr) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   float4 s = f4(0.f), ss = f4(0.f);
@@ -163,6 +301,7 @@ __global__ __launch_bounds__(TPB) void bn_stats(const float4* __restrict__ x, fl
       for (int u = 0; u < UNR; ++u) { add4(s, v[u]); fma4v(ss, v[u], v[u]); }
     }
     block_merge_store<TPB>(s, ss, partial, g.C, g.CH, g.RRP, q, ql, rp);
+    if (tickets != nullptr) group_merge<TPB, 2>(partial, g.C, g.CH, g.RRP, q, ql, rp, gridDim.x, tickets);
     return;
   }
   int r_end;
@@ -180,6 +319,7 @@ __global__ __launch_bounds__(TPB) void bn_stats(const float4* __restrict__ x, fl
     fma4v(ss, v, v);
   }
   block_merge_store<TPB>(s, ss, partial, g.C, g.CH, g.RRP, q, ql, rp);
+  if (tickets != nullptr) group_merge<TPB, 2>(partial, g.C, g.CH, g.RRP, q, ql, rp, gridDim.x, tickets);
 }
 
 // 4 channels x 64 partial phases per workgroup; fp64 merge in a fixed order.  coef: [0] scale, [1] shift (forward) -- saved for backward.
@@ -243,15 +383,29 @@ __global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ par
 template <bool RES, bool RELU, bool RAFF = false>
 __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, const float4* __restrict__ res,
                                                 const float* __restrict__ coef, float4* __restrict__ y, BnGeom g,
-                                                const float* __restrict__ rcoef = nullptr, int rev = 0) {
+                                                const float* __restrict__ rcoef, int rev, BnFin fin, BnFin fin_d) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
-  const float4 sc = reinterpret_cast<const float4*>(coef)[q];
-  float4 sh = reinterpret_cast<const float4*>(coef + g.C)[q];
+  const bool writer = blockIdx.x == 0 && rp == 0;
+  float4 sc, sh;
+  if (fin.partial != nullptr) {                                      // finalize in the prologue (see group_merge)
+    fin_forward(fin, g.C, q, writer, &sc, &sh);
+    if (fin.nbt != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *fin.nbt += 1;
+  } else {
+    sc = reinterpret_cast<const float4*>(coef)[q];
+    sh = reinterpret_cast<const float4*>(coef + g.C)[q];
+  }
   float4 rsc = f4(1.f);
   if (RAFF) {
-    rsc = reinterpret_cast<const float4*>(rcoef)[q];
-    add4(sh, reinterpret_cast<const float4*>(rcoef + g.C)[q]);       // both shifts in one constant
+    float4 rsh;
+    if (fin_d.partial != nullptr) {
+      fin_forward(fin_d, g.C, q, writer, &rsc, &rsh);
+      if (fin_d.nbt != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *fin_d.nbt += 1;
+    } else {
+      rsc = reinterpret_cast<const float4*>(rcoef)[q];
+      rsh = reinterpret_cast<const float4*>(rcoef + g.C)[q];
+    }
+    add4(sh, rsh);                                                   // both shifts in one constant
   }
   const int stride = g.RP;
   int r_end;
@@ -309,7 +463,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ 
                                                      const float4* __restrict__ y, const float* __restrict__ coef,
                                                      const float* __restrict__ save_mean,
                                                      const float* __restrict__ save_invstd,
-                                                     float* __restrict__ partial, BnGeom g) {
+                                                     float* __restrict__ partial, BnGeom g,
+                                                     unsigned* __restrict__ tickets = nullptr) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 sc = reinterpret_cast<const float4*>(coef)[q];
@@ -348,6 +503,37 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ 
     }
   }
   block_merge_store<TPB>(db, dg, partial, g.C, g.CH, g.RRP, q, ql, rp);
+  if (tickets != nullptr) group_merge<TPB, 2>(partial, g.C, g.CH, g.RRP, q, ql, rp, gridDim.x, tickets);
+}
+
+// backward finalize in a consumer's prologue: A, B, Cc of dx = A * dz + B * x + Cc from the merged (sum dz, sum dz * xhat)
+struct BnBfin {
+  const float* partial;           // nullptr: coefficients come from memory (bn_bwd_finalize ran)
+  int nbx, M;
+  const float *gamma, *save_mean, *save_invstd;
+  float *dgamma, *dbeta;
+};
+
+__device__ __forceinline__ void fin_coefs(double s, double sq, double gamma, double mu, double is, int M, float* A, float* B, float* Cc) {
+  const double a = gamma * is;
+  *A = static_cast<float>(a);
+  *B = static_cast<float>(-a * is * sq / M);
+  *Cc = static_cast<float>(a * (mu * is * sq - s) / M);
+}
+
+__device__ __forceinline__ void fin_backward(const BnBfin& f, int C, int q, bool write, float4* A, float4* B, float4* Cc) {
+  d4 m[2];
+  merged_rows<2>(f.partial, C, q, f.nbx, m);
+  const float4 ga = reinterpret_cast<const float4*>(f.gamma)[q], mu = reinterpret_cast<const float4*>(f.save_mean)[q];
+  const float4 is = reinterpret_cast<const float4*>(f.save_invstd)[q];
+  fin_coefs(m[0].x, m[1].x, ga.x, mu.x, is.x, f.M, &A->x, &B->x, &Cc->x);
+  fin_coefs(m[0].y, m[1].y, ga.y, mu.y, is.y, f.M, &A->y, &B->y, &Cc->y);
+  fin_coefs(m[0].z, m[1].z, ga.z, mu.z, is.z, f.M, &A->z, &B->z, &Cc->z);
+  fin_coefs(m[0].w, m[1].w, ga.w, mu.w, is.w, f.M, &A->w, &B->w, &Cc->w);
+  if (write) {
+    reinterpret_cast<float4*>(f.dbeta)[q] = make_float4(static_cast<float>(m[0].x), static_cast<float>(m[0].y), static_cast<float>(m[0].z), static_cast<float>(m[0].w));
+    reinterpret_cast<float4*>(f.dgamma)[q] = make_float4(static_cast<float>(m[1].x), static_cast<float>(m[1].y), static_cast<float>(m[1].z), static_cast<float>(m[1].w));
+  }
 }
 
 // dgamma, dbeta and the per-channel coefficients of dx = A * dz + B * x + Cc  (bcoef: [0] A, [1] B, [2] Cc)
@@ -401,14 +587,19 @@ template <int MASK, bool DRES>
 __global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, const float4* __restrict__ x,
                                                  const float4* __restrict__ y, const float* __restrict__ coef,
                                                  const float* __restrict__ bcoef, float4* __restrict__ dx,
-                                                 float4* __restrict__ dres, BnGeom g) {
+                                                 float4* __restrict__ dres, BnGeom g, BnBfin fin) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 sc = reinterpret_cast<const float4*>(coef)[q];
   const float4 sh = reinterpret_cast<const float4*>(coef + g.C)[q];
-  const float4 A = reinterpret_cast<const float4*>(bcoef)[q];
-  const float4 Bc = reinterpret_cast<const float4*>(bcoef + g.C)[q];
-  const float4 Cc = reinterpret_cast<const float4*>(bcoef + 2 * g.C)[q];
+  float4 A, Bc, Cc;
+  if (fin.partial != nullptr) {
+    fin_backward(fin, g.C, q, blockIdx.x == 0 && rp == 0, &A, &Bc, &Cc);
+  } else {
+    A = reinterpret_cast<const float4*>(bcoef)[q];
+    Bc = reinterpret_cast<const float4*>(bcoef + g.C)[q];
+    Cc = reinterpret_cast<const float4*>(bcoef + 2 * g.C)[q];
+  }
   const int stride = g.RP;
   int r_end;
   for (int r0 = block_rows(g, &r_end, g.RP) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
@@ -473,7 +664,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restri
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ mean_d,
                                                           const float* __restrict__ invstd_d, float* __restrict__ partial,
-                                                          BnGeom g) {
+                                                          BnGeom g, unsigned* __restrict__ tickets = nullptr) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 mu = reinterpret_cast<const float4*>(mean)[q], is = reinterpret_cast<const float4*>(invstd)[q];
@@ -513,6 +704,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restri
     }
   }
   block_merge_store3<TPB>(db, dg, dgd, partial, g.C, g.CH, g.RRP, q, ql, rp);
+  if (tickets != nullptr) group_merge<TPB, 3>(partial, g.C, g.CH, g.RRP, q, ql, rp, gridDim.x, tickets);
 }
 
 // dgamma / dbeta of both norms (dbeta is the same sum for both) and their dx coefficients: bcoef [0..2] main, [3..5] branch
@@ -562,13 +754,34 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_dx_dual(const float4* __restrict__ dy, const float4* __restrict__ x,
                                                       const float4* __restrict__ xd, const float4* __restrict__ y,
                                                       const float* __restrict__ bcoef, float4* __restrict__ dx,
-                                                      float4* __restrict__ dxd, BnGeom g) {
+                                                      float4* __restrict__ dxd, BnGeom g, BnBfin fin, BnBfin fin_d) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
-  const float4 A = reinterpret_cast<const float4*>(bcoef)[q], Bc = reinterpret_cast<const float4*>(bcoef + g.C)[q];
-  const float4 Cc = reinterpret_cast<const float4*>(bcoef + 2 * g.C)[q];
-  const float4 Ad = reinterpret_cast<const float4*>(bcoef + 3 * g.C)[q], Bd = reinterpret_cast<const float4*>(bcoef + 4 * g.C)[q];
-  const float4 Cd = reinterpret_cast<const float4*>(bcoef + 5 * g.C)[q];
+  float4 A, Bc, Cc, Ad, Bd, Cd;
+  if (fin.partial != nullptr) {                          // (sum dz, sum dz xhat, sum dz xhat_d) rows of three values
+    d4 m[3];
+    merged_rows<3>(fin.partial, g.C, q, fin.nbx, m);
+    const float4 ga = reinterpret_cast<const float4*>(fin.gamma)[q], mu = reinterpret_cast<const float4*>(fin.save_mean)[q];
+    const float4 is = reinterpret_cast<const float4*>(fin.save_invstd)[q];
+    const float4 gd = reinterpret_cast<const float4*>(fin_d.gamma)[q], mud = reinterpret_cast<const float4*>(fin_d.save_mean)[q];
+    const float4 isd = reinterpret_cast<const float4*>(fin_d.save_invstd)[q];
+    fin_coefs(m[0].x, m[1].x, ga.x, mu.x, is.x, fin.M, &A.x, &Bc.x, &Cc.x);  fin_coefs(m[0].x, m[2].x, gd.x, mud.x, isd.x, fin.M, &Ad.x, &Bd.x, &Cd.x);
+    fin_coefs(m[0].y, m[1].y, ga.y, mu.y, is.y, fin.M, &A.y, &Bc.y, &Cc.y);  fin_coefs(m[0].y, m[2].y, gd.y, mud.y, isd.y, fin.M, &Ad.y, &Bd.y, &Cd.y);
+    fin_coefs(m[0].z, m[1].z, ga.z, mu.z, is.z, fin.M, &A.z, &Bc.z, &Cc.z);  fin_coefs(m[0].z, m[2].z, gd.z, mud.z, isd.z, fin.M, &Ad.z, &Bd.z, &Cd.z);
+    fin_coefs(m[0].w, m[1].w, ga.w, mu.w, is.w, fin.M, &A.w, &Bc.w, &Cc.w);  fin_coefs(m[0].w, m[2].w, gd.w, mud.w, isd.w, fin.M, &Ad.w, &Bd.w, &Cd.w);
+    if (blockIdx.x == 0 && rp == 0) {
+      const float4 s4 = make_float4(static_cast<float>(m[0].x), static_cast<float>(m[0].y), static_cast<float>(m[0].z), static_cast<float>(m[0].w));
+      reinterpret_cast<float4*>(fin.dbeta)[q] = s4;
+      reinterpret_cast<float4*>(fin_d.dbeta)[q] = s4;
+      reinterpret_cast<float4*>(fin.dgamma)[q] = make_float4(static_cast<float>(m[1].x), static_cast<float>(m[1].y), static_cast<float>(m[1].z), static_cast<float>(m[1].w));
+      reinterpret_cast<float4*>(fin_d.dgamma)[q] = make_float4(static_cast<float>(m[2].x), static_cast<float>(m[2].y), static_cast<float>(m[2].z), static_cast<float>(m[2].w));
+    }
+  } else {
+    A = reinterpret_cast<const float4*>(bcoef)[q]; Bc = reinterpret_cast<const float4*>(bcoef + g.C)[q];
+    Cc = reinterpret_cast<const float4*>(bcoef + 2 * g.C)[q];
+    Ad = reinterpret_cast<const float4*>(bcoef + 3 * g.C)[q]; Bd = reinterpret_cast<const float4*>(bcoef + 4 * g.C)[q];
+    Cd = reinterpret_cast<const float4*>(bcoef + 5 * g.C)[q];
+  }
   const int stride = g.RP;
   int r_end;
   for (int r0 = block_rows(g, &r_end, g.RP) + rp; r0 < r_end; r0 += BN_ROWS_UNROLL * stride) {
@@ -620,18 +833,38 @@ __global__ __launch_bounds__(256) void bn_infer_coef(const float* __restrict__ g
     else { if (g.RUNR == 8) CALL(256, 8); else CALL(256, 4); }        \
   } while (0)
 
-void launch_stats(const BnGeom& g, dim3 grid, hipStream_t s, const float4* x, float* partial) {
-#define BN_CALL(T, U) hipLaunchKernelGGL((bn_stats<T, U>), grid, dim3(T), 0, s, x, partial, g)
+void launch_stats(const BnGeom& g, dim3 grid, hipStream_t s, const float4* x, float* partial, unsigned* tickets = nullptr) {
+#define BN_CALL(T, U) hipLaunchKernelGGL((bn_stats<T, U>), grid, dim3(T), 0, s, x, partial, g, tickets)
   BN_DISPATCH_TPB_UNR(BN_CALL);
 #undef BN_CALL
 }
 
 template <int MASK>
 void launch_bwd_reduce(const BnGeom& g, dim3 grid, hipStream_t s, const float4* dy, const float4* x, const float4* y,
-                       const float* coef, const float* mean, const float* invstd, float* partial) {
-#define BN_CALL(T, U) hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, x, y, coef, mean, invstd, partial, g)
+                       const float* coef, const float* mean, const float* invstd, float* partial, unsigned* tickets = nullptr) {
+#define BN_CALL(T, U) hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, x, y, coef, mean, invstd, partial, g, tickets)
   BN_DISPATCH_TPB_UNR(BN_CALL);
 #undef BN_CALL
+}
+
+// ticket slots of one call (see group_merge): a rotating window of the device array; every slot returns to zero after its use
+unsigned* bn_tickets(int sets) {
+  static unsigned* base = [] {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_bn_tickets)) == hipSuccess ? static_cast<unsigned*>(p) : nullptr;
+  }();
+  static std::atomic<unsigned> next{0};
+  constexpr unsigned per = 2 * BN_MAX_GROUPS;               // up to two column chunks per set
+  if (base == nullptr) return nullptr;
+  const unsigned first = next.fetch_add(per * static_cast<unsigned>(sets)) % (BN_TICKET_SLOTS - 4 * per);
+  return base + first / per * per;
+}
+bool bn_ticket_ok(const BnGeom& g) {
+  // opt-in (DBEV_BN_TICKET=1, read per call so that a test can switch it): measured SLOWER than the finalize launches it removes --
+  // 149.0 vs 146.6 ms per step, bn_stats 4.5 vs 2.6+1.1 ms -- because every producer workgroup pays a release fence (an L2 write-back
+  // on gfx950) and every consumer workgroup a dependent 16-row merge before its first load
+  const char* e = getenv("DBEV_BN_TICKET");
+  return e != nullptr && atoi(e) != 0 && g.GY <= 2 && g.NBX <= BN_GROUP * BN_MAX_GROUPS;
 }
 
 struct BnWs { size_t partial, total; };
@@ -679,6 +912,7 @@ extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residu
   float* partial = static_cast<float*>(workspace);
   const dim3 grid(g.NBX, g.GY);
   const long long T = 4LL * g.M * C;                       // bytes of one full-tensor pass
+  unsigned* tk = (stats_partial == nullptr && bn_ticket_ok(g)) ? bn_tickets(1) : nullptr;
   int nrows = g.NBX;
   const float* rows = partial;
   if (stats_partial != nullptr) {
@@ -686,12 +920,18 @@ extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residu
     rows = stats_partial;
   } else {
     DbevKt kt(DBEV_K_BN_STATS, T, s);
-    launch_stats(g, grid, s, reinterpret_cast<const float4*>(x), partial);
+    launch_stats(g, grid, s, reinterpret_cast<const float4*>(x), partial, tk);
   }
-  { DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nrows * C, s);
+  BnFin fin{};                                               // tickets: the apply pass merges the group rows itself
+  if (tk != nullptr) {
+    fin = BnFin{partial, g.NBX, g.M, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
+                num_batches_tracked};
+  } else {
+    DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nrows * C, s);
     hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, rows, nrows, g.M, C, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
-                       num_batches_tracked); }
+                       num_batches_tracked);
+  }
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* r4 = reinterpret_cast<const float4*>(residual);
   float4* y4 = reinterpret_cast<float4*>(y);
@@ -703,12 +943,13 @@ extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residu
     DbevKt kt(residual != nullptr ? DBEV_K_BN_APPLY_RES : DBEV_K_BN_APPLY, T * (residual != nullptr ? 3 : 2), s);
     const float* none = nullptr;
     const int rev = stats_partial != nullptr ? 1 : 0;
+    const BnFin nofin{};
     if (residual != nullptr) {
-      if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev);
-      else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev);
+      if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev, fin, nofin);
+      else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev, fin, nofin);
     } else {
-      if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev);
-      else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev);
+      if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev, fin, nofin);
+      else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev, fin, nofin);
     }
   }
   DBEV_LAUNCH_CHECK();
@@ -733,12 +974,14 @@ extern "C" int dbev_bn_act_infer(const float* x, const float* residual, const fl
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
+  const float* none = nullptr;
+  const BnFin nofin{};
   if (residual != nullptr) {
-    if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g);
-    else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g);
+    if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g, none, 0, nofin, nofin);
+    else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g, none, 0, nofin, nofin);
   } else {
-    if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g);
-    else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g);
+    if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g, none, 0, nofin, nofin);
+    else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, coef, y4, g, none, 0, nofin, nofin);
   }
   DBEV_LAUNCH_CHECK();
   return 0;
@@ -766,15 +1009,21 @@ extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const f
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* y4 = reinterpret_cast<const float4*>(y);
   const long long T = 4LL * g.M * C;
+  unsigned* tk = bn_ticket_ok(g) ? bn_tickets(1) : nullptr;
   {
     DbevKt kt(mask == 2 ? DBEV_K_BN_BWD_REDUCE_Y : DBEV_K_BN_BWD_REDUCE, T * (mask == 2 ? 3 : 2), s);
-    if (mask == 0) launch_bwd_reduce<0>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial);
-    else if (mask == 1) launch_bwd_reduce<1>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial);
-    else launch_bwd_reduce<2>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial);
+    if (mask == 0) launch_bwd_reduce<0>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
+    else if (mask == 1) launch_bwd_reduce<1>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
+    else launch_bwd_reduce<2>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
   }
-  { DbevKt kt(DBEV_K_BN_BWD_FINALIZE, 8LL * g.NBX * g.GY * C, s);
+  BnBfin fin{};
+  if (tk != nullptr) {
+    fin = BnBfin{partial, g.NBX, g.M, gamma, save_mean, save_invstd, grad_gamma, grad_beta};
+  } else {
+    DbevKt kt(DBEV_K_BN_BWD_FINALIZE, 8LL * g.NBX * g.GY * C, s);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma,
-                       save_mean, save_invstd, grad_gamma, grad_beta, bcoef); }
+                       save_mean, save_invstd, grad_gamma, grad_beta, bcoef);
+  }
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
@@ -783,11 +1032,11 @@ extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const f
   DbevKt kt(grad_residual != nullptr ? DBEV_K_BN_BWD_DX_RES : DBEV_K_BN_BWD_DX,
             T * (3 + (mask == 2 ? 1 : 0) + (grad_residual != nullptr && mask != 0 ? 1 : 0)), s);
   if (grad_residual != nullptr) {
-    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
-    else hipLaunchKernelGGL((bn_bwd_dx<0, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
+    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
+    else hipLaunchKernelGGL((bn_bwd_dx<0, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
   } else {
-    if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx<1, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
-    else hipLaunchKernelGGL((bn_bwd_dx<0, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g);
+    if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx<1, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
+    else hipLaunchKernelGGL((bn_bwd_dx<0, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
   }
   DBEV_LAUNCH_CHECK();
   return 0;
@@ -797,7 +1046,9 @@ extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const f
 extern "C" size_t dbev_bn_dual_workspace_bytes(long long M, int C) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return 0;
-  return sizeof(float) * static_cast<size_t>(g.NBX) * 3 * C + sizeof(float) * 6 * static_cast<size_t>(C);
+  // forward: the partial tables of BOTH inputs are live until the apply pass merges them (2 + 2 values per row);
+  // backward: three values per row, then the six coefficient rows of the finalize-kernel path
+  return sizeof(float) * static_cast<size_t>(g.NBX) * 4 * C + sizeof(float) * 6 * static_cast<size_t>(C);
 }
 
 extern "C" int dbev_bn_dual_train_forward(const float* x, const float* xd, const float* gamma, const float* beta,
@@ -838,28 +1089,44 @@ extern "C" int dbev_bn_dual_train_forward_pre(const float* x, const float* xd, c
   const long long T = 4LL * g.M * C;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* d4 = reinterpret_cast<const float4*>(xd);
-  // statistics of the branch first, then of the main input: the same partial buffer serves both (stream order)
   if ((stats_partial != nullptr && partial_rows <= 0) || (stats_partial_d != nullptr && partial_rows_d <= 0)) return DBEV_EINVAL;
-  if (stats_partial_d == nullptr) { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, d4, partial); }
-  { const int nr = stats_partial_d != nullptr ? partial_rows_d : g.NBX;
+  // statistics of the branch, then of the main input, each into its own partial table
+  float* partial_d = partial + static_cast<size_t>(g.NBX) * 2 * C;
+  const bool tko = bn_ticket_ok(g);
+  unsigned* tk = tko ? bn_tickets(2) : nullptr;
+  unsigned* tk_d = (tk != nullptr && stats_partial_d == nullptr) ? tk + 2 * BN_MAX_GROUPS : nullptr;
+  if (stats_partial != nullptr) tk = nullptr;
+  BnFin fin{}, fin_d{};
+  if (stats_partial_d == nullptr) { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, d4, partial_d, tk_d); }
+  if (tk_d != nullptr) {
+    fin_d = BnFin{partial_d, g.NBX, g.M, gamma_d, beta_d, running_mean_d, running_var_d, momentum_d, eps_d, save_mean_d, save_invstd_d,
+                  save_scale_shift_d, num_batches_tracked_d};
+  } else {
+    const int nr = stats_partial_d != nullptr ? partial_rows_d : g.NBX;
     DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nr * C, s);
-    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, stats_partial_d != nullptr ? stats_partial_d : partial,
+    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, stats_partial_d != nullptr ? stats_partial_d : partial_d,
                        nr, g.M, C, gamma_d, beta_d, running_mean_d, running_var_d, momentum_d, eps_d, save_mean_d, save_invstd_d,
-                       save_scale_shift_d, num_batches_tracked_d); }
-  if (stats_partial == nullptr) { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, x4, partial); }
-  { const int nr = stats_partial != nullptr ? partial_rows : g.NBX;
+                       save_scale_shift_d, num_batches_tracked_d);
+  }
+  if (stats_partial == nullptr) { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, x4, partial, tk); }
+  if (tk != nullptr) {
+    fin = BnFin{partial, g.NBX, g.M, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
+                num_batches_tracked};
+  } else {
+    const int nr = stats_partial != nullptr ? partial_rows : g.NBX;
     DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nr * C, s);
     hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, stats_partial != nullptr ? stats_partial : partial,
                        nr, g.M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
-                       num_batches_tracked); }
+                       num_batches_tracked);
+  }
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
   DbevKt kt(DBEV_K_BN_APPLY_RES, T * 3, s);
   float4* y4 = reinterpret_cast<float4*>(y);
   const int rev = (stats_partial != nullptr && stats_partial_d != nullptr) ? 1 : 0;
-  if (relu) hipLaunchKernelGGL((bn_apply<true, true, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev);
-  else hipLaunchKernelGGL((bn_apply<true, false, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev);
+  if (relu) hipLaunchKernelGGL((bn_apply<true, true, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev, fin, fin_d);
+  else hipLaunchKernelGGL((bn_apply<true, false, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev, fin, fin_d);
   DBEV_LAUNCH_CHECK();
   return 0;
 }
@@ -881,6 +1148,7 @@ extern "C" int dbev_bn_dual_backward(const float* grad_y, const float* x, const 
   hipStream_t s = dbev_stream(stream);
   float* partial = static_cast<float*>(workspace);
   float* bcoef = partial + static_cast<size_t>(g.NBX) * 3 * C;
+  unsigned* tk = bn_ticket_ok(g) ? bn_tickets(1) : nullptr;
   const dim3 grid(g.NBX, g.GY);
   const float4* dy4 = reinterpret_cast<const float4*>(grad_y);
   const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -892,25 +1160,31 @@ extern "C" int dbev_bn_dual_backward(const float* grad_y, const float* x, const 
 #define BN_CALL(TP, U)                                                                                                        \
   do {                                                                                                                        \
     if (relu) hipLaunchKernelGGL((bn_bwd_reduce_dual<true, TP, U>), grid, dim3(TP), 0, s, dy4, x4, d4, y4, save_mean,         \
-                                 save_invstd, save_mean_d, save_invstd_d, partial, g);                                        \
+                                 save_invstd, save_mean_d, save_invstd_d, partial, g, tk);                                    \
     else hipLaunchKernelGGL((bn_bwd_reduce_dual<false, TP, U>), grid, dim3(TP), 0, s, dy4, x4, d4, y4, save_mean, save_invstd, \
-                            save_mean_d, save_invstd_d, partial, g);                                                          \
+                            save_mean_d, save_invstd_d, partial, g, tk);                                                      \
   } while (0)
     BN_DISPATCH_TPB_UNR(BN_CALL);
 #undef BN_CALL
   }
-  { DbevKt kt(DBEV_K_BN_BWD_FINALIZE, 12LL * g.NBX * g.GY * C, s);
+  BnBfin fin{}, fin_d{};
+  if (tk != nullptr) {
+    fin = BnBfin{partial, g.NBX, g.M, gamma, save_mean, save_invstd, grad_gamma, grad_beta};
+    fin_d = BnBfin{partial, g.NBX, g.M, gamma_d, save_mean_d, save_invstd_d, grad_gamma_d, grad_beta_d};
+  } else {
+    DbevKt kt(DBEV_K_BN_BWD_FINALIZE, 12LL * g.NBX * g.GY * C, s);
     hipLaunchKernelGGL(bn_bwd_finalize_dual, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, g.NBX, g.M, C, gamma,
                        save_mean, save_invstd, gamma_d, save_mean_d, save_invstd_d, grad_gamma, grad_beta, grad_gamma_d,
-                       grad_beta_d, bcoef); }
+                       grad_beta_d, bcoef);
+  }
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
   DbevKt kt(DBEV_K_BN_BWD_DX_RES, T * (relu ? 6 : 5), s);
   if (relu) hipLaunchKernelGGL((bn_bwd_dx_dual<true>), agrid, dim3(256), 0, s, dy4, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
-                               reinterpret_cast<float4*>(grad_xd), g);
+                               reinterpret_cast<float4*>(grad_xd), g, fin, fin_d);
   else hipLaunchKernelGGL((bn_bwd_dx_dual<false>), agrid, dim3(256), 0, s, dy4, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
-                          reinterpret_cast<float4*>(grad_xd), g);
+                          reinterpret_cast<float4*>(grad_xd), g, fin, fin_d);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -25,6 +25,14 @@ def _ref(x, res, bn, relu, training):
     return out, (x, r, w, b), (rm, rv)
 
 
+@pytest.fixture(params=["finalize", "ticket"])
+def merge_mode(request, monkeypatch):
+    """How the per-workgroup partial rows are merged: by the small finalize launches (default), or by last-arriver tickets in the
+    producer + a merge in the consumer's prologue (DBEV_BN_TICKET=1; opt-in, measured slower -- DESIGN.md section 7)."""
+    monkeypatch.setenv("DBEV_BN_TICKET", "1" if request.param == "ticket" else "0")
+    return request.param
+
+
 def _close(a, r, tol, what):
     a = a.detach().double().cpu(); r = r.detach().double().cpu()
     scale = float(r.abs().max()) + 1e-12
@@ -41,7 +49,7 @@ def _close(a, r, tol, what):
     (2, 1024, 6, 5, True, True),     # C/4 = 256
     (5, 4, 3, 2, False, True),       # C/4 = 1
 ])
-def test_train_forward_backward_and_running_stats(N, C, H, W, res, relu):
+def test_train_forward_backward_and_running_stats(N, C, H, W, res, relu, merge_mode):
     from distill_bev_amd.bn_act import bn_act, eligible
     g = torch.Generator().manual_seed(C + H)
     x = (torch.randn((N, C, H, W), generator=g) * 2.0 + 0.7)
@@ -166,7 +174,7 @@ def test_edge_cases_single_value_per_channel_and_tiny_tensors():
 
 
 @pytest.mark.parametrize("N,C,H,W,relu", [(2, 256, 16, 11, True), (3, 64, 9, 7, True), (1, 2048, 4, 3, True), (2, 512, 7, 5, False)])
-def test_dual_norm_add_relu_of_a_stage_first_residual_block(N, C, H, W, relu):
+def test_dual_norm_add_relu_of_a_stage_first_residual_block(N, C, H, W, relu, merge_mode):
     """bn_act_dual = relu(bn(x) + bn_d(xd)) (dbev_bn_dual_*): output, the two input gradients, the four parameter gradients
     and both sets of running statistics against the fp64 torch sequence; bit-identical when repeated; eval / no-grad calls
     take the two-step path and give the same values."""
