@@ -34,6 +34,7 @@ struct Bil {
   int o1, o2, o3, o4;        // key offsets inside the level (y * W + x) or -1
   float w1, w2, w3, w4;      // hh*hw, hh*lw, lh*hw, lh*lw
   float hh, hw, lh, lw;
+  int ay, ax;                // anchor cell (h_low + 1, w_low + 1) in the (H + 1) x (W + 1) anchor grid
   bool any;
 };
 
@@ -43,6 +44,7 @@ __device__ __forceinline__ Bil bil_of(float lx, float ly, int H, int W) {
   t.any = h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(H) && w_im < static_cast<float>(W);
   const int h_low = static_cast<int>(floorf(h_im)), w_low = static_cast<int>(floorf(w_im));
   const int h_high = h_low + 1, w_high = w_low + 1;
+  t.ay = h_high; t.ax = w_high;
   t.lh = h_im - static_cast<float>(h_low);
   t.lw = w_im - static_cast<float>(w_low);
   t.hh = 1.f - t.lh;
@@ -127,12 +129,14 @@ __device__ __forceinline__ float group_sum(float v, int G) {
   return v;
 }
 
-// per-sample gradients wrt attention weight and sampling location; PB samples (4 PB corner gathers) in flight per lane
-template <int GT, int PB>
+// per-sample gradients wrt attention weight and sampling location; PB samples (4 PB corner gathers) in flight per lane.
+// BIN: the lane that stores a sample's gradients also counts the sample into its anchor bin (first half of the CSR build of the
+// d value pass, see msda_anchor_bin: the integer atomics ride under this kernel's gathers instead of a pass of their own).
+template <int GT, int PB, bool BIN>
 __global__ __launch_bounds__(256) void msda_bwd_sample(const float4* __restrict__ value, const float* __restrict__ loc,
                                                        const float* __restrict__ attn, const float4* __restrict__ gout,
                                                        float* __restrict__ gloc, float* __restrict__ gattn, MsdaDims d,
-                                                       long long rows) {
+                                                       long long rows, int* __restrict__ count, int* __restrict__ rank) {
   const int G = GT ? GT : d.D4;
   const long long gid = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) / G;
   if (gid >= rows) return;
@@ -142,6 +146,10 @@ __global__ __launch_bounds__(256) void msda_bwd_sample(const float4* __restrict_
   const float4 go = gout[static_cast<size_t>(gid) * G + q4];
   const size_t s0 = static_cast<size_t>(gid) * d.L * d.P;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  int prank[PB];                                               // BIN: the previous batch's arrival ranks, stored one batch late so
+  long long psi[PB];                                           // that the atomics' round trip hides under this batch's gathers
+#pragma unroll
+  for (int u = 0; u < PB; ++u) { prank[u] = 0; psi[u] = -1; }
   for (int l = 0; l < d.L; ++l) {
     const int H = d.h[l], W = d.w[l], st = d.start[l];
     for (int p0 = 0; p0 < d.P; p0 += PB) {
@@ -155,6 +163,11 @@ __global__ __launch_bounds__(256) void msda_bwd_sample(const float4* __restrict_
         v[u][1] = t[u].o2 >= 0 ? ld_row(value, d, b, st + t[u].o2, head, q4) : z;
         v[u][2] = t[u].o3 >= 0 ? ld_row(value, d, b, st + t[u].o3, head, q4) : z;
         v[u][3] = t[u].o4 >= 0 ? ld_row(value, d, b, st + t[u].o4, head, q4) : z;
+      }
+      if (BIN && q4 == 0) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+          if (psi[u] >= 0) rank[psi[u]] = prank[u];
       }
 #pragma unroll
       for (int u = 0; u < PB; ++u) {
@@ -173,9 +186,18 @@ __global__ __launch_bounds__(256) void msda_bwd_sample(const float4* __restrict_
           gattn[si] = t[u].any ? ga : 0.f;
           gloc[2 * si] = t[u].any ? static_cast<float>(W) * a * gw : 0.f;
           gloc[2 * si + 1] = t[u].any ? static_cast<float>(H) * a * gh : 0.f;
+          if (BIN) {
+            psi[u] = t[u].any ? static_cast<long long>(si) : -1;
+            if (t[u].any) prank[u] = atomicAdd(&count[(b * d.A + d.astart[l] + t[u].ay * (W + 1) + t[u].ax) * d.NH + head], 1);
+          }
         }
       }
     }
+  }
+  if (BIN && q4 == 0) {
+#pragma unroll
+    for (int u = 0; u < PB; ++u)
+      if (psi[u] >= 0) rank[psi[u]] = prank[u];
   }
 }
 
@@ -276,6 +298,104 @@ __global__ __launch_bounds__(256) void msda_gv_gather(const float4* __restrict__
     }
   }
   gvalue[static_cast<size_t>(row) * G + q4] = acc;
+}
+
+// d value, D = 32 (8 lanes per row): one workgroup per 8 x 8 tile of value rows of one (sample, level, head).  Its 32 lane groups
+// walk the 9 x 9 anchor bins that touch the tile, each bin ONCE for all four corners it feeds (msda_gv_gather walks every bin four
+// times, once from each corner's value row: 4 x the grad_out gathers and 4 x the record reads); a sample's coefficients are
+// rebuilt from its location / weight here, so the record pass (msda_expand) is gone as well.  Every (corner, value row) of the
+// tile is produced by exactly one anchor: the four per-corner partial tiles sit in LDS, are written once each -- no atomics, no
+// ordering between groups -- and summed in corner order at the end: bit-reproducible.  Anchors on a tile edge are walked by the
+// neighbouring tile too (81 bins per 64 rows: 1.27 x instead of 4 x).
+constexpr int MSDA_MT = 8;
+__global__ __launch_bounds__(256) void msda_gv_tile(const float4* __restrict__ gout, const int* __restrict__ start,
+                                                    const unsigned* __restrict__ sorted, const float* __restrict__ loc,
+                                                    const float* __restrict__ attn, float4* __restrict__ gvalue, MsdaDims d,
+                                                    int tiles_per_bh, int nblocks) {
+  constexpr int G = 8, MT = MSDA_MT, NA = (MT + 1) * (MT + 1);
+  __shared__ float4 part[4][MT * MT][G];                       // 32 KB
+  // one XCD walks whole (sample, head) slices: the grad_out rows, locations and weights such a slice touches (Q x 128 + 256 + 128
+  // bytes) stay in ITS L2 instead of being fetched line by line into all eight
+  const int lb = xcd_block();
+  if (lb >= nblocks) return;
+  const int bh = lb / tiles_per_bh;
+  int t = lb - bh * tiles_per_bh;
+  const int b = bh / d.NH, head = bh - b * d.NH;
+  int l = 0;
+  for (;; ++l) {
+    const int nt = ((d.h[l] + MT - 1) / MT) * ((d.w[l] + MT - 1) / MT);
+    if (t < nt) break;
+    t -= nt;
+  }
+  const int H = d.h[l], W = d.w[l];
+  const int tw = (W + MT - 1) / MT;
+  const int ty = t / tw, tx = t - ty * tw;
+  const int lane = threadIdx.x & 63;
+  const int g0 = lane & ~(G - 1), q4 = lane & (G - 1);
+  const int grp = threadIdx.x / G;                             // 32 groups
+  const int base = b * d.A + d.astart[l];
+  const unsigned LP = static_cast<unsigned>(d.L * d.P);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+  for (int a = grp; a < NA; a += 32) {
+    const int aty = a / (MT + 1), atx = a - aty * (MT + 1);
+    const int ay = ty * MT + aty, ax = tx * MT + atx;
+    float4 acc[4] = {z, z, z, z};
+    if (ay <= H && ax <= W) {
+      const int bin = (base + ay * (W + 1) + ax) * d.NH + head;
+      const int st = start[bin];
+      const int n = start[bin + 1] - st;
+      // three-deep pipeline over batches of 8 samples: sample ids two batches ahead, location / weight one batch ahead, the
+      // grad_out rows of the current batch -- one L2 round trip per batch instead of three dependent ones
+      unsigned sm_n = q4 < n ? sorted[st + q4] : 0u;                       // batch 0
+      float2 xy = *reinterpret_cast<const float2*>(loc + 2 * static_cast<size_t>(sm_n));
+      float aw = q4 < n ? attn[sm_n] : 0.f;
+      unsigned sm = sm_n;
+      sm_n = G + q4 < n ? sorted[st + G + q4] : 0u;                        // batch 1
+      for (int j0 = 0; j0 < n; j0 += G) {
+        const int nb = min(G, n - j0);
+        const unsigned mygid = sm / LP;
+        const float h_im = xy.y * static_cast<float>(H) - 0.5f, w_im = xy.x * static_cast<float>(W) - 0.5f;
+        const float lh = h_im - static_cast<float>(ay - 1), lw = w_im - static_cast<float>(ax - 1);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float c0 = aw * (hh * hw), c1 = aw * (hh * lw), c2 = aw * (lh * hw), c3 = aw * (lh * lw);   // aw = 0 past the bin's end
+        float4 v[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const unsigned gi = __shfl(mygid, g0 | u);
+          v[u] = u < nb ? gout[static_cast<size_t>(gi) * G + q4] : z;
+        }
+        sm = sm_n;                                                          // next batch's location / weight, the one after's ids
+        xy = *reinterpret_cast<const float2*>(loc + 2 * static_cast<size_t>(sm));
+        aw = j0 + G + q4 < n ? attn[sm] : 0.f;
+        sm_n = j0 + 2 * G + q4 < n ? sorted[st + j0 + 2 * G + q4] : 0u;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {                          // ascending sample id inside each corner's sum
+          fma4s(acc[0], __shfl(c0, g0 | u), v[u]);              // (lanes past nb hold zero coefficients and zero rows)
+          fma4s(acc[1], __shfl(c1, g0 | u), v[u]);
+          fma4s(acc[2], __shfl(c2, g0 | u), v[u]);
+          fma4s(acc[3], __shfl(c3, g0 | u), v[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                              // corner k of anchor (ay, ax) is value row (ay - 1 + k/2, ax - 1 + k%2)
+      const int ly = aty - 1 + (k >> 1), lx = atx - 1 + (k & 1);
+      if (ly >= 0 && ly < MT && lx >= 0 && lx < MT) part[k][ly * MT + lx][q4] = acc[k];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < MT * MT * G; i += 256) {
+    const int r = i / G, q = i - r * G;
+    const int y = ty * MT + r / MT, x = tx * MT + (r & (MT - 1));
+    if (y < H && x < W) {
+      float4 s0 = part[0][r][q];
+      const float4 s1 = part[1][r][q], s2 = part[2][r][q], s3 = part[3][r][q];
+      s0.x = ((s0.x + s1.x) + s2.x) + s3.x; s0.y = ((s0.y + s1.y) + s2.y) + s3.y;
+      s0.z = ((s0.z + s1.z) + s2.z) + s3.z; s0.w = ((s0.w + s1.w) + s2.w) + s3.w;
+      st_nt(&gvalue[((static_cast<size_t>(b) * d.S + d.start[l] + y * W + x) * d.NH + head) * G + q], s0);
+    }
+  }
 }
 
 size_t align_up256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
@@ -379,29 +499,54 @@ extern "C" int dbev_msda_backward(const float* value, const int32_t* spatial_sha
   unsigned* sorted = reinterpret_cast<unsigned*>(ws + Lw.sorted);
   const float4* v4 = reinterpret_cast<const float4*>(value);
   const float4* g4 = reinterpret_cast<const float4*>(grad_out);
+  int* rank = reinterpret_cast<int*>(sorted);                 // dead before the sort writes `sorted`
+  static const bool fused_count = !(getenv("DBEV_MSDA_FUSED_COUNT") && atoi(getenv("DBEV_MSDA_FUSED_COUNT")) == 0);
+  static const bool tile_ok = !(getenv("DBEV_MSDA_TILE") && atoi(getenv("DBEV_MSDA_TILE")) == 0);
+  DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * bins, s));
   { DbevKt kt(DBEV_K_MSDA_BWD_SAMPLE, 4LL * B * S * NH * D + 24LL * nsamples + 4LL * rows * D, s);
   const dim3 bgrid(static_cast<unsigned>((rows * d.D4 + 255) / 256));
-  if (d.D4 == 8)
-    hipLaunchKernelGGL((msda_bwd_sample<8, 4>), bgrid, dim3(256), 0, s, v4, sampling_loc, attn_weight, g4, grad_sampling_loc,
-                       grad_attn_weight, d, rows);
+  if (d.D4 == 8 && fused_count)
+    hipLaunchKernelGGL((msda_bwd_sample<8, 4, true>), bgrid, dim3(256), 0, s, v4, sampling_loc, attn_weight, g4, grad_sampling_loc,
+                       grad_attn_weight, d, rows, count, rank);
+  else if (d.D4 == 8)
+    hipLaunchKernelGGL((msda_bwd_sample<8, 4, false>), bgrid, dim3(256), 0, s, v4, sampling_loc, attn_weight, g4, grad_sampling_loc,
+                       grad_attn_weight, d, rows, count, rank);
+  else if (fused_count)
+    hipLaunchKernelGGL((msda_bwd_sample<0, 4, true>), bgrid, dim3(256), 0, s, v4, sampling_loc, attn_weight, g4, grad_sampling_loc,
+                       grad_attn_weight, d, rows, count, rank);
   else
-    hipLaunchKernelGGL((msda_bwd_sample<0, 4>), bgrid, dim3(256), 0, s, v4, sampling_loc, attn_weight, g4, grad_sampling_loc,
-                       grad_attn_weight, d, rows); }
-  DBEV_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * bins, s));
+    hipLaunchKernelGGL((msda_bwd_sample<0, 4, false>), bgrid, dim3(256), 0, s, v4, sampling_loc, attn_weight, g4, grad_sampling_loc,
+                       grad_attn_weight, d, rows, count, rank); }
   const dim3 sgrid(static_cast<unsigned>((nsamples + 255) / 256));
-  int* rank = reinterpret_cast<int*>(sorted);                 // dead before the sort writes `sorted`
-  hipLaunchKernelGGL((msda_anchor_bin<false>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, rank, list);
+  if (!fused_count)
+    hipLaunchKernelGGL((msda_anchor_bin<false>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, rank, list);
   int rc = dbev::exclusive_scan_i32(count, start, bins, false, nullptr, reinterpret_cast<int*>(ws + Lw.scanws), s);
   if (rc) return rc;
   hipLaunchKernelGGL((msda_anchor_bin<true>), sgrid, dim3(256), 0, s, sampling_loc, d, nsamples, start, count, rank, list);
   rc = dbev::segment_sort_u32(start, list, sorted, static_cast<int>(bins), reinterpret_cast<int*>(ws + Lw.sortws), s);
   if (rc) return rc;
-  float4* rec_w = reinterpret_cast<float4*>(ws + Lw.recw);
-  hipLaunchKernelGGL(msda_expand, sgrid, dim3(256), 0, s, sorted, start, bins, sampling_loc, attn_weight, d, list /* reused */,
-                     rec_w);
   DbevKt kt(DBEV_K_MSDA_GV_GATHER, 4LL * B * S * NH * D + 20LL * nsamples + 4LL * rows * D, s);
-  hipLaunchKernelGGL(msda_gv_gather, dim3(static_cast<unsigned>((vrows * d.D4 + 255) / 256)), dim3(256), 0, s, g4, start, list,
-                     rec_w, reinterpret_cast<float4*>(grad_value), d, vrows);
+  if (d.D4 == 8 && tile_ok) {
+    long long cells = 0, tiles = 0;
+    bool dense = true;                                          // the levels tile [0, S) without gaps: every row is written
+    for (int l = 0; l < L; ++l) {
+      dense = dense && d.start[l] == cells;
+      cells += static_cast<long long>(d.h[l]) * d.w[l];
+      tiles += static_cast<long long>((d.h[l] + MSDA_MT - 1) / MSDA_MT) * ((d.w[l] + MSDA_MT - 1) / MSDA_MT);
+    }
+    dense = dense && cells == S;
+    if (tiles * B * NH >= 0x7fffffffLL) return DBEV_EINVAL;
+    if (!dense) DBEV_HIP_TRY(hipMemsetAsync(grad_value, 0, sizeof(float) * vrows * D, s));
+    const int nblocks = static_cast<int>(tiles * B * NH);
+    hipLaunchKernelGGL(msda_gv_tile, dim3(dbev_round_xcd(nblocks)), dim3(256), 0, s, g4, start, sorted, sampling_loc,
+                       attn_weight, reinterpret_cast<float4*>(grad_value), d, static_cast<int>(tiles), nblocks);
+  } else {
+    float4* rec_w = reinterpret_cast<float4*>(ws + Lw.recw);
+    hipLaunchKernelGGL(msda_expand, sgrid, dim3(256), 0, s, sorted, start, bins, sampling_loc, attn_weight, d, list /* reused */,
+                       rec_w);
+    hipLaunchKernelGGL(msda_gv_gather, dim3(static_cast<unsigned>((vrows * d.D4 + 255) / 256)), dim3(256), 0, s, g4, start, list,
+                       rec_w, reinterpret_cast<float4*>(grad_value), d, vrows);
+  }
   DBEV_LAUNCH_CHECK();
   return 0;
 }
