@@ -13,10 +13,12 @@
 // registers (v_mfma_f32_16x16x4_f32, exact fp32); offsets no site of the workgroup uses are skipped.  The output is
 // written once.  No float atomics -> bit-reproducible.
 //
-// Rulebook: input coordinates -> open-addressing hash table (int32 linear cell id); output sites of a strided
-// convolution = set bits of a bitmap over the output grid, enumerated in ascending cell order by a popcount scan (the
-// reference sorts the unique cell ids: same order); neighbour table by K hash probes per output site.  The reference's
-// own (K, 2, N) pair lists are derived from the table for API compatibility (ops.get_indice_pairs).
+// Rulebook: the occupied cells of a grid are a BITMAP + a popcount prefix per 32-cell word (a rank structure): the row of a
+// cell is rank -> row[start[word] + popc(bits below)], two adjacent-word reads that the 27 neighbours of a site and the sites
+// of a wave share (round 2 probed an open-addressing hash table: one random 64-byte sector per probe, 9 of the voxel teacher's
+// 100 ms).  Output sites of a strided convolution = set bits of the bitmap over the output grid, enumerated in ascending cell
+// order by the same popcount scan (the reference sorts the unique cell ids: same order).  The reference's own (K, 2, N) pair
+// lists are derived from the neighbour table for API compatibility (ops.get_indice_pairs).
 #include "common.h"
 #include "prims.h"
 
@@ -24,66 +26,66 @@
 
 namespace {
 
-constexpr int SP_EMPTY = -1;
-
 struct SpGeom {
   int B, in_d[3], out_d[3], ks[3], st[3], pd[3], dl[3], K;
 };
 
-__device__ __forceinline__ unsigned sp_hash(int key, unsigned mask) {
-  return (static_cast<unsigned>(key) * 2654435761u >> 7) & mask;
+// occupied input cells: one bit per cell of the [B, D, H, W] grid (rows with out-of-range coordinates are ignored)
+__device__ __forceinline__ long long sp_in_cell(const int4& c, const SpGeom& g) {
+  if (c.x < 0 || c.x >= g.B || c.y < 0 || c.y >= g.in_d[0] || c.z < 0 || c.z >= g.in_d[1] || c.w < 0 || c.w >= g.in_d[2])
+    return -1;
+  return ((static_cast<long long>(c.x) * g.in_d[0] + c.y) * g.in_d[1] + c.z) * g.in_d[2] + c.w;
 }
 
-__global__ __launch_bounds__(256) void sp_hash_insert(const int* __restrict__ idx, int n, SpGeom g, int* __restrict__ keys,
-                                                      int* __restrict__ vals, unsigned mask) {
+__global__ __launch_bounds__(256) void sp_mark_inputs(const int* __restrict__ idx, int n, SpGeom g, unsigned* __restrict__ bits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int4 c = reinterpret_cast<const int4*>(idx)[i];                  // (b, z, y, x)
-  if (c.x < 0 || c.x >= g.B || c.y < 0 || c.y >= g.in_d[0] || c.z < 0 || c.z >= g.in_d[1] || c.w < 0 || c.w >= g.in_d[2])
-    return;
-  const int key = ((c.x * g.in_d[0] + c.y) * g.in_d[1] + c.z) * g.in_d[2] + c.w;
-  unsigned s = sp_hash(key, mask);
-  for (;;) {
-    const int old = atomicCAS(&keys[s], SP_EMPTY, key);
-    if (old == SP_EMPTY || old == key) {
-      if (old == key) atomicMin(&vals[s], i); else atomicMin(&vals[s], i);   // duplicate coordinates: lowest row wins
-      return;
-    }
-    s = (s + 1) & mask;
-  }
+  const long long lin = sp_in_cell(reinterpret_cast<const int4*>(idx)[i], g);
+  if (lin >= 0) atomicOr(&bits[lin >> 5], 1u << (lin & 31));
 }
 
-__device__ __forceinline__ int sp_lookup(int key, const int* __restrict__ keys, const int* __restrict__ vals,
-                                         unsigned mask) {
-  unsigned s = sp_hash(key, mask);
-  for (;;) {
-    const int k = keys[s];
-    if (k == key) return vals[s];
-    if (k == SP_EMPTY) return -1;
-    s = (s + 1) & mask;
-  }
+// rank -> row: duplicate coordinates keep the lowest row (row is pre-set to INT_MAX)
+__global__ __launch_bounds__(256) void sp_rank_rows(const int* __restrict__ idx, int n, SpGeom g, const unsigned* __restrict__ bits,
+                                                    const int* __restrict__ start, int* __restrict__ row) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long lin = sp_in_cell(reinterpret_cast<const int4*>(idx)[i], g);
+  if (lin < 0) return;
+  const unsigned w = bits[lin >> 5];
+  atomicMin(&row[start[lin >> 5] + __popc(w & ((1u << (lin & 31)) - 1u))], i);
 }
 
-// strided / padded convolution: mark every output cell some (input, offset) pair reaches
+// strided / padded convolution: mark every output cell some (input, offset) pair reaches.  One thread per input site: per axis the
+// kernel taps whose output coordinate is integral and in range (at stride 2, kernel 3: one or two of the three), then their product
+// (<= 8 of the 27 offsets) -- a thread per (input, offset) pair spent 19 of 27 threads on the parity test alone.
 __global__ __launch_bounds__(256) void sp_mark_outputs(const int* __restrict__ idx, int n, SpGeom g,
                                                        unsigned* __restrict__ bits) {
-  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= static_cast<long long>(n) * g.K) return;
-  const int i = static_cast<int>(t / g.K), k = static_cast<int>(t - static_cast<long long>(i) * g.K);
+  constexpr int MAXT = 8;                                  // taps kept per axis (sp_geom admits kernel sizes <= 8 per axis)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
   const int4 c = reinterpret_cast<const int4*>(idx)[i];
-  const int kz = k / (g.ks[1] * g.ks[2]), ky = (k / g.ks[2]) % g.ks[1], kx = k % g.ks[2];
-  const int in[3] = {c.y, c.z, c.w}, kk[3] = {kz, ky, kx};
-  int o[3];
+  if (c.x < 0 || c.x >= g.B) return;
+  const int in[3] = {c.y, c.z, c.w};
+  int o[3][MAXT], cnt[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const int num = in[a] + g.pd[a] - kk[a] * g.dl[a];
-    if (num < 0 || num % g.st[a]) return;
-    o[a] = num / g.st[a];
-    if (o[a] >= g.out_d[a]) return;
+    cnt[a] = 0;
+    for (int kk = 0; kk < g.ks[a]; ++kk) {
+      const int num = in[a] + g.pd[a] - kk * g.dl[a];
+      if (num < 0 || num % g.st[a]) continue;
+      const int oo = num / g.st[a];
+      if (oo >= g.out_d[a] || cnt[a] >= MAXT) continue;
+      o[a][cnt[a]++] = oo;
+    }
   }
-  if (c.x < 0 || c.x >= g.B) return;
-  const long long lin = ((static_cast<long long>(c.x) * g.out_d[0] + o[0]) * g.out_d[1] + o[1]) * g.out_d[2] + o[2];
-  atomicOr(&bits[lin >> 5], 1u << (lin & 31));
+  for (int a0 = 0; a0 < cnt[0]; ++a0)
+    for (int a1 = 0; a1 < cnt[1]; ++a1) {
+      const long long rowl = (static_cast<long long>(c.x) * g.out_d[0] + o[0][a0]) * g.out_d[1] + o[1][a1];
+      for (int a2 = 0; a2 < cnt[2]; ++a2) {
+        const long long lin = rowl * g.out_d[2] + o[2][a2];
+        atomicOr(&bits[lin >> 5], 1u << (lin & 31));
+      }
+    }
 }
 
 __global__ __launch_bounds__(256) void sp_popcount(const unsigned* __restrict__ bits, int nwords, int* __restrict__ cnt) {
@@ -110,8 +112,9 @@ __global__ __launch_bounds__(256) void sp_emit_outputs(const unsigned* __restric
 
 // nbr[o, k] = input row at  o * stride - pad + k * dilation  (cross-correlation, like the dense convolution)
 __global__ __launch_bounds__(256) void sp_neighbors(const int* __restrict__ out_idx, int m, SpGeom g,
-                                                    const int* __restrict__ keys, const int* __restrict__ vals,
-                                                    unsigned mask, int* __restrict__ nbr, int* __restrict__ inv /* [N, K] or null */) {
+                                                    const unsigned* __restrict__ bits, const int* __restrict__ start,
+                                                    const int* __restrict__ row, int* __restrict__ nbr,
+                                                    int* __restrict__ inv /* [N, K] or null */) {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= static_cast<long long>(m) * g.K) return;
   const int o = static_cast<int>(t / g.K), k = static_cast<int>(t - static_cast<long long>(o) * g.K);
@@ -120,10 +123,21 @@ __global__ __launch_bounds__(256) void sp_neighbors(const int* __restrict__ out_
   const int z = c.y * g.st[0] - g.pd[0] + kz * g.dl[0], y = c.z * g.st[1] - g.pd[1] + ky * g.dl[1],
             x = c.w * g.st[2] - g.pd[2] + kx * g.dl[2];
   int r = -1;
-  if (z >= 0 && z < g.in_d[0] && y >= 0 && y < g.in_d[1] && x >= 0 && x < g.in_d[2] && c.x >= 0 && c.x < g.B)
-    r = sp_lookup(((c.x * g.in_d[0] + z) * g.in_d[1] + y) * g.in_d[2] + x, keys, vals, mask);
+  if (z >= 0 && z < g.in_d[0] && y >= 0 && y < g.in_d[1] && x >= 0 && x < g.in_d[2] && c.x >= 0 && c.x < g.B) {
+    const long long lin = ((static_cast<long long>(c.x) * g.in_d[0] + z) * g.in_d[1] + y) * g.in_d[2] + x;
+    const unsigned w = bits[lin >> 5], bit = 1u << (lin & 31);
+    if (w & bit) r = row[start[lin >> 5] + __popc(w & (bit - 1u))];
+  }
   nbr[t] = r;
   if (inv != nullptr && r >= 0) inv[static_cast<size_t>(r) * g.K + k] = o;     // unique writer per (input, offset)
+}
+
+// inverse table from the neighbour table: inv[r, k] = output row that offset k pairs with input row r (unique writer per entry)
+__global__ __launch_bounds__(256) void sp_inverse(const int* __restrict__ nbr, long long nt, int K, int* __restrict__ inv) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const int r = nbr[t];
+  if (r >= 0) inv[static_cast<size_t>(r) * K + t % K] = static_cast<int>(t / K);
 }
 
 // reference-format pair lists from the table: flags laid out [K, M]
@@ -158,7 +172,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int SP_NS = 2;
 constexpr int SP_SITES = 64 * SP_NS;        // output sites per workgroup
 
-template <int CT>
+// NCH > 1: the weight slice is staged in NCH chunks of Cin / NCH input channels (128 -> 128: 34 KB instead of 68 KB of LDS per
+// workgroup, three resident workgroups per CU instead of two, for two more barriers per offset).
+template <int CT, int NCH = 1>
 __global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in, const float* __restrict__ W,
                                                    const float* __restrict__ bias, const int* __restrict__ nbr,
                                                    float* __restrict__ out, int M, int K, int Cin,
@@ -192,52 +208,60 @@ __global__ __launch_bounds__(256) void sp_conv_fwd(const float* __restrict__ in,
     }
     const bool wave_any = __any(mine);
     if (!__syncthreads_or(wave_any)) continue;      // also the barrier that lets sW be overwritten
-    for (int i = tid; i < Cin * (COUT / 4); i += 256) {
-      const int row = i / (COUT / 4), c4 = i - row * (COUT / 4);
-      *reinterpret_cast<float4*>(&sW[row * STR + 4 * c4]) = W4[(static_cast<size_t>(k) * Cin + row) * (COUT / 4) + c4];
-    }
-    // this lane's slices of the two neighbour rows (cin = 16 g + 4 kk + t), 2 groups (32 input channels) at a time: requested
-    // before the barrier so that the gathers overlap the weight staging, the next pair is fetched under the MFMAs
+    const int CR = Cin / NCH, GR = G16 / NCH;       // input channels / 16-channel groups per staged chunk
     const float* row[SP_NS];
-    float4 bv[SP_NS][2];
 #pragma unroll
-    for (int s = 0; s < SP_NS; ++s) {
-      row[s] = in + static_cast<size_t>(nb[s] >= 0 ? nb[s] : 0) * Cin + 4 * kk;
+    for (int s = 0; s < SP_NS; ++s) row[s] = in + static_cast<size_t>(nb[s] >= 0 ? nb[s] : 0) * Cin + 4 * kk;
+#pragma unroll 1
+    for (int h = 0; h < NCH; ++h) {
+      if (h > 0) __syncthreads();                   // every wave is done with the previous chunk
+      for (int i = tid; i < CR * (COUT / 4); i += 256) {
+        const int r = i / (COUT / 4), c4 = i - r * (COUT / 4);
+        *reinterpret_cast<float4*>(&sW[r * STR + 4 * c4]) = W4[(static_cast<size_t>(k) * Cin + h * CR + r) * (COUT / 4) + c4];
+      }
+      // this lane's slices of the two neighbour rows (cin = 16 g + 4 kk + t), 2 groups (32 input channels) at a time: requested
+      // before the barrier so that the gathers overlap the weight staging, the next pair is fetched under the MFMAs
+      const int gb = h * GR, ge = gb + GR;
+      float4 bv[SP_NS][2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        bv[s][u] = (nb[s] >= 0 && u < G16) ? *reinterpret_cast<const float4*>(row[s] + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    if (wave_any) {
-      for (int g0 = 0; g0 < G16; g0 += 2) {
-        float4 nx[SP_NS][2];
+      for (int s = 0; s < SP_NS; ++s) {
 #pragma unroll
-        for (int s = 0; s < SP_NS; ++s)
+        for (int u = 0; u < 2; ++u)
+          bv[s][u] = (nb[s] >= 0 && gb + u < ge) ? *reinterpret_cast<const float4*>(row[s] + 16 * (gb + u))
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __syncthreads();
+      if (wave_any) {
+        for (int g0 = gb; g0 < ge; g0 += 2) {
+          float4 nx[SP_NS][2];
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
-            nx[s][u] = (nb[s] >= 0 && g0 + 2 + u < G16) ? *reinterpret_cast<const float4*>(row[s] + 16 * (g0 + 2 + u))
-                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int s = 0; s < SP_NS; ++s)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (g0 + u < G16) {
-            const float b0[4] = {bv[0][u].x, bv[0][u].y, bv[0][u].z, bv[0][u].w};
-            const float b1[4] = {bv[1][u].x, bv[1][u].y, bv[1][u].z, bv[1][u].w};
+            for (int u = 0; u < 2; ++u)
+              nx[s][u] = (nb[s] >= 0 && g0 + 2 + u < ge) ? *reinterpret_cast<const float4*>(row[s] + 16 * (g0 + 2 + u))
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float* wr = &sW[(16 * (g0 + u) + 4 * kk + t) * STR + j];
+          for (int u = 0; u < 2; ++u) {
+            if (g0 + u < ge) {
+              const float b0[4] = {bv[0][u].x, bv[0][u].y, bv[0][u].z, bv[0][u].w};
+              const float b1[4] = {bv[1][u].x, bv[1][u].y, bv[1][u].z, bv[1][u].w};
 #pragma unroll
-              for (int ct = 0; ct < CT; ++ct) {
-                const float a = wr[16 * ct];
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[t], acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[t], acc[1][ct], 0, 0, 0);
+              for (int t = 0; t < 4; ++t) {
+                const float* wr = &sW[(16 * (g0 + u - gb) + 4 * kk + t) * STR + j];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                  const float a = wr[16 * ct];
+                  acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0[t], acc[0][ct], 0, 0, 0);
+                  acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1[t], acc[1][ct], 0, 0, 0);
+                }
               }
             }
           }
+#pragma unroll
+          for (int s = 0; s < SP_NS; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bv[s][u] = nx[s][u];
         }
-#pragma unroll
-        for (int s = 0; s < SP_NS; ++s)
-#pragma unroll
-          for (int u = 0; u < 2; ++u) bv[s][u] = nx[s][u];
       }
     }
   }
@@ -541,30 +565,53 @@ bool sp_geom(int B, const int32_t* in_d, const int32_t* out_d, const int32_t* ks
     vin *= in_d[a]; vout *= out_d[a];
     g->K *= ks[a];
   }
-  return vin < 0x7fffffffLL && vout < (1LL << 36) && g->K <= 125;
-}
-
-unsigned hash_capacity(int n) {
-  unsigned c = 1024;
-  while (c < 2u * static_cast<unsigned>(n > 0 ? n : 1)) c <<= 1;
-  return c;
+  return vin < (1LL << 36) && vout < (1LL << 36) && g->K <= 125 && ks[0] <= 8 && ks[1] <= 8 && ks[2] <= 8;
 }
 
 size_t sp_align(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 
+// one workspace serves dbev_spconv_outputs and dbev_spconv_neighbors
+struct SpWs { size_t obits, ocnt, ostart, ibits, icnt, istart, irow, flags, pos, scan, total; long long nwo, nwi; };
+SpWs sp_ws(int n_in, int B, const int32_t* in_d, const int32_t* out_d, int K, int max_out) {
+  SpWs w;
+  const long long vin = static_cast<long long>(B) * in_d[0] * in_d[1] * in_d[2];
+  const long long vout = static_cast<long long>(B) * out_d[0] * out_d[1] * out_d[2];
+  w.nwi = (vin + 31) / 32;
+  w.nwo = (vout + 31) / 32;
+  const long long nflag = static_cast<long long>(K) * (max_out > 0 ? max_out : 1) + 1;
+  long long nscan = w.nwo > nflag ? w.nwo : nflag;
+  if (w.nwi > nscan) nscan = w.nwi;
+  size_t o = 0;
+  w.obits = o;  o += sp_align(sizeof(int) * w.nwo);
+  w.ocnt = o;   o += sp_align(sizeof(int) * w.nwo);
+  w.ostart = o; o += sp_align(sizeof(int) * (w.nwo + 1));
+  w.ibits = o;  o += sp_align(sizeof(int) * w.nwi);
+  w.icnt = o;   o += sp_align(sizeof(int) * w.nwi);
+  w.istart = o; o += sp_align(sizeof(int) * (w.nwi + 1));
+  w.irow = o;   o += sp_align(sizeof(int) * (n_in > 0 ? n_in : 1));
+  w.flags = o;  o += sp_align(sizeof(int) * nflag);
+  w.pos = o;    o += sp_align(sizeof(int) * nflag);
+  w.scan = o;   o += sp_align(sizeof(int) * dbev::scan_workspace_ints(nscan));
+  w.total = o + 4096;
+  return w;
+}
+
+bool sp_dims_ok(int B, const int32_t* in_d, const int32_t* out_d) {
+  if (B <= 0 || in_d == nullptr || out_d == nullptr) return false;
+  for (int a = 0; a < 3; ++a)
+    if (in_d[a] <= 0 || out_d[a] <= 0) return false;
+  return static_cast<long long>(B) * in_d[0] * in_d[1] * in_d[2] < (1LL << 36) &&
+         static_cast<long long>(B) * out_d[0] * out_d[1] * out_d[2] < (1LL << 36);
+}
+
 }  // namespace
 
 // ---- rulebook --------------------------------------------------------------------------------------------------------
-// workspace: hash keys + values, bitmap + per-word counts/starts (strided only), scan scratch
-extern "C" size_t dbev_spconv_build_workspace_bytes(int n_in, int B, const int32_t* out_dims_host, int K, int max_out) {
-  if (n_in < 0 || B <= 0 || out_dims_host == nullptr) return 0;
-  const unsigned cap = hash_capacity(n_in);
-  const long long vout = static_cast<long long>(B) * out_dims_host[0] * out_dims_host[1] * out_dims_host[2];
-  const long long nwords = (vout + 31) / 32;
-  const long long nflag = static_cast<long long>(K) * (max_out > 0 ? max_out : 1) + 1;
-  const long long nscan = nwords > nflag ? nwords : nflag;
-  return sp_align(sizeof(int) * cap) * 2 + sp_align(sizeof(int) * nwords) * 2 + sp_align(sizeof(int) * (nwords + 1)) +
-         sp_align(sizeof(int) * nflag) * 2 + sp_align(sizeof(int) * dbev::scan_workspace_ints(nscan)) + 4096;
+// workspace: bitmaps + per-word counts / starts over the input and the output grid, rank -> row table, pair-list flags, scan scratch
+extern "C" size_t dbev_spconv_build_workspace_bytes(int n_in, int B, const int32_t* in_dims_host, const int32_t* out_dims_host, int K,
+                                                    int max_out) {
+  if (n_in < 0 || K <= 0 || !sp_dims_ok(B, in_dims_host, out_dims_host)) return 0;
+  return sp_ws(n_in, B, in_dims_host, out_dims_host, K, max_out).total;
 }
 
 // Step 1 (strided / padded convolutions only; submanifold convolutions keep the input sites): enumerate the output sites.
@@ -577,24 +624,20 @@ extern "C" int dbev_spconv_outputs(const int32_t* indices, int n_in, int B, cons
                                    dbevStream_t stream) {
   SpGeom g;
   if (!sp_geom(B, in_dims_host, out_dims_host, ksize_host, stride_host, padding_host, dilation_host, &g)) return DBEV_EINVAL;
-  if (n_in < 0 || (n_in > 0 && indices == nullptr) || out_indices == nullptr || n_out_device == nullptr ||
-      workspace == nullptr || workspace_bytes < dbev_spconv_build_workspace_bytes(n_in, B, out_dims_host, g.K, max_out))
+  if (n_in < 0 || (n_in > 0 && indices == nullptr) || out_indices == nullptr || n_out_device == nullptr || workspace == nullptr)
     return DBEV_EINVAL;
+  const SpWs L = sp_ws(n_in, B, in_dims_host, out_dims_host, g.K, max_out);
+  if (workspace_bytes < L.total) return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
-  const unsigned cap = hash_capacity(n_in);
-  const long long vout = static_cast<long long>(B) * g.out_d[0] * g.out_d[1] * g.out_d[2];
-  const int nwords = static_cast<int>((vout + 31) / 32);
+  const int nwords = static_cast<int>(L.nwo);
   char* ws = static_cast<char*>(workspace);
-  size_t o = sp_align(sizeof(int) * cap) * 2;
-  unsigned* bits = reinterpret_cast<unsigned*>(ws + o); o += sp_align(sizeof(int) * nwords);
-  int* cnt = reinterpret_cast<int*>(ws + o);            o += sp_align(sizeof(int) * nwords);
-  int* start = reinterpret_cast<int*>(ws + o);          o += sp_align(sizeof(int) * (nwords + 1));
-  o += sp_align(sizeof(int) * (static_cast<long long>(g.K) * (max_out > 0 ? max_out : 1) + 1)) * 2;
-  int* scanws = reinterpret_cast<int*>(ws + o);
+  unsigned* bits = reinterpret_cast<unsigned*>(ws + L.obits);
+  int* cnt = reinterpret_cast<int*>(ws + L.ocnt);
+  int* start = reinterpret_cast<int*>(ws + L.ostart);
+  int* scanws = reinterpret_cast<int*>(ws + L.scan);
   DBEV_HIP_TRY(hipMemsetAsync(bits, 0, sizeof(int) * nwords, s));
   if (n_in > 0)
-    hipLaunchKernelGGL(sp_mark_outputs, dim3(dbev_ceil_div(static_cast<long long>(n_in) * g.K, 256)), dim3(256), 0, s,
-                       indices, n_in, g, bits);
+    hipLaunchKernelGGL(sp_mark_outputs, dim3(dbev_ceil_div(n_in, 256)), dim3(256), 0, s, indices, n_in, g, bits);
   hipLaunchKernelGGL(sp_popcount, dim3(dbev_ceil_div(nwords, 256)), dim3(256), 0, s, bits, nwords, cnt);
   int rc = dbev::exclusive_scan_i32(cnt, start, nwords, false, n_out_device, scanws, s);
   if (rc) return rc;
@@ -615,33 +658,40 @@ extern "C" int dbev_spconv_neighbors(const int32_t* indices, int n_in, const int
   SpGeom g;
   if (!sp_geom(B, in_dims_host, out_dims_host, ksize_host, stride_host, padding_host, dilation_host, &g)) return DBEV_EINVAL;
   if (n_in < 0 || n_out < 0 || (n_in > 0 && indices == nullptr) || (n_out > 0 && (out_indices == nullptr || nbr == nullptr)) ||
-      workspace == nullptr || workspace_bytes < dbev_spconv_build_workspace_bytes(n_in, B, out_dims_host, g.K, n_out))
+      workspace == nullptr)
     return DBEV_EINVAL;
+  const SpWs L = sp_ws(n_in, B, in_dims_host, out_dims_host, g.K, n_out);
+  if (workspace_bytes < L.total) return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
-  const unsigned cap = hash_capacity(n_in);
   char* ws = static_cast<char*>(workspace);
-  int* keys = reinterpret_cast<int*>(ws);
-  int* vals = reinterpret_cast<int*>(ws + sp_align(sizeof(int) * cap));
-  const long long vout = static_cast<long long>(B) * g.out_d[0] * g.out_d[1] * g.out_d[2];
-  const long long nwords = (vout + 31) / 32;
-  size_t o = sp_align(sizeof(int) * cap) * 2 + sp_align(sizeof(int) * nwords) * 2 + sp_align(sizeof(int) * (nwords + 1));
-  const long long nflag = static_cast<long long>(g.K) * (n_out > 0 ? n_out : 1) + 1;
-  int* flags = reinterpret_cast<int*>(ws + o); o += sp_align(sizeof(int) * nflag);
-  int* pos = reinterpret_cast<int*>(ws + o);   o += sp_align(sizeof(int) * nflag);
-  int* scanws = reinterpret_cast<int*>(ws + o);
-  DBEV_HIP_TRY(hipMemsetAsync(keys, 0xff, sizeof(int) * cap, s));
-  DBEV_HIP_TRY(hipMemsetAsync(vals, 0x7f, sizeof(int) * cap, s));
+  unsigned* ibits = reinterpret_cast<unsigned*>(ws + L.ibits);
+  int* icnt = reinterpret_cast<int*>(ws + L.icnt);
+  int* istart = reinterpret_cast<int*>(ws + L.istart);
+  int* irow = reinterpret_cast<int*>(ws + L.irow);
+  int* flags = reinterpret_cast<int*>(ws + L.flags);
+  int* pos = reinterpret_cast<int*>(ws + L.pos);
+  int* scanws = reinterpret_cast<int*>(ws + L.scan);
+  const int nwi = static_cast<int>(L.nwi);
+  // rank structure of the occupied input cells
+  DBEV_HIP_TRY(hipMemsetAsync(ibits, 0, sizeof(int) * nwi, s));
+  if (n_in > 0) {
+    hipLaunchKernelGGL(sp_mark_inputs, dim3(dbev_ceil_div(n_in, 256)), dim3(256), 0, s, indices, n_in, g, ibits);
+    DBEV_HIP_TRY(hipMemsetAsync(irow, 0x7f, sizeof(int) * n_in, s));
+  }
+  hipLaunchKernelGGL(sp_popcount, dim3(dbev_ceil_div(nwi, 256)), dim3(256), 0, s, ibits, nwi, icnt);
+  int rc = dbev::exclusive_scan_i32(icnt, istart, nwi, false, nullptr, scanws, s);
+  if (rc) return rc;
   if (n_in > 0)
-    hipLaunchKernelGGL(sp_hash_insert, dim3(dbev_ceil_div(n_in, 256)), dim3(256), 0, s, indices, n_in, g, keys, vals, cap - 1);
+    hipLaunchKernelGGL(sp_rank_rows, dim3(dbev_ceil_div(n_in, 256)), dim3(256), 0, s, indices, n_in, g, ibits, istart, irow);
   if (inv != nullptr && n_in > 0) DBEV_HIP_TRY(hipMemsetAsync(inv, 0xff, sizeof(int) * static_cast<size_t>(n_in) * g.K, s));
   if (n_out > 0) {
     const long long nt = static_cast<long long>(n_out) * g.K;
-    hipLaunchKernelGGL(sp_neighbors, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, out_indices, n_out, g, keys, vals, cap - 1,
+    hipLaunchKernelGGL(sp_neighbors, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, out_indices, n_out, g, ibits, istart, irow,
                        nbr, inv);
     if (indice_pairs != nullptr && indice_pair_num != nullptr && n_in > 0) {
       DBEV_HIP_TRY(hipMemsetAsync(indice_pairs, 0xff, sizeof(int) * static_cast<size_t>(g.K) * 2 * n_in, s));
       hipLaunchKernelGGL(sp_pair_flags, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, n_out, g.K, flags);
-      int rc = dbev::exclusive_scan_i32(flags, pos, nt, false, nullptr, scanws, s);
+      rc = dbev::exclusive_scan_i32(flags, pos, nt, false, nullptr, scanws, s);
       if (rc) return rc;
       hipLaunchKernelGGL(sp_pair_fill, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, pos, n_out, g.K, n_in,
                          indice_pairs, indice_pair_num);
@@ -681,6 +731,21 @@ extern "C" int dbev_spconv_pair_lists(const int32_t* nbr, int n_out, int K, int 
   if (rc) return rc;
   hipLaunchKernelGGL(sp_pair_fill, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, pos, n_out, K, n_in, indice_pairs,
                      indice_pair_num);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+// Step 2c (on demand): the inverse table alone, from an existing neighbour table (what dbev_spconv_neighbors writes when
+// inv != NULL).  SparseInverseConv3d and the data gradient read it; an inference forward of the encoder never does.
+extern "C" int dbev_spconv_inverse_table(const int32_t* nbr, int n_out, int K, int n_in, int32_t* inv, dbevStream_t stream) {
+  if (n_out < 0 || n_in < 0 || K <= 0 || (n_in > 0 && inv == nullptr) || (n_out > 0 && nbr == nullptr)) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  if (n_in == 0) return 0;
+  DBEV_HIP_TRY(hipMemsetAsync(inv, 0xff, sizeof(int) * static_cast<size_t>(n_in) * K, s));
+  if (n_out > 0) {
+    const long long nt = static_cast<long long>(n_out) * K;
+    hipLaunchKernelGGL(sp_inverse, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, nt, K, inv);
+  }
   DBEV_LAUNCH_CHECK();
   return 0;
 }
@@ -733,16 +798,21 @@ extern "C" int dbev_spconv_forward_fused(const float* features, const float* wei
     DBEV_LAUNCH_CHECK();
     return 0;
   }
-  const size_t lds = sizeof(float) * static_cast<size_t>(Cin) * (Cout + 4);
+  static const int nch_env = getenv("DBEV_SPCONV_CHUNKS") ? atoi(getenv("DBEV_SPCONV_CHUNKS")) : 0;
+  // two chunks when a whole slice would leave two workgroups per CU (68 KB at 128 -> 128)
+  int nch = nch_env > 0 ? nch_env : (sizeof(float) * static_cast<size_t>(Cin) * (Cout + 4) > 48 * 1024 ? 2 : 1);
+  if ((nch != 1 && nch != 2 && nch != 4) || Cin % (16 * nch) != 0 || Cout != 128) nch = 1;
+  const size_t lds = sizeof(float) * static_cast<size_t>(Cin / nch) * (Cout + 4);
   const dim3 grid(dbev_ceil_div(n_out, SP_SITES));
-#define SP_LAUNCH(CTV)                                                                                              \
+#define SP_LAUNCH2(CTV, NCHV)                                                                                       \
   do {                                                                                                              \
     if (lds > 64 * 1024)                                                                                            \
-      DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sp_conv_fwd<CTV>),                             \
+      DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sp_conv_fwd<CTV, NCHV>),                       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));         \
-    hipLaunchKernelGGL((sp_conv_fwd<CTV>), grid, dim3(256), lds, s, features, weight, bias, nbr, out_features, n_out, K, Cin,  \
-                       scale, residual, relu);                                                                      \
+    hipLaunchKernelGGL((sp_conv_fwd<CTV, NCHV>), grid, dim3(256), lds, s, features, weight, bias, nbr, out_features, n_out, K,  \
+                       Cin, scale, residual, relu);                                                                 \
   } while (0)
+#define SP_LAUNCH(CTV) SP_LAUNCH2(CTV, 1)
   // log entry: output rows + neighbour table + weights (the gathered input rows depend on the rulebook: added by the caller)
   DbevKt kt(DBEV_K_SPCONV_FWD, 4LL * n_out * (Cout + K) + 4LL * K * Cin * Cout, s);
   switch (Cout / 16) {
@@ -753,9 +823,14 @@ extern "C" int dbev_spconv_forward_fused(const float* features, const float* wei
     case 5: SP_LAUNCH(5); break;
     case 6: SP_LAUNCH(6); break;
     case 7: SP_LAUNCH(7); break;
-    default: SP_LAUNCH(8); break;
+    default:
+      if (nch == 2) SP_LAUNCH2(8, 2);
+      else if (nch == 4) SP_LAUNCH2(8, 4);
+      else SP_LAUNCH(8);
+      break;
   }
 #undef SP_LAUNCH
+#undef SP_LAUNCH2
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -55,8 +55,19 @@ def _t3(v, ndim):
 
 class Rulebook:
     """One convolution geometry on one index set: the neighbour table the kernel reads, plus -- on demand -- the reference's
-    pair lists (the backward pass and get_indice_pairs() read them; an inference forward never does)."""
-    __slots__ = ("nbr", "inv", "outids", "_pairs", "_pair_num", "n_in", "n_out", "K", "out_shape", "_pn_host")
+    pair lists (the backward pass and get_indice_pairs() read them) and the inverse table (SparseInverseConv3d and the data
+    gradient read it); an inference forward of the encoder needs neither."""
+    __slots__ = ("nbr", "_inv", "outids", "_pairs", "_pair_num", "n_in", "n_out", "K", "out_shape", "_pn_host")
+
+    @property
+    def inv(self):
+        if self._inv is None:
+            dev = self.nbr.device
+            self._inv = torch.empty((max(self.n_in, 1), self.K), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                L.call("dbev_spconv_inverse_table", L.ptr(self.nbr), self.n_out, self.K, self.n_in, L.ptr(self._inv),
+                       L.stream_ptr(dev))
+        return self._inv
 
     def _build_pairs(self):
         dev = self.nbr.device
@@ -126,13 +137,13 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     n_in = idx4.shape[0]
     K = ks[0] * ks[1] * ks[2]
     rb = Rulebook()
-    rb.n_in, rb.K, rb._pn_host, rb._pairs, rb._pair_num = n_in, K, None, None, None
+    rb.n_in, rb.K, rb._pn_host, rb._pairs, rb._pair_num, rb._inv = n_in, K, None, None, None, None
     rb.out_shape = out_shape[3 - ndim:]
     hi = L.host_ints
     with torch.cuda.device(dev):
         vol = batch_size * out_shape[0] * out_shape[1] * out_shape[2]
         max_out = n_in if subm else int(min(max(n_in * K, 1), vol))
-        nbytes = int(L.call("dbev_spconv_build_workspace_bytes", n_in, batch_size, hi(out_shape), K, max_out))
+        nbytes = int(L.call("dbev_spconv_build_workspace_bytes", n_in, batch_size, hi(in_shape), hi(out_shape), K, max_out))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         if subm:
             out4, n_out = idx4, n_in
@@ -145,9 +156,8 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
             out4 = out4[:n_out]
         rb.n_out = n_out
         rb.nbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
-        rb.inv = torch.empty((max(n_in, 1), K), dtype=torch.int32, device=dev)
         L.call("dbev_spconv_neighbors", L.ptr(idx4), n_in, L.ptr(out4), n_out, batch_size, hi(in_shape), hi(out_shape), hi(ks),
-               hi(st), hi(pd), hi(dl), L.ptr(rb.nbr), L.ptr(rb.inv), L.ptr(None), L.ptr(None), L.ptr(ws), ws.numel(),
+               hi(st), hi(pd), hi(dl), L.ptr(rb.nbr), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(ws), ws.numel(),
                L.stream_ptr(dev))
     rb.outids = indices if subm else (out4 if ndim == 3 else out4[:, [0, 2, 3]].contiguous())
     return rb

@@ -582,7 +582,8 @@ int dbev_msda_backward(const float* value, const int32_t* spatial_shapes_hw_host
  *                         Cin % 16 == 0, Cout % 16 == 0, Cout <= 128, Cin <= 256; fp32 MFMA; bias may be NULL)
  *  dbev_sparse_to_dense   SparseConvTensor.dense(): [B, C, D, H, W] canvas, zero elsewhere (structure.py:52-62)
  * ---------------------------------------------------------------------------------- */
-size_t dbev_spconv_build_workspace_bytes(int n_in, int B, const int32_t* out_dims_host, int K, int max_out);
+size_t dbev_spconv_build_workspace_bytes(int n_in, int B, const int32_t* in_dims_host, const int32_t* out_dims_host, int K,
+                                         int max_out);
 int dbev_spconv_outputs(const int32_t* indices, int n_in, int B, const int32_t* in_dims_host, const int32_t* out_dims_host,
                         const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
                         const int32_t* dilation_host, int32_t* out_indices, int max_out, int32_t* n_out_device,
@@ -597,6 +598,10 @@ int dbev_spconv_neighbors(const int32_t* indices, int n_in, const int32_t* out_i
 size_t dbev_spconv_pair_lists_workspace_bytes(int n_out, int K);
 int dbev_spconv_pair_lists(const int32_t* nbr, int n_out, int K, int n_in, int32_t* indice_pairs, int32_t* indice_pair_num,
                            void* workspace, size_t workspace_bytes, dbevStream_t stream);
+/* the inverse table alone, from an existing neighbour table (what dbev_spconv_neighbors writes when inv != NULL): inv[r, k] = output
+ * row paired with input row r by offset k, or -1.  SparseInverseConv3d (conv.py:143-160) and the data gradient
+ * (spconv_ops.h:352-420) read it; built on demand */
+int dbev_spconv_inverse_table(const int32_t* nbr, int n_out, int K, int n_in, int32_t* inv, dbevStream_t stream);
 int dbev_spconv_forward(const float* features, const float* weight, const float* bias, const int32_t* nbr, int n_out,
                         int K, int Cin, int Cout, float* out_features, dbevStream_t stream);
 /* dbev_spconv_forward with the epilogue of a conv -> eval BatchNorm1d -> (+ residual) -> ReLU chain folded in (the reference's
