@@ -83,12 +83,14 @@ _SIGNATURES = {
     "dbev_skinny_conv3x3_multi_forward": [_p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_skinny_conv3x3_multi_backward": [_p, _p, _ll, _p, _p, _ll, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
     "dbev_spconv_build_workspace_bytes": [_i, _i, _p, _p, _i, _i],
-    "dbev_spconv_outputs": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _sz, _p],
-    "dbev_spconv_neighbors": [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "dbev_spconv_outputs": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _sz, _p],
+    "dbev_spconv_neighbors": [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _sz, _p],
     "dbev_spconv_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "dbev_spconv_pair_lists_workspace_bytes": [_i, _i],
     "dbev_spconv_pair_lists": [_p, _i, _i, _i, _p, _p, _p, _sz, _p],
     "dbev_spconv_inverse_table": [_p, _i, _i, _i, _p, _p],
+    "dbev_spconv_maxpool_forward": [_p, _p, _i, _i, _i, _p, _p],
+    "dbev_spconv_maxpool_backward": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dbev_spconv_forward_fused": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "dbev_sparse_to_dense": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "dbev_spconv_backward_data": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p],

@@ -23,6 +23,8 @@
 // Teacher and difference tiles go through LDS so that both move as whole rows.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -33,7 +35,7 @@ constexpr int AM_KC = 32;     // K chunk
 constexpr int AM_STR = AM_PXB + 1;   // LDS row stride of the k-major operand stages (pad 1: the coalesced loader's writes spread over banks)
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void adapt_mse_fwd(const float* __restrict__ X, const float* __restrict__ Wt,
+__global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void adapt_mse_fwd(const float* __restrict__ X, const float* __restrict__ Wt,
                                                          const float* __restrict__ bias, const float* __restrict__ T,
                                                          const float* __restrict__ Cc, float* __restrict__ D,
                                                          float* __restrict__ maps, int M, int K, int N, int HW) {
@@ -203,7 +205,11 @@ __global__ __launch_bounds__(256) void adapt_mse_ds(const float4* __restrict__ D
 int pick_nt(int N) {
   const int t = N / 32;
   if (N % 32) return 0;
-  for (int nt : {4, 3, 2, 1})       // 4 tiles = 128 channels per workgroup: 210 VGPRs, no spills, 2 waves per SIMD (6 tiles spill)
+  static const int force = getenv("DBEV_ADAPT_NT") ? atoi(getenv("DBEV_ADAPT_NT")) : 0;     // A/B runs
+  if (force >= 1 && force <= 4 && t % force == 0) return force;
+  // 2 tiles = 64 channels per workgroup: 114 VGPRs and 50 KB of LDS -> three workgroups per CU, whose epilogues (teacher tile in,
+  // difference tile out) hide under each other's MFMAs; 4 tiles (210 VGPRs, 68 KB, two per CU) measured 7 % slower, 1 tile 11 %
+  for (int nt : {2, 3, 4, 1})
     if (t % nt == 0) return nt;
   return 0;
 }

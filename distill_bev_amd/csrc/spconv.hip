@@ -28,6 +28,7 @@ namespace {
 
 struct SpGeom {
   int B, in_d[3], out_d[3], ks[3], st[3], pd[3], dl[3], K;
+  int tr;      // transposed convolution (conv.py SparseConvTranspose*, indice.h getValidOutPosTranspose): out = in * stride - pad + k * dil
 };
 
 // occupied input cells: one bit per cell of the [B, D, H, W] grid (rows with out-of-range coordinates are ignored)
@@ -71,9 +72,15 @@ __global__ __launch_bounds__(256) void sp_mark_outputs(const int* __restrict__ i
   for (int a = 0; a < 3; ++a) {
     cnt[a] = 0;
     for (int kk = 0; kk < g.ks[a]; ++kk) {
-      const int num = in[a] + g.pd[a] - kk * g.dl[a];
-      if (num < 0 || num % g.st[a]) continue;
-      const int oo = num / g.st[a];
+      int oo;
+      if (g.tr) {
+        oo = in[a] * g.st[a] - g.pd[a] + kk * g.dl[a];
+        if (oo < 0) continue;
+      } else {
+        const int num = in[a] + g.pd[a] - kk * g.dl[a];
+        if (num < 0 || num % g.st[a]) continue;
+        oo = num / g.st[a];
+      }
       if (oo >= g.out_d[a] || cnt[a] >= MAXT) continue;
       o[a][cnt[a]++] = oo;
     }
@@ -120,10 +127,18 @@ __global__ __launch_bounds__(256) void sp_neighbors(const int* __restrict__ out_
   const int o = static_cast<int>(t / g.K), k = static_cast<int>(t - static_cast<long long>(o) * g.K);
   const int4 c = reinterpret_cast<const int4*>(out_idx)[o];
   const int kz = k / (g.ks[1] * g.ks[2]), ky = (k / g.ks[2]) % g.ks[1], kx = k % g.ks[2];
-  const int z = c.y * g.st[0] - g.pd[0] + kz * g.dl[0], y = c.z * g.st[1] - g.pd[1] + ky * g.dl[1],
-            x = c.w * g.st[2] - g.pd[2] + kx * g.dl[2];
+  int z, y, x;
+  bool ok = true;
+  if (g.tr) {                                 // in = (out + pad - k * dil) / stride where that is integral
+    const int nz = c.y + g.pd[0] - kz * g.dl[0], ny = c.z + g.pd[1] - ky * g.dl[1], nx = c.w + g.pd[2] - kx * g.dl[2];
+    ok = nz >= 0 && ny >= 0 && nx >= 0 && nz % g.st[0] == 0 && ny % g.st[1] == 0 && nx % g.st[2] == 0;
+    z = nz / g.st[0]; y = ny / g.st[1]; x = nx / g.st[2];
+  } else {
+    z = c.y * g.st[0] - g.pd[0] + kz * g.dl[0]; y = c.z * g.st[1] - g.pd[1] + ky * g.dl[1];
+    x = c.w * g.st[2] - g.pd[2] + kx * g.dl[2];
+  }
   int r = -1;
-  if (z >= 0 && z < g.in_d[0] && y >= 0 && y < g.in_d[1] && x >= 0 && x < g.in_d[2] && c.x >= 0 && c.x < g.B) {
+  if (ok && z >= 0 && z < g.in_d[0] && y >= 0 && y < g.in_d[1] && x >= 0 && x < g.in_d[2] && c.x >= 0 && c.x < g.B) {
     const long long lin = ((static_cast<long long>(c.x) * g.in_d[0] + z) * g.in_d[1] + y) * g.in_d[2] + x;
     const unsigned w = bits[lin >> 5], bit = 1u << (lin & 31);
     if (w & bit) r = row[start[lin >> 5] + __popc(w & (bit - 1u))];
@@ -138,6 +153,47 @@ __global__ __launch_bounds__(256) void sp_inverse(const int* __restrict__ nbr, l
   if (t >= nt) return;
   const int r = nbr[t];
   if (r >= 0) inv[static_cast<size_t>(r) * K + t % K] = static_cast<int>(t / K);
+}
+
+// Sparse max pooling (pool.py:21-74, pool_ops.h:26-58, maxpool_cuda.cu:28-160): the reference starts from a ZERO output and raises it
+// with every paired input, i.e. out[o, c] = max(0, max_k in[nbr[o, k], c]).  One float4 of channels per lane, offsets in order.
+__global__ __launch_bounds__(256) void sp_maxpool_fwd(const float4* __restrict__ in, const int* __restrict__ nbr, long long total,
+                                                      int K, int C4, float4* __restrict__ out) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long long o = t / C4;
+  const int c = static_cast<int>(t - o * C4);
+  float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < K; ++k) {
+    const int r = nbr[o * K + k];
+    if (r < 0) continue;
+    const float4 v = in[static_cast<size_t>(r) * C4 + c];
+    m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y; m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+  }
+  out[t] = m;
+}
+
+// din[r, c] = sum over the pairs (r, o) with in[r, c] == out[o, c] of dout[o, c]  (maxpool_cuda.cu:165-230: every tie gets the
+// gradient); gathered through the inverse table in offset order -- the order the reference's per-offset launches add in, no atomics
+__global__ __launch_bounds__(256) void sp_maxpool_bwd(const float4* __restrict__ in, const float4* __restrict__ out,
+                                                      const float4* __restrict__ dout, const int* __restrict__ inv,
+                                                      long long total, int K, int C4, float4* __restrict__ din) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long long r = t / C4;
+  const int c = static_cast<int>(t - r * C4);
+  const float4 v = in[t];
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < K; ++k) {
+    const int o = inv[r * K + k];
+    if (o < 0) continue;
+    const float4 y = out[static_cast<size_t>(o) * C4 + c], d = dout[static_cast<size_t>(o) * C4 + c];
+    if (v.x == y.x) g.x += d.x;
+    if (v.y == y.y) g.y += d.y;
+    if (v.z == y.z) g.z += d.z;
+    if (v.w == y.w) g.w += d.w;
+  }
+  din[t] = g;
 }
 
 // reference-format pair lists from the table: flags laid out [K, M]
@@ -554,9 +610,10 @@ __global__ __launch_bounds__(256) void sp_to_dense(const float* __restrict__ fea
 }
 
 bool sp_geom(int B, const int32_t* in_d, const int32_t* out_d, const int32_t* ks, const int32_t* st, const int32_t* pd,
-             const int32_t* dl, SpGeom* g) {
+             const int32_t* dl, int transposed, SpGeom* g) {
   if (B <= 0 || !in_d || !out_d || !ks || !st || !pd || !dl) return false;
   g->B = B;
+  g->tr = transposed ? 1 : 0;
   long long vin = B, vout = B;
   g->K = 1;
   for (int a = 0; a < 3; ++a) {
@@ -619,11 +676,12 @@ extern "C" size_t dbev_spconv_build_workspace_bytes(int n_in, int B, const int32
 // does the same through num_act_out) and calls dbev_spconv_neighbors with it.
 extern "C" int dbev_spconv_outputs(const int32_t* indices, int n_in, int B, const int32_t* in_dims_host,
                                    const int32_t* out_dims_host, const int32_t* ksize_host, const int32_t* stride_host,
-                                   const int32_t* padding_host, const int32_t* dilation_host, int32_t* out_indices,
-                                   int max_out, int32_t* n_out_device, void* workspace, size_t workspace_bytes,
-                                   dbevStream_t stream) {
+                                   const int32_t* padding_host, const int32_t* dilation_host, int transposed,
+                                   int32_t* out_indices, int max_out, int32_t* n_out_device, void* workspace,
+                                   size_t workspace_bytes, dbevStream_t stream) {
   SpGeom g;
-  if (!sp_geom(B, in_dims_host, out_dims_host, ksize_host, stride_host, padding_host, dilation_host, &g)) return DBEV_EINVAL;
+  if (!sp_geom(B, in_dims_host, out_dims_host, ksize_host, stride_host, padding_host, dilation_host, transposed, &g))
+    return DBEV_EINVAL;
   if (n_in < 0 || (n_in > 0 && indices == nullptr) || out_indices == nullptr || n_out_device == nullptr || workspace == nullptr)
     return DBEV_EINVAL;
   const SpWs L = sp_ws(n_in, B, in_dims_host, out_dims_host, g.K, max_out);
@@ -652,11 +710,12 @@ extern "C" int dbev_spconv_outputs(const int32_t* indices, int n_in, int B, cons
 extern "C" int dbev_spconv_neighbors(const int32_t* indices, int n_in, const int32_t* out_indices, int n_out, int B,
                                      const int32_t* in_dims_host, const int32_t* out_dims_host, const int32_t* ksize_host,
                                      const int32_t* stride_host, const int32_t* padding_host,
-                                     const int32_t* dilation_host, int32_t* nbr, int32_t* inv, int32_t* indice_pairs,
-                                     int32_t* indice_pair_num, void* workspace, size_t workspace_bytes,
+                                     const int32_t* dilation_host, int transposed, int32_t* nbr, int32_t* inv,
+                                     int32_t* indice_pairs, int32_t* indice_pair_num, void* workspace, size_t workspace_bytes,
                                      dbevStream_t stream) {
   SpGeom g;
-  if (!sp_geom(B, in_dims_host, out_dims_host, ksize_host, stride_host, padding_host, dilation_host, &g)) return DBEV_EINVAL;
+  if (!sp_geom(B, in_dims_host, out_dims_host, ksize_host, stride_host, padding_host, dilation_host, transposed, &g))
+    return DBEV_EINVAL;
   if (n_in < 0 || n_out < 0 || (n_in > 0 && indices == nullptr) || (n_out > 0 && (out_indices == nullptr || nbr == nullptr)) ||
       workspace == nullptr)
     return DBEV_EINVAL;
@@ -746,6 +805,33 @@ extern "C" int dbev_spconv_inverse_table(const int32_t* nbr, int n_out, int K, i
     const long long nt = static_cast<long long>(n_out) * K;
     hipLaunchKernelGGL(sp_inverse, dim3(dbev_ceil_div(nt, 256)), dim3(256), 0, s, nbr, nt, K, inv);
   }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- max pooling -----------------------------------------------------------------------------------------------------
+extern "C" int dbev_spconv_maxpool_forward(const float* features, const int32_t* nbr, int n_out, int K, int C, float* out_features,
+                                           dbevStream_t stream) {
+  if (n_out < 0 || K <= 0 || C <= 0 || (C & 3)) return DBEV_EINVAL;
+  if (n_out == 0) return 0;
+  if (features == nullptr || nbr == nullptr || out_features == nullptr) return DBEV_EINVAL;
+  const long long total = static_cast<long long>(n_out) * (C / 4);
+  hipLaunchKernelGGL(sp_maxpool_fwd, dim3(dbev_ceil_div(total, 256)), dim3(256), 0, dbev_stream(stream),
+                     reinterpret_cast<const float4*>(features), nbr, total, K, C / 4, reinterpret_cast<float4*>(out_features));
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_spconv_maxpool_backward(const float* features, const float* out_features, const float* grad_out,
+                                            const int32_t* inv, int n_in, int K, int C, float* grad_in, dbevStream_t stream) {
+  if (n_in < 0 || K <= 0 || C <= 0 || (C & 3)) return DBEV_EINVAL;
+  if (n_in == 0) return 0;
+  if (features == nullptr || out_features == nullptr || grad_out == nullptr || inv == nullptr || grad_in == nullptr)
+    return DBEV_EINVAL;
+  const long long total = static_cast<long long>(n_in) * (C / 4);
+  hipLaunchKernelGGL(sp_maxpool_bwd, dim3(dbev_ceil_div(total, 256)), dim3(256), 0, dbev_stream(stream),
+                     reinterpret_cast<const float4*>(features), reinterpret_cast<const float4*>(out_features),
+                     reinterpret_cast<const float4*>(grad_out), inv, total, K, C / 4, reinterpret_cast<float4*>(grad_in));
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -121,8 +121,9 @@ class IndiceData(object):
         return (self._get(j) for j in range(5))
 
 
-def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm):
-    """-> Rulebook.  indices int32 [n, ndim + 1] (batch first), ndim in (2, 3)."""
+def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, transposed=False, output_padding=0):
+    """-> Rulebook.  indices int32 [n, ndim + 1] (batch first), ndim in (2, 3).  transposed: SparseConvTranspose* (an input at i
+    reaches the outputs i * stride - padding + k * dilation, ops.py:73-76)."""
     dev = L.require_cuda(indices)
     ndim = indices.shape[1] - 1
     assert ndim in (2, 3), "sparse convolutions over 2 or 3 spatial dimensions"
@@ -133,7 +134,17 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     idx4 = indices.int().contiguous()
     if ndim == 2:
         idx4 = torch.cat([idx4[:, :1], torch.zeros_like(idx4[:, :1]), idx4[:, 1:]], dim=1).contiguous()
-    out_shape = in_shape if subm else get_conv_output_size(in_shape, ks, st, pd, dl)
+    assert not (subm and transposed)
+    op = _t3(output_padding, ndim)
+    if ndim == 2:                                 # the dummy z axis of a 2-D geometry: kernel 1, stride 1, no padding
+        pd[0], op[0] = 0, 0
+    if subm:
+        out_shape = in_shape
+    elif transposed:
+        out_shape = get_deconv_output_size(in_shape, ks, st, pd, dl, op)
+    else:
+        out_shape = get_conv_output_size(in_shape, ks, st, pd, dl)
+    tr = 1 if transposed else 0
     n_in = idx4.shape[0]
     K = ks[0] * ks[1] * ks[2]
     rb = Rulebook()
@@ -151,13 +162,13 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
             out4 = torch.empty((max(max_out, 1), 4), dtype=torch.int32, device=dev)
             n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
             L.call("dbev_spconv_outputs", L.ptr(idx4), n_in, batch_size, hi(in_shape), hi(out_shape), hi(ks), hi(st), hi(pd),
-                   hi(dl), L.ptr(out4), max_out, L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+                   hi(dl), tr, L.ptr(out4), max_out, L.ptr(n_dev), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
             n_out = int(n_dev.item())                       # num_act_out of the reference (one read-back per rulebook)
             out4 = out4[:n_out]
         rb.n_out = n_out
         rb.nbr = torch.empty((max(n_out, 1), K), dtype=torch.int32, device=dev)
         L.call("dbev_spconv_neighbors", L.ptr(idx4), n_in, L.ptr(out4), n_out, batch_size, hi(in_shape), hi(out_shape), hi(ks),
-               hi(st), hi(pd), hi(dl), L.ptr(rb.nbr), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(ws), ws.numel(),
+               hi(st), hi(pd), hi(dl), tr, L.ptr(rb.nbr), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(ws), ws.numel(),
                L.stream_ptr(dev))
     rb.outids = indices if subm else (out4 if ndim == 3 else out4[:, [0, 2, 3]].contiguous())
     return rb
@@ -166,8 +177,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
                      subm=False, transpose=False, grid=None):
     """ops.py:46-104 -> (outids, indice_pairs [K, 2, N], indice_pair_num [K])."""
-    assert not transpose, "transposed sparse convolutions are not used by the reference's encoders"
-    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, transpose, out_padding)
     return rb.outids, rb.indice_pairs, rb.indice_pair_num
 
 
@@ -454,7 +464,7 @@ class SparseConvolution(SparseModule):
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None, fused_bn=False):
         super().__init__()
-        assert groups == 1 and not transposed, "grouped / transposed sparse convolutions are not part of the encoders"
+        assert groups == 1, "grouped sparse convolutions are not part of the reference's layers"
         lst = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
         kernel_size, stride, padding, dilation = lst(kernel_size), lst(stride), lst(padding), lst(dilation)
         for d, s in zip(dilation, stride):
@@ -480,7 +490,7 @@ class SparseConvolution(SparseModule):
 
     def _auto_key(self, input):
         # identifies the geometry on this index tensor (a submanifold convolution ignores its stride / padding)
-        sp = () if self.subm else (tuple(self.stride), tuple(self.padding))
+        sp = () if self.subm else (tuple(self.stride), tuple(self.padding), self.transposed, tuple(self.output_padding))
         return ("auto", input.indices.data_ptr(), input.indices.shape[0], tuple(self.kernel_size), sp, tuple(self.dilation),
                 self.subm)
 
@@ -514,7 +524,7 @@ class SparseConvolution(SparseModule):
                 rb = input.rulebooks.get(auto)          # the same geometry built under another (or no) indice_key
                 if rb is None:
                     rb = build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,
-                                        self.dilation, self.subm)
+                                        self.dilation, self.subm, self.transposed, self.output_padding)
                 input.rulebooks[key] = input.rulebooks[auto] = rb
                 if self.indice_key is not None:         # the reference's cache entry, same layout (conv.py:176-180)
                     input.indice_dict[self.indice_key] = IndiceData(rb, indices, spatial_shape)
@@ -550,5 +560,85 @@ SparseConv2d = _make("SparseConv2d", 2)
 SparseConv3d = _make("SparseConv3d", 3)
 SubMConv2d = _make("SubMConv2d", 2, subm=True)
 SubMConv3d = _make("SubMConv3d", 3, subm=True)
+SparseConvTranspose2d = _make("SparseConvTranspose2d", 2, transposed=True)
+SparseConvTranspose3d = _make("SparseConvTranspose3d", 3, transposed=True)
 SparseInverseConv2d = _make("SparseInverseConv2d", 2, inverse=True)
 SparseInverseConv3d = _make("SparseInverseConv3d", 3, inverse=True)
+
+
+# ---- pool.py ---------------------------------------------------------------------------------------------------------
+class _SparseMaxPoolFn(Function):
+    """functional.py:77-92 (SparseMaxPoolFunction) on the neighbour / inverse tables: out = max(0, max over the paired inputs)."""
+
+    @staticmethod
+    def forward(ctx, features, table, n_out, book):
+        dev = L.require_cuda(features)
+        f = features.float().contiguous()
+        C = f.shape[1]
+        cp = (C + 3) // 4 * 4
+        if cp != C:
+            f = torch.nn.functional.pad(f, (0, cp - C))
+        out = torch.zeros((n_out, cp), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.call("dbev_spconv_maxpool_forward", L.ptr(f), L.ptr(table), n_out, table.shape[1], cp, L.ptr(out), L.stream_ptr(dev))
+        ctx.book, ctx.C = book, C
+        ctx.save_for_backward(f, out)
+        return out[:, :C] if cp != C else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        f, out = ctx.saved_tensors
+        dev, C, cp = f.device, ctx.C, f.shape[1]
+        g = grad_out.float()
+        if cp != C:
+            g = torch.nn.functional.pad(g, (0, cp - C))
+        g = g.contiguous()
+        inv = ctx.book.inv
+        din = torch.zeros_like(f)
+        with torch.cuda.device(dev):
+            L.call("dbev_spconv_maxpool_backward", L.ptr(f), L.ptr(out), L.ptr(g), L.ptr(inv), f.shape[0], inv.shape[1], cp,
+                   L.ptr(din), L.stream_ptr(dev))
+        return (din[:, :C] if cp != C else din), None, None, None
+
+
+def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
+    """functional.py:98 / ops.py:161-171 on the reference's own pair lists [K, 2, N] (-1 padded)."""
+    K, n_in = indice_pairs.shape[0], features.shape[0]
+    dev = features.device
+    nbr = torch.full((max(num_activate_out, 1), K), -1, dtype=torch.int32, device=dev)
+    inv = torch.full((max(n_in, 1), K), -1, dtype=torch.int32, device=dev)
+    for k, n in enumerate(indice_pair_num.cpu().tolist()):
+        if n:
+            nbr[indice_pairs[k, 1, :n].long(), k] = indice_pairs[k, 0, :n]
+            inv[indice_pairs[k, 0, :n].long(), k] = indice_pairs[k, 1, :n]
+    book = _PairsView(indice_pairs.int().contiguous(), indice_pair_num.int().contiguous(), None, inv)
+    return _SparseMaxPoolFn.apply(features, nbr, num_activate_out, book)
+
+
+class SparseMaxPool(SparseModule):
+    """pool.py:21-74"""
+
+    def __init__(self, ndim, kernel_size, stride=1, padding=0, dilation=1, subm=False):
+        super().__init__()
+        lst = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+        self.ndim, self.kernel_size, self.stride, self.padding = ndim, lst(kernel_size), lst(stride), lst(padding)
+        self.subm, self.dilation = subm, lst(dilation)
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        rb = build_rulebook(input.indices, input.batch_size, input.spatial_shape, self.kernel_size, self.stride, self.padding,
+                            self.dilation, self.subm)
+        out_features = _SparseMaxPoolFn.apply(input.features, rb.nbr, rb.n_out, rb)
+        out = SparseConvTensor(out_features, rb.outids, input.spatial_shape if self.subm else rb.out_shape, input.batch_size)
+        out.indice_dict, out.rulebooks, out.grid = input.indice_dict, input.rulebooks, input.grid
+        return out
+
+
+class SparseMaxPool2d(SparseMaxPool):
+    def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
+        super().__init__(2, kernel_size, stride, padding, dilation)
+
+
+class SparseMaxPool3d(SparseMaxPool):
+    def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
+        super().__init__(3, kernel_size, stride, padding, dilation)

@@ -581,18 +581,24 @@ int dbev_msda_backward(const float* value, const int32_t* spatial_shapes_hw_host
  *  dbev_spconv_forward    out[o, :] = bias + sum_k features[nbr[o, k], :] @ weight[k]   (weight [K, Cin, Cout];
  *                         Cin % 16 == 0, Cout % 16 == 0, Cout <= 128, Cin <= 256; fp32 MFMA; bias may be NULL)
  *  dbev_sparse_to_dense   SparseConvTensor.dense(): [B, C, D, H, W] canvas, zero elsewhere (structure.py:52-62)
+ *  transposed != 0        SparseConvTranspose2d / 3d (conv.py:300-346, indice.h:88-140 getValidOutPosTranspose): an input at i
+ *                         reaches the outputs i * stride - padding + k * dilation; out_dims = get_deconv_output_size (ops.py:33-44)
+ *  dbev_spconv_maxpool_*  SparseMaxPool2d / 3d (pool.py:21-88; indice_maxpool_fp32 / indice_maxpool_backward_fp32 of all.cc:40-47,
+ *                         pool_ops.h:26-98, maxpool_cuda.cu:28-230): out[o, c] = max(0, max_k features[nbr[o, k], c]) (the reference
+ *                         raises a zero-initialised output); backward: every input equal to its output's value receives that output's
+ *                         gradient, summed over the input's pairs in offset order (inv = the inverse table).  C % 4 == 0
  * ---------------------------------------------------------------------------------- */
 size_t dbev_spconv_build_workspace_bytes(int n_in, int B, const int32_t* in_dims_host, const int32_t* out_dims_host, int K,
                                          int max_out);
 int dbev_spconv_outputs(const int32_t* indices, int n_in, int B, const int32_t* in_dims_host, const int32_t* out_dims_host,
                         const int32_t* ksize_host, const int32_t* stride_host, const int32_t* padding_host,
-                        const int32_t* dilation_host, int32_t* out_indices, int max_out, int32_t* n_out_device,
-                        void* workspace, size_t workspace_bytes, dbevStream_t stream);
+                        const int32_t* dilation_host, int transposed, int32_t* out_indices, int max_out,
+                        int32_t* n_out_device, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 int dbev_spconv_neighbors(const int32_t* indices, int n_in, const int32_t* out_indices, int n_out, int B,
                           const int32_t* in_dims_host, const int32_t* out_dims_host, const int32_t* ksize_host,
                           const int32_t* stride_host, const int32_t* padding_host, const int32_t* dilation_host,
-                          int32_t* nbr, int32_t* inv, int32_t* indice_pairs, int32_t* indice_pair_num, void* workspace,
-                          size_t workspace_bytes, dbevStream_t stream);
+                          int transposed, int32_t* nbr, int32_t* inv, int32_t* indice_pairs, int32_t* indice_pair_num,
+                          void* workspace, size_t workspace_bytes, dbevStream_t stream);
 /* the pair lists alone, from an existing table (what dbev_spconv_neighbors writes when indice_pairs != NULL): built on demand
  * for the backward pass and for get_indice_pairs() (ops.py:46-104); an inference forward never reads them */
 size_t dbev_spconv_pair_lists_workspace_bytes(int n_out, int K);
@@ -602,6 +608,10 @@ int dbev_spconv_pair_lists(const int32_t* nbr, int n_out, int K, int n_in, int32
  * row paired with input row r by offset k, or -1.  SparseInverseConv3d (conv.py:143-160) and the data gradient
  * (spconv_ops.h:352-420) read it; built on demand */
 int dbev_spconv_inverse_table(const int32_t* nbr, int n_out, int K, int n_in, int32_t* inv, dbevStream_t stream);
+int dbev_spconv_maxpool_forward(const float* features, const int32_t* nbr, int n_out, int K, int C, float* out_features,
+                                dbevStream_t stream);
+int dbev_spconv_maxpool_backward(const float* features, const float* out_features, const float* grad_out, const int32_t* inv,
+                                 int n_in, int K, int C, float* grad_in, dbevStream_t stream);
 int dbev_spconv_forward(const float* features, const float* weight, const float* bias, const int32_t* nbr, int n_out,
                         int K, int Cin, int Cout, float* out_features, dbevStream_t stream);
 /* dbev_spconv_forward with the epilogue of a conv -> eval BatchNorm1d -> (+ residual) -> ReLU chain folded in (the reference's

@@ -2,7 +2,7 @@
   (a) the unfused product sequence it replaces (MIOpen 1x1 conv -> abs-mean kernel -> masked-MSE kernels) and
   (b) the fp64 oracle (oracle/distill.py, pinned against the imported bevdet_distill.py by tests/golden/fgd_losses.npz),
 losses 1e-4 relative, gradients of the student input / conv weight / bias 2e-4 of their scale.  Shapes cover every tile
-variant (Ct = 32, 64, 96, 128 per slice; 3 slices at Ct = 384), a pixel count that is not a multiple of the 128-pixel
+variant (Ct = 32, 64, 96, 128 per slice; 6 slices of 64 channels at Ct = 384), a pixel count that is not a multiple of the 128-pixel
 tile, the fp term on / off, and the recipe's real channel counts (256 -> 384)."""
 import numpy as np
 import pytest

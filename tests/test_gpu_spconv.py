@@ -352,3 +352,107 @@ def test_indice_conv_api_backward_and_empty_inputs():
     assert ye.shape == (0, 64)
     ge = torch.autograd.grad(ye.sum(), conv.weight, allow_unused=True)[0]
     assert ge is None or float(ge.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ndim,kw,Cin,Cout", [
+    (3, dict(kernel_size=3, stride=2, padding=1), 32, 64),
+    (3, dict(kernel_size=2, stride=2, padding=0), 16, 32),            # the usual up-sampling layer: every input owns a 2x2x2 block
+    (3, dict(kernel_size=(3, 1, 3), stride=(1, 2, 2), padding=(1, 0, 1)), 16, 16),
+    (3, dict(kernel_size=3, stride=1, padding=0, dilation=2), 16, 48),
+    (2, dict(kernel_size=3, stride=2, padding=1), 16, 32),
+])
+def test_sparse_conv_transpose_vs_dense_definition_and_pair_list_gradients(ndim, kw, Cin, Cout):
+    """SparseConvTranspose2d / 3d (conv.py:300-346; rulebook indice.h:88-140: out = in * stride - padding + k * dilation): output
+    sites (ascending cell order), features against the dense fp64 conv_transpose3d of the densified input (oracle/spconv.py
+    sparse_deconv_dense) at 1e-5 of scale, input / weight gradients against the fp64 sums over the oracle's pair lists, repeated runs
+    bit-identical."""
+    from distill_bev_amd import spconv
+    from oracle import spconv as OS
+    dev = torch.device("cuda:0")
+    shape3, B = (6, 9, 8), 2
+    idx, feats = _cloud(31 + Cin, B, shape3, 260, Cin)
+    if ndim == 2:
+        idx = idx[idx[:, 1] == 0]
+        feats = feats[: idx.shape[0]]
+        idx_in, shape_in = idx[:, [0, 2, 3]], list(shape3[1:])
+        idx3 = idx.copy()
+        shape_or = (1, *shape3[1:])
+    else:
+        idx_in, shape_in, idx3, shape_or = idx, list(shape3), idx, shape3
+    cls = spconv.SparseConvTranspose3d if ndim == 3 else spconv.SparseConvTranspose2d
+    conv = cls(Cin, Cout, bias=True, **kw).to(dev)
+    f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    x = spconv.SparseConvTensor(f, torch.from_numpy(np.ascontiguousarray(idx_in)).to(dev), shape_in, B)
+    t3 = lambda v, fill: [int(q) for q in v] if isinstance(v, (list, tuple)) else [int(v)] * 3
+    ks, st, pd, dl = kw["kernel_size"], kw.get("stride", 1), kw.get("padding", 0), kw.get("dilation", 1)
+    if ndim == 2:
+        ks, st, pd, dl = (1, ks, ks), (1, st, st), (0, pd, pd), (1, dl, dl)
+    w = conv.weight.detach().cpu().double().numpy()
+    w5 = w if ndim == 3 else w[None]
+    ref, oi, osh = OS.sparse_deconv_dense(feats, idx3, shape_or, B, w5, conv.bias.detach().cpu().double().numpy(), st, pd, dl, 0)
+    runs = []
+    for _ in range(2):
+        y = conv(x)
+        g = torch.from_numpy(np.random.default_rng(3).normal(size=tuple(y.features.shape)).astype(np.float32)).to(dev)
+        runs.append((y.features.detach().clone(),) + torch.autograd.grad(y.features, (f, conv.weight), g))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1]))
+    assert list(y.spatial_shape) == list(osh[3 - ndim:])
+    got_idx = y.indices.cpu().numpy().astype(np.int64)
+    want_idx = oi.numpy() if ndim == 3 else oi.numpy()[:, [0, 2, 3]]
+    assert np.array_equal(got_idx, want_idx) and len(want_idx) > len(idx3)
+    refn = ref.numpy()
+    assert np.abs(runs[0][0].cpu().double().numpy() - refn).max() <= 1e-5 * np.abs(refn).max()
+    _, pairs = OS.rulebook_pairs(idx3, shape_or, B, t3(ks, 1), st, pd, dl, False, True, 0)
+    K = len(pairs)
+    f64, g64, w64 = feats.astype(np.float64), g.cpu().double().numpy(), w.reshape(K, Cin, Cout)
+    rf, rw = np.zeros_like(f64), np.zeros_like(w64)
+    for k, pr in enumerate(pairs):
+        if len(pr):
+            rw[k] = f64[pr[:, 0]].T @ g64[pr[:, 1]]
+            np.add.at(rf, pr[:, 0], g64[pr[:, 1]] @ w64[k].T)
+    gf, gw = runs[0][1].cpu().double().numpy(), runs[0][2].cpu().double().numpy().reshape(K, Cin, Cout)
+    assert np.abs(gf - rf).max() <= 1e-5 * np.abs(rf).max()
+    assert np.abs(gw - rw).max() <= 1e-5 * np.abs(rw).max()
+
+
+@pytest.mark.parametrize("ndim,C,kw", [(3, 32, dict(kernel_size=3, stride=2, padding=1)), (3, 6, dict(kernel_size=2, stride=2)),
+                                       (2, 16, dict(kernel_size=3, stride=2, padding=1)), (3, 64, dict(kernel_size=3, stride=1, padding=1))])
+def test_sparse_max_pool_forward_and_tie_gradients_bit_exact(ndim, C, kw):
+    """SparseMaxPool2d / 3d (pool.py:21-88, pool_ops.h:26-98): the reference raises a ZERO-initialised output with every paired input
+    (so all-negative windows give 0) and hands an output's gradient to EVERY input equal to its value; features quantised to halves
+    so that ties happen.  Output sites, values and input gradients are bit-exact against oracle/spconv.py's pair-list restatement
+    (sums of at most K gradients in offset order on both sides); the functional surface (indice_maxpool on the reference's pair
+    lists) gives the same tensors."""
+    from distill_bev_amd import spconv
+    from oracle import spconv as OS
+    dev = torch.device("cuda:0")
+    shape3, B = (7, 10, 9), 2
+    idx, feats = _cloud(57 + C, B, shape3, 400, C)
+    feats = (np.round(feats * 2) / 2).astype(np.float32)
+    if ndim == 2:
+        idx = idx[idx[:, 1] == 0]
+        feats = feats[: idx.shape[0]]
+        idx_in, shape_in, shape_or = idx[:, [0, 2, 3]], list(shape3[1:]), (1, *shape3[1:])
+        ks, st, pd = (1, kw["kernel_size"], kw["kernel_size"]), (1, kw.get("stride", 1), kw.get("stride", 1)), (0, kw.get("padding", 0), kw.get("padding", 0))
+    else:
+        idx_in, shape_in, shape_or = idx, list(shape3), shape3
+        ks, st, pd = kw["kernel_size"], kw.get("stride", 1), kw.get("padding", 0)
+    pool = (spconv.SparseMaxPool3d if ndim == 3 else spconv.SparseMaxPool2d)(**kw)
+    f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    x = spconv.SparseConvTensor(f, torch.from_numpy(np.ascontiguousarray(idx_in)).to(dev), shape_in, B)
+    y = pool(x)
+    out_idx, pairs = OS.rulebook_pairs(idx, shape_or, B, ks, st, pd, 1, False)
+    want_idx = out_idx if ndim == 3 else out_idx[:, [0, 2, 3]]
+    assert np.array_equal(y.indices.cpu().numpy().astype(np.int64), want_idx)
+    ref = OS.maxpool_from_pairs(feats, pairs, len(out_idx))
+    assert np.array_equal(y.features.detach().cpu().numpy().astype(np.float64), ref) and (ref == 0).any()
+    g = (np.round(np.random.default_rng(2).normal(size=ref.shape) * 4) / 4).astype(np.float32)      # exactly summable
+    (gf,) = torch.autograd.grad(y.features, f, torch.from_numpy(g).to(dev))
+    rf = OS.maxpool_backward_from_pairs(feats, ref, g, pairs)
+    assert np.array_equal(gf.cpu().numpy().astype(np.float64), rf) and np.abs(rf).max() > 0
+    # the reference's functional entry on its own pair lists
+    f2 = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    rb = spconv.build_rulebook(x.indices, B, shape_in, kw["kernel_size"], kw.get("stride", 1), kw.get("padding", 0), 1, False)
+    y2 = spconv.indice_maxpool(f2, rb.indice_pairs, rb.indice_pair_num, rb.n_out)
+    (gf2,) = torch.autograd.grad(y2, f2, torch.from_numpy(g).to(dev))
+    assert torch.equal(y2, y.features) and torch.equal(gf2, gf)
