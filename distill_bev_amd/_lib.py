@@ -82,6 +82,7 @@ _SIGNATURES = {
     "dbev_skinny_conv3x3_multi_workspace_bytes": [_i, _i],
     "dbev_skinny_conv3x3_multi_forward": [_p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_skinny_conv3x3_multi_backward": [_p, _p, _ll, _p, _p, _ll, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
+    "dbev_depth_head_forward": [_p, _p, _p, _p, _ll, _i, _i, _p, _p, _p, _p],
     "dbev_spconv_build_workspace_bytes": [_i, _i, _p, _p, _i, _i],
     "dbev_spconv_outputs": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _sz, _p],
     "dbev_spconv_neighbors": [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _sz, _p],
@@ -252,7 +253,7 @@ def kernel_timing_read():
     return out
 
 
-FALLBACK_SITES = {"bn_act": 0, "skinny_conv": 1, "adapt_mse": 2, "pillar_vfe": 3, "head_batch": 4}   # DBEV_FB_*
+FALLBACK_SITES = {"bn_act": 0, "skinny_conv": 1, "adapt_mse": 2, "pillar_vfe": 3, "head_batch": 4, "depth_head": 5}   # DBEV_FB_*
 _warned_fallbacks = set()
 
 

@@ -904,15 +904,18 @@ extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residu
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
   if (stats_partial != nullptr && partial_rows <= 0) return DBEV_EINVAL;
-  if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || save_mean == nullptr ||
+  // y == NULL: statistics + finalize only (mean / invstd / scale / shift, running statistics) -- the caller applies them inside its
+  // own kernel (dbev_depth_head_forward)
+  if (x == nullptr || gamma == nullptr || beta == nullptr || save_mean == nullptr ||
       save_invstd == nullptr || save_scale_shift == nullptr || workspace == nullptr ||
-      workspace_bytes < bn_ws(g).total || (running_mean == nullptr) != (running_var == nullptr))
+      workspace_bytes < bn_ws(g).total || (running_mean == nullptr) != (running_var == nullptr) ||
+      (y == nullptr && residual != nullptr))
     return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   float* partial = static_cast<float*>(workspace);
   const dim3 grid(g.NBX, g.GY);
   const long long T = 4LL * g.M * C;                       // bytes of one full-tensor pass
-  unsigned* tk = (stats_partial == nullptr && bn_ticket_ok(g)) ? bn_tickets(1) : nullptr;
+  unsigned* tk = (stats_partial == nullptr && y != nullptr && bn_ticket_ok(g)) ? bn_tickets(1) : nullptr;
   int nrows = g.NBX;
   const float* rows = partial;
   if (stats_partial != nullptr) {
@@ -931,6 +934,10 @@ extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residu
     hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, rows, nrows, g.M, C, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
                        num_batches_tracked);
+  }
+  if (y == nullptr) {
+    DBEV_LAUNCH_CHECK();
+    return 0;
   }
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* r4 = reinterpret_cast<const float4*>(residual);

@@ -418,9 +418,8 @@ class BEVDepth4DDistill(CenterPoint):
             with torch.set_grad_enabled(torch.is_grad_enabled() and not (self.detach and fi == 1)):
                 x = self.image_encoder(im)
                 Bx, Nx, C, fH, fW = x.shape
-                img_feat, depth_digit = vt.depth_and_feat(x.view(Bx * Nx, C, fH, fW), rot, tran, intrin, post_rot,
-                                                          post_tran)
-                depth = vt.get_depth_dist(depth_digit)
+                img_feat, depth_digit, depth = vt.depth_feat_and_prob(x.view(Bx * Nx, C, fH, fW), rot, tran, intrin, post_rot,
+                                                                      post_tran)
                 # get_geometry + lift + voxel_pooling (:411-421) in three library calls, no volume, no geom tensor
                 bev_feat_list.append(vt.lift_splat_cameras(rot, tran, intrin, post_rot, post_tran, depth, img_feat))
             depth_digit_list.append(depth_digit)

@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import dcn  # noqa: F401  (registers conv type 'DCNv2')
 from . import lss as LSS
+from .depth_head import depth_head
 from .lift_splat import lift_splat, lift_splat_prepare, lift_splat_prepare_cam, voxel_pooling as _voxel_pooling
 from .nets import SELikeModule
 from .registry import MODELS, build_backbone, build_conv_layer
@@ -98,22 +99,31 @@ class ViewTransformerLSSBEVDepth(ViewTransformerLiftSplatShoot):
                                  nn.BatchNorm2d(c))
         self.se = SELikeModule(self.numC_input, feat_channel=c, **se_config)
 
-    def depth_and_feat(self, x, rots, trans, intrins, post_rots, post_trans):
-        """vt_mine.py:311-323 / bevdet_distill_more.py:396-410 -> (img_feat, depth_digit)."""
+    def depth_feat_and_prob(self, x, rots, trans, intrins, post_rots, post_trans):
+        """vt_mine.py:311-327 / bevdet_distill_more.py:396-411 -> (img_feat, depth_digit, depth_prob); the tail of the depth branch
+        -- self.dcn's BatchNorm2d, self.depthnet, get_depth_dist -- is one kernel after the norm's statistics (depth_head.py)."""
         BN = x.shape[0]
         img_feat = self.featnet(x)
         cam_params = torch.cat([intrins.reshape(BN, -1), post_rots.reshape(BN, -1), post_trans.reshape(BN, -1),
                                 rots.reshape(BN, -1), trans.reshape(BN, -1)], dim=1)
         depth_feat = self.se(x, cam_params)
         depth_feat = self.extra_depthnet(depth_feat)[0]
-        depth_feat = self.dcn(depth_feat)
-        return img_feat, self.depthnet(depth_feat)
+        if type(self).get_depth_dist is ViewTransformerLiftSplatShoot.get_depth_dist and len(self.dcn) == 2:
+            depth_digit, depth_prob = depth_head(self.dcn[0](depth_feat), self.dcn[1], self.depthnet)
+        else:                                       # a subclass with its own depth distribution / another dcn stack
+            depth_digit = self.depthnet(self.dcn(depth_feat))
+            depth_prob = self.get_depth_dist(depth_digit)
+        return img_feat, depth_digit, depth_prob
+
+    def depth_and_feat(self, x, rots, trans, intrins, post_rots, post_trans):
+        """vt_mine.py:311-323 / bevdet_distill_more.py:396-410 -> (img_feat, depth_digit)."""
+        return self.depth_feat_and_prob(x, rots, trans, intrins, post_rots, post_trans)[:2]
 
     def forward(self, input):
         x, rots, trans, intrins, post_rots, post_trans = input[:6]
         B, N, C, H, W = x.shape
-        img_feat, depth_digit = self.depth_and_feat(x.view(B * N, C, H, W), rots, trans, intrins, post_rots, post_trans)
-        depth_prob = self.get_depth_dist(depth_digit)
+        img_feat, depth_digit, depth_prob = self.depth_feat_and_prob(x.view(B * N, C, H, W), rots, trans, intrins, post_rots,
+                                                                     post_trans)
         return self.lift_splat_cameras(rots, trans, intrins, post_rots, post_trans, depth_prob, img_feat), depth_digit
 
 

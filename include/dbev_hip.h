@@ -65,7 +65,8 @@ const char* dbev_kernel_name(int kernel_id);
  * sites.  bench.py prints the count of its timed region (config.fallbacks), tests/test_gpu_full_size.py asserts 0 for the step.
  * ---------------------------------------------------------------------------------- */
 enum {
-  DBEV_FB_BN_ACT = 0, DBEV_FB_SKINNY_CONV, DBEV_FB_ADAPT_MSE, DBEV_FB_PILLAR_VFE, DBEV_FB_HEAD_BATCH, DBEV_FB_SITES
+  DBEV_FB_BN_ACT = 0, DBEV_FB_SKINNY_CONV, DBEV_FB_ADAPT_MSE, DBEV_FB_PILLAR_VFE, DBEV_FB_HEAD_BATCH, DBEV_FB_DEPTH_HEAD,
+  DBEV_FB_SITES
 };
 int dbev_fallback_note(int site);
 long long dbev_fallback_count(int site);
@@ -464,7 +465,9 @@ int dbev_bn_act_train_forward(const float* x, const float* residual, const float
                               float* save_scale_shift, long long M, int C, void* workspace, size_t workspace_bytes,
                               dbevStream_t stream);
 /* the same with the statistics pass replaced by partial sums the PRODUCER of x already took (dbev_conv1x1_forward's epilogue):
- * stats_partial f32[partial_rows, 2, C] = per row (sum x, sum x^2) per channel over a disjoint share of the M rows; NULL = as above */
+ * stats_partial f32[partial_rows, 2, C] = per row (sum x, sum x^2) per channel over a disjoint share of the M rows; NULL = as above.
+ * y == NULL (then residual must be NULL): statistics only -- save_mean / save_invstd / save_scale_shift and the running statistics
+ * are produced, nothing is applied (the consumer normalises inside its own kernel: dbev_depth_head_forward) */
 int dbev_bn_act_train_forward_pre(const float* x, const float* residual, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                                   float eps, int relu, float* y, float* save_mean, float* save_invstd, float* save_scale_shift,
@@ -565,6 +568,19 @@ int dbev_msda_backward(const float* value, const int32_t* spatial_shapes_hw_host
                        const float* sampling_loc, const float* attn_weight, const float* grad_out, int B, int S, int NH,
                        int D, int Q, int L, int P, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
                        void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Depth head of the BEVDepth view transformer, forward (mmdet3d/models/necks/view_transformer_mine.py:300-309 self.dcn's
+ * BatchNorm2d, :326 depth_digit = self.depthnet(depth_feat) (nn.Conv2d(c, D, 1), :291), :327 get_depth_dist = softmax(dim=1);
+ * same in detectors/bevdet_distill_more.py:398-416): normalise -> 1x1 convolution -> softmax in one pass.
+ *  x_nhwc [M, C] the deformable convolution's output, scale_shift f32[2C] (y = x * scale + shift: save_scale_shift of
+ *  dbev_bn_act_train_forward_pre(..., y = NULL, ...), or gamma / sqrt(running_var + eps) etc. in eval mode), weight [N, C], bias [N],
+ *  C % 4 == 0, C <= 256, N <= 64.  depth_digit_nhwc / depth_prob_nhwc [M, N]; normalised_nhwc [M, C] or NULL (the 1x1's weight
+ *  gradient reads it).  fp32 MFMA, fp32 softmax (expf).
+ * ---------------------------------------------------------------------------------- */
+int dbev_depth_head_forward(const float* x_nhwc, const float* scale_shift, const float* weight, const float* bias, long long M,
+                            int C, int N, float* depth_digit_nhwc, float* depth_prob_nhwc, float* normalised_nhwc,
+                            dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Sparse 3-D convolution (replaces the bundled spconv v1.x extension `sparse_conv_ext`:
