@@ -280,6 +280,15 @@ def fallback_reset():
     lib().dbev_fallback_reset()
 
 
+def h2d(t, device):
+    """CPU tensor -> device without stalling the host on the GPU queue: a copy from PAGEABLE memory blocks until everything queued
+    before it has run (the host then sits idle for most of a step); staged through the pinned-memory cache the copy is asynchronous
+    and the cache keeps the staging block alive until the copy has completed."""
+    if torch.device(device).type != "cuda" or t.is_cuda:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def host_ptrs(tensors):
     """HOST array of device pointers (argument tables of the multi-tensor entry points)."""
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

@@ -272,8 +272,8 @@ class CenterHead(nn.Module):
             t9 = torch.cat((boxes.gravity_center, boxes.tensor[:, 3:]), dim=1).float()
             b9.append(t9.cpu()); labs.append(torch.as_tensor(labels).to(torch.int32).cpu())
             starts.append(starts[-1] + t9.shape[0])
-        boxes_d = torch.cat(b9).contiguous().to(device) if starts[-1] else torch.zeros((1, 9), device=device)
-        labels_d = torch.cat(labs).contiguous().to(device) if starts[-1] else torch.zeros((1,), dtype=torch.int32, device=device)
+        boxes_d = L.h2d(torch.cat(b9).contiguous(), device) if starts[-1] else torch.zeros((1, 9), device=device)
+        labels_d = L.h2d(torch.cat(labs).contiguous(), device) if starts[-1] else torch.zeros((1,), dtype=torch.int32, device=device)
         max_objs = cfg["max_objs"] * cfg["dense_reg"]
         osf = cfg["out_size_factor"]
         W, H = int(cfg["grid_size"][0]) // osf, int(cfg["grid_size"][1]) // osf

@@ -363,6 +363,22 @@ class BEVDepth4DDistill(CenterPoint):
                 x = x[0]
         return x.view(B, N, *x.shape[1:])
 
+    def _feat2bev(self, dev, dt):
+        """feature-map index -> BEV metres (bevdet_distill_more.py:70-78) and its inverse, built once per device: the matrix only
+        holds the grid constants"""
+        cache = self.__dict__.setdefault("_feat2bev_cache", {})
+        key = (str(dev), dt)
+        if key not in cache:
+            vt = self.img_view_transformer
+            dx, bx = vt.dx.detach().to(dev, dt), vt.bx.detach().to(dev, dt)
+            m = torch.zeros((3, 3), dtype=dt, device=dev)
+            m[0, 0] = dx[0]; m[1, 1] = dx[1]
+            m[0, 2] = bx[0] - dx[0] / 2.0; m[1, 2] = bx[1] - dx[1] / 2.0
+            m[2, 2] = 1
+            m = m.view(1, 3, 3)
+            cache[key] = (m, LSS.inverse_nosync(m))
+        return cache[key]
+
     def shift_feature(self, input, trans, rots):
         """bevdet_distill_more.py:41-94: warp the adjacent-frame BEV into the current ego frame."""
         n, c, h, w = input.shape
@@ -376,22 +392,17 @@ class BEVDepth4DDistill(CenterPoint):
         c12l0 = torch.zeros((n, v, 4, 4), dtype=dt, device=dev)
         c12l0[:, :, :3, :3] = rots[1]; c12l0[:, :, :3, 3] = trans[1]; c12l0[:, :, 3, 3] = 1
         l02l1 = c02l0.matmul(LSS.inverse_nosync(c12l0))[:, 0, :, :].view(n, 1, 1, 4, 4)
-        keep = [0, 1, 3]
-        l02l1 = l02l1[:, :, :, keep, :][:, :, :, :, keep]
-        vt = self.img_view_transformer
-        feat2bev = torch.zeros((3, 3), dtype=dt, device=dev)
-        feat2bev[0, 0] = vt.dx[0]; feat2bev[1, 1] = vt.dx[1]
-        feat2bev[0, 2] = vt.bx[0] - vt.dx[0] / 2.0; feat2bev[1, 2] = vt.bx[1] - vt.dx[1] / 2.0
-        feat2bev[2, 2] = 1
-        feat2bev = feat2bev.view(1, 3, 3)
-        tf = LSS.inverse_nosync(feat2bev).matmul(l02l1).matmul(feat2bev)
+        # rows / columns (0, 1, 3) as slices: indexing with a Python list uploads the index with a blocking copy, and the host then
+        # waits here for everything queued before (82 ms per step)
+        l02l1 = torch.cat((l02l1[..., :2, :], l02l1[..., 3:, :]), -2)
+        l02l1 = torch.cat((l02l1[..., :2], l02l1[..., 3:]), -1)
+        feat2bev, feat2bev_inv = self._feat2bev(dev, dt)
+        tf = feat2bev_inv.matmul(l02l1).matmul(feat2bev)
         # tf [n,1,1,3,3] @ grid [n,h,w,3,1]: written as broadcast multiply-adds (a broadcast matmul
         # becomes n*h*w tiny GEMMs -- see lss._apply3x3)
         g = grid[..., 0]
-        grid = torch.stack([tf[..., i, 0] * g[..., 0] + tf[..., i, 1] * g[..., 1] + tf[..., i, 2] * g[..., 2]
-                            for i in range(2)], -1)
-        norm = torch.tensor([w - 1.0, h - 1.0], dtype=dt, device=dev)
-        grid = grid / norm.view(1, 1, 1, 2) * 2.0 - 1.0
+        gx, gy = [tf[..., i, 0] * g[..., 0] + tf[..., i, 1] * g[..., 1] + tf[..., i, 2] * g[..., 2] for i in range(2)]
+        grid = torch.stack((gx / (w - 1.0) * 2.0 - 1.0, gy / (h - 1.0) * 2.0 - 1.0), -1)
         return F.grid_sample(input, grid.to(dt), align_corners=True, mode=self.interpolation_mode)
 
     def bev_encoder(self, x, return_backbone_feature=False):

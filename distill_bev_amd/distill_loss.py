@@ -89,11 +89,11 @@ class ForegroundMaskRasterizer:
         B = len(gt_boxes)
         pl = np.concatenate(planes) if offs[-1] else np.zeros((1, 4), np.float32)
         sc = np.concatenate(scales) if offs[-1] else np.zeros((1,), np.float32)
-        # blocking copies: the sources are pageable temporaries (an async H2D from pageable
-        # memory may still be reading them after they are freed)
-        pl_d = torch.from_numpy(np.ascontiguousarray(pl)).to(device)
-        sc_d = torch.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)).to(device)
-        of_d = torch.tensor(offs, dtype=torch.int32).to(device)
+        # the sources are pageable temporaries: staged through pinned memory (L.h2d), not copied straight (a pageable H2D blocks
+        # the host until the GPU queue has drained)
+        pl_d = L.h2d(torch.from_numpy(np.ascontiguousarray(pl)), device)
+        sc_d = L.h2d(torch.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)), device)
+        of_d = L.h2d(torch.tensor(offs, dtype=torch.int32), device)
         fg = torch.empty((B, 1, H, W), dtype=torch.float32, device=device)
         fs = torch.empty_like(fg)
         bs = torch.empty_like(fg)
