@@ -289,6 +289,11 @@ def h2d(t, device):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+def h2d_like(ref, data, dtype=None):
+    """ref.new_tensor(data) without the blocking pageable copy (see h2d)"""
+    return h2d(torch.as_tensor(data, dtype=dtype or ref.dtype), ref.device)
+
+
 def host_ptrs(tensors):
     """HOST array of device pointers (argument tables of the multi-tensor entry points)."""
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .center_head import LiDARBoxes
+from . import _lib as L
 from .config import Config
 from .detectors import BEVDepth4DDistill, _pick, install_fgd_modules, load_checkpoint
 from .distill_loss import ForegroundMaskRasterizer
@@ -60,11 +61,11 @@ class GridMask(nn.Module):
         if self.use_w:
             mask[:, bands(ww, st_w)] = 0
         mask = mask[(hh - h) // 2:(hh - h) // 2 + h, (ww - w) // 2:(ww - w) // 2 + w]
-        mask = torch.from_numpy(np.ascontiguousarray(mask)).to(x.dtype).to(x.device)
+        mask = L.h2d(torch.from_numpy(np.ascontiguousarray(mask)).to(x.dtype), x.device)
         if self.mode == 1:
             mask = 1 - mask
         if self.offset:
-            off = torch.from_numpy(2 * (np.random.rand(h, w) - 0.5)).to(x.dtype).to(x.device)
+            off = L.h2d(torch.from_numpy(2 * (np.random.rand(h, w) - 0.5)).to(x.dtype), x.device)
             return x * mask + off * (1 - mask)
         return x * mask
 

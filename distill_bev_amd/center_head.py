@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib as L
 from .registry import BBOX_CODERS, MODELS, ConvModule, build_conv_layer, build_head, build_loss
 
 
@@ -364,7 +365,7 @@ class CenterHead(nn.Module):
             pred = self._gather_feat(pred.view(pred.size(0), -1, pred.size(3)), ind)
             mask = masks[task_id].unsqueeze(2).expand_as(target_box).float()
             mask = mask * (~torch.isnan(target_box)).float()
-            bbox_weights = mask * mask.new_tensor(code_weights)
+            bbox_weights = mask * L.h2d_like(mask, code_weights)
             if self.task_specific:
                 names, clip = ["xy", "z", "whl", "yaw", "vel"], [0, 2, 3, 6, 8, 10]
                 for r, nm in enumerate(names):

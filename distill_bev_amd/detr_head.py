@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .registry import BBOX_CODERS, MODELS
+from . import _lib as L
 from .transformer import build_positional_encoding, build_transformer, inverse_sigmoid
 
 _EPS32 = torch.finfo(torch.float32).eps
@@ -158,8 +159,8 @@ class HungarianAssigner3D(object):
                 gt_inds[:] = 0
             return AssignResult(num_gts, gt_inds, None, labels=labels)
         rows, cols = linear_sum_assignment(self.cost_matrix(bbox_pred, cls_pred, gt_bboxes, gt_labels).detach().cpu())
-        rows = torch.from_numpy(rows).to(bbox_pred.device)
-        cols = torch.from_numpy(cols).to(bbox_pred.device)
+        rows = L.h2d(torch.from_numpy(rows), bbox_pred.device)
+        cols = L.h2d(torch.from_numpy(cols), bbox_pred.device)
         gt_inds[:] = 0
         gt_inds[rows] = cols + 1
         labels[rows] = gt_labels[cols]
@@ -391,8 +392,8 @@ class _SetPredictionHead(nn.Module):
             bbox_preds = all_box[lv].reshape(-1, all_box.size(-1))
             labels = torch.full((bs * nq,), self.num_classes, dtype=torch.long, device=device)
             if num_pos:
-                pos = torch.from_numpy(np.concatenate(q_idx)).to(device)
-                sel = [torch.from_numpy(c).to(device) for c in g_idx]
+                pos = L.h2d(torch.from_numpy(np.concatenate(q_idx)), device)
+                sel = [L.h2d(torch.from_numpy(c), device) for c in g_idx]
                 labels[pos] = torch.cat([gt_labels[i][c] for i, c in zip(g_smp, sel)])
                 pos_boxes = torch.cat([gt_boxes[i][c] for i, c in zip(g_smp, sel)])
             cls_avg_factor = num_pos * 1.0 + num_neg * self.bg_cls_weight

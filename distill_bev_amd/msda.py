@@ -30,8 +30,8 @@ def level_tensors(shapes, device):
         for h, w in key[0]:
             st.append(acc)
             acc += h * w
-        ss = torch.tensor(key[0], dtype=torch.long, device=device)
-        ls = torch.tensor(st, dtype=torch.long, device=device)
+        ss = L.h2d(torch.tensor(key[0], dtype=torch.long), device)
+        ls = L.h2d(torch.tensor(st, dtype=torch.long), device)
         ss._dbev_host, ls._dbev_host = hw, st
         hit = _LEVELS[key] = (ss, ls)
     return hit

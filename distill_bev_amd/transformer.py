@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 
 from .msda import level_tensors, multi_scale_deformable_attn
+from . import _lib as L
 from .registry import MODELS, build_activation_layer, build_norm_layer
 
 build_attention = build_feedforward_network = build_positional_encoding = MODELS.build
@@ -619,10 +620,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
 
     def point_sampling(self, reference_points, pc_range, img_metas):
         """:92-152 -> reference_points_cam [num_cam, B, Q, D, 2] (image-normalised), bev_mask [num_cam, B, Q, D]"""
-        lidar2img = reference_points.new_tensor(np.asarray([m["lidar2img"] for m in img_metas], dtype=np.float64)).float()
+        lidar2img = L.h2d_like(reference_points, np.asarray([m["lidar2img"] for m in img_metas], dtype=np.float64)).float()
         B, D, Q, _ = reference_points.shape
-        lo = reference_points.new_tensor(pc_range[:3])
-        ext = reference_points.new_tensor([pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]])
+        lo = L.h2d_like(reference_points, [float(v) for v in pc_range[:3]])
+        ext = L.h2d_like(reference_points, [pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]])
         pts = reference_points.float() * ext + lo
         pts = torch.cat((pts, torch.ones_like(pts[..., :1])), -1).reshape(B, 1, D * Q, 4)       # homogeneous
         cam = torch.matmul(pts, lidar2img.transpose(-1, -2)).view(B, -1, D, Q, 4)              # [B, N, D, Q, 4]
@@ -631,7 +632,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         mask = depth > eps
         xy = cam[..., 0:2] / torch.maximum(depth, torch.ones_like(depth) * eps)
         H, W = img_metas[0]["img_shape"][0][0], img_metas[0]["img_shape"][0][1]
-        xy = xy / xy.new_tensor([W, H])
+        xy = xy / L.h2d_like(xy, [W, H])
         mask = mask & (xy[..., 1:2] > 0.0) & (xy[..., 1:2] < 1.0) & (xy[..., 0:1] < 1.0) & (xy[..., 0:1] > 0.0)
         return xy.permute(1, 0, 3, 2, 4), mask.permute(1, 0, 3, 2, 4).squeeze(-1)
 
@@ -700,12 +701,12 @@ def rotate_nearest(img, angle, center):
     m = [math.cos(rot), math.sin(rot), 0.0, -math.sin(rot), math.cos(rot), 0.0]
     m[2] += m[0] * (-cx) + m[1] * (-cy) + cx
     m[5] += m[3] * (-cx) + m[4] * (-cy) + cy
-    theta = torch.tensor(m, dtype=img.dtype, device=img.device).reshape(1, 2, 3)
+    theta = L.h2d_like(img, m).reshape(1, 2, 3)
     base = torch.empty(1, H, W, 3, dtype=img.dtype, device=img.device)
     base[..., 0] = torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W, device=img.device, dtype=img.dtype)
     base[..., 1] = torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H, device=img.device, dtype=img.dtype).unsqueeze(-1)
     base[..., 2] = 1
-    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H], dtype=img.dtype, device=img.device)
+    rescaled = theta.transpose(1, 2) / L.h2d_like(img, [0.5 * W, 0.5 * H])
     grid = base.view(1, H * W, 3).bmm(rescaled).view(1, H, W, 2)
     return torch.nn.functional.grid_sample(img[None], grid, mode="nearest", padding_mode="zeros", align_corners=False)[0]
 
@@ -758,7 +759,7 @@ class PerceptionTransformer(nn.Module):
         bev_angle = ego_angle - np.arctan2(dy, dx) / np.pi * 180
         shift_y = length * np.cos(bev_angle / 180 * np.pi) / grid_length[0] / bev_h * self.use_shift
         shift_x = length * np.sin(bev_angle / 180 * np.pi) / grid_length[1] / bev_w * self.use_shift
-        shift = bev_queries.new_tensor(np.array([shift_x, shift_y])).permute(1, 0)
+        shift = L.h2d_like(bev_queries, np.array([shift_x, shift_y])).permute(1, 0)
         if prev_bev is not None:
             if prev_bev.shape[1] == bev_h * bev_w:
                 prev_bev = prev_bev.permute(1, 0, 2)
@@ -768,7 +769,7 @@ class PerceptionTransformer(nn.Module):
                     tmp = prev_bev[:, i].reshape(bev_h, bev_w, -1).permute(2, 0, 1)
                     tmp = rotate_nearest(tmp, metas[i]["can_bus"][-1], center=self.rotate_center)
                     prev_bev[:, i] = tmp.permute(1, 2, 0).reshape(bev_h * bev_w, -1)
-        can_bus = bev_queries.new_tensor(np.array([m["can_bus"] for m in metas]))
+        can_bus = L.h2d_like(bev_queries, np.array([m["can_bus"] for m in metas]))
         bev_queries = bev_queries + self.can_bus_mlp(can_bus)[None, :, :] * self.use_can_bus
         feat_flatten, spatial_shapes = [], []
         for lvl, feat in enumerate(mlvl_feats):
