@@ -34,19 +34,19 @@ constexpr int AM_KC = 32;     // K chunk
 
 constexpr int AM_STR = AM_PXB + 1;   // LDS row stride of the k-major operand stages (pad 1: the coalesced loader's writes spread over banks)
 
-template <int NT>
-__global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void adapt_mse_fwd(const float* __restrict__ X, const float* __restrict__ Wt,
+template <int NT, int KC = AM_KC>
+__global__ __launch_bounds__(256, (NT >= 3 ? 2 : (KC <= 16 ? 4 : 3))) void adapt_mse_fwd(const float* __restrict__ X, const float* __restrict__ Wt,
                                                          const float* __restrict__ bias, const float* __restrict__ T,
                                                          const float* __restrict__ Cc, float* __restrict__ D,
                                                          float* __restrict__ maps, int M, int K, int N, int HW) {
   constexpr int NCH = NT * 32;
   constexpr int WSTR = NCH + 1;
   constexpr int TSTR = NCH + 4;                               // epilogue tile [pixel][channel], 16-byte aligned rows
-  constexpr int OPER = 2 * AM_KC * (AM_STR + WSTR);           // floats of the two double-buffered operand stages
+  constexpr int OPER = 2 * KC * (AM_STR + WSTR);           // floats of the two double-buffered operand stages
   constexpr int TILE = AM_PXB * TSTR;
   __shared__ float smem[OPER > TILE ? OPER : TILE];
-  float (*sX)[AM_KC][AM_STR] = reinterpret_cast<float (*)[AM_KC][AM_STR]>(smem);
-  float (*sW)[AM_KC][WSTR] = reinterpret_cast<float (*)[AM_KC][WSTR]>(smem + 2 * AM_KC * AM_STR);
+  float (*sX)[KC][AM_STR] = reinterpret_cast<float (*)[KC][AM_STR]>(smem);
+  float (*sW)[KC][WSTR] = reinterpret_cast<float (*)[KC][WSTR]>(smem + 2 * KC * AM_STR);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // XCD-aware order: the N / NCH channel slices of one pixel tile re-read the same 128 x K activation rows; logical block id L walks
   // (tile, slice) with the slice fastest and xcd_block() keeps consecutive L on ONE XCD back to back, so the second and third read
@@ -59,38 +59,39 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void adapt_mse_fwd(const fl
   const int half = lane >> 5, l31 = lane & 31;
 
   // loader: 8 consecutive lanes read one row's 128-byte chunk (whole cache lines per wave instruction)
-  constexpr int XV = AM_PXB * AM_KC / 4 / 256;                // float4 loads per thread per chunk
-  constexpr int WV = (NCH * AM_KC / 4 + 255) / 256;
+  constexpr int KQ = KC / 4;                                  // float4 per row chunk
+  constexpr int XV = AM_PXB * KC / 4 / 256;                // float4 loads per thread per chunk
+  constexpr int WV = (NCH * KC / 4 + 255) / 256;
   float4 rx[XV], rw[WV];
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int f = tid + 256 * i, px = f >> 3, kq = f & 7;
+      const int f = tid + 256 * i, px = f / KQ, kq = f % KQ;
       const int m = m0 + px;
-      rx[i] = m < M ? *reinterpret_cast<const float4*>(X + static_cast<size_t>(m) * K + kc * AM_KC + 4 * kq)
+      rx[i] = m < M ? *reinterpret_cast<const float4*>(X + static_cast<size_t>(m) * K + kc * KC + 4 * kq)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int f = tid + 256 * i;
-      if (f < NCH * AM_KC / 4) {
-        const int ch = f >> 3, kq = f & 7;
-        rw[i] = *reinterpret_cast<const float4*>(Wt + static_cast<size_t>(n0 + ch) * K + kc * AM_KC + 4 * kq);
+      if (f < NCH * KC / 4) {
+        const int ch = f / KQ, kq = f % KQ;
+        rw[i] = *reinterpret_cast<const float4*>(Wt + static_cast<size_t>(n0 + ch) * K + kc * KC + 4 * kq);
       }
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int f = tid + 256 * i, px = f >> 3, kq = f & 7;
+      const int f = tid + 256 * i, px = f / KQ, kq = f % KQ;
       sX[buf][4 * kq + 0][px] = rx[i].x; sX[buf][4 * kq + 1][px] = rx[i].y;
       sX[buf][4 * kq + 2][px] = rx[i].z; sX[buf][4 * kq + 3][px] = rx[i].w;
     }
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int f = tid + 256 * i;
-      if (f < NCH * AM_KC / 4) {
-        const int ch = f >> 3, kq = f & 7;
+      if (f < NCH * KC / 4) {
+        const int ch = f / KQ, kq = f % KQ;
         sW[buf][4 * kq + 0][ch] = rw[i].x; sW[buf][4 * kq + 1][ch] = rw[i].y;
         sW[buf][4 * kq + 2][ch] = rw[i].z; sW[buf][4 * kq + 3][ch] = rw[i].w;
       }
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void adapt_mse_fwd(const fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int nchunk = K / AM_KC;
+  const int nchunk = K / KC;
   load_chunk(0);
   store_chunk(0);
   __syncthreads();
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void adapt_mse_fwd(const fl
     const int buf = c & 1;
     if (c + 1 < nchunk) load_chunk(c + 1);                   // in flight during the MFMAs below
 #pragma unroll
-    for (int kk = 0; kk < AM_KC / 2; ++kk) {
+    for (int kk = 0; kk < KC / 2; ++kk) {
       const int k = 2 * kk + half;
       const float b = sX[buf][k][32 * w + l31];
 #pragma unroll
@@ -235,6 +236,15 @@ extern "C" int dbev_adapt_mse_forward(const float* x_nhwc, const float* weight, 
   const dim3 grid(dbev_round_xcd(dbev_ceil_div(M, AM_PXB) * (Ct / (32 * nt))));
 #define AM_LAUNCH(NTV) hipLaunchKernelGGL((adapt_mse_fwd<NTV>), grid, dim3(256), 0, s, x_nhwc, weight, bias, teacher_nhwc, \
                                          channel_weight, diff_nhwc, maps, static_cast<int>(M), Cs, Ct, HW)
+  // 64-channel slices walk K in chunks of 16: 35 KB of LDS (the epilogue tile) and four workgroups per CU; chunks of 32 (50 KB, three
+  // per CU) measured 3 % slower (DBEV_ADAPT_KC=32 for A/B runs)
+  static const int kc_env = getenv("DBEV_ADAPT_KC") ? atoi(getenv("DBEV_ADAPT_KC")) : 16;
+  if (nt == 2 && kc_env == 16 && Cs % 16 == 0) {
+    hipLaunchKernelGGL((adapt_mse_fwd<2, 16>), grid, dim3(256), 0, s, x_nhwc, weight, bias, teacher_nhwc, channel_weight, diff_nhwc,
+                       maps, static_cast<int>(M), Cs, Ct, HW);
+    DBEV_LAUNCH_CHECK();
+    return 0;
+  }
   DbevKt kt(DBEV_K_ADAPT_MSE_FWD, 4LL * M * (Cs + 2LL * Ct), s);      // x + teacher read, difference written
   switch (nt) {
     case 4: AM_LAUNCH(4); break;
