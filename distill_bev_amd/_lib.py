@@ -112,6 +112,7 @@ _SIGNATURES = {
     "dbev_bn_act_train_forward_pre": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _i, _p, _sz, _p],
     "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_act_backward2": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_points_to_depth_maps": [_p, _i, _i, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "dbev_bn_dual_workspace_bytes": [_ll, _i],
     "dbev_bn_dual_train_forward": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p,
@@ -119,6 +120,7 @@ _SIGNATURES = {
     "dbev_bn_dual_train_forward_pre": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p,
                                        _ll, _i, _p, _i, _p, _i, _p, _sz, _p],
     "dbev_bn_dual_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_dual_backward2": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_fallback_count": ctypes.c_longlong,

@@ -22,7 +22,8 @@ from torch.autograd import Function
 
 from . import _lib as L
 
-_state = {"enabled": os.environ.get("DBEV_FUSED_BN", "1") != "0"}
+_state = {"enabled": os.environ.get("DBEV_FUSED_BN", "1") != "0",
+          "fork": os.environ.get("DBEV_BN_FORK", "1") != "0"}      # residual-block outputs carry a second handle (see _BNActTrain.forward)
 
 
 @contextlib.contextmanager
@@ -77,10 +78,32 @@ def _why_not(x, bn, residual):
     return "eval-mode norm inside autograd"
 
 
+def _alias(y):
+    """a second tensor on y's storage with no view relation to it (a plain `y.view(...)` returned from a Function is tracked as a view
+    of the first output)"""
+    return torch.empty((0,), dtype=y.dtype, device=y.device).set_(y.untyped_storage(), y.storage_offset(), y.size(), y.stride())
+
+
+def _two_addends(dy, dy2):
+    """incoming gradients of a forked output -> (first, second or None), channels-last"""
+    if dy is None:
+        dy, dy2 = dy2, None
+    cl = lambda t: None if t is None else t.contiguous(memory_format=torch.channels_last)
+    return cl(dy), cl(dy2)
+
+
+def forked(t):
+    """the second handle of a forked block output (bn_act(..., fork=True)), or t itself"""
+    return getattr(t, "_dbev_fork", t)
+
+
 class _BNActTrain(Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, pre=None):
-        """pre: f32[rows, 2, C] partial (sum, sum of squares) rows the producer of x already took (conv1x1_stats): no statistics pass"""
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, momentum, eps, relu, pre=None, fork=False):
+        """pre: f32[rows, 2, C] partial (sum, sum of squares) rows the producer of x already took (conv1x1_stats): no statistics pass.
+        fork: return the output TWICE (two tensors on one storage): the next residual block hands one to its first convolution and
+        the other to its identity branch, their gradients come back separately and the backward kernels add them on the way in --
+        autograd's own accumulation is a full read-read-write pass per junction (2.6 ms of the step)."""
         dev = x.device
         N, C, H, W = x.shape
         M = N * H * W
@@ -99,14 +122,19 @@ class _BNActTrain(Function):
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, weight, save_mean, save_invstd, coef)
         ctx.cfg = (M, C, bool(relu), residual is not None)
+        if fork:
+            ctx.set_materialize_grads(False)
+            return y, _alias(y)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, y, weight, save_mean, save_invstd, coef = ctx.saved_tensors
         M, C, relu, has_res = ctx.cfg
+        dy, dy2 = _two_addends(dy, dy2)
+        if dy is None:
+            return (None,) * 12
         dev = dy.device
-        dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         # without ReLU the residual branch receives dy itself: nothing to write
         dres = torch.empty_like(x) if (has_res and relu) else None
@@ -115,18 +143,20 @@ class _BNActTrain(Function):
         nbytes = L.lib().dbev_bn_act_workspace_bytes(M, C)
         ws = torch.empty((nbytes + 12 * C,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.call("dbev_bn_act_backward", L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(weight), L.ptr(save_mean),
+            L.call("dbev_bn_act_backward2", L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(y), L.ptr(weight), L.ptr(save_mean),
                    L.ptr(save_invstd), L.ptr(coef), int(relu), L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), M, C,
                    L.ptr(ws), ws.numel(), L.stream_ptr(dev),
-                   alg_bytes=4 * M * C * (5 + 3 * (dres is not None)))     # dy, x twice each + dx [+ y twice + dres]
-        return dx, (dres if relu else dy) if has_res else None, dgamma, dbeta, None, None, None, None, None, None, None
+                   alg_bytes=4 * M * C * (5 + 3 * (dres is not None) + 2 * (dy2 is not None)))   # dy [+ dy2], x twice each + dx [+ y twice + dres]
+        if has_res and not relu:                    # without ReLU the residual branch receives the incoming gradient itself
+            dres = dy if dy2 is None else dy + dy2
+        return dx, dres if has_res else None, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class _BNDualTrain(Function):
     """relu(bn(x) + bn_d(xd)): dbev_bn_dual_train_forward / dbev_bn_dual_backward"""
 
     @staticmethod
-    def forward(ctx, x, xd, w, b, rm, rv, nbt, mom, eps, wd, bd, rmd, rvd, nbtd, momd, epsd, relu, pre=None, pre_d=None):
+    def forward(ctx, x, xd, w, b, rm, rv, nbt, mom, eps, wd, bd, rmd, rvd, nbtd, momd, epsd, relu, pre=None, pre_d=None, fork=False):
         dev = x.device
         N, C, H, W = x.shape
         M = N * H * W
@@ -143,35 +173,50 @@ class _BNDualTrain(Function):
                    alg_bytes=4 * M * C * (5 - (pre is not None) - (pre_d is not None)))
         ctx.save_for_backward(x, xd, y if relu else None, w, wd, stats)
         ctx.cfg = (M, C, bool(relu))
+        if fork:
+            ctx.set_materialize_grads(False)
+            return y, _alias(y)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, xd, y, w, wd, stats = ctx.saved_tensors
         M, C, relu = ctx.cfg
+        dy, dy2 = _two_addends(dy, dy2)
+        if dy is None:
+            return (None,) * 20
         dev = dy.device
-        dy = dy.contiguous(memory_format=torch.channels_last)
         dx, dxd = torch.empty_like(x), torch.empty_like(xd)
         g = torch.empty((4, C), dtype=torch.float32, device=dev)
         nbytes = L.lib().dbev_bn_dual_workspace_bytes(M, C)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.call("dbev_bn_dual_backward", L.ptr(dy), L.ptr(x), L.ptr(xd), L.ptr(y), L.ptr(w), L.ptr(stats[0]), L.ptr(stats[1]),
-                   L.ptr(wd), L.ptr(stats[4]), L.ptr(stats[5]), int(relu), L.ptr(dx), L.ptr(dxd), L.ptr(g[0]), L.ptr(g[1]),
-                   L.ptr(g[2]), L.ptr(g[3]), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev), alg_bytes=4 * M * C * 10)
-        return (dx, dxd, g[0], g[1], None, None, None, None, None, g[2], g[3], None, None, None, None, None, None, None, None)
+            L.call("dbev_bn_dual_backward2", L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(xd), L.ptr(y), L.ptr(w), L.ptr(stats[0]),
+                   L.ptr(stats[1]), L.ptr(wd), L.ptr(stats[4]), L.ptr(stats[5]), int(relu), L.ptr(dx), L.ptr(dxd), L.ptr(g[0]),
+                   L.ptr(g[1]), L.ptr(g[2]), L.ptr(g[3]), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+                   alg_bytes=4 * M * C * (10 + 2 * (dy2 is not None)))
+        return (dx, dxd, g[0], g[1], None, None, None, None, None, g[2], g[3], None, None, None, None, None, None, None, None, None)
 
 
-def bn_act_dual(x, bn, xd, bn_d, relu=True, pre=None, pre_d=None):
+def _fork_out(out, fork):
+    if fork and _state.get("fork", True):
+        y, y2 = out
+        y._dbev_fork = y2
+        return y
+    return out
+
+
+def bn_act_dual(x, bn, xd, bn_d, relu=True, pre=None, pre_d=None, fork=False):
     """relu(bn(x) + bn_d(xd)) -- the tail of a residual block whose identity branch ends in its own BatchNorm (`downsample`).
     Training mode on channels-last tensors: one fused forward / backward that never writes bn_d(xd) or the gated gradient;
     otherwise the same value through bn_act(x, bn, residual=bn_d(xd))."""
     if (eligible(x, bn, xd) and eligible(xd, bn_d) and bn.training and bn_d.training and bn.running_mean is not None
             and bn_d.running_mean is not None and torch.is_grad_enabled()):
-        return _BNDualTrain.apply(x, xd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                                  bn.eps, bn_d.weight, bn_d.bias, bn_d.running_mean, bn_d.running_var, bn_d.num_batches_tracked,
-                                  bn_d.momentum, bn_d.eps, relu, pre, pre_d)
-    return bn_act(x, bn, bn_act(xd, bn_d, None, False, pre=pre_d), relu, pre=pre)
+        fk = bool(fork and _state.get("fork", True))
+        return _fork_out(_BNDualTrain.apply(x, xd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                            bn.momentum, bn.eps, bn_d.weight, bn_d.bias, bn_d.running_mean, bn_d.running_var,
+                                            bn_d.num_batches_tracked, bn_d.momentum, bn_d.eps, relu, pre, pre_d, fk), fk)
+    return bn_act(x, bn, bn_act(xd, bn_d, None, False, pre=pre_d), relu, pre=pre, fork=fork)
 
 
 class _Conv1x1Stats(Function):
@@ -250,14 +295,17 @@ def _infer(x, residual, bn, relu):
     return y
 
 
-def bn_act(x, bn, residual=None, relu=True, pre=None):
+def bn_act(x, bn, residual=None, relu=True, pre=None, fork=False):
     """relu(bn(x) + residual) with the module `bn`'s parameters, statistics and mode.  `pre`: partial statistics rows of x taken by
-    its producer (conv1x1_stats) -- only handed over when the training-mode kernel path applies (conv1x1_bn_ready)."""
+    its producer (conv1x1_stats) -- only handed over when the training-mode kernel path applies (conv1x1_bn_ready).  `fork`: the
+    result is a residual block's output; under autograd it then carries a second handle (`forked(y)`) for the next block's identity
+    branch (see _BNActTrain.forward)."""
     if eligible(x, bn, residual):
         if bn.training or bn.running_mean is None:
             # num_batches_tracked += 1 happens inside the finalize kernel (no extra launch)
-            return _BNActTrain.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     bn.num_batches_tracked, bn.momentum, bn.eps, relu, pre)
+            fk = bool(fork and _state.get("fork", True) and torch.is_grad_enabled())
+            return _fork_out(_BNActTrain.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                               bn.num_batches_tracked, bn.momentum, bn.eps, relu, pre, fk), fk)
         return _infer(x, residual, bn, relu)
     if x.is_cuda and _state["enabled"] and x.numel() > 0:
         L.note_fallback("bn_act", _why_not(x, bn, residual))

@@ -459,7 +459,7 @@ __device__ __forceinline__ float4 gate(const float4& dy, const float4& x, const 
 }
 
 template <int MASK, int TPB, int UNR>
-__global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ dy, const float4* __restrict__ x,
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ dy, const float4* __restrict__ dy2, const float4* __restrict__ x,
                                                      const float4* __restrict__ y, const float* __restrict__ coef,
                                                      const float* __restrict__ save_mean,
                                                      const float* __restrict__ save_invstd,
@@ -488,6 +488,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ 
       a[u] = f4(0.f); v[u] = f4(0.f); o[u] = f4(0.f);
       if (r < r_end) {
         a[u] = dy[static_cast<size_t>(r) * g.C4 + q];
+        if (dy2 != nullptr) {                      // the gradient arrives as two addends (a residual junction): summed here, not by a pass of its own
+          const float4 b2 = dy2[static_cast<size_t>(r) * g.C4 + q];
+          a[u].x += b2.x; a[u].y += b2.y; a[u].z += b2.z; a[u].w += b2.w;
+        }
         v[u] = x[static_cast<size_t>(r) * g.C4 + q];
         if (MASK == 2) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
       }
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__
 }
 
 template <int MASK, bool DRES>
-__global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, const float4* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, const float4* __restrict__ dy2, const float4* __restrict__ x,
                                                  const float4* __restrict__ y, const float* __restrict__ coef,
                                                  const float* __restrict__ bcoef, float4* __restrict__ dx,
                                                  float4* __restrict__ dres, BnGeom g, BnBfin fin) {
@@ -610,6 +614,10 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, 
       a[u] = f4(0.f); v[u] = f4(0.f); o[u] = f4(0.f);
       if (r < r_end) {
         a[u] = dy[static_cast<size_t>(r) * g.C4 + q];
+        if (dy2 != nullptr) {                      // the gradient arrives as two addends (a residual junction): summed here, not by a pass of its own
+          const float4 b2 = dy2[static_cast<size_t>(r) * g.C4 + q];
+          a[u].x += b2.x; a[u].y += b2.y; a[u].z += b2.z; a[u].w += b2.w;
+        }
         v[u] = x[static_cast<size_t>(r) * g.C4 + q];
         if (MASK == 2) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
       }
@@ -659,7 +667,7 @@ __device__ __forceinline__ void block_merge_store3(float4 a, float4 b, float4 c,
 }
 
 template <bool RELU, int TPB, int UNR>
-__global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restrict__ dy, const float4* __restrict__ x,
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restrict__ dy, const float4* __restrict__ dy2, const float4* __restrict__ x,
                                                           const float4* __restrict__ xd, const float4* __restrict__ y,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ mean_d,
@@ -686,6 +694,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restri
       a[u] = f4(0.f); v[u] = f4(0.f); vd[u] = f4(0.f); o[u] = f4(0.f);
       if (r < r_end) {
         a[u] = dy[static_cast<size_t>(r) * g.C4 + q];
+        if (dy2 != nullptr) {                      // the gradient arrives as two addends (a residual junction): summed here, not by a pass of its own
+          const float4 b2 = dy2[static_cast<size_t>(r) * g.C4 + q];
+          a[u].x += b2.x; a[u].y += b2.y; a[u].z += b2.z; a[u].w += b2.w;
+        }
         v[u] = x[static_cast<size_t>(r) * g.C4 + q];
         vd[u] = xd[static_cast<size_t>(r) * g.C4 + q];
         if (RELU) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
@@ -751,7 +763,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_dual(const float* __restr
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(256) void bn_bwd_dx_dual(const float4* __restrict__ dy, const float4* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_dx_dual(const float4* __restrict__ dy, const float4* __restrict__ dy2, const float4* __restrict__ x,
                                                       const float4* __restrict__ xd, const float4* __restrict__ y,
                                                       const float* __restrict__ bcoef, float4* __restrict__ dx,
                                                       float4* __restrict__ dxd, BnGeom g, BnBfin fin, BnBfin fin_d) {
@@ -792,6 +804,10 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_dual(const float4* __restrict__
       a[u] = f4(0.f); v[u] = f4(0.f); vd[u] = f4(0.f); o[u] = f4(0.f);
       if (r < r_end) {
         a[u] = dy[static_cast<size_t>(r) * g.C4 + q];
+        if (dy2 != nullptr) {                      // the gradient arrives as two addends (a residual junction): summed here, not by a pass of its own
+          const float4 b2 = dy2[static_cast<size_t>(r) * g.C4 + q];
+          a[u].x += b2.x; a[u].y += b2.y; a[u].z += b2.z; a[u].w += b2.w;
+        }
         v[u] = x[static_cast<size_t>(r) * g.C4 + q];
         vd[u] = xd[static_cast<size_t>(r) * g.C4 + q];
         if (RELU) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
@@ -840,9 +856,11 @@ void launch_stats(const BnGeom& g, dim3 grid, hipStream_t s, const float4* x, fl
 }
 
 template <int MASK>
-void launch_bwd_reduce(const BnGeom& g, dim3 grid, hipStream_t s, const float4* dy, const float4* x, const float4* y,
-                       const float* coef, const float* mean, const float* invstd, float* partial, unsigned* tickets = nullptr) {
-#define BN_CALL(T, U) hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, x, y, coef, mean, invstd, partial, g, tickets)
+void launch_bwd_reduce(const BnGeom& g, dim3 grid, hipStream_t s, const float4* dy, const float4* dy2, const float4* x,
+                       const float4* y, const float* coef, const float* mean, const float* invstd, float* partial,
+                       unsigned* tickets = nullptr) {
+#define BN_CALL(T, U) \
+  hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, dy2, x, y, coef, mean, invstd, partial, g, tickets)
   BN_DISPATCH_TPB_UNR(BN_CALL);
 #undef BN_CALL
 }
@@ -998,6 +1016,14 @@ extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const f
                                     const float* save_mean, const float* save_invstd, const float* save_scale_shift,
                                     int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                                     long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  return dbev_bn_act_backward2(grad_y, nullptr, x, y, gamma, save_mean, save_invstd, save_scale_shift, relu, grad_x, grad_residual,
+                               grad_gamma, grad_beta, M, C, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dbev_bn_act_backward2(const float* grad_y, const float* grad_y2, const float* x, const float* y, const float* gamma,
+                                     const float* save_mean, const float* save_invstd, const float* save_scale_shift,
+                                     int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                                     long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
   const size_t need = bn_ws(g).total + sizeof(float) * 3 * static_cast<size_t>(C);
@@ -1013,15 +1039,16 @@ extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const f
   float* bcoef = reinterpret_cast<float*>(static_cast<char*>(workspace) + bn_ws(g).total);
   const dim3 grid(g.NBX, g.GY);
   const float4* dy4 = reinterpret_cast<const float4*>(grad_y);
+  const float4* dy24 = reinterpret_cast<const float4*>(grad_y2);
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* y4 = reinterpret_cast<const float4*>(y);
   const long long T = 4LL * g.M * C;
   unsigned* tk = bn_ticket_ok(g) ? bn_tickets(1) : nullptr;
   {
     DbevKt kt(mask == 2 ? DBEV_K_BN_BWD_REDUCE_Y : DBEV_K_BN_BWD_REDUCE, T * (mask == 2 ? 3 : 2), s);
-    if (mask == 0) launch_bwd_reduce<0>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
-    else if (mask == 1) launch_bwd_reduce<1>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
-    else launch_bwd_reduce<2>(g, grid, s, dy4, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
+    if (mask == 0) launch_bwd_reduce<0>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
+    else if (mask == 1) launch_bwd_reduce<1>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
+    else launch_bwd_reduce<2>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
   }
   BnBfin fin{};
   if (tk != nullptr) {
@@ -1039,11 +1066,11 @@ extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const f
   DbevKt kt(grad_residual != nullptr ? DBEV_K_BN_BWD_DX_RES : DBEV_K_BN_BWD_DX,
             T * (3 + (mask == 2 ? 1 : 0) + (grad_residual != nullptr && mask != 0 ? 1 : 0)), s);
   if (grad_residual != nullptr) {
-    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
-    else hipLaunchKernelGGL((bn_bwd_dx<0, true>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
+    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
+    else hipLaunchKernelGGL((bn_bwd_dx<0, true>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
   } else {
-    if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx<1, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
-    else hipLaunchKernelGGL((bn_bwd_dx<0, false>), agrid, dim3(256), 0, s, dy4, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
+    if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx<1, false>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
+    else hipLaunchKernelGGL((bn_bwd_dx<0, false>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
   }
   DBEV_LAUNCH_CHECK();
   return 0;
@@ -1144,6 +1171,17 @@ extern "C" int dbev_bn_dual_backward(const float* grad_y, const float* x, const 
                                      float* grad_x, float* grad_xd, float* grad_gamma, float* grad_beta,
                                      float* grad_gamma_d, float* grad_beta_d, long long M, int C, void* workspace,
                                      size_t workspace_bytes, dbevStream_t stream) {
+  return dbev_bn_dual_backward2(grad_y, nullptr, x, xd, y, gamma, save_mean, save_invstd, gamma_d, save_mean_d, save_invstd_d, relu,
+                                grad_x, grad_xd, grad_gamma, grad_beta, grad_gamma_d, grad_beta_d, M, C, workspace, workspace_bytes,
+                                stream);
+}
+
+extern "C" int dbev_bn_dual_backward2(const float* grad_y, const float* grad_y2, const float* x, const float* xd, const float* y,
+                                      const float* gamma, const float* save_mean, const float* save_invstd,
+                                      const float* gamma_d, const float* save_mean_d, const float* save_invstd_d, int relu,
+                                      float* grad_x, float* grad_xd, float* grad_gamma, float* grad_beta,
+                                      float* grad_gamma_d, float* grad_beta_d, long long M, int C, void* workspace,
+                                      size_t workspace_bytes, dbevStream_t stream) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
   if (grad_y == nullptr || x == nullptr || xd == nullptr || (relu && y == nullptr) || gamma == nullptr ||
@@ -1158,6 +1196,7 @@ extern "C" int dbev_bn_dual_backward(const float* grad_y, const float* x, const 
   unsigned* tk = bn_ticket_ok(g) ? bn_tickets(1) : nullptr;
   const dim3 grid(g.NBX, g.GY);
   const float4* dy4 = reinterpret_cast<const float4*>(grad_y);
+  const float4* dy24 = reinterpret_cast<const float4*>(grad_y2);
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* d4 = reinterpret_cast<const float4*>(xd);
   const float4* y4 = reinterpret_cast<const float4*>(y);
@@ -1166,9 +1205,9 @@ extern "C" int dbev_bn_dual_backward(const float* grad_y, const float* x, const 
     DbevKt kt(DBEV_K_BN_BWD_REDUCE_Y, T * (relu ? 4 : 3), s);
 #define BN_CALL(TP, U)                                                                                                        \
   do {                                                                                                                        \
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_dual<true, TP, U>), grid, dim3(TP), 0, s, dy4, x4, d4, y4, save_mean,         \
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_dual<true, TP, U>), grid, dim3(TP), 0, s, dy4, dy24, x4, d4, y4, save_mean,         \
                                  save_invstd, save_mean_d, save_invstd_d, partial, g, tk);                                    \
-    else hipLaunchKernelGGL((bn_bwd_reduce_dual<false, TP, U>), grid, dim3(TP), 0, s, dy4, x4, d4, y4, save_mean, save_invstd, \
+    else hipLaunchKernelGGL((bn_bwd_reduce_dual<false, TP, U>), grid, dim3(TP), 0, s, dy4, dy24, x4, d4, y4, save_mean, save_invstd, \
                             save_mean_d, save_invstd_d, partial, g, tk);                                                      \
   } while (0)
     BN_DISPATCH_TPB_UNR(BN_CALL);
@@ -1188,9 +1227,9 @@ extern "C" int dbev_bn_dual_backward(const float* grad_y, const float* x, const 
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
   DbevKt kt(DBEV_K_BN_BWD_DX_RES, T * (relu ? 6 : 5), s);
-  if (relu) hipLaunchKernelGGL((bn_bwd_dx_dual<true>), agrid, dim3(256), 0, s, dy4, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
+  if (relu) hipLaunchKernelGGL((bn_bwd_dx_dual<true>), agrid, dim3(256), 0, s, dy4, dy24, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
                                reinterpret_cast<float4*>(grad_xd), g, fin, fin_d);
-  else hipLaunchKernelGGL((bn_bwd_dx_dual<false>), agrid, dim3(256), 0, s, dy4, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
+  else hipLaunchKernelGGL((bn_bwd_dx_dual<false>), agrid, dim3(256), 0, s, dy4, dy24, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
                           reinterpret_cast<float4*>(grad_xd), g, fin, fin_d);
   DBEV_LAUNCH_CHECK();
   return 0;

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 
-from .bn_act import bn_act, bn_act_dual, conv1x1_bn_ready, conv1x1_stats, split_downsample
+from .bn_act import bn_act, bn_act_dual, conv1x1_bn_ready, conv1x1_stats, forked, split_downsample
 from .registry import (MODELS, ConvModule, build_activation_layer, build_conv_layer, build_norm_layer,
                        build_upsample_layer, register_conv)
 
@@ -56,12 +56,15 @@ class BasicBlock(nn.Module):
 
     def _fused(self, x):
         """same op sequence with norm -> (+identity) -> relu on the fused kernels (bn_act falls back by itself)"""
+        # x feeds the first convolution, its second handle (the previous block's forked output, bn_act.forked) the identity branch:
+        # the two gradients reach that block's fused norm backward as two addends instead of being summed by a pass of their own
+        xi = forked(x)
         out = bn_act(self.conv1(x), getattr(self, self.norm1_name), None, True)
         ds = split_downsample(self.downsample)
         if ds is not None:         # norm of the main path and norm of the identity branch, add and ReLU in one pass
-            return bn_act_dual(self.conv2(out), getattr(self, self.norm2_name), ds[0](x), ds[1], True)
-        identity = x if self.downsample is None else self.downsample(x)
-        return bn_act(self.conv2(out), getattr(self, self.norm2_name), identity, True)
+            return bn_act_dual(self.conv2(out), getattr(self, self.norm2_name), ds[0](xi), ds[1], True, fork=True)
+        identity = xi if self.downsample is None else self.downsample(xi)
+        return bn_act(self.conv2(out), getattr(self, self.norm2_name), identity, True, fork=True)
 
     def forward(self, x):
         if self.with_cp and x.requires_grad:
@@ -108,6 +111,7 @@ class Bottleneck(nn.Module):
     def _fused(self, x):
         """same op sequence with norm -> (+identity) -> relu on the fused kernels (bn_act falls back by itself)"""
         n1, n3 = getattr(self, self.norm1_name), getattr(self, self.norm3_name)
+        xi = forked(x)             # second handle of the previous block's output for the identity branch (see BasicBlock._fused)
         # 1x1 convolutions of the large maps: fp32-MFMA GEMM with the norm's batch statistics in its epilogue (no statistics pass)
         z1, p1 = conv1x1_stats(self.conv1, x) if conv1x1_bn_ready(self.conv1, n1, x) else (self.conv1(x), None)
         out = bn_act(z1, n1, None, True, pre=p1)
@@ -115,10 +119,10 @@ class Bottleneck(nn.Module):
         z3, p3 = conv1x1_stats(self.conv3, out) if conv1x1_bn_ready(self.conv3, n3, out) else (self.conv3(out), None)
         ds = split_downsample(self.downsample)
         if ds is not None:
-            zd, pd = conv1x1_stats(ds[0], x) if conv1x1_bn_ready(ds[0], ds[1], x) else (ds[0](x), None)
-            return bn_act_dual(z3, n3, zd, ds[1], True, pre=p3, pre_d=pd)
-        identity = x if self.downsample is None else self.downsample(x)
-        return bn_act(z3, n3, identity, True, pre=p3)
+            zd, pd = conv1x1_stats(ds[0], xi) if conv1x1_bn_ready(ds[0], ds[1], xi) else (ds[0](xi), None)
+            return bn_act_dual(z3, n3, zd, ds[1], True, pre=p3, pre_d=pd, fork=True)
+        identity = xi if self.downsample is None else self.downsample(xi)
+        return bn_act(z3, n3, identity, True, pre=p3, fork=True)
 
     def forward(self, x):
         if self.with_cp and x.requires_grad:

@@ -481,6 +481,13 @@ int dbev_bn_act_backward(const float* grad_y, const float* x, const float* y, co
                          const float* save_mean, const float* save_invstd, const float* save_scale_shift,
                          int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                          long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+/* the same with the incoming gradient given as TWO addends (grad_y2 may be NULL): the output of a residual block feeds the next block's
+ * first convolution and its identity branch, autograd would sum their two gradients in a pass of its own (read 2, write 1); the
+ * reduction and the dx pass add them on the way in instead */
+int dbev_bn_act_backward2(const float* grad_y, const float* grad_y2, const float* x, const float* y, const float* gamma,
+                          const float* save_mean, const float* save_invstd, const float* save_scale_shift, int relu,
+                          float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta, long long M, int C,
+                          void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* Two training-mode BatchNorm2d layers feeding one add (+ ReLU):  y = [relu]( bn(x) + bn_d(xd) )  -- the main and the
  * `downsample` branch of a stage-first residual block (mmdet ResNet Bottleneck / BasicBlock: `identity = self.downsample(x)`,
@@ -509,6 +516,11 @@ int dbev_bn_dual_backward(const float* grad_y, const float* x, const float* xd, 
                           const float* save_invstd_d, int relu, float* grad_x, float* grad_xd, float* grad_gamma,
                           float* grad_beta, float* grad_gamma_d, float* grad_beta_d, long long M, int C, void* workspace,
                           size_t workspace_bytes, dbevStream_t stream);
+int dbev_bn_dual_backward2(const float* grad_y, const float* grad_y2, const float* x, const float* xd, const float* y,
+                           const float* gamma, const float* save_mean, const float* save_invstd, const float* gamma_d,
+                           const float* save_mean_d, const float* save_invstd_d, int relu, float* grad_x, float* grad_xd,
+                           float* grad_gamma, float* grad_beta, float* grad_gamma_d, float* grad_beta_d, long long M, int C,
+                           void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* LiDAR sweep -> per-camera sparse depth maps, the depth supervision BEVDepth's img_inputs carry as their last element.
  * Replaces the loader transform PointToMultiViewDepth.__call__ / points2depthmap (mmdet3d/datasets/pipelines/loading.py:18-61).

@@ -219,3 +219,57 @@ def test_dual_norm_add_relu_of_a_stage_first_residual_block(N, C, H, W, relu, me
             bn.load_state_dict(st)
         y3 = bn_act_dual(a, bns[0], b, bns[1], relu)
     _close(y3, ref, 2e-6, "two-step forward")
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_forked_block_output_hands_two_gradient_addends_to_the_fused_backward(dual):
+    """A residual block's output feeds the next block's first convolution and its identity branch.  bn_act(..., fork=True) returns the
+    output with a second handle (forked(y)); the two gradients then reach the fused norm backward as two addends
+    (dbev_bn_act_backward2 / dbev_bn_dual_backward2) instead of being summed by autograd's accumulation pass.  a + b is the same
+    float either way: every gradient is BIT-identical to the unforked graph, and the forked graph has no accumulation add."""
+    from distill_bev_amd import bn_act as BA
+    torch.manual_seed(3)
+    N, C, H, W = 2, 64, 9, 12
+    mk = lambda: nn.BatchNorm2d(C).to(DEV).train()
+    bn0, bnd, bn1, bn2 = mk(), mk(), mk(), mk()
+    conv = nn.Conv2d(C, C, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    z, zd, r = [cl(torch.randn(N, C, H, W)).requires_grad_(True) for _ in range(3)]
+    gout = cl(torch.randn(N, C, H, W))
+    params = [z, zd, r, bn0.weight, bn0.bias, bnd.weight, bnd.bias, bn1.weight, bn1.bias, bn2.weight, bn2.bias, conv.weight]
+    init = [{k: v.clone() for k, v in m.state_dict().items()} for m in (bn0, bnd, bn1, bn2)]
+
+    def run(fork):
+        for m, st in zip((bn0, bnd, bn1, bn2), init):
+            m.load_state_dict(st)
+        BA._state["fork"] = fork
+        try:
+            if dual:
+                y = BA.bn_act_dual(z, bn0, zd, bnd, True, fork=True)                  # block k: relu(bn(z) + bn_d(zd))
+            else:
+                y = BA.bn_act(z, bn0, r, True, fork=True)                             # block k: relu(bn(z) + r)
+            assert (getattr(y, "_dbev_fork", None) is not None) == fork
+            if fork:
+                assert BA.forked(y).data_ptr() == y.data_ptr() and BA.forked(y) is not y
+            h = BA.bn_act(conv(y), bn1, None, True)                                   # block k+1: first convolution on y ...
+            out = BA.bn_act(h, bn2, BA.forked(y), True)                               # ... identity branch on its second handle
+            grads = torch.autograd.grad(out, params, gout, allow_unused=True)
+            names = set()
+            stack, seen = [out.grad_fn], set()
+            while stack:
+                f = stack.pop()
+                if f is None or f in seen:
+                    continue
+                seen.add(f); names.add(type(f).__name__)
+                stack.extend(g for g, _ in f.next_functions)
+            return grads, out.detach().clone()
+        finally:
+            BA._state["fork"] = True
+    (ga, oa), (gb, ob) = run(True), run(False)
+    assert torch.equal(oa, ob)
+    for a, b, p in zip(ga, gb, params):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b), float((a - b).abs().max())
+    used = [g is not None for g in ga]
+    assert used[0] and used[-1] and (used[1] if dual else used[2])
