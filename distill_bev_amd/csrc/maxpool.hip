@@ -1,0 +1,112 @@
+// MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem on channels-last tensors, forward + backward.
+//
+// Replaces ATen's max_pool2d_with_indices / max_pool2d_with_indices_backward (mmdet ResNet stem `self.maxpool`, called from
+// mmdet3d/models/detectors/bevdet_distill_more.py's image_encoder -> self.img_backbone): same values, the same winner on ties
+// (the FIRST maximum in (row, column) scan order of the window, a NaN wins) -- the stem's ReLU output is full of tied zeros.
+// Forward: one float4 of channels per lane, the nine taps of a window are contiguous 16-byte reads; it also stores the winning tap
+// (0..8, one byte per output element).  Backward as a GATHER: an input pixel is covered by at most 2 x 2 windows; its gradient is
+// the sum (window row, then window column ascending) of the output gradients of the windows whose winner it is -- no atomics, the
+// 554 MB input gradient is written once (ATen's NHWC backward: 461 us for the step's stem; this: one pass at the streaming rate).
+#include "common.h"
+
+namespace {
+
+struct MpDims { int N, H, W, C4, Ho, Wo; };
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd(const float4* __restrict__ x, float4* __restrict__ y,
+                                                        uchar4* __restrict__ tap, MpDims d, long long total) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = static_cast<int>(t % d.C4);
+  long long p = t / d.C4;
+  const int ow = static_cast<int>(p % d.Wo); p /= d.Wo;
+  const int oh = static_cast<int>(p % d.Ho);
+  const int n = static_cast<int>(p / d.Ho);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  uchar4 w = make_uchar4(0, 0, 0, 0);
+  bool first = true;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int h = 2 * oh - 1 + kh;
+    if (h < 0 || h >= d.H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ww = 2 * ow - 1 + kw;
+      if (ww < 0 || ww >= d.W) continue;
+      const float4 v = x[(static_cast<size_t>(n) * d.H + h) * d.W * d.C4 + static_cast<size_t>(ww) * d.C4 + c];
+      const unsigned char k = static_cast<unsigned char>(3 * kh + kw);
+      // ATen: (val > maxval) || isnan(val), maxval starts at -inf with the window's first element as its index
+      if (first || v.x > m.x || v.x != v.x) { m.x = v.x; w.x = k; }
+      if (first || v.y > m.y || v.y != v.y) { m.y = v.y; w.y = k; }
+      if (first || v.z > m.z || v.z != v.z) { m.z = v.z; w.z = k; }
+      if (first || v.w > m.w || v.w != v.w) { m.w = v.w; w.w = k; }
+      first = false;
+    }
+  }
+  y[t] = m;
+  tap[t] = w;
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd(const float4* __restrict__ gy, const uchar4* __restrict__ tap,
+                                                        float4* __restrict__ gx, MpDims d, long long total) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int c = static_cast<int>(t % d.C4);
+  long long p = t / d.C4;
+  const int w = static_cast<int>(p % d.W); p /= d.W;
+  const int h = static_cast<int>(p % d.H);
+  const int n = static_cast<int>(p / d.H);
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  // windows oh with 2 oh - 1 <= h <= 2 oh + 1
+  const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;
+  for (int oh = oh0; oh <= oh1; ++oh) {
+    if (oh >= d.Ho) continue;
+    const int kh = h - (2 * oh - 1);
+    for (int ow = ow0; ow <= ow1; ++ow) {
+      if (ow >= d.Wo) continue;
+      const int k = 3 * kh + (w - (2 * ow - 1));
+      const size_t o = ((static_cast<size_t>(n) * d.Ho + oh) * d.Wo + ow) * d.C4 + c;
+      const uchar4 s = tap[o];
+      const float4 v = gy[o];
+      if (s.x == k) g.x += v.x;
+      if (s.y == k) g.y += v.y;
+      if (s.z == k) g.z += v.z;
+      if (s.w == k) g.w += v.w;
+    }
+  }
+  st_nt(&gx[t], g);
+}
+
+bool mp_dims(int N, int H, int W, int C, MpDims* d) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return false;
+  d->N = N; d->H = H; d->W = W; d->C4 = C >> 2;
+  d->Ho = (H + 2 - 3) / 2 + 1;
+  d->Wo = (W + 2 - 3) / 2 + 1;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int dbev_maxpool3x3s2_forward(const float* x_nhwc, int N, int H, int W, int C, float* y_nhwc, unsigned char* winner,
+                                         dbevStream_t stream) {
+  MpDims d;
+  if (!mp_dims(N, H, W, C, &d) || x_nhwc == nullptr || y_nhwc == nullptr || winner == nullptr) return DBEV_EINVAL;
+  const long long total = static_cast<long long>(N) * d.Ho * d.Wo * d.C4;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd, dim3(dbev_ceil_div(total, 256)), dim3(256), 0, dbev_stream(stream),
+                     reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<float4*>(y_nhwc), reinterpret_cast<uchar4*>(winner), d,
+                     total);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* winner, int N, int H, int W, int C,
+                                          float* grad_x_nhwc, dbevStream_t stream) {
+  MpDims d;
+  if (!mp_dims(N, H, W, C, &d) || grad_y_nhwc == nullptr || winner == nullptr || grad_x_nhwc == nullptr) return DBEV_EINVAL;
+  const long long total = static_cast<long long>(N) * H * W * d.C4;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd, dim3(dbev_ceil_div(total, 256)), dim3(256), 0, dbev_stream(stream),
+                     reinterpret_cast<const float4*>(grad_y_nhwc), reinterpret_cast<const uchar4*>(winner),
+                     reinterpret_cast<float4*>(grad_x_nhwc), d, total);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}

@@ -582,6 +582,17 @@ int dbev_msda_backward(const float* value, const int32_t* spatial_shapes_hw_host
                        void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem, channels-last (replaces ATen max_pool2d_with_indices(_backward) behind
+ * mmdet ResNet `self.maxpool`, reached from bevdet_distill_more.py image_encoder -> self.img_backbone).  x_nhwc [N, H, W, C],
+ * C % 4 == 0; y [N, Ho, Wo, C], Ho = (H - 1) / 2 + 1; winner u8 [N, Ho, Wo, C] = winning tap 0..8 (first maximum in scan order, a NaN
+ * wins: ATen's rule).  backward: gather over the <= 2 x 2 windows that cover an input pixel, no atomics.
+ * ---------------------------------------------------------------------------------- */
+int dbev_maxpool3x3s2_forward(const float* x_nhwc, int N, int H, int W, int C, float* y_nhwc, unsigned char* winner,
+                              dbevStream_t stream);
+int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* winner, int N, int H, int W, int C, float* grad_x_nhwc,
+                               dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Depth head of the BEVDepth view transformer, forward (mmdet3d/models/necks/view_transformer_mine.py:300-309 self.dcn's
  * BatchNorm2d, :326 depth_digit = self.depthnet(depth_feat) (nn.Conv2d(c, D, 1), :291), :327 get_depth_dist = softmax(dim=1);
  * same in detectors/bevdet_distill_more.py:398-416): normalise -> 1x1 convolution -> softmax in one pass.
