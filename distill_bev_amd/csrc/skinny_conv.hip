@@ -13,6 +13,8 @@
 //   y    f32[N, H, W, Cout]    (NHWC image of [N, Cout, H, W])
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int SK_MAX_CO = 3;
@@ -287,6 +289,95 @@ __global__ __launch_bounds__(256) void sk_fwd_multi(const float4* __restrict__ x
       for (int tap = 0; tap < 9; ++tap) s += dot4f(v[tap], wr[co * 9 + tap]);
       for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
       if (live && q == 0 && co < con) y[p * con + co] = s + br_[co];
+    }
+  }
+}
+
+// Forward for 64-channel maps (16 lanes per pixel) through an LDS tile: a workgroup stages the (4 + 2) x (32 + 2) pixel halo tile of
+// its branch once (52 KB, whole 256-byte pixel rows), every lane group then walks 8 pixels of one tile row with a sliding window
+// of ds_read_b128 taps -- each input element crosses HBM / L2 1.3 times instead of being fetched 9 times through L1 (the kernel above)
+// or 3 times through L2 (a register strip walk).  Per-lane partial sums of the 8 pixels x 3 outputs are reduce-scattered over the
+// group's 16 lanes (30 shuffles instead of 96) and leave from all lanes.
+constexpr int SKT_H = 4, SKT_W = 32, SKT_G = 16;
+constexpr int SKT_PIX = (SKT_H + 2) * (SKT_W + 2);
+
+__device__ __forceinline__ void fma4v(float4& a, const float4& v, const float4& w) {
+  a.x = fmaf(v.x, w.x, a.x); a.y = fmaf(v.y, w.y, a.y); a.z = fmaf(v.z, w.z, a.z); a.w = fmaf(v.w, w.w, a.w);
+}
+
+__global__ __launch_bounds__(256, 2) void sk_fwd_multi_lds(const float4* __restrict__ xbase, const float4* __restrict__ wpk,
+                                                           const float* __restrict__ bpk, SkMulti m, SkDims d, int tiles_h, int tiles_w) {
+  constexpr int CO = 3, G = SKT_G;
+  __shared__ float4 tile[SKT_PIX * G];                                        // [halo pixel][q]
+  const int br = blockIdx.y, con = m.co[br];
+  const int q = threadIdx.x & (G - 1), grp = threadIdx.x / G;                 // 16 groups: tile row grp / 4, columns 8 (grp % 4) ..
+  const float4* __restrict__ x = xbase + static_cast<size_t>(br) * G;
+  const float4* __restrict__ wp = wpk + static_cast<size_t>(br) * CO * 9 * G;
+  float* __restrict__ y = m.y[br];
+  float4 wr[CO * 9];
+#pragma unroll
+  for (int i = 0; i < CO * 9; ++i) wr[i] = wp[i * G + q];
+  const float b0v = bpk[br * CO + 0], b1v = bpk[br * CO + 1], b2v = bpk[br * CO + 2];
+  const int ntile = d.N * tiles_h * tiles_w;
+  const bool b3 = (q & 8) != 0, b2 = (q & 4) != 0, b1 = (q & 2) != 0, b0 = (q & 1) != 0;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int tw = t % tiles_w, th = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
+    const int h0 = th * SKT_H, w0 = tw * SKT_W;
+    __syncthreads();                                                          // the previous tile is consumed
+    for (int i = threadIdx.x; i < SKT_PIX * G; i += 256) {
+      const int pix = i / G, qq = i - pix * G;
+      const int hh = h0 - 1 + pix / (SKT_W + 2), ww = w0 - 1 + pix % (SKT_W + 2);
+      tile[i] = (hh >= 0 && hh < d.H && ww >= 0 && ww < d.W)
+                    ? x[((static_cast<size_t>(n) * d.H + hh) * d.W + ww) * d.XP4 + qq] : z;
+    }
+    __syncthreads();
+    const int tr = grp >> 2, tc = (grp & 3) * 8;                               // this group's output row / first column inside the tile
+    const float4* __restrict__ r0 = tile + (static_cast<size_t>(tr) * (SKT_W + 2) + tc) * G + q;   // halo row tr = image row h - 1
+    const float4* __restrict__ r1 = r0 + (SKT_W + 2) * G;
+    const float4* __restrict__ r2 = r1 + (SKT_W + 2) * G;
+    float4 c0[3] = {r0[0], r1[0], r2[0]}, c1[3] = {r0[G], r1[G], r2[G]}, c2[3];
+    float ps[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      c2[0] = r0[(i + 2) * G]; c2[1] = r1[(i + 2) * G]; c2[2] = r2[(i + 2) * G];
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        float4 a4 = z;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          fma4v(a4, c0[r], wr[co * 9 + 3 * r + 0]);
+          fma4v(a4, c1[r], wr[co * 9 + 3 * r + 1]);
+          fma4v(a4, c2[r], wr[co * 9 + 3 * r + 2]);
+        }
+        ps[i][co] = (a4.x + a4.y) + (a4.z + a4.w);
+      }
+      ps[i][3] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; }
+    }
+    // reduce-scatter of the 32 slots 4 i + co: lane (b3 b2 b1 b0) ends up with pixel 4 b3 + 2 b2 + b1, outputs 2 b0 + (0, 1)
+    float v16[16], v8[8], v4[4], v2[2];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float lo = ps[k >> 2][k & 3], hi = ps[4 + (k >> 2)][k & 3];
+      v16[k] = (b3 ? hi : lo) + __shfl_xor(b3 ? lo : hi, 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v8[k] = (b2 ? v16[8 + k] : v16[k]) + __shfl_xor(b2 ? v16[k] : v16[8 + k], 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v4[k] = (b1 ? v8[4 + k] : v8[k]) + __shfl_xor(b1 ? v8[k] : v8[4 + k], 2);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v2[k] = (b0 ? v4[2 + k] : v4[k]) + __shfl_xor(b0 ? v4[k] : v4[2 + k], 1);
+    const int h = h0 + tr, w = w0 + tc + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
+    if (h < d.H && w < d.W) {
+      float* __restrict__ yo = y + ((static_cast<size_t>(n) * d.H + h) * d.W + w) * con;
+      if (!b0) {
+        yo[0] = v2[0] + b0v;
+        if (con > 1) yo[1] = v2[1] + b1v;
+      } else if (con > 2) {
+        yo[2] = v2[0] + b2v;
+      }
     }
   }
 }
@@ -582,6 +673,19 @@ extern "C" int dbev_skinny_conv3x3_multi_forward(const float* x_nhwc, long long 
       (reinterpret_cast<uintptr_t>(x_nhwc) & 15) || !sk_multi_args(&m, y_nhwc, nullptr, cout, n_branch) ||
       x_pitch < static_cast<long long>(n_branch) * Cin)
     return DBEV_EINVAL;
+  static const bool lds_ok = !(getenv("DBEV_SKINNY_LDS") && atoi(getenv("DBEV_SKINNY_LDS")) == 0);
+  if (d.C4 == SKT_G && lds_ok) {                   // 64-channel maps (the CenterHead branches): LDS-tiled kernel
+    const int th = (H + SKT_H - 1) / SKT_H, tw = (W + SKT_W - 1) / SKT_W;
+    const long long ntile = static_cast<long long>(N) * th * tw;
+    if (ntile > 0x7fffffffLL) return DBEV_EINVAL;
+    long long blocks = ntile;
+    const long long cap = DBEV_NUM_CU * 12 / n_branch > 32 ? DBEV_NUM_CU * 12 / n_branch : 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sk_fwd_multi_lds, dim3(static_cast<unsigned>(blocks), n_branch), dim3(256), 0, dbev_stream(stream),
+                       reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<const float4*>(weights_packed), bias_packed, m, d, th, tw);
+    DBEV_LAUNCH_CHECK();
+    return 0;
+  }
   const long long threads = static_cast<long long>(N) * H * W * d.C4;
   long long blocks = (threads + 255) / 256;
   const long long cap = SK_PERSIST_BLOCKS * 2 / n_branch > 64 ? SK_PERSIST_BLOCKS * 2 / n_branch : 64;
