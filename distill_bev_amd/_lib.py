@@ -114,6 +114,8 @@ _SIGNATURES = {
     "dbev_bn_act_train_forward_pre": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _i, _p, _sz, _p],
     "dbev_bn_act_infer": [_p, _p, _p, _p, _p, _p, _f, _i, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_act_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_infer_coef": [_p, _p, _p, _p, _f, _i, _p, _p],
+    "dbev_bn_act_apply": [_p, _p, _p, _i, _p, _ll, _i, _p],
     "dbev_bn_act_backward2": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_points_to_depth_maps": [_p, _i, _i, _p, _i, _i, _i, _i, _f, _f, _p, _p],
     "dbev_bn_dual_workspace_bytes": [_ll, _i],
@@ -282,6 +284,14 @@ def fallback_counts():
 
 def fallback_reset():
     lib().dbev_fallback_reset()
+
+
+def touched(*tensors):
+    """the library wrote these tensors through raw pointers (running statistics updated inside a kernel): bump their version counters so
+    that everything keyed on `_version` (autograd's saved-tensor check, the kept eval coefficients of bn_act) sees the change"""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
 
 
 def h2d(t, device):

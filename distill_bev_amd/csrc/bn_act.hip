@@ -1012,6 +1012,43 @@ extern "C" int dbev_bn_act_infer(const float* x, const float* residual, const fl
   return 0;
 }
 
+// eval mode with the coefficients kept by the caller (a frozen teacher's norms: scale / shift never change between steps, the
+// coefficient launch of dbev_bn_act_infer is 37 x 5 us of the step): dbev_bn_infer_coef once, dbev_bn_act_apply per call
+extern "C" int dbev_bn_infer_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                  int C, float* scale_shift, dbevStream_t stream) {
+  if (C <= 0 || gamma == nullptr || beta == nullptr || running_mean == nullptr || running_var == nullptr || scale_shift == nullptr)
+    return DBEV_EINVAL;
+  hipLaunchKernelGGL(bn_infer_coef, dim3(dbev_ceil_div(C, 256)), dim3(256), 0, dbev_stream(stream), gamma, beta, running_mean,
+                     running_var, eps, C, scale_shift);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_bn_act_apply(const float* x, const float* residual, const float* scale_shift, int relu, float* y, long long M,
+                                 int C, dbevStream_t stream) {
+  BnGeom g;
+  if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
+  if (x == nullptr || scale_shift == nullptr || y == nullptr) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* r4 = reinterpret_cast<const float4*>(residual);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
+  const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
+  const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
+  const float* none = nullptr;
+  const BnFin nofin{};
+  if (residual != nullptr) {
+    if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, scale_shift, y4, g, none, 0, nofin, nofin);
+    else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, scale_shift, y4, g, none, 0, nofin, nofin);
+  } else {
+    if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, scale_shift, y4, g, none, 0, nofin, nofin);
+    else hipLaunchKernelGGL((bn_apply<false, false>), agrid, dim3(256), 0, s, x4, r4, scale_shift, y4, g, none, 0, nofin, nofin);
+  }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dbev_bn_act_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
                                     const float* save_mean, const float* save_invstd, const float* save_scale_shift,
                                     int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,

@@ -57,6 +57,7 @@ class _DepthHead(Function):
                        L.ptr(running_var), L.ptr(nbt), float(momentum or 0.0), float(eps), 0, L.ptr(None), L.ptr(save_mean),
                        L.ptr(save_invstd), L.ptr(coef), M, C, L.ptr(None), 0, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
                        alg_bytes=4 * M * C)
+                L.touched(running_mean, running_var, nbt)
             else:
                 scale = bn_w * torch.rsqrt(running_var + eps)
                 coef[:C] = scale

@@ -477,6 +477,12 @@ int dbev_bn_act_train_forward_pre(const float* x, const float* residual, const f
 int dbev_bn_act_infer(const float* x, const float* residual, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, float eps, int relu, float* y,
                       long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream);
+/* the same in two parts for norms whose parameters and running statistics do not change between calls (a frozen teacher): the
+ * coefficients (scale | shift, f32[2C], bit-identical to what dbev_bn_act_infer derives) once, then only the apply pass per call */
+int dbev_bn_infer_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                       float* scale_shift, dbevStream_t stream);
+int dbev_bn_act_apply(const float* x, const float* residual, const float* scale_shift, int relu, float* y, long long M, int C,
+                      dbevStream_t stream);
 int dbev_bn_act_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
                          const float* save_mean, const float* save_invstd, const float* save_scale_shift,
                          int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,

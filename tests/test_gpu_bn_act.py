@@ -273,3 +273,31 @@ def test_forked_block_output_hands_two_gradient_addends_to_the_fused_backward(du
             assert torch.equal(a, b), float((a - b).abs().max())
     used = [g is not None for g in ga]
     assert used[0] and used[-1] and (used[1] if dual else used[2])
+
+
+def test_eval_coefficients_are_kept_on_the_module_and_follow_every_change_of_its_tensors():
+    """eval-mode bn_act keeps scale | shift on the module (dbev_bn_infer_coef once, dbev_bn_act_apply per call): the values must follow
+    a training step that moves the running statistics, an optimizer-style in-place update of gamma / beta, and load_state_dict."""
+    from distill_bev_amd import bn_act as BA
+    torch.manual_seed(1)
+    bn = nn.BatchNorm2d(32).to(DEV)
+    x = torch.randn(2, 32, 6, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+
+    def check():
+        bn.eval()
+        with torch.no_grad():
+            got = BA.bn_act(x, bn, None, True)
+            ref = torch.relu(torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
+        assert torch.allclose(got, ref, atol=2e-6), float((got - ref).abs().max())
+        return bn.__dict__["_dbev_eval_coef"][1]
+    c0 = check()
+    assert check() is c0                                        # unchanged module: the kept tensor is reused
+    bn.train(); BA.bn_act(x * 3 + 1, bn, None, True)            # running statistics move (in-kernel update)
+    c1 = check()
+    assert c1 is not c0
+    with torch.no_grad():
+        bn.weight.mul_(1.5); bn.bias.add_(0.25)                 # optimizer-style in-place parameter update
+    c2 = check()
+    assert c2 is not c1
+    bn.load_state_dict({k: torch.rand_like(v.float()).to(v.dtype) + 0.5 if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    assert check() is not c2
