@@ -47,34 +47,57 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd(const float4* __restrict
   tap[t] = w;
 }
 
+// one lane = one float4 of channels of a 2 x 2 block of input pixels (rows 2i, 2i + 1, columns 2j, 2j + 1): the block is covered by the
+// windows (i, i + 1) x (j, j + 1) only, so the four (gradient, winner) pairs are read once for four outputs (a lane per pixel read
+// them 2.25 times on average: FETCH 3.4 x the two tensors).  Sums in (window row, window column) order as before.
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd(const float4* __restrict__ gy, const uchar4* __restrict__ tap,
-                                                        float4* __restrict__ gx, MpDims d, long long total) {
+                                                        float4* __restrict__ gx, MpDims d, int Hb, int Wb, long long total) {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int c = static_cast<int>(t % d.C4);
   long long p = t / d.C4;
-  const int w = static_cast<int>(p % d.W); p /= d.W;
-  const int h = static_cast<int>(p % d.H);
-  const int n = static_cast<int>(p / d.H);
-  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-  // windows oh with 2 oh - 1 <= h <= 2 oh + 1
-  const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;
-  for (int oh = oh0; oh <= oh1; ++oh) {
-    if (oh >= d.Ho) continue;
-    const int kh = h - (2 * oh - 1);
-    for (int ow = ow0; ow <= ow1; ++ow) {
-      if (ow >= d.Wo) continue;
-      const int k = 3 * kh + (w - (2 * ow - 1));
-      const size_t o = ((static_cast<size_t>(n) * d.Ho + oh) * d.Wo + ow) * d.C4 + c;
-      const uchar4 s = tap[o];
-      const float4 v = gy[o];
-      if (s.x == k) g.x += v.x;
-      if (s.y == k) g.y += v.y;
-      if (s.z == k) g.z += v.z;
-      if (s.w == k) g.w += v.w;
+  const int j = static_cast<int>(p % Wb); p /= Wb;
+  const int i = static_cast<int>(p % Hb);
+  const int n = static_cast<int>(p / Hb);
+  float4 v[2][2];
+  uchar4 s[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oh = i + a, ow = j + b;
+      if (oh < d.Ho && ow < d.Wo) {
+        const size_t o = ((static_cast<size_t>(n) * d.Ho + oh) * d.Wo + ow) * d.C4 + c;
+        v[a][b] = gy[o];
+        s[a][b] = tap[o];
+      } else {
+        v[a][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s[a][b] = make_uchar4(255, 255, 255, 255);
+      }
+    }
+#pragma unroll
+  for (int dh = 0; dh < 2; ++dh) {
+    const int h = 2 * i + dh;
+    if (h >= d.H) continue;
+#pragma unroll
+    for (int dw = 0; dw < 2; ++dw) {
+      const int w = 2 * j + dw;
+      if (w >= d.W) continue;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      // windows oh with 2 oh - 1 <= h <= 2 oh + 1: an even row belongs to window i only, an odd row to i and i + 1 (same for columns)
+#pragma unroll
+      for (int a = 0; a <= dh; ++a)
+#pragma unroll
+        for (int b = 0; b <= dw; ++b) {
+          const int k = 3 * (h - (2 * (i + a) - 1)) + (w - (2 * (j + b) - 1));
+          if (s[a][b].x == k) g.x += v[a][b].x;
+          if (s[a][b].y == k) g.y += v[a][b].y;
+          if (s[a][b].z == k) g.z += v[a][b].z;
+          if (s[a][b].w == k) g.w += v[a][b].w;
+        }
+      st_nt(&gx[((static_cast<size_t>(n) * d.H + h) * d.W + w) * d.C4 + c], g);
     }
   }
-  st_nt(&gx[t], g);
 }
 
 bool mp_dims(int N, int H, int W, int C, MpDims* d) {
@@ -103,10 +126,11 @@ extern "C" int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsign
                                           float* grad_x_nhwc, dbevStream_t stream) {
   MpDims d;
   if (!mp_dims(N, H, W, C, &d) || grad_y_nhwc == nullptr || winner == nullptr || grad_x_nhwc == nullptr) return DBEV_EINVAL;
-  const long long total = static_cast<long long>(N) * H * W * d.C4;
+  const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;                                 // 2 x 2 input blocks
+  const long long total = static_cast<long long>(N) * Hb * Wb * d.C4;
   hipLaunchKernelGGL(maxpool3x3s2_bwd, dim3(dbev_ceil_div(total, 256)), dim3(256), 0, dbev_stream(stream),
                      reinterpret_cast<const float4*>(grad_y_nhwc), reinterpret_cast<const uchar4*>(winner),
-                     reinterpret_cast<float4*>(grad_x_nhwc), d, total);
+                     reinterpret_cast<float4*>(grad_x_nhwc), d, Hb, Wb, total);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

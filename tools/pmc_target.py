@@ -83,6 +83,32 @@ yc = torch.empty((Mc, Nc), device=dev)
 pc = torch.empty((int(L.call("dbev_conv1x1_stats_rows", Mc, Kc, Nc)), 2, Nc), device=dev)
 for _ in range(5):
     L.call("dbev_conv1x1_forward", L.ptr(xc), L.ptr(wc), L.ptr(yc), L.ptr(pc), Mc, Kc, Nc, Kc, L.stream_ptr(dev))
+# round 3: the 36 final convolutions of the student head in one launch each way (8 x 36 x 64 x 128 x 128 wide map: 1.2 GB)
+from distill_bev_amd.head_batch import _BranchFinalConvs
+nbr, Chh = 36, 64
+Ah = torch.randn((B, nbr * Chh, 128, 128), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+couts = [2, 1, 3, 2, 2, 1] * 6
+wbs = []
+for co in couts:
+    wbs += [(torch.randn((co, Chh, 3, 3), device=dev) * 0.05).requires_grad_(True), torch.zeros((co,), device=dev).requires_grad_(True)]
+for _ in range(3):
+    ys = _BranchFinalConvs.apply(Ah, Chh, *wbs)
+    torch.autograd.grad(sum(y.sum() for y in ys), [Ah] + wbs)
+print("head branches: wide map", Ah.numel() * 4, "bytes")
+# round 3: stem max pooling at the step's shape (48 x 64 x 128 x 352 -> 64 x 176)
+from distill_bev_amd.pool import max_pool
+xs = torch.relu(torch.randn((48, 64, 128, 352), device=dev)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+mp = nn.MaxPool2d(3, 2, 1)
+for _ in range(3):
+    ym = max_pool(mp, xs)
+    torch.autograd.grad(ym.sum(), xs)
+# round 3: depth-head tail at the step's shape (48 x 256 x 16 x 44 -> 59 depth bins)
+from distill_bev_amd.depth_head import depth_head
+bnd, cvd = nn.BatchNorm2d(256).to(dev).train(), nn.Conv2d(256, 59, 1).to(dev)
+xd = torch.randn((48, 256, 16, 44), device=dev).contiguous(memory_format=torch.channels_last)
+with torch.no_grad():
+    for _ in range(5):
+        depth_head(xd, bnd, cvd)
 # calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (MI355X_MICROARCH.md, HBM section)
 buf = torch.empty((128 * 1024 * 1024,), device=dev); src = torch.randn_like(buf)   # 512 MiB each
 for _ in range(3):
