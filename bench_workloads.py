@@ -16,7 +16,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # profiles/r02_pmc_*.txt; filled in by the profiling pass of the round, None until then
 # bn_apply<true,true> at 48x256x64x176: FETCH_SIZE 540 702.1 KB x 2 + WRITE_SIZE 540 672.0 KB = 1 661 029 786 B per launch
 # against 3 x 553 648 128 B = 1 660 944 384 B algorithmic -> ratio 1.00005 (no over-fetch, no write amplification)
-PMC_TRAFFIC = {"bn_apply_res_ratio": (540741.6 * 2 + 540672.1) * 1024 / (3 * 553648128.0),
+PMC_TRAFFIC = {"bn_apply_res_ratio": (540720.8 * 2 + 540672.0) * 1024 / (3 * 553648128.0),
                "source": "profiles/r03_pmc_FETCH_SIZE.txt (x2 gfx950 wide-read correction) + profiles/r03_pmc_WRITE_SIZE.txt, separate "
                          "--pmc passes at the kernel's largest shape (48x256x64x176); traffic = algorithmic bytes of the timed "
                          "launches x that measured ratio (not collected live)"}
