@@ -82,6 +82,7 @@ _SIGNATURES = {
     "dbev_skinny_conv3x3_multi_workspace_bytes": [_i, _i],
     "dbev_skinny_conv3x3_multi_forward": [_p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_skinny_conv3x3_multi_backward": [_p, _p, _ll, _p, _p, _ll, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p],
+    "dbev_grid_sample_bilinear_nhwc": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "dbev_maxpool3x3s2_forward": [_p, _i, _i, _i, _i, _p, _p, _p],
     "dbev_maxpool3x3s2_backward": [_p, _p, _i, _i, _i, _i, _p, _p],
     "dbev_depth_head_forward": [_p, _p, _p, _p, _ll, _i, _i, _p, _p, _p, _p],

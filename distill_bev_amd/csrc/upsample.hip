@@ -135,6 +135,43 @@ bool mk(int B, int C, int IH, int IW, int OH, int OW, UpDims* d) {
   return true;
 }
 
+// ---- F.grid_sample(bilinear, padding_mode='zeros', align_corners=True), channels-last, forward ---------------------------------
+// (shift_feature of BEVDepth4D warps the adjacent frame's BEV map into the current ego frame, bevdet_distill_more.py:41-94; the
+// adjacent frame is detached, so the step only needs the forward.)  ATen's arithmetic (GridSampler.cuh): source index
+// ((g + 1) / 2) * (size - 1), corner weights as products of the distances to the opposite corner, out-of-map corners skipped,
+// accumulation order nw, ne, sw, se.  One float4 of channels per lane: ATen's kernel walks the channels of a pixel serially
+// (220 us for the step's 8 x 80 x 128 x 128 map; this: one pass).
+__global__ __launch_bounds__(256) void grid_sample_bilinear_nhwc(const float4* __restrict__ x, const float2* __restrict__ grid,
+                                                                 float4* __restrict__ y, int H, int W, int C4, long long npix_out,
+                                                                 int HoWo) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= npix_out * C4) return;
+  const long long p = t / C4;
+  const int c = static_cast<int>(t - p * C4);
+  const long long n = p / HoWo;
+  const float2 g = grid[p];
+  float ix, iy, fx, fy, nw, ne, sw, se;
+  {
+    // ATen rounds the source index before it takes the corner distances: contracted into an FMA, (x_se - ix) uses the unrounded
+    // product and the weights move by an ulp of ix (1e-5 of the output at index ~100)
+#pragma clang fp contract(off)
+    ix = ((g.x + 1.f) / 2.f) * static_cast<float>(W - 1);
+    iy = ((g.y + 1.f) / 2.f) * static_cast<float>(H - 1);
+    fx = floorf(ix); fy = floorf(iy);
+    const float xs = fx + 1.f, ys = fy + 1.f;                                 // south-east corner
+    nw = (xs - ix) * (ys - iy); ne = (ix - fx) * (ys - iy); sw = (xs - ix) * (iy - fy); se = (ix - fx) * (iy - fy);
+  }
+  const int x0 = static_cast<int>(fx), y0 = static_cast<int>(fy);
+  const float4* __restrict__ xb = x + static_cast<size_t>(n) * H * W * C4 + c;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W, yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+  if (yin0 && xin0) { const float4 v = xb[(static_cast<size_t>(y0) * W + x0) * C4]; o.x += v.x * nw; o.y += v.y * nw; o.z += v.z * nw; o.w += v.w * nw; }
+  if (yin0 && xin1) { const float4 v = xb[(static_cast<size_t>(y0) * W + x0 + 1) * C4]; o.x += v.x * ne; o.y += v.y * ne; o.z += v.z * ne; o.w += v.w * ne; }
+  if (yin1 && xin0) { const float4 v = xb[(static_cast<size_t>(y0 + 1) * W + x0) * C4]; o.x += v.x * sw; o.y += v.y * sw; o.z += v.z * sw; o.w += v.w * sw; }
+  if (yin1 && xin1) { const float4 v = xb[(static_cast<size_t>(y0 + 1) * W + x0 + 1) * C4]; o.x += v.x * se; o.y += v.y * se; o.z += v.z * se; o.w += v.w * se; }
+  y[t] = o;
+}
+
 }  // namespace
 
 extern "C" int dbev_upsample_bilinear_ac_forward(const float* x, float* y, int B, int C, int IH, int IW, int OH,
@@ -170,6 +207,20 @@ extern "C" int dbev_upsample_bilinear_ac_backward(const float* grad_y, float* gr
     if (static_cast<long long>(B) * C > 65535) return DBEV_EINVAL;
     hipLaunchKernelGGL(up_bwd_nchw, dim3(dbev_ceil_div(IW, 64), dbev_ceil_div(IH, 4), B * C), dim3(64, 4), 0, s, grad_y, grad_x, d);
   }
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_grid_sample_bilinear_nhwc(const float* x_nhwc, const float* grid_xy, int N, int C, int H, int W, int Ho, int Wo,
+                                              float* y_nhwc, dbevStream_t stream) {
+  if (N <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || x_nhwc == nullptr || grid_xy == nullptr ||
+      y_nhwc == nullptr)
+    return DBEV_EINVAL;
+  const long long npix = static_cast<long long>(N) * Ho * Wo;
+  const int C4 = C >> 2;
+  hipLaunchKernelGGL(grid_sample_bilinear_nhwc, dim3(dbev_ceil_div(npix * C4, 256)), dim3(256), 0, dbev_stream(stream),
+                     reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<const float2*>(grid_xy), reinterpret_cast<float4*>(y_nhwc),
+                     H, W, C4, npix, Ho * Wo);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -403,7 +403,16 @@ class BEVDepth4DDistill(CenterPoint):
         g = grid[..., 0]
         gx, gy = [tf[..., i, 0] * g[..., 0] + tf[..., i, 1] * g[..., 1] + tf[..., i, 2] * g[..., 2] for i in range(2)]
         grid = torch.stack((gx / (w - 1.0) * 2.0 - 1.0, gy / (h - 1.0) * 2.0 - 1.0), -1)
-        return F.grid_sample(input, grid.to(dt), align_corners=True, mode=self.interpolation_mode)
+        grid = grid.to(dt)
+        if (self.interpolation_mode == "bilinear" and input.is_cuda and dt == torch.float32 and c % 4 == 0
+                and input.is_contiguous(memory_format=torch.channels_last)
+                and not (torch.is_grad_enabled() and (input.requires_grad or grid.requires_grad))):
+            out = torch.empty_like(input)               # the step's case: the adjacent frame's map is detached, forward only
+            gr = grid.contiguous()
+            with torch.cuda.device(dev):
+                L.call("dbev_grid_sample_bilinear_nhwc", L.ptr(input), L.ptr(gr), n, c, h, w, h, w, L.ptr(out), L.stream_ptr(dev))
+            return out
+        return F.grid_sample(input, grid, align_corners=True, mode=self.interpolation_mode)
 
     def bev_encoder(self, x, return_backbone_feature=False):
         feats = self.img_bev_encoder_backbone(x)

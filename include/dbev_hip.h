@@ -350,6 +350,11 @@ int dbev_upsample_bilinear_ac_forward(const float* x, float* y, int B, int C, in
                                       int channels_last, dbevStream_t stream);
 int dbev_upsample_bilinear_ac_backward(const float* grad_y, float* grad_x, int B, int C, int IH, int IW, int OH,
                                        int OW, int channels_last, dbevStream_t stream);
+/* F.grid_sample(input, grid, mode='bilinear', padding_mode='zeros', align_corners=True) on a channels-last input, forward only
+ * (BEVDepth4D.shift_feature, detectors/bevdet_distill_more.py:41-94: the warped adjacent-frame map is detached).  grid_xy f32[N, Ho, Wo, 2]
+ * normalised (x, y); ATen's arithmetic and accumulation order.  C % 4 == 0 */
+int dbev_grid_sample_bilinear_nhwc(const float* x_nhwc, const float* grid_xy, int N, int C, int H, int W, int Ho, int Wo, float* y_nhwc,
+                                   dbevStream_t stream);
 
 /* Modulated deformable convolution (DCNv2) sampling stage, channels-last.  Replaces mmcv-full 1.6.0
  * `modulated_deform_conv` (un-vendored dependency; reference call site
