@@ -443,11 +443,20 @@ class BEVDepth4DDistill(CenterPoint):
                 # get_geometry + lift + voxel_pooling (:411-421) in three library calls, no volume, no geom tensor
                 bev_feat_list.append(vt.lift_splat_cameras(rot, tran, intrin, post_rot, post_tran, depth, img_feat))
             depth_digit_list.append(depth_digit)
+        # the adjacent frame's map is detached below (:440-441): with self.detach nothing of its branch is recorded -- same values,
+        # no saved activations of pre_process_net, and the warp runs on the forward-only kernel
+        record = torch.is_grad_enabled() and not self.detach
+        adj = lambda: torch.set_grad_enabled(record)          # (constructing it already switches the mode: one per `with`)
         if self.before and self.pre_process:
-            bev_feat_list = [self.pre_process_net(b)[0] for b in bev_feat_list]
-        bev_feat_list[1] = self.shift_feature(bev_feat_list[1], trans, rots)
+            cur = self.pre_process_net(bev_feat_list[0])[0]
+            with adj():
+                bev_feat_list = [cur, self.pre_process_net(bev_feat_list[1])[0]]
+        with adj():
+            bev_feat_list[1] = self.shift_feature(bev_feat_list[1], trans, rots)
         if self.pre_process and not self.before:
-            bev_feat_list = [self.pre_process_net(b)[0] for b in bev_feat_list]
+            cur = self.pre_process_net(bev_feat_list[0])[0]
+            with adj():
+                bev_feat_list = [cur, self.pre_process_net(bev_feat_list[1])[0]]
         if self.detach:
             bev_feat_list[1] = bev_feat_list[1].detach()
         bev_feat = torch.cat(bev_feat_list, dim=1)
@@ -720,11 +729,20 @@ class BEVDet4DDistill(BEVDepth4DDistill):
                 depth = vt.get_depth_dist(x[:, :vt.D])
                 img_feat = x[:, vt.D:(vt.D + vt.numC_Trans)]
                 bev_feat_list.append(vt.lift_splat_cameras(rot, tran, intrin, post_rot, post_tran, depth, img_feat))
+        # the adjacent frame's map is detached below (:440-441): with self.detach nothing of its branch is recorded -- same values,
+        # no saved activations of pre_process_net, and the warp runs on the forward-only kernel
+        record = torch.is_grad_enabled() and not self.detach
+        adj = lambda: torch.set_grad_enabled(record)          # (constructing it already switches the mode: one per `with`)
         if self.before and self.pre_process:
-            bev_feat_list = [self.pre_process_net(b)[0] for b in bev_feat_list]
-        bev_feat_list[1] = self.shift_feature(bev_feat_list[1], trans, rots)
+            cur = self.pre_process_net(bev_feat_list[0])[0]
+            with adj():
+                bev_feat_list = [cur, self.pre_process_net(bev_feat_list[1])[0]]
+        with adj():
+            bev_feat_list[1] = self.shift_feature(bev_feat_list[1], trans, rots)
         if self.pre_process and not self.before:
-            bev_feat_list = [self.pre_process_net(b)[0] for b in bev_feat_list]
+            cur = self.pre_process_net(bev_feat_list[0])[0]
+            with adj():
+                bev_feat_list = [cur, self.pre_process_net(bev_feat_list[1])[0]]
         if self.detach:
             bev_feat_list[1] = bev_feat_list[1].detach()
         bev_feat = torch.cat(bev_feat_list, dim=1)
