@@ -367,9 +367,10 @@ class BEVDepth4DDistill(CenterPoint):
         """feature-map index -> BEV metres (bevdet_distill_more.py:70-78) and its inverse, built once per device: the matrix only
         holds the grid constants"""
         cache = self.__dict__.setdefault("_feat2bev_cache", {})
-        key = (str(dev), dt)
+        vt = self.img_view_transformer
+        key = (str(dev), dt, vt.dx._version, vt.bx._version, vt.dx.data_ptr(), vt.bx.data_ptr())     # load_state_dict bumps the versions
         if key not in cache:
-            vt = self.img_view_transformer
+            cache.clear()
             dx, bx = vt.dx.detach().to(dev, dt), vt.bx.detach().to(dev, dt)
             m = torch.zeros((3, 3), dtype=dt, device=dev)
             m[0, 0] = dx[0]; m[1, 1] = dx[1]
