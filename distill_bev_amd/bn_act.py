@@ -121,17 +121,24 @@ class _BNActTrain(Function):
                    alg_bytes=4 * M * C * (3 + (residual is not None) - (pre is not None)))     # x (stats), x (apply) [+ res] + y
         L.touched(running_mean, running_var, nbt)
         need_y = relu and residual is not None
-        ctx.save_for_backward(x, y if need_y else None, weight, save_mean, save_invstd, coef)
-        ctx.cfg = (M, C, bool(relu), residual is not None)
+        y2 = _alias(y) if fork else None
+        # both handles of a forked output are SAVED (whether or not the backward reads y): they share one storage but have separate
+        # version counters, so an in-place op on either handle (`feat += ...`, `relu_`) would silently change what the other handle's
+        # consumer saved for its backward -- saved, autograd's version check turns that into its usual "modified by an inplace
+        # operation" error when this node's backward unpacks them.  Contract: forked outputs are never written in place.
+        ctx.save_for_backward(x, y if (need_y or fork) else None, weight, save_mean, save_invstd, coef, y2)
+        ctx.cfg = (M, C, bool(relu), residual is not None, need_y)
         if fork:
             ctx.set_materialize_grads(False)
-            return y, _alias(y)
+            return y, y2
         return y
 
     @staticmethod
     def backward(ctx, dy, dy2=None):
-        x, y, weight, save_mean, save_invstd, coef = ctx.saved_tensors
-        M, C, relu, has_res = ctx.cfg
+        x, y, weight, save_mean, save_invstd, coef, _y2 = ctx.saved_tensors      # unpacking checks the versions of both handles
+        M, C, relu, has_res, need_y = ctx.cfg
+        if not need_y:
+            y = None
         dy, dy2 = _two_addends(dy, dy2)
         if dy is None:
             return (None,) * 12
@@ -173,17 +180,20 @@ class _BNDualTrain(Function):
                    0 if pre_d is None else pre_d.shape[0], L.ptr(ws), ws.numel(), L.stream_ptr(dev),
                    alg_bytes=4 * M * C * (5 - (pre is not None) - (pre_d is not None)))
         L.touched(rm, rv, nbt, rmd, rvd, nbtd)
-        ctx.save_for_backward(x, xd, y if relu else None, w, wd, stats)
+        y2 = _alias(y) if fork else None
+        ctx.save_for_backward(x, xd, y if (relu or fork) else None, w, wd, stats, y2)     # both handles saved: see _BNActTrain.forward
         ctx.cfg = (M, C, bool(relu))
         if fork:
             ctx.set_materialize_grads(False)
-            return y, _alias(y)
+            return y, y2
         return y
 
     @staticmethod
     def backward(ctx, dy, dy2=None):
-        x, xd, y, w, wd, stats = ctx.saved_tensors
+        x, xd, y, w, wd, stats, _y2 = ctx.saved_tensors
         M, C, relu = ctx.cfg
+        if not relu:
+            y = None
         dy, dy2 = _two_addends(dy, dy2)
         if dy is None:
             return (None,) * 20
@@ -299,6 +309,14 @@ def _eval_coef(bn, dev):
         hit = (key, coef)
         bn.__dict__["_dbev_eval_coef"] = hit
     return hit[1]
+
+
+def invalidate_eval_coef(root):
+    """forget the kept eval-mode coefficients of every norm under `root`.  The cache follows version counters, which writes through
+    `.data` (EMA hooks, mmcv-style `.data` loads, collectives on `t.data`) do NOT move: code that updates norm tensors that way calls
+    this afterwards (GradReducer's construction-time broadcast bumps the versions itself)."""
+    for m in root.modules():
+        m.__dict__.pop("_dbev_eval_coef", None)
 
 
 def _infer(x, residual, bn, relu):

@@ -403,7 +403,15 @@ class BEVDepth4DDistill(CenterPoint):
         # becomes n*h*w tiny GEMMs -- see lss._apply3x3)
         g = grid[..., 0]
         gx, gy = [tf[..., i, 0] * g[..., 0] + tf[..., i, 1] * g[..., 1] + tf[..., i, 2] * g[..., 2] for i in range(2)]
-        grid = torch.stack((gx / (w - 1.0) * 2.0 - 1.0, gy / (h - 1.0) * 2.0 - 1.0), -1)
+        # divide by a DEVICE tensor as the reference does (`/ normalize_factor`, :90-91): a true IEEE divide.  `gx / (w - 1.0)` with a
+        # Python scalar is evaluated as gx * (1 / (w - 1.0)) by ATen's device kernels and can land 1 ulp away; the
+        # factor is built once per (device, dtype, h, w) through pinned staging, so the step still has no blocking upload
+        nfc = self.__dict__.setdefault("_shift_norm_cache", {})
+        nkey = (str(dev), dt, h, w)
+        if nkey not in nfc:
+            nfc[nkey] = L.h2d(torch.tensor([w - 1.0, h - 1.0], dtype=dt), dev)
+        nf = nfc[nkey]
+        grid = torch.stack((gx / nf[0] * 2.0 - 1.0, gy / nf[1] * 2.0 - 1.0), -1)
         grid = grid.to(dt)
         if (self.interpolation_mode == "bilinear" and input.is_cuda and dt == torch.float32 and c % 4 == 0
                 and input.is_contiguous(memory_format=torch.channels_last)

@@ -227,11 +227,36 @@ def _pad_pow2(n):
 def _conv_backward(features, weight, grad_out, book, swap, need_input_grad, need_weight_grad):
     """indice_conv_backward (spconv_ops.h:352-420) on the kernels: the data gradient is the forward gather-GEMM over the table of
     the opposite direction with transposed weights, the weight gradient one MFMA GEMM per kernel offset over that offset's
-    compacted pair list.  No host read-back, no float atomics."""
+    compacted pair list.  No host read-back, no float atomics.  The kernels tile up to 128 channels a side; wider layers
+    (the reference's SparseEncoder stops at 128, but the module surface takes any width, as the forward does) run them per
+    128-channel slice pair: the weight gradient of a slice pair is independent of the others, the data gradient of an input
+    slice is the sum over the output slices (added in slice order: still bit-reproducible)."""
+    Cin, Cout = weight.shape[1], weight.shape[2]
+    if Cin <= 128 and Cout <= 128:
+        return _conv_backward_tile(features, weight, grad_out, book, swap, need_input_grad, need_weight_grad)
+    cuts = lambda n: [(a, min(a + 128, n)) for a in range(0, n, 128)]
+    gin = torch.empty((features.shape[0], Cin), dtype=torch.float32, device=features.device) if need_input_grad else None
+    gw = torch.empty((weight.shape[0], Cin, Cout), dtype=torch.float32, device=features.device) if need_weight_grad else None
+    for i0, i1 in cuts(Cin):
+        acc = None
+        for o0, o1 in cuts(Cout):
+            gi, gwp = _conv_backward_tile(features[:, i0:i1], weight[:, i0:i1, o0:o1], grad_out[:, o0:o1], book, swap,
+                                          need_input_grad, need_weight_grad)
+            if need_weight_grad:
+                gw[:, i0:i1, o0:o1] = gwp
+            if need_input_grad:
+                acc = gi if acc is None else acc + gi
+        if need_input_grad:
+            gin[:, i0:i1] = acc
+    return gin, gw
+
+
+def _conv_backward_tile(features, weight, grad_out, book, swap, need_input_grad, need_weight_grad):
+    """one call of the two backward kernels, <= 128 channels a side (padded to 16 / 32 / 64 / 128)"""
     dev = L.require_cuda(features, weight, grad_out)
     K, Cin, Cout = weight.shape
     ci, co = _pad_pow2(Cin), _pad_pow2(Cout)
-    assert ci <= 128 and co <= 128, "sparse convolution backward: up to 128 channels"
+    assert ci <= 128 and co <= 128
     pad = torch.nn.functional.pad
     f, g, w = features.float(), grad_out.float(), weight.float()
     if ci != Cin:

@@ -189,11 +189,12 @@ class GradReducer:
         with torch.no_grad():
             for t in list(self.params) + list(buffers):
                 if self.host_staged and t.is_cuda:
-                    h = t.data.cpu()
+                    h = t.detach().cpu()
                     dist.broadcast(h, 0)
-                    t.data.copy_(h)
+                    t.copy_(h)                     # in place on the tensor itself (not .data): the version counter moves
                 else:
-                    dist.broadcast(t.data, 0)
+                    dist.broadcast(t.detach(), 0)  # the collective writes through a raw pointer ...
+                    torch.autograd.graph.increment_version(t)   # ... so everything keyed on _version (bn_act's kept eval coefficients) is told
         cap = int(bucket_mb) * (1 << 20)
         self.buckets, cur, size = [], [], 0
         for p in reversed(self.params):            # gradients become ready roughly in reverse parameter order
@@ -213,7 +214,38 @@ class GradReducer:
         self._bucket_of = {id(p): i for i, bucket in enumerate(self.buckets) for p in bucket}
         self._seen = [set() for _ in self.buckets]
         self._fired, self._pending, self.fired_in_backward = 0, [], 0
+        self._flags = {}                  # (bucket index, have pattern) -> device flag row, built once (no per-step upload)
+        self._accumulating = False        # inside no_sync(): hooks do nothing
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.overlap else []
+
+    def close(self):
+        """detach from the parameters: remove the autograd hooks and drop anything in flight (a discarded reducer must not keep
+        launching collectives from another reducer's / trainer's backward)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for work, *_ in self._pending:
+            work.wait()
+        self._pending = []
+        self._fired = 0
+        for s_ in self._seen:
+            s_.clear()
+
+    class _NoSync:
+        def __init__(self, r):
+            self.r = r
+
+        def __enter__(self):
+            self.prev, self.r._accumulating = self.r._accumulating, True
+
+        def __exit__(self, *exc):
+            self.r._accumulating = self.prev
+
+    def no_sync(self):
+        """gradient accumulation (DDP's ``no_sync``): backward passes inside the context only accumulate into ``p.grad``; the ONE
+        backward outside it -- followed by all_reduce_grads() -- reduces the accumulated sum.  Without it a second backward before
+        all_reduce_grads() raises (its gradients would arrive after their bucket has been packed)."""
+        return GradReducer._NoSync(self)
 
     @staticmethod
     def _in_param_layout(p, g):
@@ -224,7 +256,14 @@ class GradReducer:
         return out
 
     def _on_grad(self, p):
+        if self._accumulating:
+            return
         i = self._bucket_of[id(p)]
+        if i < self._fired or id(p) in self._seen[i]:
+            # the bucket was packed (or the parameter counted) by an earlier backward of this step: the state machine is one
+            # backward per all_reduce_grads() -- anything else would silently average a stale bucket
+            raise RuntimeError("GradReducer: a second gradient arrived for a parameter before all_reduce_grads(); wrap the extra "
+                               "backward passes of a gradient-accumulation step in reducer.no_sync()")
         self._seen[i].add(id(p))
         if i == self._fired:
             n0 = self._fired
@@ -237,6 +276,23 @@ class GradReducer:
             self._launch(self.buckets[self._fired])
             self._fired += 1
 
+    def _flag_row(self, bucket, have, like):
+        """per-parameter "this rank has a gradient" flags (x world, the pre-division brings them back to 0 / 1) as a device row; kept
+        per (bucket, pattern): a training run sees one or two patterns per bucket, so after the first step there is no upload at all
+        -- the first one goes through pinned staging (`_lib.h2d`): a pageable copy issued from the autograd thread would block the host
+        until the GPU queue drains, once per bucket, inside backward"""
+        key = (id(bucket), tuple(have))
+        row = self._flags.get(key)
+        if row is None:
+            host = torch.tensor([float(h) * self.world for h in have], dtype=like.dtype)
+            if like.is_cuda:
+                from ._lib import h2d
+                row = h2d(host, like.device)
+            else:
+                row = host
+            self._flags[key] = row
+        return row
+
     def _launch(self, bucket):
         """pack one bucket (ONE concat kernel over memory-order views + the per-parameter flags), pre-divide, start its all-reduce"""
         grads, have = [], []
@@ -247,8 +303,7 @@ class GradReducer:
                 p.grad = g
             grads.append(g)
         flats = [_flat_view(g) for g in grads]          # memory-order 1-D views: no per-tensor copy kernels
-        flags = torch.tensor(have, dtype=flats[0].dtype).to(flats[0].device, non_blocking=True) * self.world
-        flat = torch.cat(flats + [flags])
+        flat = torch.cat(flats + [self._flag_row(bucket, have, flats[0])])
         flat.div_(self.world)
         host = flat.cpu() if self.host_staged and flat.is_cuda else None
         work = dist.all_reduce(host if host is not None else flat, op=dist.ReduceOp.SUM, async_op=True)
@@ -354,6 +409,12 @@ class Trainer:
         gc = oc.get("grad_clip", None)
         self.grad_clip = dict(gc) if gc else None
         self.params = params
+
+    def close(self):
+        """drop the data-parallel reducer's autograd hooks (a Trainer that is discarded while its detector lives on)"""
+        if self.reducer is not None:
+            self.reducer.close()
+            self.reducer = None
 
     def step(self, batch):
         losses = self.module(**batch)

@@ -270,3 +270,70 @@ def test_bucket_all_reduces_start_inside_backward_in_bucket_order(tmp_path):
     # (the FIRST bucket: parameters are bucketed in reverse order), so nothing can start early there -- and nothing hangs
     assert r1[True]["fired"][1] - r1[True]["fired"][0] >= r1[True]["n_buckets"] - 1
     assert r0[True]["fired"] == [0, 0]
+
+
+# ---- the hook state machine: one backward per all_reduce_grads(), no_sync() for accumulation, close() -------------------------
+def _state_machine_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distill_bev_amd.train_step import GradReducer
+    torch.manual_seed(0)
+    net = nn.Sequential(*[nn.Linear(32, 32) for _ in range(4)], nn.Linear(32, 1))
+    params = list(net.parameters())
+    red = GradReducer(params, bucket_mb=0.005, overlap=True)
+    xs = [torch.randn(8, 32, generator=torch.Generator().manual_seed(20 + 2 * rank + i)) for i in range(2)]
+    res = {}
+    # (a) a second backward before all_reduce_grads() is an error, not a silently stale bucket
+    net(xs[0]).square().mean().backward()
+    try:
+        net(xs[1]).square().mean().backward()
+        res["second_backward_raised"] = False
+    except RuntimeError as e:
+        res["second_backward_raised"] = "no_sync" in str(e)
+    red.all_reduce_grads()
+    # (b) accumulation under no_sync(): the reduced gradient is the average over ranks of the SUM of both micro-batches
+    for p in params:
+        p.grad = None
+    with red.no_sync():
+        net(xs[0]).square().mean().backward()
+    assert red.fired_in_backward == res.get("_f", red.fired_in_backward)
+    net(xs[1]).square().mean().backward()
+    red.all_reduce_grads()
+    res["accum"] = [p.grad.clone() for p in params]
+    # reference: plain autograd on each rank, averaged with one all_reduce per tensor
+    for p in params:
+        p.grad = None
+    red.close()
+    res["hooks_after_close"] = len(red._hooks)
+    (net(xs[0]).square().mean() + net(xs[1]).square().mean()).backward()
+    net(xs[0]).square().mean().backward()              # would raise if a hook were still attached
+    ref = []
+    for p in params:
+        p.grad = None
+    (net(xs[0]).square().mean() + net(xs[1]).square().mean()).backward()
+    for p in params:
+        g = p.grad.clone() / world
+        dist.all_reduce(g)
+        ref.append(g)
+    res["ref"] = ref
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_rejects_a_second_backward_and_accumulates_under_no_sync(tmp_path):
+    """the overlap hooks assume one backward per all_reduce_grads().  A second one now raises (instead of being averaged
+    into nothing), `no_sync()` gives DDP's accumulation semantics, and `close()` detaches the hooks."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sm.pt")
+    mp.spawn(_state_machine_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out, weights_only=False)
+    for r in (r0, r1):
+        assert r["second_backward_raised"] is True
+        assert r["hooks_after_close"] == 0
+        for a, b in zip(r["accum"], r["ref"]):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert all(torch.equal(a, b) for a, b in zip(r0["accum"], r1["accum"]))

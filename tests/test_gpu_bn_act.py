@@ -275,6 +275,27 @@ def test_forked_block_output_hands_two_gradient_addends_to_the_fused_backward(du
     assert used[0] and used[-1] and (used[1] if dual else used[2])
 
 
+@pytest.mark.parametrize("which", ["first", "second"])
+def test_in_place_write_to_a_forked_output_is_an_autograd_error_not_a_wrong_gradient(which):
+    """The two handles of a forked output share storage but not a version counter.  Both are saved by the fused norm's node, so an
+    in-place op on EITHER handle (a neck doing `feat += ...` / `relu_` on a stage output) raises autograd's "modified by an inplace
+    operation" error in backward instead of silently changing what the other handle's consumer saved (ADVICE r3)."""
+    from distill_bev_amd import bn_act as BA
+    torch.manual_seed(4)
+    N, C, H, W = 2, 64, 5, 6
+    bn = nn.BatchNorm2d(C).to(DEV).train()
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    z = cl(torch.randn(N, C, H, W)).requires_grad_(True)
+    y = BA.bn_act(z, bn, None, True, fork=True)
+    y2 = BA.forked(y)
+    assert y2 is not y
+    out = (y * 2.0).sum() + (y2 * 3.0).sum()
+    with torch.no_grad():
+        (y if which == "first" else y2).add_(1.0)
+    with pytest.raises(RuntimeError, match="inplace|in-place"):
+        out.backward()
+
+
 def test_eval_coefficients_are_kept_on_the_module_and_follow_every_change_of_its_tensors():
     """eval-mode bn_act keeps scale | shift on the module (dbev_bn_infer_coef once, dbev_bn_act_apply per call): the values must follow
     a training step that moves the running statistics, an optimizer-style in-place update of gamma / beta, and load_state_dict."""

@@ -277,11 +277,13 @@ def test_edge_cases_empty_and_single_site_tensors():
 
 
 @pytest.mark.parametrize("n,Cin,Cout,kind", [(3000, 16, 16, "subm"), (3000, 32, 64, "down"), (2500, 64, 128, "down"), (1500, 128, 128, "subm"),
-                                               (2000, 23, 16, "subm"), (1200, 48, 24, "down"), (800, 32, 16, "inverse")])
+                                               (2000, 23, 16, "subm"), (1200, 48, 24, "down"), (800, 32, 16, "inverse"),
+                                               (900, 192, 144, "subm"), (700, 256, 64, "down")])   # wider than the kernels' 128-channel tiles
 def test_sparse_conv_backward_kernels_vs_pair_list_definition(n, Cin, Cout, kind):
     """indice_conv_backward (spconv_ops.h:352-420) on the kernels (dbev_spconv_backward_data / _weight): input and weight gradients
     against the fp64 definition summed over the oracle's pair lists (oracle/spconv.py rulebook_pairs), 1e-5 of scale; bit-identical
-    when repeated (no float atomics); regular, submanifold and inverse layers, channel counts that need padding."""
+    when repeated (no float atomics); regular, submanifold and inverse layers, channel counts that need padding, and layers wider
+    than 128 channels (run per 128-channel slice pair, ADVICE r3: they used to assert)."""
     from distill_bev_amd import spconv
     from oracle import spconv as OS
     dev = torch.device("cuda:0")
