@@ -102,6 +102,12 @@ _SIGNATURES = {
     "dbev_spconv_backward_weight": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p],
     "dbev_conv1x1_stats_rows": [_ll, _i, _i],
     "dbev_conv1x1_forward": [_p, _p, _p, _p, _ll, _i, _i, _i, _p],
+    "dbev_wino_filter_floats": [_i, _i],
+    "dbev_wino_filter_pack": [_p, _ll, _ll, _ll, _ll, _i, _i, _i, _p, _p],
+    "dbev_wino_conv3x3_stats_rows": [_i, _i, _i, _i, _i],
+    "dbev_wino_conv3x3_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dbev_wino_conv3x3_backward_weight_workspace_bytes": [_i, _i, _i, _i, _i],
+    "dbev_wino_conv3x3_backward_weight": [_p, _p, _p, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _p, _sz, _p],
     "dbev_range_voxel_coords": [_p, _i, _i, _p, _p, _i, _p, _p],
     "dbev_virtual_voxel_reduce": [_p, _p, _p, _p, _i, _p],
     "dbev_msda_backward_workspace_bytes": [_i, _i, _i, _i, _i, _i],
@@ -128,6 +134,8 @@ _SIGNATURES = {
     "dbev_bn_dual_backward2": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
+             "dbev_wino_filter_floats": ctypes.c_longlong,
+             "dbev_wino_conv3x3_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_fallback_count": ctypes.c_longlong,
              "dbev_kernel_name": ctypes.c_char_p,
              "dbev_msda_backward_workspace_bytes": ctypes.c_size_t,
@@ -149,7 +157,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
-_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows"}
+_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows", "dbev_wino_conv3x3_stats_rows"}
 
 
 class DbevHipError(RuntimeError):

@@ -1,0 +1,568 @@
+// 3x3 / stride 1 / pad 1 convolutions of the dense stack (the 3x3 layer of every ResNet bottleneck, the BasicBlocks of the depth net /
+// BEV encoder, FPN_LSS, the CenterHead branch stacks, SECOND: mmdet3d/models/bricks/res_block.py:11-230, necks/lss_fpn.py:30-60,
+// dense_heads/centerpoint_head.py:17-130, backbones/second.py:60-78 -- ~60 % of the step's convolution FLOPs) as Winograd F(2x2, 3x3)
+// on the fp32 matrix cores:
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        d = 4x4 input tile (stride 2), g = 3x3 filter, Y = 2x2 output tile
+//
+// 16 multiplications per 4 outputs and channel pair instead of 36: the direct algorithm's MFMA work divided by 2.25, at fp32
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains; the transforms are additions and multiplications by 1/2).  Per Winograd position
+// p = (i, j) the channel contraction is an ordinary GEMM  M_p[tile, co] = sum_c V_p[tile, c] * U_p[c, co].
+//
+// Mapping.  A workgroup (4 waves, ONE wave per SIMD) owns BH x BW = 64 tiles of one image x 64 output channels; wave (mi, ni) owns
+// the 32 tiles x 32 channels sub-block for ALL 16 positions: 16 accumulator tiles of 32x32 = 256 registers per lane.  That choice
+// makes both transforms register-local: the lane that feeds tile t into the MFMA A operand reads t's 4x4 input pixels from the LDS
+// patch and transforms them itself (no transformed-input tensor anywhere), and since the C layout of the 16 accumulators is the same
+// lane/register for the same (tile, channel), the output transform is 24 in-register adds per tile -- no exchange, and the BatchNorm
+// statistics of the output (sum y, sum y^2 per channel, `partial` rows in bn_finalize's layout) are in-register adds as in conv1x1.hip.
+// Operands: the input patch ((2 BH + 2) x (2 BW + 2) pixels, zero padded) is staged 16 channels at a time, double-buffered; the
+// transformed filters U are PRE-PACKED by wino_filter_pack in exactly the order the lanes consume them ([co block][k group of 8]
+// [position][ni][lane][4 steps]), so a k group's 32 KB is one contiguous run that goes global -> LDS by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, which the 256 accumulators leave no room for) and the B operand of 4 MFMA steps is ONE conflict-free
+// ds_read_b128.  The reduction index is consumed in the permuted order of conv1x1.hip (step 4j+e takes k = 8j + 4*half + e).
+// Per k group a wave issues 64 MFMAs (4096 cycles) against 16 + 16 LDS reads, ~130 VALU and one barrier.
+// The data gradient of such a layer is the same kernel on dy with the filters rotated and transposed (mode 1 of the pack kernel).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int WN_KP = 16;                       // channels per patch stage (two k groups of 8)
+constexpr int WN_PSTR = 20;                     // floats per patch pixel in LDS (16 + 4: keeps the b128 accesses aligned)
+constexpr int WN_UCHUNK = 16 * 2 * 64 * 4;      // floats of one (channel block, k group) of packed filters = 32 KB
+
+// ---- filter transform + packing -------------------------------------------------------------------------------------------------
+// weight element (co, c, a, b) at co*so + c*sc + a*sa + b*sb (any strides: OIHW or channels-last).
+// mode 0 (forward):        reduction index k = c,  output index j = co, taps g[a][b] = w[co][c][a][b]
+// mode 1 (data gradient):  k = co, j = c, taps g[a][b] = w[co][c][2-a][2-b]
+// U[((jb * (K/8) + kg) * 16 + p) * 2 + ni][lane][e] = (G g G^T)[p] for k = 8 kg + 4 (lane >> 5) + e, j = 64 jb + 32 ni + (lane & 31)
+__global__ __launch_bounds__(256) void wino_filter_pack(const float* __restrict__ w, long long so, long long sc, long long sa,
+                                                        long long sb, int K, int J, int mode, float* __restrict__ U) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const int nkg = K / 8;
+  const long long total = static_cast<long long>(J / 64) * nkg * 512;
+  if (idx >= total) return;
+  const int e = idx & 3, lane = (idx >> 2) & 63, ni = (idx >> 8) & 1;
+  const long long rest = idx >> 9;
+  const int kg = static_cast<int>(rest % nkg), jb = static_cast<int>(rest / nkg);
+  const int k = 8 * kg + 4 * (lane >> 5) + e, j = 64 * jb + 32 * ni + (lane & 31);
+  const int co = mode ? k : j, c = mode ? j : k;
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int aa = mode ? 2 - a : a, bb = mode ? 2 - b : b;
+      g[a][b] = w[co * so + c * sc + aa * sa + bb * sb];
+    }
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * ((g[0][b] + g[2][b]) + g[1][b]);
+    t[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
+    t[3][b] = g[2][b];
+  }
+  float* out = U + ((static_cast<long long>(jb) * nkg + kg) * 16) * 512 + ni * 256 + lane * 4 + e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u0 = t[i][0], u1 = 0.5f * ((t[i][0] + t[i][2]) + t[i][1]), u2 = 0.5f * ((t[i][0] + t[i][2]) - t[i][1]), u3 = t[i][2];
+    out[(4 * i + 0) * 512] = u0;
+    out[(4 * i + 1) * 512] = u1;
+    out[(4 * i + 2) * 512] = u2;
+    out[(4 * i + 3) * 512] = u3;
+  }
+}
+
+__device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ---- the convolution ------------------------------------------------------------------------------------------------------------
+// X [N, H, W, C] channels-last, U packed by wino_filter_pack (K = C, J = Co), Y [N, H, W, Co]; H, W even, C % 16 == 0, Co % 64 == 0.
+// partial (STATS): f32[ntb, 2, Co] per tile block (sum y, sum y^2) per channel.
+template <int BH, int BW, bool STATS>
+__global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, const float* __restrict__ U, const float* __restrict__ bias,
+                                                   float* __restrict__ Y, float* __restrict__ partial, int N, int H, int W, int C,
+                                                   int Co, int ntb, int dbg) {
+  constexpr int PW = 2 * BW + 2, PH = 2 * BH + 2, NPIX = PW * PH, NLD = (NPIX * 4 + 255) / 256;
+  constexpr int PBUF = NPIX * WN_PSTR;
+  __shared__ __attribute__((aligned(16))) float smem[2 * PBUF + 2 * WN_UCHUNK];
+  float* sP = smem;
+  float* sU = smem + 2 * PBUF;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mi = w & 1, ni = w >> 1, half = lane >> 5, l31 = lane & 31;
+  const int ncb = Co / 64;
+  const int L = xcd_block();
+  const int cb = L % ncb, tb = L / ncb;
+  if (tb >= ntb) return;
+  const int TH = H >> 1, TW = W >> 1;
+  const int NBW = (TW + BW - 1) / BW, NBH = (TH + BH - 1) / BH;
+  const int bw = tb % NBW, bh = (tb / NBW) % NBH, n = tb / (NBW * NBH);
+  const int th0 = bh * BH, tw0 = bw * BW;
+  const int nkg = C / 8;
+
+  // patch loader: float4 f of the stage = pixel f >> 2, channels 4 (f & 3) ... +3; global offsets fixed for the whole K loop
+  int goff[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int f = tid + 256 * i, pix = f >> 2, q = f & 3;
+    const int pr = pix / PW, pc = pix - pr * PW;
+    const int h = 2 * th0 - 1 + pr, x = 2 * tw0 - 1 + pc;
+    const bool ok = pix < NPIX && h >= 0 && h < H && x >= 0 && x < W;
+    goff[i] = ok ? ((n * H + h) * W + x) * C + 4 * q : -1;
+  }
+  // out-of-image pixels load element 0 (valid memory) and are zeroed on the way into LDS: unconditional loads, no exec-mask branches
+  float4 rp[NLD];
+#define WN_LOAD_PATCH(stage_)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < NLD; ++i)                                                                    \
+    rp[i] = *reinterpret_cast<const float4*>(X + (goff[i] >= 0 ? goff[i] + (stage_) * WN_KP : 0))
+#define WN_STORE_PATCH(buf_)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                                  \
+    const int f = tid + 256 * i;                                                                                     \
+    if (f < NPIX * 4)                                                                                                \
+      *reinterpret_cast<float4*>(sP + (buf_) * PBUF + (f >> 2) * WN_PSTR + 4 * (f & 3)) =                            \
+          goff[i] >= 0 ? rp[i] : make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+  }
+  // packed filters of k group kg_ -> sU[buf_]: 32 pieces of 1 KB, 8 per wave, by LDS-DMA (destination = wave-uniform base + 16 lane)
+  const float* Ucb = U + static_cast<size_t>(cb) * nkg * WN_UCHUNK;
+  // (inline asm: beside a compiler-visible LDS-DMA hipcc drains vmcnt(0) before the next ds_read of ANY address of the array -- the
+  // whole load latency exposed once per k group; the asm form is waited for by hand, once, before the barrier that publishes it)
+#define WN_LOAD_U(kg_, buf_)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
+    const int piece = 8 * w + i;                                                                                     \
+    const float* src_ = Ucb + static_cast<size_t>(kg_) * WN_UCHUNK + piece * 256 + lane * 4;                          \
+    const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + static_cast<unsigned>(((buf_) * WN_UCHUNK + piece * 256) * 4)); \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                                  \
+  }
+#define WN_WAIT_U() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((lds_ptr_t)sU));
+
+  // this lane's A-operand tile: t = 32 mi + l31 -> (tr, tc); top-left patch pixel (2 tr, 2 tc)
+  const int t_a = 32 * mi + l31, tr_a = t_a / BW, tc_a = t_a - tr_a * BW;
+  const int abase = ((2 * tr_a) * PW + 2 * tc_a) * WN_PSTR + 4 * half;
+
+  floatx16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+  WN_LOAD_PATCH(0);
+  WN_LOAD_U(0, 0);
+  WN_STORE_PATCH(0);
+  WN_WAIT_U();
+  __syncthreads();
+
+  // Software pipeline: the transformed input of k group kg + 1 is built WHILE the MFMAs of k group kg run, INTO the registers the
+  // current group has finished with: positions are consumed row by row (p = 4 i + j), so row i of the next group's V can overwrite
+  // V[4 i .. 4 i + 3] once position 4 i + 3 has issued.  The 16 LDS reads go out under positions 0..3, row i's 32 additions under
+  // position 4 i + 4 (row 3's under position 13 into a spare row that is moved in after the last MFMA); every piece is pinned
+  // between two positions' MFMAs (sched_barrier) and the B operand of position p + 1 is read before position p's MFMAs.  A wave is
+  // alone on its SIMD: whatever is not issued under an MFMA's 64 cycles is exposed.
+  float4 V[16], V3n[4], d[4][4];
+#define WN_DROW(ptr_, a_)                                                                                            \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b) d[a_][b] = *reinterpret_cast<const float4*>((ptr_) + ((a_) * PW + b) * WN_PSTR)
+  // row i of V = (row i of B^T d) B; rows of B^T d: d0 - d2, d1 + d2, d2 - d1, d1 - d3
+#define WN_VROW(DST, o_, OPA, ra_, rb_)                                                                              \
+  do {                                                                                                               \
+    const float4 t0 = OPA(d[ra_][0], d[rb_][0]), t1 = OPA(d[ra_][1], d[rb_][1]);                                      \
+    const float4 t2 = OPA(d[ra_][2], d[rb_][2]), t3 = OPA(d[ra_][3], d[rb_][3]);                                      \
+    DST[(o_) + 0] = f4sub(t0, t2);                                                                                   \
+    DST[(o_) + 1] = f4add(t1, t2);                                                                                   \
+    DST[(o_) + 2] = f4sub(t2, t1);                                                                                   \
+    DST[(o_) + 3] = f4sub(t1, t3);                                                                                   \
+  } while (0)
+  {
+    const float* ap = sP + abase;                                // k group 0: stage buffer 0, jj = 0
+#pragma unroll
+    for (int a = 0; a < 4; ++a) WN_DROW(ap, a);
+    WN_VROW(V, 0, f4sub, 0, 2);
+    WN_VROW(V, 4, f4add, 1, 2);
+    WN_VROW(V, 8, f4sub, 2, 1);
+    WN_VROW(V, 12, f4sub, 1, 3);
+  }
+
+  for (int kg = 0; kg < ((dbg & 2) ? 1 : nkg); ++kg) {
+    const int ub = kg & 1, pb = (kg >> 1) & 1, jj = kg & 1;
+    const bool more_u = kg + 1 < nkg;
+    const bool more_p = jj == 0 && kg + 2 < nkg;                 // first k group of a stage: fetch the next stage
+    // next k group's patch values: same stage (jj 0 -> 1) or the next stage's buffer (complete since the previous barrier)
+    const float* apn = sP + (((kg + 1) >> 1) & 1) * PBUF + abase + 8 * ((kg + 1) & 1);
+    const float4* bp = reinterpret_cast<const float4*>(sU + ub * WN_UCHUNK) + ni * 64 + lane;
+    float4 bv = bp[0];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      float4 bn = bv;
+      if (p < 15) bn = bp[(p + 1) * 128];
+      if (p == 1) {          // the next chunks' loads go out under position 0's MFMAs (not ahead of them: ~60 issue slots)
+        if (more_p) { WN_LOAD_PATCH((kg >> 1) + 1); }      // ahead of the LDS-DMA: hipcc guards the staging registers with a vmcnt(0)
+        if (more_u) { WN_LOAD_U(kg + 1, ub ^ 1); }
+      }
+      if (more_u) {
+        if (p == 0) WN_DROW(apn, 0);
+        if (p == 1) WN_DROW(apn, 2);
+        if (p == 2) WN_DROW(apn, 1);
+        if (p == 3) WN_DROW(apn, 3);
+        if (p == 4) WN_VROW(V, 0, f4sub, 0, 2);
+        if (p == 8) WN_VROW(V, 4, f4add, 1, 2);
+        if (p == 12) WN_VROW(V, 8, f4sub, 2, 1);
+        if (p == 13) WN_VROW(V3n, 0, f4sub, 1, 3);
+      }
+      const float4 av = V[p];
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[p], 0, 0, 0);
+      bv = bn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more_u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) V[12 + j] = V3n[j];
+    }
+    if (more_p) { WN_STORE_PATCH(pb ^ 1); }
+    WN_WAIT_U();
+    __syncthreads();
+  }
+#undef WN_DROW
+#undef WN_VROW
+#undef WN_LOAD_PATCH
+#undef WN_STORE_PATCH
+#undef WN_LOAD_U
+#undef WN_WAIT_U
+
+  // output transform + store: register r of every accumulator = tile ti = (r & 3) + 8 (r >> 2) + 4 half of this wave's 32, channel l31
+  const int co = 64 * cb + 32 * ni + l31;
+  const float bco = bias != nullptr ? bias[co] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int tr = t / BW, tc = t - tr * BW;
+    const int th = th0 + tr, tw = tw0 + tc;
+    float s0[4], s1r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s0[j] = (acc[0 + j][r] + acc[4 + j][r]) + acc[8 + j][r];
+      s1r[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
+    }
+    const float y00 = (s0[0] + s0[1]) + s0[2] + bco, y01 = (s0[1] - s0[2]) - s0[3] + bco;
+    const float y10 = (s1r[0] + s1r[1]) + s1r[2] + bco, y11 = (s1r[1] - s1r[2]) - s1r[3] + bco;
+    if (th < TH && tw < TW && !(dbg & 1)) {
+      float* yp = Y + (static_cast<size_t>(n * H + 2 * th) * W + 2 * tw) * Co + co;
+      yp[0] = y00;
+      yp[Co] = y01;
+      yp[static_cast<size_t>(W) * Co] = y10;
+      yp[static_cast<size_t>(W) * Co + Co] = y11;
+      if (STATS) {
+        s1 += (y00 + y01) + (y10 + y11);
+        s2 = fmaf(y00, y00, s2); s2 = fmaf(y01, y01, s2); s2 = fmaf(y10, y10, s2); s2 = fmaf(y11, y11, s2);
+      }
+    }
+  }
+  if (STATS) {
+    float* red = smem;                                           // [2 which][2 mi][64 channels of the block]
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    __syncthreads();
+    if (half == 0) {
+      red[(0 * 2 + mi) * 64 + 32 * ni + l31] = s1;
+      red[(1 * 2 + mi) * 64 + 32 * ni + l31] = s2;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      partial[(static_cast<size_t>(tb) * 2 + which) * Co + 64 * cb + c] = red[(which * 2 + 0) * 64 + c] + red[(which * 2 + 1) * 64 + c];
+    }
+  }
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------------
+// dU_p[c, co] = sum over tiles of V_p[tile, c] * Z_p[tile, co],  V = B^T d B (the forward's input transform), Z = A dY A^T (2x2 output
+// gradient tile -> 4x4), then grad g = G^T dU G per (c, co): the adjoint of the forward in the filter, 16 multiplications per tile and
+// channel pair instead of 36.  Per position a GEMM with the TILES as the reduction index: MFMA rows = input channels, columns = output
+// channels, one step = two tiles (lanes 0-31 / 32-63).  A workgroup (4 waves, one per SIMD) owns 64 x 64 channels for all 16 positions
+// (256 accumulators per lane, as in the forward) and a contiguous share of the image tiles, staged 2 x 8 tiles at a time (6 x 18 input
+// pixels + 4 x 16 gradient pixels x 64 channels, double-buffered); both transforms are per-lane register arithmetic on plain
+// ds_read_b32 rows (32 consecutive channels per half wave: conflict-free).  The per-share partial dU go to a workspace
+// [share][position][co][c] and wino_wgrad_reduce adds them in share order (no atomics: bit-reproducible) and applies G^T . G.
+constexpr int WG_SBH = 2, WG_SBW = 8;                                   // tiles per stage
+constexpr int WG_PW = 2 * WG_SBW + 2, WG_PH = 2 * WG_SBH + 2;          // 18 x 6 input pixels
+constexpr int WG_NPX = WG_PW * WG_PH;                                   // 108
+constexpr int WG_NDY = (2 * WG_SBH) * (2 * WG_SBW);                     // 64 gradient pixels
+constexpr int WG_STAGE = (WG_NPX + WG_NDY) * 64;                        // floats per stage buffer
+
+__global__ __launch_bounds__(256, 1) void wino_wgrad(const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part,
+                                                     int N, int H, int W, int C, int Co, int nsb, int per, int nblk, int nsplit) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * WG_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ci = w & 1, coi = w >> 1, half = lane >> 5, l31 = lane & 31;
+  const int L = xcd_block();
+  const int blk = L % nblk, split = L / nblk;
+  if (split >= nsplit) return;
+  const int ncb = C / 64;
+  const int c0 = (blk % ncb) * 64, o0 = (blk / ncb) * 64;
+  const int TH = H >> 1, TW = W >> 1;
+  const int NSW = (TW + WG_SBW - 1) / WG_SBW, NSH = (TH + WG_SBH - 1) / WG_SBH;
+  const int sb_begin = split * per, sb_end = min(nsb, sb_begin + per);
+
+  constexpr int NLX = (WG_NPX * 16 + 255) / 256, NLY = WG_NDY * 16 / 256;      // float4 per thread per stage: 7 + 4
+  float4 rx[NLX], ry[NLY];
+#define WG_LOAD(sb_)                                                                                                 \
+  do {                                                                                                               \
+    const int sbw_ = (sb_) % NSW, sbh_ = ((sb_) / NSW) % NSH, n_ = (sb_) / (NSW * NSH);                              \
+    const int h0_ = 2 * WG_SBH * sbh_, w0_ = 2 * WG_SBW * sbw_;                                                      \
+    _Pragma("unroll") for (int i = 0; i < NLX; ++i) {                                                                \
+      const int f = tid + 256 * i, pix = f >> 4, q = f & 15;                                                         \
+      const int pr = pix / WG_PW, pc = pix - pr * WG_PW;                                                             \
+      const int h = h0_ - 1 + pr, x = w0_ - 1 + pc;                                                                  \
+      const bool ok = pix < WG_NPX && h >= 0 && h < H && x >= 0 && x < W;                                            \
+      rx[i] = ok ? *reinterpret_cast<const float4*>(X + (static_cast<size_t>(n_ * H + h) * W + x) * C + c0 + 4 * q)  \
+                 : make_float4(0.f, 0.f, 0.f, 0.f);                                                                  \
+    }                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NLY; ++i) {                                                                \
+      const int f = tid + 256 * i, pix = f >> 4, q = f & 15;                                                         \
+      const int h = h0_ + pix / (2 * WG_SBW), x = w0_ + pix % (2 * WG_SBW);                                          \
+      ry[i] = (h < H && x < W) ? *reinterpret_cast<const float4*>(DY + (static_cast<size_t>(n_ * H + h) * W + x) * Co + o0 + 4 * q) \
+                               : make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+    }                                                                                                                \
+  } while (0)
+#define WG_STORE(buf_)                                                                                               \
+  do {                                                                                                               \
+    float* sx_ = smem + (buf_) * WG_STAGE;                                                                           \
+    float* sy_ = sx_ + WG_NPX * 64;                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NLX; ++i) {                                                                \
+      const int f = tid + 256 * i;                                                                                   \
+      if (f < WG_NPX * 16) *reinterpret_cast<float4*>(sx_ + 4 * f) = rx[i];                                          \
+    }                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NLY; ++i) *reinterpret_cast<float4*>(sy_ + 4 * (tid + 256 * i)) = ry[i];   \
+  } while (0)
+
+  floatx16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+  // operands of one MFMA step (tiles 2 s + half of the stage): 16 input pixels, 4 gradient pixels, this lane's channel
+  float d[4][4], g[2][2], V[16], Z[16], Vn[16], Zn[16];
+#define WG_READ(sx_, sy_, s_)                                                                                        \
+  do {                                                                                                               \
+    const int t_ = 2 * (s_) + half, tr_ = t_ / WG_SBW, tc_ = t_ % WG_SBW;                                            \
+    const float* px_ = (sx_) + ((2 * tr_) * WG_PW + 2 * tc_) * 64 + 32 * ci + l31;                                   \
+    const float* py_ = (sy_) + ((2 * tr_) * (2 * WG_SBW) + 2 * tc_) * 64 + 32 * coi + l31;                           \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                    \
+      _Pragma("unroll") for (int b = 0; b < 4; ++b) d[a][b] = px_[(a * WG_PW + b) * 64];                             \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                    \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) g[a][b] = py_[(a * (2 * WG_SBW) + b) * 64];                      \
+  } while (0)
+#define WG_VROWS(DST, i0_, i1_)                                                                                      \
+  _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i) {                                                            \
+    float t[4];                                                                                                      \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                                    \
+      t[b] = i == 0 ? d[0][b] - d[2][b] : i == 1 ? d[1][b] + d[2][b] : i == 2 ? d[2][b] - d[1][b] : d[1][b] - d[3][b]; \
+    DST[4 * i + 0] = t[0] - t[2]; DST[4 * i + 1] = t[1] + t[2]; DST[4 * i + 2] = t[2] - t[1]; DST[4 * i + 3] = t[1] - t[3]; \
+  }
+  // Z = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+#define WG_Z(DST)                                                                                                    \
+  do {                                                                                                               \
+    const float w_[4][2] = {{g[0][0], g[0][1]}, {g[0][0] + g[1][0], g[0][1] + g[1][1]},                              \
+                            {g[0][0] - g[1][0], g[0][1] - g[1][1]}, {-g[1][0], -g[1][1]}};                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+      DST[4 * i + 0] = w_[i][0]; DST[4 * i + 1] = w_[i][0] + w_[i][1]; DST[4 * i + 2] = w_[i][0] - w_[i][1]; DST[4 * i + 3] = -w_[i][1]; \
+    }                                                                                                                \
+  } while (0)
+
+  if (sb_begin < sb_end) {
+    WG_LOAD(sb_begin);
+    WG_STORE(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int sb = sb_begin; sb < sb_end; ++sb) {
+    const bool more = sb + 1 < sb_end;
+    if (more) WG_LOAD(sb + 1);
+    const float* sx = smem + buf * WG_STAGE;
+    const float* sy = sx + WG_NPX * 64;
+    WG_READ(sx, sy, 0);
+    WG_VROWS(V, 0, 4);
+    WG_Z(Z);
+#pragma unroll
+    for (int s = 0; s < WG_SBH * WG_SBW / 2; ++s) {
+      const bool nxt = s + 1 < WG_SBH * WG_SBW / 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                       // the next step's operands are read / transformed under this step's MFMAs
+        if (nxt) {
+          if (q == 0) WG_READ(sx, sy, s + 1);
+          if (q == 1) WG_VROWS(Vn, 0, 2);
+          if (q == 2) WG_VROWS(Vn, 2, 4);
+          if (q == 3) WG_Z(Zn);
+        }
+#pragma unroll
+        for (int p = 4 * q; p < 4 * q + 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p], Z[p], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nxt) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) { V[p] = Vn[p]; Z[p] = Zn[p]; }
+      }
+    }
+    if (more) WG_STORE(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#undef WG_LOAD
+#undef WG_STORE
+#undef WG_READ
+#undef WG_VROWS
+#undef WG_Z
+  // accumulator register 4 q + r of position p = input channel c0 + 32 ci + 8 q + 4 half + r, output channel o0 + 32 coi + l31
+  float* out = part + (static_cast<size_t>(split) * 16 * Co + o0 + 32 * coi + l31) * C + c0 + 32 * ci + 4 * half;
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(out + static_cast<size_t>(p) * Co * C + 8 * q) =
+          make_float4(acc[p][4 * q + 0], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]);
+}
+
+// part [nsplit][16][Co][C] -> grad_w (co, c, a, b) at co*so + c*sc + a*sa + b*sb:  G^T (sum over shares) G
+__global__ __launch_bounds__(256) void wino_wgrad_reduce(const float* __restrict__ part, int nsplit, int C, int Co, float* __restrict__ gw,
+                                                         long long so, long long sc, long long sa, long long sb) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= static_cast<long long>(C) * Co) return;
+  const int c = static_cast<int>(idx % C), co = static_cast<int>(idx / C);
+  float u[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) u[p] = 0.f;
+  const size_t plane = static_cast<size_t>(Co) * C;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* ps = part + static_cast<size_t>(s) * 16 * plane + static_cast<size_t>(co) * C + c;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) u[p] += ps[p * plane];
+  }
+  float t[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float hs = 0.5f * (u[4 + j] + u[8 + j]), hd = 0.5f * (u[4 + j] - u[8 + j]);
+    t[0][j] = u[j] + hs;
+    t[1][j] = hd;
+    t[2][j] = hs + u[12 + j];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float hs = 0.5f * (t[a][1] + t[a][2]), hd = 0.5f * (t[a][1] - t[a][2]);
+    float* o = gw + co * so + c * sc + a * sa;
+    o[0] = t[a][0] + hs;
+    o[sb] = hd;
+    o[2 * sb] = hs + t[a][3];
+  }
+}
+
+struct WinoWgPlan { int nsb, nblk, nsplit, per, grid; };
+
+bool wino_wg_plan(int N, int H, int W, int C, int Co, WinoWgPlan* p) {
+  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 64) || Co <= 0 || (Co % 64)) return false;
+  if (static_cast<long long>(N) * H * W * (C > Co ? C : Co) >= 0x7fffffffLL) return false;
+  const int TH = H / 2, TW = W / 2;
+  const long long nsb = static_cast<long long>(N) * ((TH + WG_SBH - 1) / WG_SBH) * ((TW + WG_SBW - 1) / WG_SBW);
+  if (nsb > 0x3fffffffLL) return false;
+  p->nsb = static_cast<int>(nsb);
+  p->nblk = (C / 64) * (Co / 64);
+  // shares of the tile range: ~2 workgroups per CU in flight over the launch (one resident per CU), never more shares than stages
+  long long ns = (2LL * DBEV_NUM_CU + p->nblk - 1) / p->nblk;
+  if (ns > nsb) ns = nsb;
+  if (ns < 1) ns = 1;
+  p->per = static_cast<int>((nsb + ns - 1) / ns);
+  p->nsplit = static_cast<int>((nsb + p->per - 1) / p->per);
+  p->grid = dbev_round_xcd(p->nblk * p->nsplit);
+  return true;
+}
+
+int wino_dbg() { static const int v = getenv("DBEV_WINO_DBG") ? atoi(getenv("DBEV_WINO_DBG")) : 0; return v; }
+
+struct WinoPlan { int bh, bw, ntb, ncb, grid; };
+
+bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
+  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % WN_KP) || Co <= 0 || (Co % 64)) return false;
+  if (static_cast<long long>(N) * H * W * (C > Co ? C : Co) >= 0x7fffffffLL) return false;      // 32-bit element offsets
+  const int TH = H / 2, TW = W / 2;
+  // tile block shape: the one that wastes fewer tile slots at the image edges
+  const long long w88 = static_cast<long long>((TH + 7) / 8) * ((TW + 7) / 8), w416 = static_cast<long long>((TH + 3) / 4) * ((TW + 15) / 16);
+  if (w416 < w88) { p->bh = 4; p->bw = 16; p->ntb = static_cast<int>(w416) * N; }
+  else { p->bh = 8; p->bw = 8; p->ntb = static_cast<int>(w88) * N; }
+  p->ncb = Co / 64;
+  const long long g = static_cast<long long>(p->ntb) * p->ncb;
+  if (g > 0x3fffffffLL) return false;
+  p->grid = dbev_round_xcd(static_cast<int>(g));
+  return true;
+}
+
+}  // namespace
+
+extern "C" long long dbev_wino_filter_floats(int K, int J) {
+  if (K <= 0 || J <= 0 || (K % 8) || (J % 64)) return 0;
+  return static_cast<long long>(J / 64) * (K / 8) * WN_UCHUNK;
+}
+
+extern "C" int dbev_wino_filter_pack(const float* weight, long long so, long long sc, long long sa, long long sb, int Cout, int Cin,
+                                     int data_gradient, float* packed, dbevStream_t stream) {
+  const int K = data_gradient ? Cout : Cin, J = data_gradient ? Cin : Cout;
+  const long long n = dbev_wino_filter_floats(K, J);
+  if (n == 0 || weight == nullptr || packed == nullptr) return DBEV_EINVAL;
+  const long long threads = n / 16;
+  hipLaunchKernelGGL(wino_filter_pack, dim3(dbev_ceil_div(threads, 256)), dim3(256), 0, dbev_stream(stream), weight, so, sc, sa, sb, K,
+                     J, data_gradient ? 1 : 0, packed);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_wino_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout) {
+  WinoPlan p;
+  return wino_plan(N, H, W, Cin, Cout, &p) ? p.ntb : 0;
+}
+
+extern "C" int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc,
+                                         float* stats_partial, int N, int H, int W, int Cin, int Cout, dbevStream_t stream) {
+  WinoPlan p;
+  if (!wino_plan(N, H, W, Cin, Cout, &p) || x_nhwc == nullptr || packed == nullptr || y_nhwc == nullptr) return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+#define WN_GO(BHV, BWV, ST)                                                                                                       \
+  hipLaunchKernelGGL((wino_fwd<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
+                     Cin, Cout, p.ntb, wino_dbg())
+  if (p.bw == 8) { if (stats_partial != nullptr) WN_GO(8, 8, true); else WN_GO(8, 8, false); }
+  else { if (stats_partial != nullptr) WN_GO(4, 16, true); else WN_GO(4, 16, false); }
+#undef WN_GO
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t dbev_wino_conv3x3_backward_weight_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  WinoWgPlan p;
+  if (!wino_wg_plan(N, H, W, Cin, Cout, &p)) return 0;
+  return static_cast<size_t>(p.nsplit) * 16 * Cin * Cout * sizeof(float);
+}
+
+extern "C" int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const float* grad_y_nhwc, float* grad_weight, long long so,
+                                                 long long sc, long long sa, long long sb, int N, int H, int W, int Cin, int Cout,
+                                                 void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  WinoWgPlan p;
+  if (!wino_wg_plan(N, H, W, Cin, Cout, &p) || x_nhwc == nullptr || grad_y_nhwc == nullptr || grad_weight == nullptr ||
+      workspace == nullptr || workspace_bytes < static_cast<size_t>(p.nsplit) * 16 * Cin * Cout * sizeof(float))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(wino_wgrad, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
+                     p.nsplit);
+  DBEV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wino_wgrad_reduce, dim3(dbev_ceil_div(static_cast<long long>(Cin) * Cout, 256)), dim3(256), 0, s, part, p.nsplit,
+                     Cin, Cout, grad_weight, so, sc, sa, sb);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}

@@ -22,8 +22,16 @@ import torch.utils.checkpoint as cp
 
 from .bn_act import bn_act, bn_act_dual, conv1x1_bn_ready, conv1x1_stats, forked, split_downsample
 from .pool import max_pool
+from .wino import conv3x3_bn_ready, conv3x3_stats
 from .registry import (MODELS, ConvModule, build_activation_layer, build_conv_layer, build_norm_layer,
                        build_upsample_layer, register_conv)
+
+
+def _conv_stats(conv, bn, x):
+    """(conv(x), partial statistics rows or None): the Winograd 3x3 kernel's epilogue takes the following norm's batch statistics"""
+    if conv3x3_bn_ready(conv, bn, x):
+        return conv3x3_stats(x, conv.weight, None)
+    return conv(x), None
 
 
 # --------------------------------------------------------------------------------------
@@ -60,12 +68,16 @@ class BasicBlock(nn.Module):
         # x feeds the first convolution, its second handle (the previous block's forked output, bn_act.forked) the identity branch:
         # the two gradients reach that block's fused norm backward as two addends instead of being summed by a pass of their own
         xi = forked(x)
-        out = bn_act(self.conv1(x), getattr(self, self.norm1_name), None, True)
+        n1, n2 = getattr(self, self.norm1_name), getattr(self, self.norm2_name)
+        # 3x3 convolutions on the Winograd kernels hand the norm its batch statistics (no statistics pass over their output)
+        z1, p1 = _conv_stats(self.conv1, n1, x)
+        out = bn_act(z1, n1, None, True, pre=p1)
+        z2, p2 = _conv_stats(self.conv2, n2, out)
         ds = split_downsample(self.downsample)
         if ds is not None:         # norm of the main path and norm of the identity branch, add and ReLU in one pass
-            return bn_act_dual(self.conv2(out), getattr(self, self.norm2_name), ds[0](xi), ds[1], True, fork=True)
+            return bn_act_dual(z2, n2, ds[0](xi), ds[1], True, pre=p2, fork=True)
         identity = xi if self.downsample is None else self.downsample(xi)
-        return bn_act(self.conv2(out), getattr(self, self.norm2_name), identity, True, fork=True)
+        return bn_act(z2, n2, identity, True, pre=p2, fork=True)
 
     def forward(self, x):
         if self.with_cp and x.requires_grad:
@@ -116,7 +128,9 @@ class Bottleneck(nn.Module):
         # 1x1 convolutions of the large maps: fp32-MFMA GEMM with the norm's batch statistics in its epilogue (no statistics pass)
         z1, p1 = conv1x1_stats(self.conv1, x) if conv1x1_bn_ready(self.conv1, n1, x) else (self.conv1(x), None)
         out = bn_act(z1, n1, None, True, pre=p1)
-        out = bn_act(self.conv2(out), getattr(self, self.norm2_name), None, True)
+        n2 = getattr(self, self.norm2_name)
+        z2, p2 = _conv_stats(self.conv2, n2, out)
+        out = bn_act(z2, n2, None, True, pre=p2)
         z3, p3 = conv1x1_stats(self.conv3, out) if conv1x1_bn_ready(self.conv3, n3, out) else (self.conv3(out), None)
         ds = split_downsample(self.downsample)
         if ds is not None:

@@ -194,7 +194,31 @@ class _PairsView(object):
 
 
 def _conv_forward(features, weight, table, n_out, scale=None, shift=None, residual=None, relu=False):
-    """dbev_spconv_forward_fused on channel counts padded to multiples of 16."""
+    """dbev_spconv_forward_fused on channel counts padded to multiples of 16.  The kernel tiles up to 256 input and 128 output
+    channels (the reference's SparseEncoder stops at 128); wider layers run it per slice: output slices are independent, the
+    input slices of an output slice are summed in slice order and the epilogue (scale / shift / residual / ReLU) is applied to the sum."""
+    K, Cin, Cout = weight.shape
+    if Cin > 256 or Cout > 128:
+        cuts = lambda n, s_: [(a, min(a + s_, n)) for a in range(0, n, s_)]
+        outs = []
+        for o0, o1 in cuts(Cout, 128):
+            acc = None
+            for i0, i1 in cuts(Cin, 256):
+                part = _conv_forward_tile(features[:, i0:i1], weight[:, i0:i1, o0:o1], table, n_out)
+                acc = part if acc is None else acc + part
+            outs.append(acc)
+        out = torch.cat(outs, 1)
+        if scale is not None:
+            out = out * scale
+        if shift is not None:
+            out = out + shift
+        if residual is not None:
+            out = out + residual
+        return torch.relu(out) if relu else out
+    return _conv_forward_tile(features, weight, table, n_out, scale, shift, residual, relu)
+
+
+def _conv_forward_tile(features, weight, table, n_out, scale=None, shift=None, residual=None, relu=False):
     dev = L.require_cuda(features, weight)
     K, Cin, Cout = weight.shape
     f, w = features.float(), weight.float()

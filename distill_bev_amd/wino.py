@@ -1,0 +1,192 @@
+"""3x3 / stride 1 / pad 1 convolutions on the Winograd F(2x2, 3x3) fp32-MFMA kernels (csrc/wino.hip).
+
+Host-side mirror of what the reference reaches through ``nn.Conv2d(k=3, s=1, p=1)`` -> cuDNN in its dense blocks
+(mmdet3d/models/bricks/res_block.py:11-230, necks/lss_fpn.py:30-60, dense_heads/centerpoint_head.py:17-130,
+backbones/second.py:60-78): same parameters, same state-dict keys, same autograd contract -- ``conv3x3(x, weight, bias)`` is
+``F.conv2d(x, weight, bias, 1, 1)`` for channels-last fp32 device tensors with even H, W, Cin % 16 == 0, Cout % 64 == 0.
+Forward and data gradient run the same kernel (the data gradient on grad_y with the rotated / transposed filters); the weight
+gradient runs ``dbev_wino_conv3x3_backward_weight`` when the layer qualifies (Cin % 64 == 0) and the library's kernel otherwise.
+"""
+import os
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib as L
+
+# Workgroups (tile blocks x 64-channel blocks) a layer must offer before the Winograd kernel takes it: one workgroup keeps a CU busy
+# for its whole life (256 accumulators per lane = one wave per SIMD), so a layer with fewer blocks than ~2 rounds of the 256 CUs
+# is quantised badly -- measured (tools/kbench_wino.py, profiles/r04_wino_vs_miopen.txt): 64 / 128 / 384 workgroups run at 0.52 / 1.06 /
+# 0.97 x the library's kernel, >= 512 at 1.4-1.9 x.
+_MIN_WG = int(os.environ.get("DBEV_WINO_MIN_WG", "448"))
+_WGRAD = os.environ.get("DBEV_WINO_WGRAD", "1") != "0"
+
+
+def _nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def eligible(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1):
+    """can `F.conv2d(x, weight, ...)` run on the Winograd kernels?"""
+    if os.environ.get("DBEV_WINO", "1") == "0":
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    if tuple(weight.shape[2:]) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or tuple(dilation) != (1, 1) or groups != 1:
+        return False
+    N, C, H, W = x.shape
+    Co = weight.shape[0]
+    if weight.shape[1] != C or H % 2 or W % 2 or C % 16 or Co % 64 or not _nhwc(x):
+        return False
+    if N * H * W * max(C, Co) >= 2 ** 31 - 1:
+        return False
+    return _blocks(N, H, W) * (Co // 64) >= _MIN_WG
+
+
+def _blocks(N, H, W):
+    """tile blocks of the kernel's plan (wino_plan in csrc/wino.hip): 8 x 8 or 4 x 16 tiles of 2 x 2 outputs, whichever wastes less"""
+    th, tw = H // 2, W // 2
+    return N * min(-(-th // 8) * -(-tw // 8), -(-th // 4) * -(-tw // 16))
+
+
+def pack_filters(weight, data_gradient=False):
+    """G g G^T of every (co, c) filter in the kernels' consumption order (dbev_wino_filter_pack)"""
+    dev = L.require_cuda(weight)
+    Co, C = weight.shape[:2]
+    K, J = (Co, C) if data_gradient else (C, Co)
+    n = int(L.call("dbev_wino_filter_floats", K, J))
+    if n == 0:
+        raise L.DbevHipError(f"wino: unsupported channel counts {C} -> {Co} (data_gradient={data_gradient})")
+    packed = torch.empty((n,), dtype=torch.float32, device=dev)
+    so, sc, sa, sb = weight.stride()
+    with torch.cuda.device(dev):
+        L.call("dbev_wino_filter_pack", L.ptr(weight), so, sc, sa, sb, Co, C, int(bool(data_gradient)), L.ptr(packed), L.stream_ptr(dev))
+    return packed
+
+
+def stats_rows(x_shape, Cout):
+    N, C, H, W = x_shape
+    return int(L.call("dbev_wino_conv3x3_stats_rows", N, H, W, C, Cout))
+
+
+def conv_packed(x, packed, Cout, bias=None, stats=False):
+    """one launch of the convolution kernel: x [N, C, H, W] channels-last, packed filters for C -> Cout.
+    -> y (channels-last) or (y, partial statistics rows f32[rows, 2, Cout]) with stats=True"""
+    dev = L.require_cuda(x, packed, bias)
+    N, C, H, W = x.shape
+    y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    part = torch.empty((stats_rows(x.shape, Cout), 2, Cout), dtype=torch.float32, device=dev) if stats else None
+    with torch.cuda.device(dev):
+        L.call("dbev_wino_conv3x3_forward", L.ptr(x), L.ptr(packed), L.ptr(bias), L.ptr(y), L.ptr(part), N, H, W, C, Cout,
+               L.stream_ptr(dev))
+    return (y, part) if stats else y
+
+
+class _Conv3x3Wino(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stats):
+        Co = weight.shape[0]
+        out = conv_packed(x, pack_filters(weight, False), Co, bias, stats)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        if stats:
+            ctx.mark_non_differentiable(out[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, gy, _gpart=None):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            C = weight.shape[1]
+            if C % 64 == 0:
+                gx = conv_packed(gy, pack_filters(weight, True), C)
+            else:                                          # e.g. a 16- or 32-channel input: the library's data gradient
+                gx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            gw = weight_gradient(x, gy, weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None
+
+
+def weight_gradient(x, gy, weight):
+    """grad of the 3x3 filters: Winograd-domain GEMMs over the tiles (dbev_wino_conv3x3_backward_weight, fixed summation order) when
+    both channel counts are multiples of 64, the library's kernel otherwise; returned with `weight`'s strides"""
+    N, C, H, W = x.shape
+    Co = weight.shape[0]
+    nbytes = int(L.call("dbev_wino_conv3x3_backward_weight_workspace_bytes", N, H, W, C, Co)) if _WGRAD else 0
+    if nbytes == 0 or not (_nhwc(x) and _nhwc(gy)):
+        return torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    dev = x.device
+    gw = torch.empty_like(weight)                       # preserve_format: the parameter's own strides
+    so, sc, sa, sb = gw.stride()
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dbev_wino_conv3x3_backward_weight", L.ptr(x), L.ptr(gy), L.ptr(gw), so, sc, sa, sb, N, H, W, C, Co, L.ptr(ws), nbytes,
+               L.stream_ptr(dev))
+    return gw
+
+
+def conv3x3(x, weight, bias=None):
+    """F.conv2d(x, weight, bias, stride=1, padding=1) for an `eligible` pair, differentiable"""
+    return _Conv3x3Wino.apply(x, weight, bias, False)
+
+
+def conv3x3_stats(x, weight, bias=None):
+    """-> (conv, partial rows of (sum y, sum y^2) per channel) for the fused BatchNorm that follows (bn_act(..., pre=rows))"""
+    return _Conv3x3Wino.apply(x, weight, bias, True)
+
+
+class WinoConv2d(nn.Conv2d):
+    """nn.Conv2d (3x3, stride 1, pad 1) whose forward and data gradient run on the Winograd kernels when the input qualifies
+    (`eligible`); the stock convolution otherwise.  Same parameters and state-dict keys (use_wino_convs re-classes in place).  With
+    gradients disabled (the frozen teacher, the student's detached frame) the packed filters are kept until the weight changes."""
+
+    def forward(self, x):
+        if self.padding_mode == "zeros" and eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+                return conv_packed(x, self._packed(), self.out_channels, self.bias)
+            return conv3x3(x, self.weight, self.bias)
+        return super().forward(x)
+
+    def _packed(self):
+        w = self.weight
+        key = (w._version, w.data_ptr(), str(w.device))
+        hit = self.__dict__.get("_dbev_wino_packed")
+        if hit is None or hit[0] != key:
+            hit = (key, pack_filters(w.detach(), False))
+            self.__dict__["_dbev_wino_packed"] = hit
+        return hit[1]
+
+
+def _wino_geometry(m):
+    return (m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1
+            and m.padding_mode == "zeros" and m.in_channels % 16 == 0 and m.out_channels % 64 == 0)
+
+
+def use_wino_convs(model):
+    """Re-class the nn.Conv2d modules with the Winograd geometry (3x3, s1, p1, Cin % 16 == 0, Cout % 64 == 0); returns how many.
+    Parameters and state-dict keys are untouched.  Idempotent."""
+    if os.environ.get("DBEV_WINO", "1") == "0":
+        return 0
+    n = 0
+    for m in model.modules():
+        if type(m) is nn.Conv2d and _wino_geometry(m):
+            m.__class__ = WinoConv2d
+            n += 1
+    return n
+
+
+def conv3x3_bn_ready(conv, bn, x):
+    """conv -> training-mode BatchNorm2d pairs whose batch statistics the convolution's epilogue can take (bn_act(..., pre=rows))"""
+    from . import bn_act as BA
+    if not (type(conv) is WinoConv2d and BA._state["enabled"] and conv.bias is None and torch.is_grad_enabled()):
+        return False
+    if not (type(bn) in BA._BN_TYPES and bn.affine and bn.training and bn.momentum is not None and bn.running_mean is not None
+            and BA._channels_ok(conv.out_channels)):
+        return False
+    return eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)

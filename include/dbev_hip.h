@@ -717,6 +717,38 @@ int dbev_conv1x1_stats_rows(long long M, int Cin, int Cout);
 int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, float* y_nhwc, float* stats_partial, long long M, int Cin,
                          int Cout, int x_row_stride, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores (csrc/wino.hip).  Replaces the cuDNN /
+ * MIOpen convolution behind `nn.Conv2d(k=3, s=1, p=1)` of the reference's dense blocks -- the 3x3 layer of the ResNet bottlenecks
+ * and BasicBlocks (mmdet3d/models/bricks/res_block.py:11-230, backbones/resnet.py:13-62), FPN_LSS (necks/lss_fpn.py:30-60), the
+ * CenterHead shared / branch convolutions (dense_heads/centerpoint_head.py:17-130), SECOND (backbones/second.py:60-78) -- forward
+ * and data gradient (the same kernel on grad_y with rotated / transposed filters).
+ *   dbev_wino_filter_floats(K, J)   size of the packed transformed filters for K reduction and J output channels (0: unsupported)
+ *   dbev_wino_filter_pack           weight element (co, c, a, b) at co*so + c*sc + a*sa + b*sb (element strides: OIHW or
+ *                                   channels-last) -> packed = G g G^T in the kernel's consumption order; data_gradient != 0 packs the
+ *                                   filters of the data gradient (K = Cout, J = Cin, taps rotated by 180 degrees)
+ *   dbev_wino_conv3x3_forward       x_nhwc f32[N, H, W, Cin] -> y_nhwc f32[N, H, W, Cout] (+ bias f32[Cout] or NULL); H, W even,
+ *                                   Cin % 16 == 0, Cout % 64 == 0, fewer than 2^31 elements per tensor.  stats_partial (may be NULL)
+ *                                   f32[rows, 2, Cout], rows = dbev_wino_conv3x3_stats_rows(...): per tile block the sums of y and
+ *                                   y^2 per channel (bias included), the partial-row layout of dbev_bn_act_train_forward_pre.
+ *   For the data gradient call it with (x = grad_y, Cin <-> Cout swapped, the data_gradient pack).
+ *   dbev_wino_conv3x3_backward_weight   grad_w[co][c][a][b] (element strides as for the pack) = sum over pixels, in the Winograd
+ *                                   domain: G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G; workspace from ..._workspace_bytes, fixed
+ *                                   summation order (no atomics).  Cin % 64 == 0, Cout % 64 == 0.
+ * Numerics: fp32 throughout (v_mfma_f32_32x32x2_f32); the transforms add / subtract and multiply by 1/2: error vs an fp64
+ * convolution 2-4x that of a direct fp32 convolution (tests/test_gpu_wino.py).
+ * ---------------------------------------------------------------------------------- */
+long long dbev_wino_filter_floats(int K, int J);
+int dbev_wino_filter_pack(const float* weight, long long so, long long sc, long long sa, long long sb, int Cout, int Cin,
+                          int data_gradient, float* packed, dbevStream_t stream);
+int dbev_wino_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout);
+int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc, float* stats_partial,
+                              int N, int H, int W, int Cin, int Cout, dbevStream_t stream);
+size_t dbev_wino_conv3x3_backward_weight_workspace_bytes(int N, int H, int W, int Cin, int Cout);   /* 0: unsupported geometry */
+int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const float* grad_y_nhwc, float* grad_weight, long long so, long long sc,
+                                      long long sa, long long sb, int N, int H, int W, int Cin, int Cout, void* workspace,
+                                      size_t workspace_bytes, dbevStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
