@@ -81,18 +81,48 @@ __global__ __launch_bounds__(256) void wino_filter_pack(const float* __restrict_
 __device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// two fp32 additions / subtractions in ONE VALU instruction (hipcc splits a float2 expression into two v_add_f32; every VALU
+// instruction costs matrix time here, see below)
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ floatx2 pk_add(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // ---- the convolution ------------------------------------------------------------------------------------------------------------
-// X [N, H, W, C] channels-last, U packed by wino_filter_pack (K = C, J = Co), Y [N, H, W, Co]; H, W even, C % 16 == 0, Co % 64 == 0.
-// partial (STATS): f32[ntb, 2, Co] per tile block (sum y, sum y^2) per channel.
+// X [N, H, W, C] channels-last, U packed by wino_filter_pack (K = C, J = Co), Y [N, H, W, Co]; H, W even, C % 8 == 0, Co % 64 == 0,
+// H * W * C * 4 < 2^31.  partial (STATS): f32[ntb, 2, Co] per tile block (sum y, sum y^2) per channel.
+//
+// What shapes the main loop (tools/mfma_filler_bench.hip, profiles/r04_mfma_fillers.txt): on gfx950 the fp32 MFMA runs on the SIMD's
+// fp32 lanes -- a VALU instruction issued by the same wave is NOT hidden in the shadow of a v_mfma_f32_32x32x2_f32, it costs ~7 cycles
+// of matrix time (11 % of an MFMA) each, while LDS reads / writes, SALU and LDS-DMA issue are free.  With one wave per SIMD the first
+// version of this kernel (every lane transforming its own tile: 128 packed adds + ~100 address / select instructions per 64 MFMAs) ran
+// the matrix pipe at 61 %.  So:
+//  * the input transform of a k group (64 tiles x 8 channels -> 16 positions) is computed ONCE per workgroup, 1/4 by each wave
+//    (thread = tile x channel pair: 16 ds_read_b64, 32 v_pk_add_f32, 16 ds_write_b64), and handed to all four waves through LDS in the
+//    MFMA A-operand order -- 32 VALU per 64 MFMAs instead of 128, the two waves that share a tile half no longer repeat each other;
+//  * nothing else in the loop is a VALU instruction: the patch stage (8 channels) and the packed filters go global -> LDS by LDS-DMA in
+//    the scalar-base form (SGPR address advanced by SALU, one constant VGPR offset per piece); patch pixels outside the image are
+//    lanes masked out of the DMA whose LDS slots were zeroed once; operands are fetched by ds_read_b128 at immediate offsets.
+// Per k group g (one barrier): MFMAs on V(g), U(g); transform of patch stage g+1 -> V(g+1); DMA of U(g+1) and of patch stage g+2.
 template <int BH, int BW, bool STATS>
 __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, const float* __restrict__ U, const float* __restrict__ bias,
                                                    float* __restrict__ Y, float* __restrict__ partial, int N, int H, int W, int C,
                                                    int Co, int ntb, int dbg) {
-  constexpr int PW = 2 * BW + 2, PH = 2 * BH + 2, NPIX = PW * PH, NLD = (NPIX * 4 + 255) / 256;
-  constexpr int PBUF = NPIX * WN_PSTR;
-  __shared__ __attribute__((aligned(16))) float smem[2 * PBUF + 2 * WN_UCHUNK];
+  constexpr int PW = 2 * BW + 2, PH = 2 * BH + 2, NPIX = PW * PH;
+  constexpr int NPC = (NPIX + 31) / 32;                   // patch DMA pieces (32 pixels x 32 bytes = 1 KB each)
+  constexpr int PBUF = NPC * 256;                         // floats per patch stage buffer
+  constexpr int VBUF = 16 * 64 * 8;                       // floats per transformed-input buffer
+  __shared__ __attribute__((aligned(16))) float smem[2 * PBUF + 2 * VBUF + 2 * WN_UCHUNK];
   float* sP = smem;
-  float* sU = smem + 2 * PBUF;
+  float* sV = smem + 2 * PBUF;
+  float* sU = sV + 2 * VBUF;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mi = w & 1, ni = w >> 1, half = lane >> 5, l31 = lane & 31;
   const int ncb = Co / 64;
@@ -104,48 +134,57 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
   const int bw = tb % NBW, bh = (tb / NBW) % NBH, n = tb / (NBW * NBH);
   const int th0 = bh * BH, tw0 = bw * BW;
   const int nkg = C / 8;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
 
-  // patch loader: float4 f of the stage = pixel f >> 2, channels 4 (f & 3) ... +3; global offsets fixed for the whole K loop
-  int goff[NLD];
+  // ---- patch DMA: piece j = pixels 32 j .. 32 j + 31, lane l = pixel 32 j + (l >> 1), channels 4 (l & 1) .. + 3 of the stage.
+  // Wave w issues pieces w, w + 4, w + 8.  voff = byte offset of the lane's pixel inside the image; lanes of pixels outside the
+  // image (or past the patch) are masked out: their LDS slots keep the zeros written below.
+  unsigned pvoff[3];
+  bool pok[3];
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int f = tid + 256 * i, pix = f >> 2, q = f & 3;
+  for (int i = 0; i < 3; ++i) {
+    const int pix = 32 * (wu + 4 * i) + (lane >> 1);
     const int pr = pix / PW, pc = pix - pr * PW;
     const int h = 2 * th0 - 1 + pr, x = 2 * tw0 - 1 + pc;
-    const bool ok = pix < NPIX && h >= 0 && h < H && x >= 0 && x < W;
-    goff[i] = ok ? ((n * H + h) * W + x) * C + 4 * q : -1;
+    pok[i] = (wu + 4 * i) < NPC && pix < NPIX && h >= 0 && h < H && x >= 0 && x < W;
+    pvoff[i] = pok[i] ? static_cast<unsigned>(((h * W + x) * C + 4 * (lane & 1)) * 4) : 0u;
   }
-  // out-of-image pixels load element 0 (valid memory) and are zeroed on the way into LDS: unconditional loads, no exec-mask branches
-  float4 rp[NLD];
-#define WN_LOAD_PATCH(stage_)                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < NLD; ++i)                                                                    \
-    rp[i] = *reinterpret_cast<const float4*>(X + (goff[i] >= 0 ? goff[i] + (stage_) * WN_KP : 0))
-#define WN_STORE_PATCH(buf_)                                                                                         \
-  _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                                  \
-    const int f = tid + 256 * i;                                                                                     \
-    if (f < NPIX * 4)                                                                                                \
-      *reinterpret_cast<float4*>(sP + (buf_) * PBUF + (f >> 2) * WN_PSTR + 4 * (f & 3)) =                            \
-          goff[i] >= 0 ? rp[i] : make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
-  }
-  // packed filters of k group kg_ -> sU[buf_]: 32 pieces of 1 KB, 8 per wave, by LDS-DMA (destination = wave-uniform base + 16 lane)
-  const float* Ucb = U + static_cast<size_t>(cb) * nkg * WN_UCHUNK;
-  // (inline asm: beside a compiler-visible LDS-DMA hipcc drains vmcnt(0) before the next ds_read of ANY address of the array -- the
-  // whole load latency exposed once per k group; the asm form is waited for by hand, once, before the barrier that publishes it)
-#define WN_LOAD_U(kg_, buf_)                                                                                         \
-  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
-    const int piece = 8 * w + i;                                                                                     \
-    const float* src_ = Ucb + static_cast<size_t>(kg_) * WN_UCHUNK + piece * 256 + lane * 4;                          \
-    const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + static_cast<unsigned>(((buf_) * WN_UCHUNK + piece * 256) * 4)); \
+  const unsigned long long ximg = reinterpret_cast<unsigned long long>(X + static_cast<size_t>(n) * H * W * C);
+  const unsigned long long ucb = reinterpret_cast<unsigned long long>(U + static_cast<size_t>(cb) * nkg * WN_UCHUNK);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_ptr_t)smem)));
+  const unsigned uvoff = lane * 16;
+#define WN_DMA(voff_, sbase_, ldsaddr_)                                                                              \
+  do {                                                                                                               \
     unsigned keep_;                                                                                                  \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                                  \
-  }
-#define WN_WAIT_U() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<size_t>((lds_ptr_t)sU));
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"  \
+                 : "=&s"(keep_) : "v"(voff_), "s"(ldsaddr_), "s"(sbase_) : "memory");                                \
+  } while (0)
+  // patch stage st_ -> sP[buf_]
+#define WN_DMA_PATCH(i_, st_, buf_)                                                                                  \
+  do {                                                                                                               \
+    if (pok[i_]) {                                                                                                   \
+      const unsigned long long sb_ = ximg + static_cast<unsigned long long>(st_) * 32ull;                            \
+      const unsigned la_ = lds0 + static_cast<unsigned>(((buf_) * PBUF + (wu + 4 * (i_)) * 256) * 4);                \
+      WN_DMA(pvoff[i_], sb_, la_);                                                                                   \
+    }                                                                                                                \
+  } while (0)
+  // piece 8 w + i_ of the packed filters of k group kg_ -> sU[buf_]
+#define WN_DMA_U(i_, kg_, buf_)                                                                                      \
+  do {                                                                                                               \
+    const unsigned long long sb_ = ucb + (static_cast<unsigned long long>(kg_) * WN_UCHUNK + (8 * wu + (i_)) * 256) * 4ull; \
+    const unsigned la_ = lds0 + static_cast<unsigned>((2 * PBUF + 2 * VBUF + (buf_) * WN_UCHUNK + (8 * wu + (i_)) * 256) * 4); \
+    WN_DMA(uvoff, sb_, la_);                                                                                         \
+  } while (0)
+#define WN_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-  // this lane's A-operand tile: t = 32 mi + l31 -> (tr, tc); top-left patch pixel (2 tr, 2 tc)
-  const int t_a = 32 * mi + l31, tr_a = t_a / BW, tc_a = t_a - tr_a * BW;
-  const int abase = ((2 * tr_a) * PW + 2 * tc_a) * WN_PSTR + 4 * half;
+  // ---- transform task of this thread: tile tt = tid >> 2 of the block, channel pair kq = tid & 3 of the stage
+  const int tt = tid >> 2, kq = tid & 3;
+  const int ttr = tt / BW, ttc = tt - ttr * BW;
+  const int tsrc = ((2 * ttr) * PW + 2 * ttc) * 8 + 2 * kq;      // float index of (pixel (2 tr, 2 tc), channel 2 kq) in a patch buffer
+  const int tdst = tt * 8 + 2 * kq;                              // float index in a V buffer; position p adds 512
+  // ---- MFMA operands of this lane: A = V[p][32 mi + l31][4 half ..], B = U[p][ni][lane]
+  const int aoff = (32 * mi + l31) * 8 + 4 * half;
+  const int boff = (ni * 64 + lane) * 4;
 
   floatx16 acc[16];
 #pragma unroll
@@ -153,89 +192,84 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-  WN_LOAD_PATCH(0);
-  WN_LOAD_U(0, 0);
-  WN_STORE_PATCH(0);
-  WN_WAIT_U();
+  floatx2 d[4][4], T[4][4];
+#define WN_DREAD(ptr_, a_, b_) d[a_][b_] = *reinterpret_cast<const floatx2*>((ptr_) + ((a_) * PW + (b_)) * 8)
+  // row i of B^T d: d0 - d2, d1 + d2, d2 - d1, d1 - d3 (per column b)
+#define WN_TOP(i_, b_) T[i_][b_] = (i_) == 0 ? pk_sub(d[0][b_], d[2][b_]) : (i_) == 1 ? pk_add(d[1][b_], d[2][b_]) : (i_) == 2 ? pk_sub(d[2][b_], d[1][b_]) : pk_sub(d[1][b_], d[3][b_])
+  // V[i][j] = (row i of B^T d) B: t0 - t2, t1 + t2, t2 - t1, t1 - t3
+#define WN_VOUT(dst_, i_, j_)                                                                                        \
+  *reinterpret_cast<floatx2*>((dst_) + (4 * (i_) + (j_)) * 512) =                                                    \
+      (j_) == 0 ? pk_sub(T[i_][0], T[i_][2]) : (j_) == 1 ? pk_add(T[i_][1], T[i_][2]) : (j_) == 2 ? pk_sub(T[i_][2], T[i_][1]) : pk_sub(T[i_][1], T[i_][3])
+
+  // prologue: zero the patch buffers (the masked-out slots stay zero for the whole kernel), then stage 0, 1 and the first filters
+  for (int i = tid; i < 2 * PBUF / 4; i += 256) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) WN_DMA_PATCH(i, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) WN_DMA_PATCH(i, nkg > 1 ? 1 : 0, 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) WN_DMA_U(i, 0, 0);
+  WN_WAIT_VM();
+  __syncthreads();
+  {
+    const float* ps = sP + tsrc;
+    float* vd = sV + tdst;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2) WN_DREAD(ps, a, b2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2) WN_TOP(i, b2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) WN_VOUT(vd, i, j);
+  }
   __syncthreads();
 
-  // Software pipeline: the transformed input of k group kg + 1 is built WHILE the MFMAs of k group kg run, INTO the registers the
-  // current group has finished with: positions are consumed row by row (p = 4 i + j), so row i of the next group's V can overwrite
-  // V[4 i .. 4 i + 3] once position 4 i + 3 has issued.  The 16 LDS reads go out under positions 0..3, row i's 32 additions under
-  // position 4 i + 4 (row 3's under position 13 into a spare row that is moved in after the last MFMA); every piece is pinned
-  // between two positions' MFMAs (sched_barrier) and the B operand of position p + 1 is read before position p's MFMAs.  A wave is
-  // alone on its SIMD: whatever is not issued under an MFMA's 64 cycles is exposed.
-  float4 V[16], V3n[4], d[4][4];
-#define WN_DROW(ptr_, a_)                                                                                            \
-  _Pragma("unroll") for (int b = 0; b < 4; ++b) d[a_][b] = *reinterpret_cast<const float4*>((ptr_) + ((a_) * PW + b) * WN_PSTR)
-  // row i of V = (row i of B^T d) B; rows of B^T d: d0 - d2, d1 + d2, d2 - d1, d1 - d3
-#define WN_VROW(DST, o_, OPA, ra_, rb_)                                                                              \
-  do {                                                                                                               \
-    const float4 t0 = OPA(d[ra_][0], d[rb_][0]), t1 = OPA(d[ra_][1], d[rb_][1]);                                      \
-    const float4 t2 = OPA(d[ra_][2], d[rb_][2]), t3 = OPA(d[ra_][3], d[rb_][3]);                                      \
-    DST[(o_) + 0] = f4sub(t0, t2);                                                                                   \
-    DST[(o_) + 1] = f4add(t1, t2);                                                                                   \
-    DST[(o_) + 2] = f4sub(t2, t1);                                                                                   \
-    DST[(o_) + 3] = f4sub(t1, t3);                                                                                   \
-  } while (0)
-  {
-    const float* ap = sP + abase;                                // k group 0: stage buffer 0, jj = 0
-#pragma unroll
-    for (int a = 0; a < 4; ++a) WN_DROW(ap, a);
-    WN_VROW(V, 0, f4sub, 0, 2);
-    WN_VROW(V, 4, f4add, 1, 2);
-    WN_VROW(V, 8, f4sub, 2, 1);
-    WN_VROW(V, 12, f4sub, 1, 3);
-  }
-
-  for (int kg = 0; kg < ((dbg & 2) ? 1 : nkg); ++kg) {
-    const int ub = kg & 1, pb = (kg >> 1) & 1, jj = kg & 1;
-    const bool more_u = kg + 1 < nkg;
-    const bool more_p = jj == 0 && kg + 2 < nkg;                 // first k group of a stage: fetch the next stage
-    // next k group's patch values: same stage (jj 0 -> 1) or the next stage's buffer (complete since the previous barrier)
-    const float* apn = sP + (((kg + 1) >> 1) & 1) * PBUF + abase + 8 * ((kg + 1) & 1);
-    const float4* bp = reinterpret_cast<const float4*>(sU + ub * WN_UCHUNK) + ni * 64 + lane;
-    float4 bv = bp[0];
+  const int nkg_run = (dbg & 2) ? 1 : nkg;
+  for (int kg = 0; kg < nkg_run; ++kg) {
+    const int cur = kg & 1, nxt = cur ^ 1;
+    // branch-free body: past the end the DMAs repeat the last chunk / stage into buffers nobody reads any more
+    const int kgn = min(kg + 1, nkg - 1), stn = min(kg + 2, nkg - 1);
+    const float* ps = sP + nxt * PBUF + tsrc;                    // patch stage kg + 1 (landed before the previous barrier)
+    float* vd = sV + nxt * VBUF + tdst;                          // V(kg + 1)
+    const float4* ap = reinterpret_cast<const float4*>(sV + cur * VBUF + aoff);
+    const float4* bp = reinterpret_cast<const float4*>(sU + cur * WN_UCHUNK + boff);
+    float4 av = ap[0], bv = bp[0], an = av, bn = bv;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      float4 bn = bv;
-      if (p < 15) bn = bp[(p + 1) * 128];
-      if (p == 1) {          // the next chunks' loads go out under position 0's MFMAs (not ahead of them: ~60 issue slots)
-        if (more_p) { WN_LOAD_PATCH((kg >> 1) + 1); }      // ahead of the LDS-DMA: hipcc guards the staging registers with a vmcnt(0)
-        if (more_u) { WN_LOAD_U(kg + 1, ub ^ 1); }
-      }
-      if (more_u) {
-        if (p == 0) WN_DROW(apn, 0);
-        if (p == 1) WN_DROW(apn, 2);
-        if (p == 2) WN_DROW(apn, 1);
-        if (p == 3) WN_DROW(apn, 3);
-        if (p == 4) WN_VROW(V, 0, f4sub, 0, 2);
-        if (p == 8) WN_VROW(V, 4, f4add, 1, 2);
-        if (p == 12) WN_VROW(V, 8, f4sub, 2, 1);
-        if (p == 13) WN_VROW(V3n, 0, f4sub, 1, 3);
-      }
-      const float4 av = V[p];
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[p], 0, 0, 0);
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[p], 0, 0, 0);
-      bv = bn;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (more_u) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) V[12 + j] = V3n[j];
+      for (int e = 0; e < 4; ++e) {
+        const int sl = 4 * p + e;
+        const float a_ = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
+        const float b_ = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, acc[p], 0, 0, 0);
+        if (e == 0 && p < 15) { an = ap[(p + 1) * 128]; bn = bp[(p + 1) * 128]; }
+        if (sl >= 1 && sl < 17) { const int q = sl - 1; WN_DREAD(ps, q >> 2, q & 3); }
+        if (sl >= 17 && sl < 33) { const int q = sl - 17; WN_TOP(q >> 2, q & 3); }
+        if (sl >= 33 && sl < 49) { const int q = sl - 33; WN_VOUT(vd, q >> 2, q & 3); }
+        if (sl >= 2 && sl < 10 && !(dbg & 16)) WN_DMA_U(sl - 2, kgn, nxt);
+        if (sl >= 10 && sl < 13 && !(dbg & 8)) WN_DMA_PATCH(sl - 10, stn, cur);     // stage kg + 2 over stage kg (read during kg - 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      av = an; bv = bn;
     }
-    if (more_p) { WN_STORE_PATCH(pb ^ 1); }
-    WN_WAIT_U();
-    __syncthreads();
+    if (!(dbg & 4)) {
+      WN_WAIT_VM();
+      __syncthreads();
+    }
   }
-#undef WN_DROW
-#undef WN_VROW
-#undef WN_LOAD_PATCH
-#undef WN_STORE_PATCH
-#undef WN_LOAD_U
-#undef WN_WAIT_U
+#undef WN_DREAD
+#undef WN_TOP
+#undef WN_VOUT
+#undef WN_DMA
+#undef WN_DMA_PATCH
+#undef WN_DMA_U
+#undef WN_WAIT_VM
 
   // output transform + store: register r of every accumulator = tile ti = (r & 3) + 8 (r >> 2) + 4 half of this wave's 32, channel l31
   const int co = 64 * cb + 32 * ni + l31;
@@ -432,21 +466,35 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad(const float* __restrict__ X
           make_float4(acc[p][4 * q + 0], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]);
 }
 
-// part [nsplit][16][Co][C] -> grad_w (co, c, a, b) at co*so + c*sc + a*sa + b*sb:  G^T (sum over shares) G
-__global__ __launch_bounds__(256) void wino_wgrad_reduce(const float* __restrict__ part, int nsplit, int C, int Co, float* __restrict__ gw,
+// part [nsplit][16][Co][C]: the shares of every element are added in a fixed order (four interleaved chains, then pairwise) into
+// share 0's slot -- one thread per (position, co, c), so that a 64 x 64 layer with hundreds of shares still fills the chip ...
+__global__ __launch_bounds__(256) void wino_wgrad_sum(float* __restrict__ part, int nsplit, long long plane16) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= plane16) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* ps = part + idx;
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    s0 += ps[(s + 0) * plane16];
+    s1 += ps[(s + 1) * plane16];
+    s2 += ps[(s + 2) * plane16];
+    s3 += ps[(s + 3) * plane16];
+  }
+  for (; s < nsplit; ++s) s0 += ps[s * plane16];
+  part[idx] = (s0 + s1) + (s2 + s3);
+}
+
+// ... then grad_w (co, c, a, b) at co*so + c*sc + a*sa + b*sb = G^T dU G per (co, c), dU = share 0's slot [16][Co][C]
+__global__ __launch_bounds__(256) void wino_wgrad_reduce(const float* __restrict__ part, int C, int Co, float* __restrict__ gw,
                                                          long long so, long long sc, long long sa, long long sb) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= static_cast<long long>(C) * Co) return;
   const int c = static_cast<int>(idx % C), co = static_cast<int>(idx / C);
   float u[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p) u[p] = 0.f;
   const size_t plane = static_cast<size_t>(Co) * C;
-  for (int s = 0; s < nsplit; ++s) {
-    const float* ps = part + static_cast<size_t>(s) * 16 * plane + static_cast<size_t>(co) * C + c;
+  const float* ps = part + static_cast<size_t>(co) * C + c;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) u[p] += ps[p * plane];
-  }
+  for (int p = 0; p < 16; ++p) u[p] = ps[p * plane];
   float t[3][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -490,8 +538,9 @@ int wino_dbg() { static const int v = getenv("DBEV_WINO_DBG") ? atoi(getenv("DBE
 struct WinoPlan { int bh, bw, ntb, ncb, grid; };
 
 bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
-  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % WN_KP) || Co <= 0 || (Co % 64)) return false;
+  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8) || Co <= 0 || (Co % 64)) return false;
   if (static_cast<long long>(N) * H * W * (C > Co ? C : Co) >= 0x7fffffffLL) return false;      // 32-bit element offsets
+  if (static_cast<long long>(H) * W * C * 4 >= 0x7fffffffLL) return false;                       // 32-bit byte offsets inside an image (LDS-DMA)
   const int TH = H / 2, TW = W / 2;
   // tile block shape: the one that wastes fewer tile slots at the image edges
   const long long w88 = static_cast<long long>((TH + 7) / 8) * ((TW + 7) / 8), w416 = static_cast<long long>((TH + 3) / 4) * ((TW + 15) / 16);
@@ -561,8 +610,13 @@ extern "C" int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const floa
   hipLaunchKernelGGL(wino_wgrad, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
                      p.nsplit);
   DBEV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wino_wgrad_reduce, dim3(dbev_ceil_div(static_cast<long long>(Cin) * Cout, 256)), dim3(256), 0, s, part, p.nsplit,
-                     Cin, Cout, grad_weight, so, sc, sa, sb);
+  const long long plane16 = 16LL * Cin * Cout;
+  if (p.nsplit > 1) {
+    hipLaunchKernelGGL(wino_wgrad_sum, dim3(dbev_ceil_div(plane16, 256)), dim3(256), 0, s, part, p.nsplit, plane16);
+    DBEV_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(wino_wgrad_reduce, dim3(dbev_ceil_div(static_cast<long long>(Cin) * Cout, 256)), dim3(256), 0, s, part, Cin, Cout,
+                     grad_weight, so, sc, sa, sb);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

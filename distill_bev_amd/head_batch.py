@@ -151,7 +151,7 @@ def forward(head, x):
         mods = [s[0] for _, _, s in group]
         bns = [m.norm for m in mods]
         w = torch.cat([m.conv.weight for m in mods], 0)
-        a = W3.conv3x3(x, w, None) if W3.eligible(x, w) else F.conv2d(x, w, None, 1, 1)
+        a = W3.conv3x3(x, w, None) if (W3.eligible(x, w) and W3.worthwhile(x, w.shape[0])) else F.conv2d(x, w, None, 1, 1)
         gamma = torch.cat([bn.weight for bn in bns])
         beta = torch.cat([bn.bias for bn in bns])
         rm = torch.cat([bn.running_mean for bn in bns])

@@ -39,9 +39,13 @@ def eligible(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1
     Co = weight.shape[0]
     if weight.shape[1] != C or H % 2 or W % 2 or C % 16 or Co % 64 or not _nhwc(x):
         return False
-    if N * H * W * max(C, Co) >= 2 ** 31 - 1:
-        return False
-    return _blocks(N, H, W) * (Co // 64) >= _MIN_WG
+    return N * H * W * max(C, Co) < 2 ** 31 - 1
+
+
+def worthwhile(x, Cout):
+    """does the layer offer enough workgroups for the kernel to beat the library's (see _MIN_WG)?"""
+    N, _, H, W = x.shape
+    return _blocks(N, H, W) * (Cout // 64) >= _MIN_WG
 
 
 def _blocks(N, H, W):
@@ -147,7 +151,8 @@ class WinoConv2d(nn.Conv2d):
     gradients disabled (the frozen teacher, the student's detached frame) the packed filters are kept until the weight changes."""
 
     def forward(self, x):
-        if self.padding_mode == "zeros" and eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+        if self.padding_mode == "zeros" and eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups) \
+                and worthwhile(x, self.out_channels):
             if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
                 return conv_packed(x, self._packed(), self.out_channels, self.bias)
             return conv3x3(x, self.weight, self.bias)
@@ -189,4 +194,4 @@ def conv3x3_bn_ready(conv, bn, x):
     if not (type(bn) in BA._BN_TYPES and bn.affine and bn.training and bn.momentum is not None and bn.running_mean is not None
             and BA._channels_ok(conv.out_channels)):
         return False
-    return eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups) and worthwhile(x, conv.out_channels)
