@@ -95,6 +95,12 @@ __device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
   return r;
 }
 
+// a wave-uniform 64-bit value the compiler cannot prove uniform -> SGPR pair (the scalar base of an LDS-DMA)
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 // ---- the convolution ------------------------------------------------------------------------------------------------------------
 // X [N, H, W, C] channels-last, U packed by wino_filter_pack (K = C, J = Co), Y [N, H, W, Co]; H, W even, C % 8 == 0, Co % 64 == 0,
 // H * W * C * 4 < 2^31.  partial (STATS): f32[ntb, 2, Co] per tile block (sum y, sum y^2) per channel.
@@ -466,6 +472,252 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad(const float* __restrict__ X
           make_float4(acc[p][4 * q + 0], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]);
 }
 
+// ---- weight gradient, second version ---------------------------------------------------------------------------------------------
+// Same GEMMs as wino_wgrad, built on what the forward kernel's measurements showed (a VALU instruction costs ~7 cycles of fp32 matrix
+// time, LDS traffic / SALU / LDS-DMA issue cost none).  wino_wgrad spends ~100 VALU instructions per 16 MFMAs (every wave transforms
+// its own operands, scalar arithmetic, register copies): 60 % matrix utilisation.  Here, per stage of 8 tiles (one tile row x 8):
+//  * the input transform V is computed ONCE per workgroup (thread = channel pair x tile: 16 ds_read_b64, 32 v_pk_add_f32, 16
+//    ds_write_b64) and handed to the waves through LDS as [position][tile][64 channels]; the A operand of a step is a ds_read_b32;
+//  * the gradient transform Z = A dY A^T (cheap: 32 packed operations for 4 tiles) stays per lane, a row of positions at a time, the
+//    tiles of two steps paired in one v_pk_add_f32;
+//  * raw input rows (4 x 18 pixels x 64 channels) and gradient rows (2 x 16 x 64) arrive by scalar-base LDS-DMA two stages ahead;
+//    pixels outside the image (and, in the last column block, which is clamped to the image and overlaps its neighbour, the gradient
+//    columns that neighbour already covered) are replaced by zeros stored by the lanes the DMA skips.
+// K order: step e of a stage multiplies tile e (lanes 0-31) and tile 4 + e (lanes 32-63).
+constexpr int W2_T = 8;                                  // tiles per stage
+constexpr int W2_PW = 2 * W2_T + 2;                      // 18 input columns, 4 rows
+constexpr int W2_PPC = (4 * W2_PW + 3) / 4;              // patch DMA pieces of 4 pixels (1 KB): 18
+constexpr int W2_PBUF = W2_PPC * 256;                    // floats per raw patch buffer
+constexpr int W2_DPC = 2 * 2 * W2_T / 4;                 // gradient DMA pieces: 8
+constexpr int W2_DBUF = W2_DPC * 256;                    // floats per raw gradient buffer
+constexpr int W2_VBUF = 16 * W2_T * 64;                  // floats per transformed-input buffer
+
+__global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part,
+                                                      int N, int H, int W, int C, int Co, int nsb, int per, int nblk, int nsplit) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * W2_PBUF + 3 * W2_DBUF + 2 * W2_VBUF];
+  float* sP = smem;
+  float* sD = smem + 2 * W2_PBUF;
+  float* sV = sD + 3 * W2_DBUF;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ci = w & 1, coi = w >> 1, half = lane >> 5, l31 = lane & 31;
+  const int L = xcd_block();
+  const int blk = L % nblk, split = L / nblk;
+  if (split >= nsplit) return;
+  const int ncb = C / 64;
+  const int c0 = (blk % ncb) * 64, o0 = (blk / ncb) * 64;
+  const int TH = H >> 1, TW = W >> 1;
+  const int NSW = (TW + W2_T - 1) / W2_T;                  // column blocks per tile row (the last one clamped to TW - 8)
+  const int ovl = NSW * W2_T - TW;                         // tiles of the last block that its left neighbour already covered
+  const int sb_begin = split * per, sb_end = min(nsb, sb_begin + per);
+  const int nst = sb_end - sb_begin;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_ptr_t)smem)));
+
+  // ---- DMA lanes.  Patch piece j = pixels 4 j .. 4 j + 3 (row-major in the 4 x 18 rows), lane l = pixel 4 j + (l >> 4), channels
+  // 4 (l & 15) .. + 3; wave w issues pieces w, w + 4, ...  flags: 1 top row, 2 bottom row, 4 left column, 8 right column -- the lane is
+  // skipped (and stores zeros) when the stage's edge mask has one of its flags.
+  unsigned pvoff[5], pflag[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int pix = 4 * (wu + 4 * i) + (lane >> 4);
+    const int pr = pix / W2_PW, pc = pix - pr * W2_PW;
+    pvoff[i] = static_cast<unsigned>(((pr * W + pc) * C + 4 * (lane & 15)) * 4);
+    pflag[i] = (pr == 0 ? 1u : 0u) | (pr == 3 ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc == W2_PW - 1 ? 8u : 0u) |
+               ((wu + 4 * i) >= W2_PPC || pix >= 4 * W2_PW ? 16u : 0u);
+  }
+  unsigned dvoff[2], dflag[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = 4 * (wu + 4 * i) + (lane >> 4);
+    const int pr = pix / (2 * W2_T), pc = pix - pr * (2 * W2_T);
+    dvoff[i] = static_cast<unsigned>(((pr * W + pc) * Co + 4 * (lane & 15)) * 4);
+    dflag[i] = pc < 2 * ovl ? 1u : 0u;
+  }
+#define W2_DMA(voff_, sbase_, ldsaddr_)                                                                              \
+  do {                                                                                                               \
+    unsigned keep_;                                                                                                  \
+    const unsigned m0v_ = __builtin_amdgcn_readfirstlane(ldsaddr_);                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"  \
+                 : "=&s"(keep_) : "v"(voff_), "s"(m0v_), "s"(sbase_) : "memory");                                    \
+  } while (0)
+  // stage geometry (scalar): n, th, column block cbk -> bases and edge masks.  Kept as counters, advanced without divisions.
+#define W2_GEOM(n_, th_, cbk_, xb_, db_, pe_, de_)                                                                   \
+  do {                                                                                                               \
+    const int tw0_ = (cbk_) == NSW - 1 ? TW - W2_T : (cbk_) * W2_T;                                                  \
+    xb_ = uniform64(reinterpret_cast<unsigned long long>(                                                            \
+        X + (static_cast<long long>((n_) * H + 2 * (th_) - 1) * W + 2 * tw0_ - 1) * C + c0));                        \
+    db_ = uniform64(reinterpret_cast<unsigned long long>(DY + (static_cast<long long>((n_) * H + 2 * (th_)) * W + 2 * tw0_) * Co + o0)); \
+    pe_ = 16u | ((th_) == 0 ? 1u : 0u) | ((th_) == TH - 1 ? 2u : 0u) | (tw0_ == 0 ? 4u : 0u) | (tw0_ + W2_T == TW ? 8u : 0u); \
+    de_ = ((cbk_) == NSW - 1 && ovl > 0) ? 1u : 0u;                                                                  \
+  } while (0)
+#define W2_ADVANCE(n_, th_, cbk_)                                                                                    \
+  do {                                                                                                               \
+    if (++(cbk_) == NSW) { (cbk_) = 0; if (++(th_) == TH) { (th_) = 0; ++(n_); } }                                   \
+  } while (0)
+  // patch piece i_ of the stage (xb_, pe_) -> sP[buf_]; gradient piece -> sD[buf_]
+#define W2_DMA_PATCH(i_, xb_, pe_, buf_)                                                                             \
+  do {                                                                                                               \
+    const unsigned la_ = lds0 + static_cast<unsigned>(((buf_) * W2_PBUF + (wu + 4 * (i_)) * 256) * 4);               \
+    if ((pflag[i_] & (pe_)) == 0) W2_DMA(pvoff[i_], xb_, la_);                                                       \
+    else if (!(pflag[i_] & 16u)) *reinterpret_cast<float4*>(sP + (buf_) * W2_PBUF + (wu + 4 * (i_)) * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f); \
+  } while (0)
+#define W2_DMA_DY(i_, db_, de_, buf_)                                                                                \
+  do {                                                                                                               \
+    const unsigned la_ = lds0 + static_cast<unsigned>((2 * W2_PBUF + (buf_) * W2_DBUF + (wu + 4 * (i_)) * 256) * 4); \
+    if ((dflag[i_] & (de_)) == 0) W2_DMA(dvoff[i_], db_, la_);                                                       \
+    else *reinterpret_cast<float4*>(sD + (buf_) * W2_DBUF + (wu + 4 * (i_)) * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f); \
+  } while (0)
+
+  // ---- transform task: channel pair cp = tid & 31, tile tl = tid >> 5 of the stage
+  const int cp = tid & 31, tl = tid >> 5;
+  const int tsrc = (2 * tl) * 64 + 2 * cp;                 // float index of (row 0, column 2 tl, channel 2 cp) in a patch buffer
+  const int tdst = tl * 64 + 2 * cp;                       // float index in a V buffer; position p adds 8 * 64
+  // ---- MFMA operands: A = V[p][4 half + e][32 ci + l31]; Z from gradient pixels (rows 0 / 1, columns 2 tile, 2 tile + 1) of tiles
+  // 4 half + e at channel 32 coi + l31
+  const int aoff = (4 * half) * 64 + 32 * ci + l31;
+  const int yoff = (2 * 4 * half) * 64 + 32 * coi + l31;
+
+  floatx16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+  floatx2 d[4][4], T[4][4];
+#define W2_DREAD(ptr_, a_, b_) d[a_][b_] = *reinterpret_cast<const floatx2*>((ptr_) + ((a_) * W2_PW + (b_)) * 64)
+#define W2_TOP(i_, b_) T[i_][b_] = (i_) == 0 ? pk_sub(d[0][b_], d[2][b_]) : (i_) == 1 ? pk_add(d[1][b_], d[2][b_]) : (i_) == 2 ? pk_sub(d[2][b_], d[1][b_]) : pk_sub(d[1][b_], d[3][b_])
+#define W2_VOUT(dst_, i_, j_)                                                                                        \
+  *reinterpret_cast<floatx2*>((dst_) + (4 * (i_) + (j_)) * (W2_T * 64)) =                                            \
+      (j_) == 0 ? pk_sub(T[i_][0], T[i_][2]) : (j_) == 1 ? pk_add(T[i_][1], T[i_][2]) : (j_) == 2 ? pk_sub(T[i_][2], T[i_][1]) : pk_sub(T[i_][1], T[i_][3])
+  // gradient pixels of this lane's 4 tiles as two tile pairs q = 0, 1 (tiles 4 half + 2 q, + 1): y[a][b][q]
+  floatx2 y[2][2][2], w1[2][2], w2[2][2];
+  floatx2 z[2][4][2];                                       // rows of positions alternate between the two sets: z[row & 1][j][q]
+#define W2_YREAD(ptr_)                                                                                               \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                      \
+    _Pragma("unroll") for (int b2 = 0; b2 < 2; ++b2)                                                                 \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                                \
+        y[a][b2][q].x = (ptr_)[((a * 2 * W2_T) + 2 * (2 * q) + b2) * 64];                                            \
+        y[a][b2][q].y = (ptr_)[((a * 2 * W2_T) + 2 * (2 * q + 1) + b2) * 64];                                        \
+      }
+  // rows of A dY: w0 = y0, w1 = y0 + y1, w2 = y0 - y1, w3 = -y1; row i of Z: (a, a + b, a - b, -b) of (w_i[0], w_i[1]).  The two
+  // negations are left out here (Z~[i][j] = s_i s_j Z[i][j], s_3 = -1): the reduce kernel flips the sign of those positions' sums
+#define W2_ZROW(dst_, i_, q_)                                                                                        \
+  do {                                                                                                               \
+    const floatx2 a_ = (i_) == 0 ? y[0][0][q_] : (i_) == 1 ? w1[0][q_] : (i_) == 2 ? w2[0][q_] : y[1][0][q_];        \
+    const floatx2 b_ = (i_) == 0 ? y[0][1][q_] : (i_) == 1 ? w1[1][q_] : (i_) == 2 ? w2[1][q_] : y[1][1][q_];        \
+    dst_[0][q_] = a_; dst_[1][q_] = pk_add(a_, b_); dst_[2][q_] = pk_sub(a_, b_); dst_[3][q_] = b_;                  \
+  } while (0)
+
+  // ---- prologue: stages 0 and 1 of this share
+  int n_a, th_a, cb_a;                                      // geometry counters of the next stage to FETCH
+  {
+    const int rows = TH * NSW;
+    n_a = sb_begin / rows;
+    const int r_ = sb_begin - n_a * rows;
+    th_a = r_ / NSW; cb_a = r_ - th_a * NSW;
+  }
+  unsigned long long xb, db;
+  unsigned pe, de;
+  W2_GEOM(n_a, th_a, cb_a, xb, db, pe, de);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) W2_DMA_PATCH(i, xb, pe, 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) W2_DMA_DY(i, db, de, 0);
+  if (nst > 1) W2_ADVANCE(n_a, th_a, cb_a);
+  W2_GEOM(n_a, th_a, cb_a, xb, db, pe, de);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) W2_DMA_PATCH(i, xb, pe, 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) W2_DMA_DY(i, db, de, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const float* ps = sP + tsrc;
+    float* vd = sV + tdst;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2) W2_DREAD(ps, a, b2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2) W2_TOP(i, b2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) W2_VOUT(vd, i, j);
+    const float* py = sD + yoff;
+    W2_YREAD(py);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) { w1[b2][q] = pk_add(y[0][b2][q], y[1][b2][q]); w2[b2][q] = pk_sub(y[0][b2][q], y[1][b2][q]); }
+      W2_ZROW(z[0], 0, q);
+    }
+  }
+  __syncthreads();
+
+  for (int k = 0; k < nst; ++k) {
+    const int cur = k & 1, nxt = cur ^ 1;
+    // fetch counters: stage k + 2 (clamped to the share's last stage: a redundant load into buffers nobody reads any more)
+    if (k + 2 < nst) W2_ADVANCE(n_a, th_a, cb_a);
+    W2_GEOM(n_a, th_a, cb_a, xb, db, pe, de);
+    const int dnx = (k + 1) % 3, dft = (k + 2) % 3;
+    const float* ps = sP + nxt * W2_PBUF + tsrc;           // raw patch of stage k + 1
+    float* vd = sV + nxt * W2_VBUF + tdst;                 // V(k + 1)
+    const float* ap = sV + cur * W2_VBUF + aoff;
+    const float* pyn = sD + dnx * W2_DBUF + yoff;          // gradient rows of stage k + 1
+    float a4[2][4];                                        // A operands of a position; positions alternate between the two sets
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a4[0][e] = ap[e * 64];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int sl = 4 * p + e;
+        const floatx2 zq = z[(p >> 2) & 1][p & 3][e >> 1];
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[p & 1][e], (e & 1) ? zq.y : zq.x, acc[p], 0, 0, 0);
+        if (p < 15) a4[(p + 1) & 1][e] = ap[((p + 1) * W2_T + e) * 64];
+        if (sl >= 1 && sl < 17) { const int q = sl - 1; W2_DREAD(ps, q >> 2, q & 3); }
+        if (sl >= 17 && sl < 33) { const int q = sl - 17; W2_TOP(q >> 2, q & 3); }
+        if (sl >= 33 && sl < 49) { const int q = sl - 33; W2_VOUT(vd, q >> 2, q & 3); }
+        // the next row of positions: rows 1..3 of this stage under rows 0..2; row 0 of the next stage, from its gradient pixels,
+        // under row 3
+        if ((p & 3) == 0 && p < 12 && e < 2) { W2_ZROW(z[((p >> 2) + 1) & 1], (p >> 2) + 1, e); }
+        if (p == 12 && e == 0) { W2_YREAD(pyn); }
+        if (p == 13 && e < 2) {
+#pragma unroll
+          for (int b2 = 0; b2 < 2; ++b2) { w1[b2][e] = pk_add(y[0][b2][e], y[1][b2][e]); w2[b2][e] = pk_sub(y[0][b2][e], y[1][b2][e]); }
+        }
+        if (p == 14 && e < 2) { W2_ZROW(z[0], 0, e); }
+        if (sl >= 2 && sl < 7) W2_DMA_PATCH(sl - 2, xb, pe, cur);     // raw patch of stage k + 2 over the one transformed during k - 1
+        if (sl >= 7 && sl < 9) W2_DMA_DY(sl - 7, db, de, dft);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef W2_DMA
+#undef W2_GEOM
+#undef W2_ADVANCE
+#undef W2_DMA_PATCH
+#undef W2_DMA_DY
+#undef W2_DREAD
+#undef W2_TOP
+#undef W2_VOUT
+#undef W2_YREAD
+#undef W2_ZROW
+  // accumulator register 4 q + r of position p = input channel c0 + 32 ci + 8 q + 4 half + r, output channel o0 + 32 coi + l31
+  float* out = part + (static_cast<size_t>(split) * 16 * Co + o0 + 32 * coi + l31) * C + c0 + 32 * ci + 4 * half;
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(out + static_cast<size_t>(p) * Co * C + 8 * q) =
+          make_float4(acc[p][4 * q + 0], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]);
+}
+
 // part [nsplit][16][Co][C]: the shares of every element are added in a fixed order (four interleaved chains, then pairwise) into
 // share 0's slot -- one thread per (position, co, c), so that a 64 x 64 layer with hundreds of shares still fills the chip ...
 __global__ __launch_bounds__(256) void wino_wgrad_sum(float* __restrict__ part, int nsplit, long long plane16) {
@@ -486,7 +738,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_sum(float* __restrict__ part, 
 
 // ... then grad_w (co, c, a, b) at co*so + c*sc + a*sa + b*sb = G^T dU G per (co, c), dU = share 0's slot [16][Co][C]
 __global__ __launch_bounds__(256) void wino_wgrad_reduce(const float* __restrict__ part, int C, int Co, float* __restrict__ gw,
-                                                         long long so, long long sc, long long sa, long long sb) {
+                                                         long long so, long long sc, long long sa, long long sb, int unsigned_z) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= static_cast<long long>(C) * Co) return;
   const int c = static_cast<int>(idx % C), co = static_cast<int>(idx / C);
@@ -495,6 +747,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce(const float* __restrict
   const float* ps = part + static_cast<size_t>(co) * C + c;
 #pragma unroll
   for (int p = 0; p < 16; ++p) u[p] = ps[p * plane];
+  if (unsigned_z) {                        // wino_wgrad2 accumulates s_i s_j dU (s_3 = -1): positions (i, 3) and (3, j), i, j < 3
+    u[3] = -u[3]; u[7] = -u[7]; u[11] = -u[11]; u[12] = -u[12]; u[13] = -u[13]; u[14] = -u[14];
+  }
   float t[3][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -513,18 +768,23 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce(const float* __restrict
   }
 }
 
-struct WinoWgPlan { int nsb, nblk, nsplit, per, grid; };
+struct WinoWgPlan { int nsb, nblk, nsplit, per, grid, v2; };
+
+int wino_wg_version() { static const int v = getenv("DBEV_WINO_WGRAD_V") ? atoi(getenv("DBEV_WINO_WGRAD_V")) : 2; return v; }
 
 bool wino_wg_plan(int N, int H, int W, int C, int Co, WinoWgPlan* p) {
   if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 64) || Co <= 0 || (Co % 64)) return false;
   if (static_cast<long long>(N) * H * W * (C > Co ? C : Co) >= 0x7fffffffLL) return false;
   const int TH = H / 2, TW = W / 2;
-  const long long nsb = static_cast<long long>(N) * ((TH + WG_SBH - 1) / WG_SBH) * ((TW + WG_SBW - 1) / WG_SBW);
+  // second version: stages of 1 x 8 tiles, byte offsets inside an image as 32-bit LDS-DMA offsets
+  p->v2 = wino_wg_version() >= 2 && TW >= W2_T && static_cast<long long>(H + 2) * W * (C > Co ? C : Co) * 4 < 0x7fffffffLL;
+  const long long nsb = p->v2 ? static_cast<long long>(N) * TH * ((TW + W2_T - 1) / W2_T)
+                              : static_cast<long long>(N) * ((TH + WG_SBH - 1) / WG_SBH) * ((TW + WG_SBW - 1) / WG_SBW);
   if (nsb > 0x3fffffffLL) return false;
   p->nsb = static_cast<int>(nsb);
   p->nblk = (C / 64) * (Co / 64);
   // shares of the tile range: ~2 workgroups per CU in flight over the launch (one resident per CU), never more shares than stages
-  long long ns = (2LL * DBEV_NUM_CU + p->nblk - 1) / p->nblk;
+  long long ns = (2LL * DBEV_NUM_CU) / p->nblk;            // rounded DOWN: 2 full rounds of the 256 CUs, never a sliver of a third
   if (ns > nsb) ns = nsb;
   if (ns < 1) ns = 1;
   p->per = static_cast<int>((nsb + ns - 1) / ns);
@@ -607,8 +867,12 @@ extern "C" int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const floa
     return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   float* part = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(wino_wgrad, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
-                     p.nsplit);
+  if (p.v2)
+    hipLaunchKernelGGL(wino_wgrad2, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
+                       p.nsplit);
+  else
+    hipLaunchKernelGGL(wino_wgrad, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
+                       p.nsplit);
   DBEV_LAUNCH_CHECK();
   const long long plane16 = 16LL * Cin * Cout;
   if (p.nsplit > 1) {
@@ -616,7 +880,7 @@ extern "C" int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const floa
     DBEV_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(wino_wgrad_reduce, dim3(dbev_ceil_div(static_cast<long long>(Cin) * Cout, 256)), dim3(256), 0, s, part, Cin, Cout,
-                     grad_weight, so, sc, sa, sb);
+                     grad_weight, so, sc, sa, sb, p.v2);
   DBEV_LAUNCH_CHECK();
   return 0;
 }
