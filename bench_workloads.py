@@ -16,7 +16,15 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # profiles/r02_pmc_*.txt; filled in by the profiling pass of the round, None until then
 # bn_apply<true,true> at 48x256x64x176: FETCH_SIZE 540 702.1 KB x 2 + WRITE_SIZE 540 672.0 KB = 1 661 029 786 B per launch
 # against 3 x 553 648 128 B = 1 660 944 384 B algorithmic -> ratio 1.00005 (no over-fetch, no write amplification)
+MFMA_F32_PEAK_TF = 157.3          # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
 PMC_TRAFFIC = {"bn_apply_res_ratio": (540720.8 * 2 + 540672.0) * 1024 / (3 * 553648128.0),
+               # wino_fwd at 48 x 256 -> 256 x 16 x 44: FETCH_SIZE 66 711.1 KB x 2 + WRITE_SIZE 34 368.0 KB = 171.8 MB per launch against
+               # 73.9 MB algorithmic (x, y once + packed filters): the four 64-channel blocks of a tile block each fetch its patch
+               # (32-byte pieces; the x 2 read correction is the guide's for wide reads and is conservative here)
+               "wino_fwd_ratio": (66711.1 * 2 + 34368.0) * 1024 / (4.0 * 48 * 16 * 44 * 512 + 4.0 * 4 * 32 * 8192),
+               "wino_source": "profiles/r04_pmc_wino_FETCH_SIZE.txt (x2 gfx950 wide-read correction) + profiles/r04_pmc_wino_WRITE_SIZE.txt, "
+                              "separate --pmc passes of wino_fwd at 48x256x16x44 -> 256; traffic = mean algorithmic bytes of the timed "
+                              "launches x that measured ratio (not collected live)",
                "source": "profiles/r03_pmc_FETCH_SIZE.txt (x2 gfx950 wide-read correction) + profiles/r03_pmc_WRITE_SIZE.txt, separate "
                          "--pmc passes at the kernel's largest shape (48x256x64x176); traffic = algorithmic bytes of the timed "
                          "launches x that measured ratio (not collected live)"}
@@ -144,8 +152,8 @@ class DistillStep(_Base):
     # BatchNorm + residual + ReLU (bn_apply<true, *>, 48 launches per step over 69 ... 554 MB activations), bracketed
     # per LAUNCH by the library's kernel event log inside the timed region; the rest of the bn_* family and every
     # other hand-written entry point are measured the same way in extra steps after it (`other_hot_kernels`).
-    ROOF_KERNEL = "bn_apply_res"
-    ROOF_KERNEL_NAME = "bn_apply<true,*>"
+    ROOF_KERNEL = "wino_fwd"
+    ROOF_KERNEL_NAME = "wino_fwd"
     EXTRA_INSTRUMENTED_STEPS = 3
     TIMED = ("dbev_pillars_canvas", "dbev_pillar_vfe_canvas", "dbev_lift_splat_prepare_cam", "dbev_lift_splat_forward",
              "dbev_lift_splat_backward", "dbev_abs_mean_maps", "dbev_abs_mean_maps_nhwc", "dbev_fgd_masked_mse_forward",
@@ -179,6 +187,8 @@ class DistillStep(_Base):
         # kernels / entry points (7000+ calls per 20 steps) are instrumented in EXTRA steps after it (roofline())
         L.kernel_timing_read()
         L.kernel_timing([self.ROOF_KERNEL])
+        from distill_bev_amd import wino
+        wino.COUNTERS.update(on=True, launches=0, flops=0, bytes=0)
         self.steps_timed = 0
 
     @staticmethod
@@ -190,6 +200,9 @@ class DistillStep(_Base):
     def roofline(self):
         roof = L.kernel_timing_read().get(self.ROOF_KERNEL_NAME)
         L.kernel_timing(False)
+        from distill_bev_amd import wino
+        wc = dict(wino.COUNTERS)
+        wino.COUNTERS["on"] = False
         if not roof:
             return None
         steps_timed = self.steps_timed
@@ -218,11 +231,17 @@ class DistillStep(_Base):
                 self.full_head_ms = (time.perf_counter() - t0) / 5 * 1e3
             finally:
                 del os.environ["DBEV_TEACHER_FULL_HEAD"]
-        rt, rb = self._fam(roof)
-        ach = rb / rt / 1e9
+        rt, rf = self._fam(roof)                    # seconds, Winograd-domain FLOPs (the log's work field) of the timed launches
+        ach = rf / rt / 1e12
         other = {}
-        for k, recs in sorted(fam.items()):         # per KERNEL: bytes and time summed over the launches of the extra steps
+        for k, recs in sorted(fam.items()):         # per KERNEL: work and time summed over the launches of the extra steps
             kt, kb = self._fam(recs)
+            if k.startswith("wino"):                # MFMA-bound kernels: the work field holds FLOPs
+                other[k] = {"launches_per_step": len(recs) / n_extra, "ms_per_step": kt * 1e3 / n_extra,
+                            "winograd_TFLOP_per_step": kb / 1e12 / n_extra, "achieved_TFLOPs": kb / kt / 1e12,
+                            "frac_of_fp32_mfma_peak": kb / kt / 1e12 / MFMA_F32_PEAK_TF,
+                            "direct_conv_equivalent_TFLOPs": 2.25 * kb / kt / 1e12}
+                continue
             other[k] = {"launches_per_step": len(recs) / n_extra, "ms_per_step": kt * 1e3 / n_extra,
                         "algorithmic_GB_per_step": kb / 1e9 / n_extra, "achieved_GBps": kb / kt / 1e9,
                         "frac": kb / kt / 1e9 / HBM_PEAK_GBS}
@@ -237,7 +256,7 @@ class DistillStep(_Base):
             a = other["dbev_adapt_mse_forward"]
             flop = 2.0 * self.B * 128 * 128 * 256 * 384
             a["tflops"] = flop / (a["avg_us"] * 1e-6) / 1e12
-            a["frac_of_fp32_mfma_peak"] = a["tflops"] / 157.3
+            a["frac_of_fp32_mfma_peak"] = a["tflops"] / MFMA_F32_PEAK_TF
             a["algorithmic_bytes_per_launch"] = 4 * self.B * 128 * 128 * (256 + 384 + 384)
         # canvas: one launch per entry call; algorithmic bytes M(4C+16) + 4*C*512^2*B
         if "dbev_pillars_canvas" in other:
@@ -246,20 +265,27 @@ class DistillStep(_Base):
             c["algorithmic_bytes_per_launch"] = alg
             c["achieved_GBps"] = alg / (c["avg_us"] * 1e-6) / 1e9
             c["frac"] = c["achieved_GBps"] / HBM_PEAK_GBS
-        return {"bound": "hbm",
-                "kernel": "bn_apply<true,true> (apply pass of the fused training BatchNorm + residual add + ReLU of the ResNet "
-                          "bottlenecks / BEV-encoder blocks: reads x and the identity branch, writes y; csrc/bn_act.hip) -- the "
-                          "hand-written kernel with the largest share of the step; one event pair per launch in the timed region",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                # separate --pmc passes of this kernel at its largest shape (profiles/r02_pmc_*.txt, tools/pmc_target.py)
-                "traffic": rb / len(roof) * PMC_TRAFFIC["bn_apply_res_ratio"], "traffic_source": PMC_TRAFFIC["source"],
-                "avg_launch_us": rt / len(roof) * 1e6, "launches": len(roof), "launches_per_step": len(roof) / max(steps_timed, 1),
-                "algorithmic_bytes_per_launch": rb / len(roof), "ms_per_step": rt * 1e3 / max(steps_timed, 1),
+        nl = len(roof)
+        alg_bytes = wc["bytes"] / max(wc["launches"], 1)
+        return {"bound": "mfma",
+                "kernel": "wino_fwd (3x3 stride-1 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: forward and data "
+                          "gradient of the ResNet / BEV-encoder / head / SECOND 3x3 layers; csrc/wino.hip) -- the hand-written kernel "
+                          "with the largest share of the step; one event pair per launch in the timed region",
+                "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
+                "flops_note": "achieved counts the Winograd-domain products the algorithm needs (2 x 16 per 2x2 output tile and "
+                              "channel pair); the direct convolution it replaces needs 2.25 x as many",
+                "direct_conv_equivalent_TFLOPs": 2.25 * ach,
+                # separate --pmc passes of this kernel (profiles/r04_pmc_*.txt): measured HBM bytes / algorithmic bytes of the launch
+                "traffic": alg_bytes * PMC_TRAFFIC["wino_fwd_ratio"], "traffic_source": PMC_TRAFFIC["wino_source"],
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": rf / nl,
+                "avg_launch_us": rt / nl * 1e6, "launches": nl, "launches_per_step": nl / max(steps_timed, 1),
+                "ms_per_step": rt * 1e3 / max(steps_timed, 1),
+                "hbm_GBps_of_the_launches": alg_bytes * nl / rt / 1e9,
                 "bn_family": {"ms_per_step": bn_t, "algorithmic_GB_per_step": bn_b,
                               "achieved_GBps": bn_b / (bn_t * 1e-3) if bn_t else None,
                               "frac": bn_b / (bn_t * 1e-3) / HBM_PEAK_GBS if bn_t else None},
-                "other_hot_kernels_note": "per-kernel rows (bn_*): the library's kernel event log; dbev_* rows: HIP-event "
-                "brackets of whole ABI entry points; both over %d extra steps run AFTER the timed region" % n_extra,
+                "other_hot_kernels_note": "per-kernel rows (bn_*, wino_*, c1x1_fwd): the library's kernel event log; dbev_* rows: "
+                "HIP-event brackets of whole ABI entry points; both over %d extra steps run AFTER the timed region" % n_extra,
                 "other_hot_kernels": other}
 
     def cpu_baseline(self):

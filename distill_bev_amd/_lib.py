@@ -236,7 +236,7 @@ def call(name, *args, alg_bytes=0):
 
 KERNEL_IDS = {"bn_stats": 1, "bn_finalize": 2, "bn_apply": 3, "bn_apply_res": 4, "bn_bwd_reduce": 5, "bn_bwd_reduce_y": 6,
               "bn_bwd_finalize": 7, "bn_bwd_dx": 8, "bn_bwd_dx_res": 9, "sp_conv_fwd": 10, "msda_fwd": 11, "msda_bwd_sample": 12,
-              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15}        # DBEV_K_* of include/dbev_hip.h
+              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15, "wino_fwd": 16, "wino_wgrad": 17}        # DBEV_K_* of include/dbev_hip.h
 
 
 def kernel_timing(which):

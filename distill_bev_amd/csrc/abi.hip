@@ -84,6 +84,8 @@ extern "C" const char* dbev_kernel_name(int kid) {
     case DBEV_K_MSDA_GV_GATHER: return "msda_gv_gather";
     case DBEV_K_ADAPT_MSE_FWD: return "adapt_mse_fwd";
     case DBEV_K_CONV1X1_FWD: return "c1x1_fwd";
+    case DBEV_K_WINO_FWD: return "wino_fwd";
+    case DBEV_K_WINO_WGRAD: return "wino_wgrad";
     default: return "?";
   }
 }

@@ -783,8 +783,9 @@ bool wino_wg_plan(int N, int H, int W, int C, int Co, WinoWgPlan* p) {
   if (nsb > 0x3fffffffLL) return false;
   p->nsb = static_cast<int>(nsb);
   p->nblk = (C / 64) * (Co / 64);
-  // shares of the tile range: ~2 workgroups per CU in flight over the launch (one resident per CU), never more shares than stages
-  long long ns = (2LL * DBEV_NUM_CU) / p->nblk;            // rounded DOWN: 2 full rounds of the 256 CUs, never a sliver of a third
+  // shares of the tile range: ONE round of the 256 CUs (rounded down: never a sliver of a second round); every share costs a
+  // 16 x Cin x Cout partial written and read back
+  long long ns = DBEV_NUM_CU / p->nblk;
   if (ns > nsb) ns = nsb;
   if (ns < 1) ns = 1;
   p->per = static_cast<int>((nsb + ns - 1) / ns);
@@ -842,6 +843,9 @@ extern "C" int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packe
   WinoPlan p;
   if (!wino_plan(N, H, W, Cin, Cout, &p) || x_nhwc == nullptr || packed == nullptr || y_nhwc == nullptr) return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
+  // the kernel log's "bytes" field carries the launch's algorithmic FLOPs here: the Winograd-domain products, 2 * 16 per tile and
+  // channel pair (the direct convolution's 2 * 36 per tile are what it replaces)
+  DbevKt kt(DBEV_K_WINO_FWD, 32LL * N * (H / 2) * (W / 2) * Cin * Cout, s);
 #define WN_GO(BHV, BWV, ST)                                                                                                       \
   hipLaunchKernelGGL((wino_fwd<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
                      Cin, Cout, p.ntb, wino_dbg())
@@ -867,6 +871,7 @@ extern "C" int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const floa
     return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   float* part = static_cast<float*>(workspace);
+  DbevKt kt(DBEV_K_WINO_WGRAD, 32LL * N * (H / 2) * (W / 2) * Cin * Cout, s);      // whole entry (GEMMs + share sum + G^T . G)
   if (p.v2)
     hipLaunchKernelGGL(wino_wgrad2, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
                        p.nsplit);

@@ -74,11 +74,18 @@ def stats_rows(x_shape, Cout):
     return int(L.call("dbev_wino_conv3x3_stats_rows", N, H, W, C, Cout))
 
 
+COUNTERS = {"on": False, "launches": 0, "flops": 0, "bytes": 0}      # bench.py: algorithmic work of the forward / data-gradient launches
+
+
 def conv_packed(x, packed, Cout, bias=None, stats=False):
     """one launch of the convolution kernel: x [N, C, H, W] channels-last, packed filters for C -> Cout.
     -> y (channels-last) or (y, partial statistics rows f32[rows, 2, Cout]) with stats=True"""
     dev = L.require_cuda(x, packed, bias)
     N, C, H, W = x.shape
+    if COUNTERS["on"]:
+        COUNTERS["launches"] += 1
+        COUNTERS["flops"] += 32 * N * (H // 2) * (W // 2) * C * Cout              # Winograd-domain products (direct: x 2.25)
+        COUNTERS["bytes"] += 4 * (N * H * W * (C + Cout) + packed.numel())         # x read once, y written once, packed filters
     y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     part = torch.empty((stats_rows(x.shape, Cout), 2, Cout), dtype=torch.float32, device=dev) if stats else None
     with torch.cuda.device(dev):

@@ -86,3 +86,55 @@ def test_filter_pack_is_the_winograd_transform_of_each_filter():
         j = 64 * jb + 32 * ni + (lane & 31)
         want = U.numpy()[j, k, p]
         assert np.abs(packed.numpy() - want).max() <= 1e-6
+
+
+@pytest.mark.parametrize("block", ["basic", "bottleneck"])
+def test_residual_blocks_on_the_winograd_kernels_match_the_stock_convolutions(block, monkeypatch):
+    """use_wino_convs re-classes the 3x3 convolutions of a residual block (res_block.py:11-230); the block then runs the Winograd
+    forward with the norm's statistics from its epilogue, the Winograd data gradient and weight gradient.  Against the same block on
+    the library's convolutions (same weights, training mode): output, running statistics, input and parameter gradients."""
+    import copy
+    from distill_bev_amd import nets, wino
+    monkeypatch.setattr(wino, "_MIN_WG", 0)                       # small test maps: take the kernels whatever the grid size
+    torch.manual_seed(11)
+    if block == "basic":
+        ref = nets.BasicBlock(64, 64)
+        x = torch.randn(2, 64, 16, 24)
+    else:
+        ds = torch.nn.Sequential(torch.nn.Conv2d(128, 256, 1, bias=False), torch.nn.BatchNorm2d(256))
+        ref = nets.Bottleneck(128, 64, downsample=ds)
+        x = torch.randn(2, 128, 12, 16)
+    ref = ref.to(DEV).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    new = copy.deepcopy(ref)
+    assert wino.use_wino_convs(new) == (2 if block == "basic" else 1)
+    assert wino.use_wino_convs(new) == 0                          # idempotent
+    assert list(new.state_dict()) == list(ref.state_dict())
+    x = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    g = torch.randn_like(x if block == "basic" else torch.empty(2, 256, 12, 16, device=DEV)).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for m, flag in ((ref, "0"), (new, "1")):
+        monkeypatch.setenv("DBEV_WINO", flag)
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        grads = torch.autograd.grad(y, [xi] + list(m.parameters()), g)
+        outs.append((y.detach(), grads, [b.clone() for b in m.buffers()]))
+    (y0, g0, b0), (y1, g1, b1) = outs
+    scale = float(y0.abs().max())
+    assert float((y0 - y1).abs().max()) <= 2e-5 * scale
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()), (a.shape, float((a - b).abs().max()) / float(a.abs().max()))
+    for a, b in zip(b0, b1):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6)
+
+
+def test_small_grids_stay_on_the_library_kernel():
+    """a layer with too few workgroups for one-workgroup-per-CU kernels is left to the library (wino.worthwhile)"""
+    from distill_bev_amd import wino
+    conv = wino.WinoConv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(1, 64, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
+    assert wino.eligible(x, conv.weight) and not wino.worthwhile(x, 64)
+    assert torch.allclose(conv(x), F.conv2d(x, conv.weight, None, 1, 1), atol=1e-5)

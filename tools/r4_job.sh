@@ -1,11 +1,13 @@
 mkdir -p gpurun_out/r4
-cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-: > $R/gpurun_out/r4/wg_trace.txt
-for sh in "48 256 256 16 44" "8 512 512 64 64" "8 640 512 64 64" "8 64 64 128 128"; do
-  tag=$(echo $sh | tr ' ' '_')
-  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r4/kt_$tag -- python $R/tools/kbench_wino_one.py $sh 10 > /dev/null 2>&1
-  echo "### $sh" >> $R/gpurun_out/r4/wg_trace.txt
-  (cd $R; python tools/rocpd_summary.py $(ls gpurun_out/r4/kt_$tag/*/*.db | head -1) 12 | cut -c1-60,110-160 >> gpurun_out/r4/wg_trace.txt; rm -rf gpurun_out/r4/kt_$tag)
+(timeout 600 python -m pytest tests/test_gpu_wino.py -x -q 2>&1 | tail -8) > gpurun_out/r4/wino_test.log
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $R/gpurun_out/r4/pmc_$c -- python $R/tools/kbench_wino_one.py 48 256 256 16 44 3 > /dev/null 2>&1
+  (cd $R; python tools/pmc_summary.py $(ls gpurun_out/r4/pmc_$c/*/*.db | head -1) wino > gpurun_out/r4/pmc_wino_$c.txt 2>&1; rm -rf gpurun_out/r4/pmc_$c)
+  rocprofv3 --pmc $c -d $R/gpurun_out/r4/pmc2_$c -- python $R/tools/kbench_wino_one.py 8 512 256 128 128 3 > /dev/null 2>&1
+  (cd $R; python tools/pmc_summary.py $(ls gpurun_out/r4/pmc2_$c/*/*.db | head -1) wino > gpurun_out/r4/pmc_wino2_$c.txt 2>&1; rm -rf gpurun_out/r4/pmc2_$c)
 done
-cat $R/gpurun_out/r4/wg_trace.txt
+cd $R
+(python bench.py --steps 10 --warmup 3 2>&1 | tail -1) > gpurun_out/r4/bench_line_a.json
+cat gpurun_out/r4/wino_test.log; cat gpurun_out/r4/pmc_wino*_*.txt | cut -c1-60,88-140; cut -c1-2500 gpurun_out/r4/bench_line_a.json
