@@ -345,6 +345,10 @@ class DistillStep(_Base):
                 # the frozen teacher's head runs the heat-map branches only -- the one output the step reads (add_fp_as_fg);
                 # DBEV_TEACHER_FULL_HEAD=1 runs all 36 branch stacks as the reference does (same losses, +4.5 ms)
                 "teacher_head_branches": "all" if os.environ.get("DBEV_TEACHER_FULL_HEAD") == "1" else "heatmap (the only ones read)",
+                "conv3x3": "Winograd F(2x2,3x3) on fp32 MFMA (csrc/wino.hip): %d modules re-classed, forward + data + weight gradient; "
+                           "layers under %d workgroups and all other convolutions: MIOpen" % (
+                               getattr(self.trainer.detector, "wino_convs", 0), __import__("distill_bev_amd.wino", fromlist=["x"])._MIN_WG),
+                "batched_head_branches": getattr(self.trainer.detector, "batched_branches", 0),
                 "ms_per_step_full_teacher_head": getattr(self, "full_head_ms", None),
                 "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py"}
 

@@ -90,7 +90,7 @@ def _branch_ok(seq):
     if not (isinstance(cm, ConvModule) and cm.with_norm and isinstance(cm.norm, BA.BatchNormAct2d) and isinstance(cm.activate, nn.Identity)):
         return False
     c = cm.conv
-    if not (type(c) is nn.Conv2d and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
+    if not (type(c) in (nn.Conv2d, W3.WinoConv2d) and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
             and c.groups == 1 and c.bias is None and c.padding_mode == "zeros"):
         return False
     bn = cm.norm

@@ -49,6 +49,10 @@ def test_full_size_forward_finite_and_stable_then_one_optimizer_step(full):
     # no fused op of the bench configuration took the stock torch path (a layout regression would show up here, not as a slower bench)
     assert L.fallback_counts()["total"] == 0, L.fallback_counts()
     assert all(bool(torch.isfinite(p).all()) for p in tr.params[:8])
+    # the module rewiring of the bench configuration is complete: every CenterHead branch of the student evaluated in the batched
+    # groups (round 4: re-classing the 3x3 convolutions first silently disabled them), 3x3 convolutions on the Winograd kernels
+    assert tr.detector.batched_branches >= 36, tr.detector.batched_branches      # (72: the teacher's head is planned as well)
+    assert tr.detector.wino_convs >= 60, tr.detector.wino_convs
 
 
 def test_full_size_hand_written_ops_are_bit_reproducible(full):

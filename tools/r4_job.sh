@@ -1,13 +1,4 @@
 mkdir -p gpurun_out/r4
-R=/root/repo
-(timeout 600 python -m pytest tests/test_gpu_wino.py -x -q 2>&1 | tail -8) > gpurun_out/r4/wino_test.log
-cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $R/gpurun_out/r4/pmc_$c -- python $R/tools/kbench_wino_one.py 48 256 256 16 44 3 > /dev/null 2>&1
-  (cd $R; python tools/pmc_summary.py $(ls gpurun_out/r4/pmc_$c/*/*.db | head -1) wino > gpurun_out/r4/pmc_wino_$c.txt 2>&1; rm -rf gpurun_out/r4/pmc_$c)
-  rocprofv3 --pmc $c -d $R/gpurun_out/r4/pmc2_$c -- python $R/tools/kbench_wino_one.py 8 512 256 128 128 3 > /dev/null 2>&1
-  (cd $R; python tools/pmc_summary.py $(ls gpurun_out/r4/pmc2_$c/*/*.db | head -1) wino > gpurun_out/r4/pmc_wino2_$c.txt 2>&1; rm -rf gpurun_out/r4/pmc2_$c)
-done
-cd $R
-(python bench.py --steps 10 --warmup 3 2>&1 | tail -1) > gpurun_out/r4/bench_line_a.json
-cat gpurun_out/r4/wino_test.log; cat gpurun_out/r4/pmc_wino*_*.txt | cut -c1-60,88-140; cut -c1-2500 gpurun_out/r4/bench_line_a.json
+(python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1) > gpurun_out/r4/bench_line_b.json
+(timeout 900 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_head_batch.py -x -q 2>&1 | tail -5) > gpurun_out/r4/fs_test.log
+cut -c1-1900 gpurun_out/r4/bench_line_b.json; cat gpurun_out/r4/fs_test.log
