@@ -105,6 +105,7 @@ _SIGNATURES = {
     "dbev_wino_filter_floats": [_i, _i],
     "dbev_wino_filter_pack": [_p, _ll, _ll, _ll, _ll, _i, _i, _i, _p, _p],
     "dbev_wino_conv3x3_stats_rows": [_i, _i, _i, _i, _i],
+    "dbev_wino_conv3x3_forward_kernel": [_i, _i, _i, _i, _i],
     "dbev_wino_conv3x3_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dbev_wino_conv3x3_backward_weight_workspace_bytes": [_i, _i, _i, _i, _i],
     "dbev_wino_conv3x3_backward_weight": [_p, _p, _p, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _p, _sz, _p],
@@ -157,7 +158,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
-_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows", "dbev_wino_conv3x3_stats_rows"}
+_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows", "dbev_wino_conv3x3_stats_rows", "dbev_wino_conv3x3_forward_kernel"}
 
 
 class DbevHipError(RuntimeError):

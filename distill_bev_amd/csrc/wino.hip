@@ -34,6 +34,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int WN_KP = 16;                       // channels per patch stage (two k groups of 8)
 constexpr int WN_PSTR = 20;                     // floats per patch pixel in LDS (16 + 4: keeps the b128 accesses aligned)
 constexpr int WN_UCHUNK = 16 * 2 * 64 * 4;      // floats of one (channel block, k group) of packed filters = 32 KB
+constexpr int W3_UCHUNK = 16 * 2 * 64 * 2;      // floats of one (channel block, k group of 4) of packed filters = 16 KB
+constexpr int W3_VBUF = 16 * 32 * 4;            // floats of one transformed-input buffer of wino_fwd3 = 8 KB
 
 // ---- filter transform + packing -------------------------------------------------------------------------------------------------
 // weight element (co, c, a, b) at co*so + c*sc + a*sa + b*sb (any strides: OIHW or channels-last).
@@ -319,6 +321,269 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
     if (tid < 128) {
       const int which = tid >> 6, c = tid & 63;
       partial[(static_cast<size_t>(tb) * 2 + which) * Co + 64 * cb + c] = red[(which * 2 + 0) * 64 + c] + red[(which * 2 + 1) * 64 + c];
+    }
+  }
+}
+
+// ---- the convolution, third version: two workgroups per CU ------------------------------------------------------------------------
+// wino_fwd keeps 256 accumulators per lane: one wave per SIMD, one workgroup per CU -- whatever a workgroup does besides MFMAs (the
+// barrier of every k group and the restart behind it: 10 % of its time; prologue, output transform and stores: ~10 us per workgroup;
+// the dispatcher's turnover between workgroups: 11 % of a launch; the last, partly filled round) leaves the matrix pipe idle.  Here a
+// wave keeps 8 of the 16 positions (rows 2 ph, 2 ph + 1; 128 accumulators) of 32 tiles x 32 channels, a workgroup (4 waves: 2 channel
+// halves x 2 position halves) owns 32 tiles x 64 channels with 57 KB of LDS, and TWO workgroups share a CU: each SIMD holds two waves
+// of different workgroups, and one's bubbles are the other's matrix time.  Per k group of 4 channels: 16 MFMAs per wave, the transform
+// of the next group's 32 x 4 patch values as 256 tasks (tile, channel pair, V row: 8 ds_read_b64, 8 packed VALU, 4 ds_write_b64), the
+// 16 KB of packed filters and the 4-channel patch stage by LDS-DMA.  The output transform needs both position halves: the ph = 1 wave
+// hands its partial 2x2 outputs to its ph = 0 partner through LDS.
+// ---- filter transform + packing for wino_fwd3 ---------------------------------------------------------------------------------------
+// weight element (co, c, a, b) at co*so + c*sc + a*sa + b*sb (any strides: OIHW or channels-last).
+// mode 0 (forward):        reduction index k = c,  output index j = co, taps g[a][b] = w[co][c][a][b]
+// mode 1 (data gradient):  k = co, j = c, taps g[a][b] = w[co][c][2-a][2-b]
+// U[((jb * (K/4) + kg) * 16 + p) * 2 + ni][lane][e] = (G g G^T)[p] for k = 4 kg + 2 (lane >> 5) + e, j = 64 jb + 32 ni + (lane & 31):
+// the B operand of position p, channel half ni, for two MFMA steps of a lane, is one ds_read_b64 of an image that LDS-DMA copies linearly
+
+__global__ __launch_bounds__(256) void wino_filter_pack3(const float* __restrict__ w, long long so, long long sc, long long sa,
+                                                         long long sb, int K, int J, int mode, float* __restrict__ U) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const int nkg = K / 4;
+  const long long total = static_cast<long long>(J / 64) * nkg * 256;
+  if (idx >= total) return;
+  const int e = idx & 1, lane = (idx >> 1) & 63, ni = (idx >> 7) & 1;
+  const long long rest = idx >> 8;
+  const int kg = static_cast<int>(rest % nkg), jb = static_cast<int>(rest / nkg);
+  const int k = 4 * kg + 2 * (lane >> 5) + e, j = 64 * jb + 32 * ni + (lane & 31);
+  const int co = mode ? k : j, c = mode ? j : k;
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int aa = mode ? 2 - a : a, bb = mode ? 2 - b : b;
+      g[a][b] = w[co * so + c * sc + aa * sa + bb * sb];
+    }
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * ((g[0][b] + g[2][b]) + g[1][b]);
+    t[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
+    t[3][b] = g[2][b];
+  }
+  float* out = U + ((static_cast<long long>(jb) * nkg + kg) * 16) * 256 + ni * 128 + lane * 2 + e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u0 = t[i][0], u1 = 0.5f * ((t[i][0] + t[i][2]) + t[i][1]), u2 = 0.5f * ((t[i][0] + t[i][2]) - t[i][1]), u3 = t[i][2];
+    out[(4 * i + 0) * 256] = u0;
+    out[(4 * i + 1) * 256] = u1;
+    out[(4 * i + 2) * 256] = u2;
+    out[(4 * i + 3) * 256] = u3;
+  }
+}
+
+__device__ __forceinline__ floatx2 pk_fma(floatx2 a, floatx2 b, floatx2 c) {       // a * b + c
+  floatx2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+template <int BH, int BW, bool STATS>
+__global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X, const float* __restrict__ U, const float* __restrict__ bias,
+                                                    float* __restrict__ Y, float* __restrict__ partial, int N, int H, int W, int C,
+                                                    int Co, int ntb, int dbg) {
+  static_assert(BH * BW == 32, "32 tiles per workgroup");
+  constexpr int PW = 2 * BW + 2, PH = 2 * BH + 2, NPIX = PW * PH;
+  constexpr int NPC = (NPIX + 63) / 64;                    // patch DMA pieces: 64 pixels x 16 bytes (4 channels) = 1 KB
+  constexpr int PBUF = NPC * 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * PBUF + 2 * W3_VBUF + 2 * W3_UCHUNK];
+  float* sP = smem;
+  float* sV = smem + 2 * PBUF;
+  float* sU = sV + 2 * W3_VBUF;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ni = w & 1, ph = w >> 1, half = lane >> 5, l31 = lane & 31;
+  const int ncb = Co / 64;
+  const int L = xcd_block();
+  const int cb = L % ncb, tb = L / ncb;
+  if (tb >= ntb) return;
+  const int TH = H >> 1, TW = W >> 1;
+  const int NBW = (TW + BW - 1) / BW, NBH = (TH + BH - 1) / BH;
+  const int bw = tb % NBW, bh = (tb / NBW) % NBH, n = tb / (NBW * NBH);
+  const int th0 = bh * BH, tw0 = bw * BW;
+  const int nkg = C / 4;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+
+  // patch DMA: piece j = pixels 64 j .. 64 j + 63, lane = pixel; wave w issues piece w (w < NPC).  Masked-out lanes (outside the
+  // image / past the patch) leave the zeros written below in their LDS slots.
+  bool pok;
+  unsigned pvoff;
+  {
+    const int pix = 64 * wu + lane;
+    const int pr = pix / PW, pc = pix - pr * PW;
+    const int h = 2 * th0 - 1 + pr, x = 2 * tw0 - 1 + pc;
+    pok = wu < NPC && pix < NPIX && h >= 0 && h < H && x >= 0 && x < W;
+    pvoff = pok ? static_cast<unsigned>(((h * W + x) * C) * 4) : 0u;
+  }
+  const unsigned long long ximg = reinterpret_cast<unsigned long long>(X + static_cast<size_t>(n) * H * W * C);
+  const unsigned long long ucb = reinterpret_cast<unsigned long long>(U + static_cast<size_t>(cb) * nkg * W3_UCHUNK);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_ptr_t)smem)));
+  const unsigned uvoff = lane * 16;
+#define W3_DMA(voff_, sbase_, ldsaddr_)                                                                              \
+  do {                                                                                                               \
+    unsigned keep_;                                                                                                  \
+    const unsigned m0v_ = __builtin_amdgcn_readfirstlane(ldsaddr_);                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"  \
+                 : "=&s"(keep_) : "v"(voff_), "s"(m0v_), "s"(sbase_) : "memory");                                    \
+  } while (0)
+#define W3_DMA_PATCH(st_, buf_)                                                                                      \
+  do {                                                                                                               \
+    if (pok) {                                                                                                       \
+      const unsigned long long sb_ = ximg + static_cast<unsigned long long>(st_) * 16ull;                            \
+      const unsigned la_ = lds0 + static_cast<unsigned>(((buf_) * PBUF + wu * 256) * 4);                             \
+      W3_DMA(pvoff, sb_, la_);                                                                                       \
+    }                                                                                                                \
+  } while (0)
+  // piece 4 w + i_ of the packed filters of k group kg_ -> sU[buf_]
+#define W3_DMA_U(i_, kg_, buf_)                                                                                      \
+  do {                                                                                                               \
+    const unsigned long long sb_ = ucb + (static_cast<unsigned long long>(kg_) * W3_UCHUNK + (4 * wu + (i_)) * 256) * 4ull; \
+    const unsigned la_ = lds0 + static_cast<unsigned>((2 * PBUF + 2 * W3_VBUF + (buf_) * W3_UCHUNK + (4 * wu + (i_)) * 256) * 4); \
+    W3_DMA(uvoff, sb_, la_);                                                                                         \
+  } while (0)
+
+  // transform task: tile tt = tid >> 3, channel pair kq = (tid >> 2) & 1 of the stage, V row vi = tid & 3.
+  // Row vi of B^T d = d[ra] + sg * d[rb] with (ra, rb, sg) = (0, 2, -), (1, 2, +), (2, 1, -), (1, 3, -)
+  const int tt = tid >> 3, kq = (tid >> 2) & 1, vi = tid & 3;
+  const int ttr = tt / BW, ttc = tt - ttr * BW;
+  const int ra = vi == 0 ? 0 : vi == 2 ? 2 : 1, rb = vi == 0 ? 2 : vi == 1 ? 2 : vi == 2 ? 1 : 3;
+  const float sgf = vi == 1 ? 1.f : -1.f;
+  const floatx2 sg = {sgf, sgf};
+  const int tsa = ((2 * ttr + ra) * PW + 2 * ttc) * 4 + 2 * kq, tsb = ((2 * ttr + rb) * PW + 2 * ttc) * 4 + 2 * kq;
+  const int tdst = ((4 * vi) * 32 + tt) * 4 + 2 * kq;            // V[4 vi + j][tt][2 kq ..]: j adds 32 * 4
+  // MFMA operands: A = V[p][l31][2 half ..], B = U[p][ni][lane][..], p = 8 ph + q
+  const int aoff = ((8 * ph) * 32 + l31) * 4 + 2 * half;
+  const int boff = ((8 * ph) * 2 + ni) * 128 + lane * 2;
+
+  floatx16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  floatx2 da[4], db[4], T[4];
+#define W3_TRANSFORM_READ(ps_, b_) do { da[b_] = *reinterpret_cast<const floatx2*>((ps_) + tsa + (b_) * 4); db[b_] = *reinterpret_cast<const floatx2*>((ps_) + tsb + (b_) * 4); } while (0)
+#define W3_VOUT(vd_, j_)                                                                                             \
+  *reinterpret_cast<floatx2*>((vd_) + tdst + (j_) * 128) =                                                           \
+      (j_) == 0 ? pk_sub(T[0], T[2]) : (j_) == 1 ? pk_add(T[1], T[2]) : (j_) == 2 ? pk_sub(T[2], T[1]) : pk_sub(T[1], T[3])
+
+  for (int i = tid; i < 2 * PBUF / 4; i += 256) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  W3_DMA_PATCH(0, 0);
+  W3_DMA_PATCH(nkg > 1 ? 1 : 0, 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) W3_DMA_U(i, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+#pragma unroll
+    for (int b2 = 0; b2 < 4; ++b2) W3_TRANSFORM_READ(sP, b2);
+#pragma unroll
+    for (int b2 = 0; b2 < 4; ++b2) T[b2] = pk_fma(db[b2], sg, da[b2]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W3_VOUT(sV, j);
+  }
+  __syncthreads();
+
+  const int nkg_run = (dbg & 2) ? 1 : nkg;
+  for (int kg = 0; kg < nkg_run; ++kg) {
+    const int cur = kg & 1, nxt = cur ^ 1;
+    const int kgn = min(kg + 1, nkg - 1), stn = min(kg + 2, nkg - 1);       // past the end: redundant loads nobody reads
+    const float* ps = sP + nxt * PBUF;                                     // patch stage kg + 1
+    float* vd = sV + nxt * W3_VBUF;                                        // V(kg + 1)
+    const floatx2* ap = reinterpret_cast<const floatx2*>(sV + cur * W3_VBUF + aoff);
+    const floatx2* bp = reinterpret_cast<const floatx2*>(sU + cur * W3_UCHUNK + boff);
+    floatx2 a2[2], b2v[2];
+    a2[0] = ap[0]; b2v[0] = bp[0];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int sl = 2 * q + e;
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(e ? a2[q & 1].y : a2[q & 1].x, e ? b2v[q & 1].y : b2v[q & 1].x, acc[q], 0, 0, 0);
+        if (e == 0 && q < 7) { a2[(q + 1) & 1] = ap[(q + 1) * 64]; b2v[(q + 1) & 1] = bp[(q + 1) * 128]; }
+        if (sl < 4) W3_TRANSFORM_READ(ps, sl);
+        if (sl >= 6 && sl < 10) T[sl - 6] = pk_fma(db[sl - 6], sg, da[sl - 6]);
+        if (sl >= 10 && sl < 14) W3_VOUT(vd, sl - 10);
+        if (sl >= 1 && sl < 5) W3_DMA_U(sl - 1, kgn, nxt);
+        if (sl == 5) W3_DMA_PATCH(stn, cur);                       // stage kg + 2 over stage kg (transformed during kg - 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef W3_DMA
+#undef W3_DMA_PATCH
+#undef W3_DMA_U
+#undef W3_TRANSFORM_READ
+#undef W3_VOUT
+
+  // ---- output transform.  This wave holds M[i][j] for i = 2 ph, 2 ph + 1.  Column sums of A^T M: s0[j] = m0j + m1j + m2j,
+  // s1[j] = m1j - m2j - m3j: the ph = 0 wave contributes (m0j + m1j, m1j), the ph = 1 wave (m2j, -m2j - m3j); the row transform is
+  // linear, so each wave forms its partial 2x2 outputs and the ph = 1 wave passes them to its partner through LDS.
+  const int co = 64 * cb + 32 * ni + l31;
+  float* xch = sU + ni * (16 * 4 * 64);                          // [r][4][64 lanes]: the filter buffers are idle now
+  if (ph == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s0[4], s1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[j] = acc[j][r]; s1[j] = -acc[j][r] - acc[4 + j][r]; }
+      xch[(r * 4 + 0) * 64 + lane] = (s0[0] + s0[1]) + s0[2];
+      xch[(r * 4 + 1) * 64 + lane] = (s0[1] - s0[2]) - s0[3];
+      xch[(r * 4 + 2) * 64 + lane] = (s1[0] + s1[1]) + s1[2];
+      xch[(r * 4 + 3) * 64 + lane] = (s1[1] - s1[2]) - s1[3];
+    }
+  }
+  __syncthreads();
+  float s1s = 0.f, s2s = 0.f;
+  if (ph == 0) {
+    const float bco = bias != nullptr ? bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int tr = t / BW, tc = t - tr * BW;
+      const int th = th0 + tr, tw = tw0 + tc;
+      float s0[4], s1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[j] = acc[j][r] + acc[4 + j][r]; s1[j] = acc[4 + j][r]; }
+      const float y00 = ((s0[0] + s0[1]) + s0[2]) + xch[(r * 4 + 0) * 64 + lane] + bco;
+      const float y01 = ((s0[1] - s0[2]) - s0[3]) + xch[(r * 4 + 1) * 64 + lane] + bco;
+      const float y10 = ((s1[0] + s1[1]) + s1[2]) + xch[(r * 4 + 2) * 64 + lane] + bco;
+      const float y11 = ((s1[1] - s1[2]) - s1[3]) + xch[(r * 4 + 3) * 64 + lane] + bco;
+      if (th < TH && tw < TW && !(dbg & 1)) {
+        float* yp = Y + (static_cast<size_t>(n * H + 2 * th) * W + 2 * tw) * Co + co;
+        yp[0] = y00;
+        yp[Co] = y01;
+        yp[static_cast<size_t>(W) * Co] = y10;
+        yp[static_cast<size_t>(W) * Co + Co] = y11;
+        if (STATS) {
+          s1s += (y00 + y01) + (y10 + y11);
+          s2s = fmaf(y00, y00, s2s); s2s = fmaf(y01, y01, s2s); s2s = fmaf(y10, y10, s2s); s2s = fmaf(y11, y11, s2s);
+        }
+      }
+    }
+  }
+  if (STATS) {
+    float* red = sV;                                             // [2 which][64 channels of the block]
+    s1s += __shfl_xor(s1s, 32);
+    s2s += __shfl_xor(s2s, 32);
+    if (ph == 0 && half == 0) {
+      red[0 * 64 + 32 * ni + l31] = s1s;
+      red[1 * 64 + 32 * ni + l31] = s2s;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      partial[(static_cast<size_t>(tb) * 2 + which) * Co + 64 * cb + c] = red[which * 64 + c];
     }
   }
 }
@@ -796,18 +1061,30 @@ bool wino_wg_plan(int N, int H, int W, int C, int Co, WinoWgPlan* p) {
 
 int wino_dbg() { static const int v = getenv("DBEV_WINO_DBG") ? atoi(getenv("DBEV_WINO_DBG")) : 0; return v; }
 
-struct WinoPlan { int bh, bw, ntb, ncb, grid; };
+struct WinoPlan { int bh, bw, ntb, ncb, grid, v3; };
+
+// DBEV_WINO_FWD_V = 2 / 3 forces one forward kernel (A/B runs); default 0: chosen per layer
+int wino_fwd_version() { static const int v = getenv("DBEV_WINO_FWD_V") ? atoi(getenv("DBEV_WINO_FWD_V")) : 0; return v; }
 
 bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
-  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 8) || Co <= 0 || (Co % 64)) return false;
+  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 4) || Co <= 0 || (Co % 64)) return false;
   if (static_cast<long long>(N) * H * W * (C > Co ? C : Co) >= 0x7fffffffLL) return false;      // 32-bit element offsets
   if (static_cast<long long>(H) * W * C * 4 >= 0x7fffffffLL) return false;                       // 32-bit byte offsets inside an image (LDS-DMA)
   const int TH = H / 2, TW = W / 2;
-  // tile block shape: the one that wastes fewer tile slots at the image edges
-  const long long w88 = static_cast<long long>((TH + 7) / 8) * ((TW + 7) / 8), w416 = static_cast<long long>((TH + 3) / 4) * ((TW + 15) / 16);
-  if (w416 < w88) { p->bh = 4; p->bw = 16; p->ntb = static_cast<int>(w416) * N; }
-  else { p->bh = 8; p->bw = 8; p->ntb = static_cast<int>(w88) * N; }
   p->ncb = Co / 64;
+  // 64-tile blocks of wino_fwd: 8 x 8 or 4 x 16, whichever wastes fewer tile slots at the image edges
+  const long long w88 = static_cast<long long>((TH + 7) / 8) * ((TW + 7) / 8), w416 = static_cast<long long>((TH + 3) / 4) * ((TW + 15) / 16);
+  const long long nb64 = (w416 < w88 ? w416 : w88) * N;
+  // Which kernel (measured, profiles/r04_wino_vs_miopen.txt): wino_fwd3 (two small workgroups per CU: bubbles filled, finer rounds, but
+  // the packed filters are fetched once per 32 tiles instead of 64) wins below ~1000 64-tile work items, wino_fwd above
+  const int ver = wino_fwd_version();
+  p->v3 = ver == 3 || (C % 8) != 0 || (ver != 2 && nb64 * p->ncb < 1024);
+  if (p->v3) {                                   // 32-tile blocks: 4 x 8 or 2 x 16
+    const long long w48 = static_cast<long long>((TH + 3) / 4) * ((TW + 7) / 8), w216 = static_cast<long long>((TH + 1) / 2) * ((TW + 15) / 16);
+    if (w216 < w48) { p->bh = 2; p->bw = 16; p->ntb = static_cast<int>(w216) * N; }
+    else { p->bh = 4; p->bw = 8; p->ntb = static_cast<int>(w48) * N; }
+  } else if (w416 < w88) { p->bh = 4; p->bw = 16; p->ntb = static_cast<int>(w416) * N; }
+  else { p->bh = 8; p->bw = 8; p->ntb = static_cast<int>(w88) * N; }
   const long long g = static_cast<long long>(p->ntb) * p->ncb;
   if (g > 0x3fffffffLL) return false;
   p->grid = dbev_round_xcd(static_cast<int>(g));
@@ -817,20 +1094,32 @@ bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
 }  // namespace
 
 extern "C" long long dbev_wino_filter_floats(int K, int J) {
-  if (K <= 0 || J <= 0 || (K % 8) || (J % 64)) return 0;
-  return static_cast<long long>(J / 64) * (K / 8) * WN_UCHUNK;
+  if (K <= 0 || J <= 0 || (K % 4) || (J % 64)) return 0;
+  // both forward kernels' formats, one after the other (the second only when wino_fwd can take the layer: K % 8 == 0)
+  return static_cast<long long>(J / 64) * (K / 4) * W3_UCHUNK * ((K % 8) == 0 ? 2 : 1);
 }
 
 extern "C" int dbev_wino_filter_pack(const float* weight, long long so, long long sc, long long sa, long long sb, int Cout, int Cin,
-                                     int data_gradient, float* packed, dbevStream_t stream) {
+                                     int flags, float* packed, dbevStream_t stream) {
+  const int data_gradient = flags & 1;
   const int K = data_gradient ? Cout : Cin, J = data_gradient ? Cin : Cout;
   const long long n = dbev_wino_filter_floats(K, J);
   if (n == 0 || weight == nullptr || packed == nullptr) return DBEV_EINVAL;
-  const long long threads = n / 16;
-  hipLaunchKernelGGL(wino_filter_pack, dim3(dbev_ceil_div(threads, 256)), dim3(256), 0, dbev_stream(stream), weight, so, sc, sa, sb, K,
-                     J, data_gradient ? 1 : 0, packed);
+  const long long one = 16LL * K * J;                       // floats of one format
+  const int only = (flags >> 1) & 3;                        // 0: both formats, 1: wino_fwd3's only, 2: wino_fwd's only
+  if (only != 2)
+    hipLaunchKernelGGL(wino_filter_pack3, dim3(dbev_ceil_div(one / 16, 256)), dim3(256), 0, dbev_stream(stream), weight, so, sc, sa, sb,
+                       K, J, data_gradient, packed);
+  if ((K % 8) == 0 && only != 1)
+    hipLaunchKernelGGL(wino_filter_pack, dim3(dbev_ceil_div(one / 16, 256)), dim3(256), 0, dbev_stream(stream), weight, so, sc, sa, sb, K,
+                       J, data_gradient, packed + one);
   DBEV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int dbev_wino_conv3x3_forward_kernel(int N, int H, int W, int Cin, int Cout) {
+  WinoPlan p;
+  return wino_plan(N, H, W, Cin, Cout, &p) ? (p.v3 ? 3 : 2) : 0;
 }
 
 extern "C" int dbev_wino_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout) {
@@ -849,9 +1138,19 @@ extern "C" int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packe
 #define WN_GO(BHV, BWV, ST)                                                                                                       \
   hipLaunchKernelGGL((wino_fwd<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
                      Cin, Cout, p.ntb, wino_dbg())
-  if (p.bw == 8) { if (stats_partial != nullptr) WN_GO(8, 8, true); else WN_GO(8, 8, false); }
-  else { if (stats_partial != nullptr) WN_GO(4, 16, true); else WN_GO(4, 16, false); }
+#define WN_GO3(BHV, BWV, ST)                                                                                                      \
+  hipLaunchKernelGGL((wino_fwd3<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
+                     Cin, Cout, p.ntb, wino_dbg())
+  if (p.v3) {
+    if (p.bw == 8) { if (stats_partial != nullptr) WN_GO3(4, 8, true); else WN_GO3(4, 8, false); }
+    else { if (stats_partial != nullptr) WN_GO3(2, 16, true); else WN_GO3(2, 16, false); }
+  } else {
+    packed += 16LL * Cin * Cout;                            // the second format of the packed buffer
+    if (p.bw == 8) { if (stats_partial != nullptr) WN_GO(8, 8, true); else WN_GO(8, 8, false); }
+    else { if (stats_partial != nullptr) WN_GO(4, 16, true); else WN_GO(4, 16, false); }
+  }
 #undef WN_GO
+#undef WN_GO3
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -15,11 +15,10 @@ from torch.autograd import Function
 
 from . import _lib as L
 
-# Workgroups (tile blocks x 64-channel blocks) a layer must offer before the Winograd kernel takes it: one workgroup keeps a CU busy
-# for its whole life (256 accumulators per lane = one wave per SIMD), so a layer with fewer blocks than ~2 rounds of the 256 CUs
-# is quantised badly -- measured (tools/kbench_wino.py, profiles/r04_wino_vs_miopen.txt): 64 / 128 / 384 workgroups run at 0.52 / 1.06 /
-# 0.97 x the library's kernel, >= 512 at 1.4-1.9 x.
-_MIN_WG = int(os.environ.get("DBEV_WINO_MIN_WG", "448"))
+# Work items (64-tile blocks x 64-channel blocks) a layer must offer before the Winograd kernels take it -- measured
+# (tools/kbench_wino.py, profiles/r04_wino_vs_miopen.txt): with the two-workgroups-per-CU kernel for small grids, 64 items run at 0.9 x
+# the library's kernel, 128 at 1.7 x, 384 at 1.3 x, larger layers at 1.6-2.2 x.
+_MIN_WG = int(os.environ.get("DBEV_WINO_MIN_WG", "100"))
 _WGRAD = os.environ.get("DBEV_WINO_WGRAD", "1") != "0"
 
 
@@ -37,7 +36,7 @@ def eligible(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1
         return False
     N, C, H, W = x.shape
     Co = weight.shape[0]
-    if weight.shape[1] != C or H % 2 or W % 2 or C % 16 or Co % 64 or not _nhwc(x):
+    if weight.shape[1] != C or H % 2 or W % 2 or C % 4 or Co % 64 or not _nhwc(x) or H * W * max(C, Co) * 4 >= 2 ** 31:
         return False
     return N * H * W * max(C, Co) < 2 ** 31 - 1
 
@@ -54,18 +53,25 @@ def _blocks(N, H, W):
     return N * min(-(-th // 8) * -(-tw // 8), -(-th // 4) * -(-tw // 16))
 
 
-def pack_filters(weight, data_gradient=False):
-    """G g G^T of every (co, c) filter in the kernels' consumption order (dbev_wino_filter_pack)"""
+def pack_filters(weight, data_gradient=False, for_input=None):
+    """G g G^T of every (co, c) filter in the kernels' consumption orders (dbev_wino_filter_pack).  `for_input`: shape [N, K, H, W] of
+    the tensor the packed filters will be applied to -- only the format of the forward kernel that layer gets is written (the other
+    slot of the buffer stays uninitialised); None: both formats."""
     dev = L.require_cuda(weight)
     Co, C = weight.shape[:2]
     K, J = (Co, C) if data_gradient else (C, Co)
+    flags = int(bool(data_gradient))
+    if for_input is not None:
+        N, _, H, W = for_input
+        ver = int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, K, J))
+        flags |= {3: 2, 2: 4}.get(ver, 0)
     n = int(L.call("dbev_wino_filter_floats", K, J))
     if n == 0:
         raise L.DbevHipError(f"wino: unsupported channel counts {C} -> {Co} (data_gradient={data_gradient})")
     packed = torch.empty((n,), dtype=torch.float32, device=dev)
     so, sc, sa, sb = weight.stride()
     with torch.cuda.device(dev):
-        L.call("dbev_wino_filter_pack", L.ptr(weight), so, sc, sa, sb, Co, C, int(bool(data_gradient)), L.ptr(packed), L.stream_ptr(dev))
+        L.call("dbev_wino_filter_pack", L.ptr(weight), so, sc, sa, sb, Co, C, flags, L.ptr(packed), L.stream_ptr(dev))
     return packed
 
 
@@ -85,7 +91,7 @@ def conv_packed(x, packed, Cout, bias=None, stats=False):
     if COUNTERS["on"]:
         COUNTERS["launches"] += 1
         COUNTERS["flops"] += 32 * N * (H // 2) * (W // 2) * C * Cout              # Winograd-domain products (direct: x 2.25)
-        COUNTERS["bytes"] += 4 * (N * H * W * (C + Cout) + packed.numel())         # x read once, y written once, packed filters
+        COUNTERS["bytes"] += 4 * (N * H * W * (C + Cout) + 16 * C * Cout)          # x read once, y written once, packed filters
     y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     part = torch.empty((stats_rows(x.shape, Cout), 2, Cout), dtype=torch.float32, device=dev) if stats else None
     with torch.cuda.device(dev):
@@ -98,7 +104,7 @@ class _Conv3x3Wino(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stats):
         Co = weight.shape[0]
-        out = conv_packed(x, pack_filters(weight, False), Co, bias, stats)
+        out = conv_packed(x, pack_filters(weight, False, x.shape), Co, bias, stats)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         if stats:
@@ -113,7 +119,7 @@ class _Conv3x3Wino(Function):
         if ctx.needs_input_grad[0]:
             C = weight.shape[1]
             if C % 64 == 0:
-                gx = conv_packed(gy, pack_filters(weight, True), C)
+                gx = conv_packed(gy, pack_filters(weight, True, gy.shape), C)
             else:                                          # e.g. a 16- or 32-channel input: the library's data gradient
                 gx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
@@ -177,7 +183,7 @@ class WinoConv2d(nn.Conv2d):
 
 def _wino_geometry(m):
     return (m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1
-            and m.padding_mode == "zeros" and m.in_channels % 16 == 0 and m.out_channels % 64 == 0)
+            and m.padding_mode == "zeros" and m.in_channels % 4 == 0 and m.out_channels % 64 == 0)
 
 
 def use_wino_convs(model):

@@ -726,10 +726,13 @@ int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, float* y_nhwc
  * and data gradient (the same kernel on grad_y with rotated / transposed filters).
  *   dbev_wino_filter_floats(K, J)   size of the packed transformed filters for K reduction and J output channels (0: unsupported)
  *   dbev_wino_filter_pack           weight element (co, c, a, b) at co*so + c*sc + a*sa + b*sb (element strides: OIHW or
- *                                   channels-last) -> packed = G g G^T in the kernel's consumption order; data_gradient != 0 packs the
- *                                   filters of the data gradient (K = Cout, J = Cin, taps rotated by 180 degrees)
+ *                                   channels-last) -> packed = G g G^T in the kernels' consumption orders: two formats one after the
+ *                                   other (k groups of 4 for wino_fwd3, of 8 for wino_fwd; the second only when K % 8 == 0).
+ *                                   flags bit 0: pack the filters of the data gradient (K = Cout, J = Cin, taps rotated by 180
+ *                                   degrees); bits 1-2: 0 both formats, 1 only wino_fwd3's, 2 only wino_fwd's (the caller asked
+ *                                   dbev_wino_conv3x3_forward_kernel which kernel its layer gets)
  *   dbev_wino_conv3x3_forward       x_nhwc f32[N, H, W, Cin] -> y_nhwc f32[N, H, W, Cout] (+ bias f32[Cout] or NULL); H, W even,
- *                                   Cin % 16 == 0, Cout % 64 == 0, fewer than 2^31 elements per tensor.  stats_partial (may be NULL)
+ *                                   Cin % 4 == 0, Cout % 64 == 0, fewer than 2^31 elements per tensor, H * W * Cin * 4 < 2^31.  stats_partial (may be NULL)
  *                                   f32[rows, 2, Cout], rows = dbev_wino_conv3x3_stats_rows(...): per tile block the sums of y and
  *                                   y^2 per channel (bias included), the partial-row layout of dbev_bn_act_train_forward_pre.
  *   For the data gradient call it with (x = grad_y, Cin <-> Cout swapped, the data_gradient pack).
@@ -741,7 +744,8 @@ int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, float* y_nhwc
  * ---------------------------------------------------------------------------------- */
 long long dbev_wino_filter_floats(int K, int J);
 int dbev_wino_filter_pack(const float* weight, long long so, long long sc, long long sa, long long sb, int Cout, int Cin,
-                          int data_gradient, float* packed, dbevStream_t stream);
+                          int flags, float* packed, dbevStream_t stream);
+int dbev_wino_conv3x3_forward_kernel(int N, int H, int W, int Cin, int Cout);    /* 2 | 3: the forward kernel the layer gets; 0: unsupported */
 int dbev_wino_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout);
 int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc, float* stats_partial,
                               int N, int H, int W, int Cin, int Cout, dbevStream_t stream);

@@ -29,6 +29,7 @@ SHAPES = [(2, 16, 64, 16, 16, False),      # one 8x8 tile block per image, a sin
 
 @pytest.mark.parametrize("N,C,Co,H,W,bias", SHAPES)
 def test_forward_and_statistics_vs_fp64(N, C, Co, H, W, bias):
+    """(the library picks wino_fwd3 for these small grids; tests/test_gpu_wino.py::test_both_forward_kernels covers wino_fwd)"""
     from distill_bev_amd import wino
     x, w, b = _mk(N, C, Co, H, W, 1, bias)
     assert wino.eligible(x, w)
@@ -69,7 +70,8 @@ def test_gradients_vs_fp64(N, C, Co, H, W, bias):
 
 
 def test_filter_pack_is_the_winograd_transform_of_each_filter():
-    """packed[(jb, kg, p, ni, lane, e)] = (G g G^T)[p] of filter (k, j); both modes (forward / rotated-transposed)"""
+    """packed[(jb, kg, p, ni, lane, e)] = (G g G^T)[p] of filter (k, j) in the two kernels' consumption orders; both modes
+    (forward / rotated-transposed)"""
     from distill_bev_amd import wino
     Co, C = 128, 24
     g = torch.Generator().manual_seed(5)
@@ -80,12 +82,19 @@ def test_filter_pack_is_the_winograd_transform_of_each_filter():
             continue
         K, J = wm.shape[1], wm.shape[0]
         U = torch.einsum("ia,jkab,cb->jkic", G, wm.double().cpu(), G).reshape(J, K, 16)        # [j, k, p]
-        packed = wino.pack_filters(w, mode).cpu().double().reshape(J // 64, K // 8, 16, 2, 64, 4)
+        both = wino.pack_filters(w, mode).cpu().double()
+        assert both.numel() == 16 * K * J * (2 if K % 8 == 0 else 1)
+        packed = both[:16 * K * J].reshape(J // 64, K // 4, 16, 2, 64, 2)            # the format of wino_fwd3 (k groups of 4)
         jb, kg, p, ni, lane, e = np.ix_(*[np.arange(n) for n in packed.shape])
-        k = 8 * kg + 4 * (lane >> 5) + e
+        k = 4 * kg + 2 * (lane >> 5) + e
         j = 64 * jb + 32 * ni + (lane & 31)
-        want = U.numpy()[j, k, p]
-        assert np.abs(packed.numpy() - want).max() <= 1e-6
+        assert np.abs(packed.numpy() - U.numpy()[j, k, p]).max() <= 1e-6
+        if K % 8 == 0:                                                               # then the format of wino_fwd (k groups of 8)
+            packed = both[16 * K * J:].reshape(J // 64, K // 8, 16, 2, 64, 4)
+            jb, kg, p, ni, lane, e = np.ix_(*[np.arange(n) for n in packed.shape])
+            k = 8 * kg + 4 * (lane >> 5) + e
+            j = 64 * jb + 32 * ni + (lane & 31)
+            assert np.abs(packed.numpy() - U.numpy()[j, k, p]).max() <= 1e-6
 
 
 @pytest.mark.parametrize("block", ["basic", "bottleneck"])
@@ -138,3 +147,28 @@ def test_small_grids_stay_on_the_library_kernel():
     x = torch.randn(1, 64, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
     assert wino.eligible(x, conv.weight) and not wino.worthwhile(x, 64)
     assert torch.allclose(conv(x), F.conv2d(x, conv.weight, None, 1, 1), atol=1e-5)
+
+
+def test_both_forward_kernels():
+    """DBEV_WINO_FWD_V forces one of the two forward kernels (64-tile workgroups, one per CU / 32-tile workgroups, two per CU); both
+    against fp64 on every test shape, in a subprocess each (the choice is read once per process)."""
+    import subprocess, sys, os
+    code = """
+import torch, torch.nn.functional as F
+from distill_bev_amd import wino
+dev = torch.device('cuda:0')
+for N, C, Co, H, W in [(2, 16, 64, 16, 16), (3, 64, 64, 16, 44), (2, 32, 128, 8, 64), (1, 48, 64, 6, 10), (2, 256, 256, 16, 12), (1, 64, 192, 34, 18)]:
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((N, C, H, W), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((Co, C, 3, 3), generator=g) / (3.0 * C ** 0.5)).to(dev).contiguous(memory_format=torch.channels_last)
+    y, part = wino.conv3x3_stats(x, w, None)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-5, (N, C, Co, H, W, err)
+    assert torch.allclose(part.double().sum(0)[0], y.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+print('OK')
+"""
+    for v in ("2", "3"):
+        env = dict(os.environ, DBEV_WINO_FWD_V=v)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "OK" in r.stdout, (v, r.stdout[-500:], r.stderr[-1500:])
