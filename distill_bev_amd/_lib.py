@@ -102,6 +102,10 @@ _SIGNATURES = {
     "dbev_spconv_backward_weight": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p],
     "dbev_conv1x1_stats_rows": [_ll, _i, _i],
     "dbev_conv1x1_forward": [_p, _p, _p, _p, _ll, _i, _i, _i, _p],
+    "dbev_gemm1x1_stats_rows": [_ll, _i, _i, _i],
+    "dbev_gemm1x1_forward": [_p, _p, _p, _p, _ll, _i, _i, _i, _p],
+    "dbev_gemm1x1_backward_weight_workspace_bytes": [_ll, _i, _i, _i],
+    "dbev_gemm1x1_backward_weight": [_p, _p, _p, _ll, _i, _i, _i, _p, _sz, _p],
     "dbev_wino_filter_floats": [_i, _i],
     "dbev_wino_filter_pack": [_p, _ll, _ll, _ll, _ll, _i, _i, _i, _p, _p],
     "dbev_wino_conv3x3_stats_rows": [_i, _i, _i, _i, _i],
@@ -136,6 +140,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_wino_filter_floats": ctypes.c_longlong,
+             "dbev_gemm1x1_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_wino_conv3x3_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_fallback_count": ctypes.c_longlong,
              "dbev_kernel_name": ctypes.c_char_p,
@@ -158,7 +163,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
-_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows", "dbev_wino_conv3x3_stats_rows", "dbev_wino_conv3x3_forward_kernel"}
+_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows", "dbev_wino_conv3x3_stats_rows", "dbev_wino_conv3x3_forward_kernel", "dbev_gemm1x1_stats_rows"}
 
 
 class DbevHipError(RuntimeError):
@@ -237,7 +242,7 @@ def call(name, *args, alg_bytes=0):
 
 KERNEL_IDS = {"bn_stats": 1, "bn_finalize": 2, "bn_apply": 3, "bn_apply_res": 4, "bn_bwd_reduce": 5, "bn_bwd_reduce_y": 6,
               "bn_bwd_finalize": 7, "bn_bwd_dx": 8, "bn_bwd_dx_res": 9, "sp_conv_fwd": 10, "msda_fwd": 11, "msda_bwd_sample": 12,
-              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15, "wino_fwd": 16, "wino_wgrad": 17}        # DBEV_K_* of include/dbev_hip.h
+              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15, "wino_fwd": 16, "wino_wgrad": 17, "g1_fwd": 18, "g1_wgrad": 19}        # DBEV_K_* of include/dbev_hip.h
 
 
 def kernel_timing(which):

@@ -86,6 +86,8 @@ extern "C" const char* dbev_kernel_name(int kid) {
     case DBEV_K_CONV1X1_FWD: return "c1x1_fwd";
     case DBEV_K_WINO_FWD: return "wino_fwd";
     case DBEV_K_WINO_WGRAD: return "wino_wgrad";
+    case DBEV_K_GEMM1X1_FWD: return "g1_fwd";
+    case DBEV_K_GEMM1X1_WGRAD: return "g1_wgrad";
     default: return "?";
   }
 }

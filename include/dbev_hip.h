@@ -53,7 +53,7 @@ enum {
   DBEV_K_BN_STATS = 1, DBEV_K_BN_FINALIZE, DBEV_K_BN_APPLY, DBEV_K_BN_APPLY_RES, DBEV_K_BN_BWD_REDUCE,
   DBEV_K_BN_BWD_REDUCE_Y, DBEV_K_BN_BWD_FINALIZE, DBEV_K_BN_BWD_DX, DBEV_K_BN_BWD_DX_RES, DBEV_K_SPCONV_FWD,
   DBEV_K_MSDA_FWD, DBEV_K_MSDA_BWD_SAMPLE, DBEV_K_MSDA_GV_GATHER, DBEV_K_ADAPT_MSE_FWD, DBEV_K_CONV1X1_FWD, DBEV_K_WINO_FWD, DBEV_K_WINO_WGRAD,
-  DBEV_K_COUNT
+  DBEV_K_GEMM1X1_FWD, DBEV_K_GEMM1X1_WGRAD, DBEV_K_COUNT
 };
 int dbev_kernel_timing_enable(int mask);
 int dbev_kernel_timing_read(int* kernel_id, float* ms, long long* algorithmic_bytes, int cap);
@@ -753,6 +753,24 @@ size_t dbev_wino_conv3x3_backward_weight_workspace_bytes(int N, int H, int W, in
 int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const float* grad_y_nhwc, float* grad_weight, long long so, long long sc,
                                       long long sa, long long sb, int N, int H, int W, int Cin, int Cout, void* workspace,
                                       size_t workspace_bytes, dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 1x1 convolutions as fp32-MFMA GEMMs with no VALU instruction in the main loop (csrc/gemm1x1.hip; round 4): forward, data gradient
+ * (the forward on grad_y with the transposed weight) and weight gradient of `nn.Conv2d(k=1)` -> cuDNN / MIOpen in the reference's
+ * bottlenecks and necks (mmdet3d/models/bricks/res_block.py:102-230, necks/fpn.py:10-204, necks/lss_fpn.py:10-72).
+ *   x_nhwc f32[M, x_row_stride >= Cin] (M = N*H*W pixels), weight f32[Cout, Cin], y_nhwc f32[M, Cout];
+ *   M % 128 == 0, Cin % 32 == 0, Cout % 64 == 0 (else DBEV_EINVAL: the caller keeps the library's convolution).
+ *   stats_partial (may be NULL) f32[rows, 2, Cout], rows = dbev_gemm1x1_stats_rows(...): per workgroup row the sums of y and y^2
+ *   (the partial-row layout of dbev_bn_act_train_forward_pre).
+ *   dbev_gemm1x1_backward_weight: grad_weight f32[Cout, Cin] = grad_y^T x, M % 32 == 0, Cin % 64 == 0, Cout % 64 == 0; shares of
+ *   the rows summed in a fixed order (no atomics).
+ * ---------------------------------------------------------------------------------- */
+int dbev_gemm1x1_stats_rows(long long M, int Cin, int Cout, int x_row_stride);
+int dbev_gemm1x1_forward(const float* x_nhwc, const float* weight, float* y_nhwc, float* stats_partial, long long M, int Cin,
+                         int Cout, int x_row_stride, dbevStream_t stream);
+size_t dbev_gemm1x1_backward_weight_workspace_bytes(long long M, int Cin, int Cout, int x_row_stride);
+int dbev_gemm1x1_backward_weight(const float* x_nhwc, const float* grad_y_nhwc, float* grad_weight, long long M, int Cin, int Cout,
+                                 int x_row_stride, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 #ifdef __cplusplus
 }
