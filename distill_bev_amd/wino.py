@@ -202,7 +202,7 @@ def use_wino_convs(model):
 def conv3x3_bn_ready(conv, bn, x):
     """conv -> training-mode BatchNorm2d pairs whose batch statistics the convolution's epilogue can take (bn_act(..., pre=rows))"""
     from . import bn_act as BA
-    if not (type(conv) is WinoConv2d and BA._state["enabled"] and conv.bias is None and torch.is_grad_enabled()):
+    if not (type(conv) is WinoConv2d and BA._state["enabled"] and conv.bias is None):       # (also without autograd: the detached frame)
         return False
     if not (type(bn) in BA._BN_TYPES and bn.affine and bn.training and bn.momentum is not None and bn.running_mean is not None
             and BA._channels_ok(conv.out_channels)):

@@ -24,7 +24,10 @@ SHAPES = [(2, 16, 64, 16, 16, False),      # one 8x8 tile block per image, a sin
           (2, 32, 128, 8, 64, False),       # 4 x 32 tiles: the (4,16) block shape
           (1, 48, 64, 6, 10, True),         # partial blocks both ways, three k stages
           (2, 256, 256, 16, 12, False),     # deep reduction (32 k groups)
-          (1, 64, 192, 34, 18, True)]       # odd tile counts, three channel blocks
+          (1, 64, 192, 34, 18, True),       # odd tile counts, three channel blocks
+          (1, 4, 64, 2, 2, False),          # a single tile, one k group of 4 (no 8-channel format: wino_fwd3 only)
+          (5, 12, 64, 4, 6, True),          # Cin % 8 != 0
+          (1, 20, 128, 10, 2, False)]       # one tile column
 
 
 @pytest.mark.parametrize("N,C,Co,H,W,bias", SHAPES)
