@@ -151,13 +151,17 @@ def forward(head, x):
         mods = [s[0] for _, _, s in group]
         bns = [m.norm for m in mods]
         w = torch.cat([m.conv.weight for m in mods], 0)
-        a = W3.conv3x3(x, w, None) if (W3.eligible(x, w) and W3.worthwhile(x, w.shape[0])) else F.conv2d(x, w, None, 1, 1)
+        rows = None
+        if W3.eligible(x, w) and W3.worthwhile(x, w.shape[0]):      # Winograd kernels: the group norm's statistics come out of the epilogue
+            a, rows = W3.conv3x3_stats(x, w, None)
+        else:
+            a = F.conv2d(x, w, None, 1, 1)
         gamma = torch.cat([bn.weight for bn in bns])
         beta = torch.cat([bn.bias for bn in bns])
         rm = torch.cat([bn.running_mean for bn in bns])
         rv = torch.cat([bn.running_var for bn in bns])
         nbt = torch.zeros((), dtype=torch.long, device=dev)
-        y = BA._BNActTrain.apply(a, None, gamma, beta, rm, rv, nbt, bns[0].momentum, bns[0].eps, True)
+        y = BA._BNActTrain.apply(a, None, gamma, beta, rm, rv, nbt, bns[0].momentum, bns[0].eps, True, rows)
         with torch.no_grad():
             torch._foreach_copy_([bn.running_mean for bn in bns], list(rm.split(Ch)))
             torch._foreach_copy_([bn.running_var for bn in bns], list(rv.split(Ch)))

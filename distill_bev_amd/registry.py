@@ -169,6 +169,15 @@ class ConvModule(nn.Module):
         return getattr(self, self.norm_name) if self.with_norm else None
 
     def forward(self, x):
+        if self.with_norm:
+            # a 3x3 convolution on the Winograd kernels hands the fused norm(+ReLU) behind it the batch statistics of its output
+            # (no statistics pass); decided per call from the modules' types / modes and the tensor (wino.conv3x3_bn_ready)
+            from .bn_act import BatchNormAct2d, bn_act
+            from .wino import conv3x3_bn_ready, conv3x3_stats
+            if type(self.norm) is BatchNormAct2d and conv3x3_bn_ready(self.conv, self.norm, x):
+                z, rows = conv3x3_stats(x, self.conv.weight, None)
+                x = bn_act(z, self.norm, None, True, pre=rows)
+                return self.activate(x) if self.with_activation else x
         x = self.conv(x)
         if self.with_norm:
             x = self.norm(x)
