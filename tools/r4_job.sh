@@ -1,4 +1,11 @@
 mkdir -p gpurun_out/r4
-(python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330) > gpurun_out/r4/bench_line_d.json
-(timeout 1700 python -m pytest tests -m gpu -q -x 2>&1 | tail -4) > gpurun_out/r4/gputests4.log
-cat gpurun_out/r4/bench_line_d.json; echo; cat gpurun_out/r4/gputests4.log
+R=/root/repo
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $R/gpurun_out/r4/pmc_$c -- python $R/tools/kbench_wino_one.py 48 256 256 16 44 3 > /dev/null 2>&1
+  (cd $R; python tools/pmc_summary.py $(ls gpurun_out/r4/pmc_$c/*/*.db | head -1) wino > gpurun_out/r4/pmc_wino_$c.txt 2>&1; rm -rf gpurun_out/r4/pmc_$c)
+  rocprofv3 --pmc $c -d $R/gpurun_out/r4/pmc2_$c -- python $R/tools/kbench_wino_one.py 8 512 256 128 128 3 > /dev/null 2>&1
+  (cd $R; python tools/pmc_summary.py $(ls gpurun_out/r4/pmc2_$c/*/*.db | head -1) wino > gpurun_out/r4/pmc_wino2_$c.txt 2>&1; rm -rf gpurun_out/r4/pmc2_$c)
+done
+cd $R
+cat gpurun_out/r4/pmc_wino*_*.txt | grep "wino_fwd\|wino_wgrad2" | cut -c1-40,88-140
