@@ -86,6 +86,7 @@ __device__ __forceinline__ float4 f4add(const float4& a, const float4& b) { retu
 // two fp32 additions / subtractions in ONE VALU instruction (hipcc splits a float2 expression into two v_add_f32; every VALU
 // instruction costs matrix time here, see below)
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ floatx2 pk_add(floatx2 a, floatx2 b) {
   floatx2 r;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -205,9 +206,11 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
   // row i of B^T d: d0 - d2, d1 + d2, d2 - d1, d1 - d3 (per column b)
 #define WN_TOP(i_, b_) T[i_][b_] = (i_) == 0 ? pk_sub(d[0][b_], d[2][b_]) : (i_) == 1 ? pk_add(d[1][b_], d[2][b_]) : (i_) == 2 ? pk_sub(d[2][b_], d[1][b_]) : pk_sub(d[1][b_], d[3][b_])
   // V[i][j] = (row i of B^T d) B: t0 - t2, t1 + t2, t2 - t1, t1 - t3
-#define WN_VOUT(dst_, i_, j_)                                                                                        \
-  *reinterpret_cast<floatx2*>((dst_) + (4 * (i_) + (j_)) * 512) =                                                    \
-      (j_) == 0 ? pk_sub(T[i_][0], T[i_][2]) : (j_) == 1 ? pk_add(T[i_][1], T[i_][2]) : (j_) == 2 ? pk_sub(T[i_][2], T[i_][1]) : pk_sub(T[i_][1], T[i_][3])
+#define WN_VCOL(i_, j_) \
+  ((j_) == 0 ? pk_sub(T[i_][0], T[i_][2]) : (j_) == 1 ? pk_add(T[i_][1], T[i_][2]) : (j_) == 2 ? pk_sub(T[i_][2], T[i_][1]) : pk_sub(T[i_][1], T[i_][3]))
+#define WN_VSTORE(dst_, i_, j_, v_) *reinterpret_cast<floatx2*>((dst_) + (4 * (i_) + (j_)) * 512) = (v_)
+#define WN_VOUT(dst_, i_, j_) WN_VSTORE(dst_, i_, j_, WN_VCOL(i_, j_))
+  floatx2 vo[8];
 
   // prologue: zero the patch buffers (the masked-out slots stay zero for the whole kernel), then stage 0, 1 and the first filters
   for (int i = tid; i < 2 * PBUF / 4; i += 256) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -257,9 +260,19 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
         const float b_ = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, acc[p], 0, 0, 0);
         if (e == 0 && p < 15) { an = ap[(p + 1) * 128]; bn = bp[(p + 1) * 128]; }
+        // the transform's VALU work in three groups (a lone VALU instruction between two MFMAs costs ~17 cycles of matrix time, one
+        // of a group of 8-16 ~6: profiles/r04_mfma_fillers.txt); the LDS reads / writes around them one per slot
         if (sl >= 1 && sl < 17) { const int q = sl - 1; WN_DREAD(ps, q >> 2, q & 3); }
-        if (sl >= 17 && sl < 33) { const int q = sl - 17; WN_TOP(q >> 2, q & 3); }
-        if (sl >= 33 && sl < 49) { const int q = sl - 33; WN_VOUT(vd, q >> 2, q & 3); }
+        if (sl == 20) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) WN_TOP(q >> 2, q & 3);
+        }
+        if (sl == 24 || sl == 34) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) vo[q] = WN_VCOL((sl == 24 ? 0 : 2) + (q >> 2), q & 3);
+        }
+        if (sl >= 25 && sl < 33) { const int q = sl - 25; WN_VSTORE(vd, q >> 2, q & 3, vo[q]); }
+        if (sl >= 35 && sl < 43) { const int q = sl - 35; WN_VSTORE(vd, 2 + (q >> 2), q & 3, vo[q]); }
         if (sl >= 2 && sl < 10 && !(dbg & 16)) WN_DMA_U(sl - 2, kgn, nxt);
         if (sl >= 10 && sl < 13 && !(dbg & 8)) WN_DMA_PATCH(sl - 10, stn, cur);     // stage kg + 2 over stage kg (read during kg - 1)
         __builtin_amdgcn_sched_barrier(0);
@@ -274,6 +287,8 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
 #undef WN_DREAD
 #undef WN_TOP
 #undef WN_VOUT
+#undef WN_VCOL
+#undef WN_VSTORE
 #undef WN_DMA
 #undef WN_DMA_PATCH
 #undef WN_DMA_U
@@ -470,9 +485,10 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
 
   floatx2 da[4], db[4], T[4];
 #define W3_TRANSFORM_READ(ps_, b_) do { da[b_] = *reinterpret_cast<const floatx2*>((ps_) + tsa + (b_) * 4); db[b_] = *reinterpret_cast<const floatx2*>((ps_) + tsb + (b_) * 4); } while (0)
-#define W3_VOUT(vd_, j_)                                                                                             \
-  *reinterpret_cast<floatx2*>((vd_) + tdst + (j_) * 128) =                                                           \
-      (j_) == 0 ? pk_sub(T[0], T[2]) : (j_) == 1 ? pk_add(T[1], T[2]) : (j_) == 2 ? pk_sub(T[2], T[1]) : pk_sub(T[1], T[3])
+#define W3_VCOL(j_) ((j_) == 0 ? pk_sub(T[0], T[2]) : (j_) == 1 ? pk_add(T[1], T[2]) : (j_) == 2 ? pk_sub(T[2], T[1]) : pk_sub(T[1], T[3]))
+#define W3_VSTORE(vd_, j_, v_) *reinterpret_cast<floatx2*>((vd_) + tdst + (j_) * 128) = (v_)
+#define W3_VOUT(vd_, j_) W3_VSTORE(vd_, j_, W3_VCOL(j_))
+  floatx2 vo[4];
 
   for (int i = tid; i < 2 * PBUF / 4; i += 256) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
@@ -510,8 +526,15 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(e ? a2[q & 1].y : a2[q & 1].x, e ? b2v[q & 1].y : b2v[q & 1].x, acc[q], 0, 0, 0);
         if (e == 0 && q < 7) { a2[(q + 1) & 1] = ap[(q + 1) * 64]; b2v[(q + 1) & 1] = bp[(q + 1) * 128]; }
         if (sl < 4) W3_TRANSFORM_READ(ps, sl);
-        if (sl >= 6 && sl < 10) T[sl - 6] = pk_fma(db[sl - 6], sg, da[sl - 6]);
-        if (sl >= 10 && sl < 14) W3_VOUT(vd, sl - 10);
+        if (sl == 6) {                                     // VALU work in two groups of 4, not one per slot (see wino_fwd)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) T[q] = pk_fma(db[q], sg, da[q]);
+        }
+        if (sl == 8) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) vo[q] = W3_VCOL(q);
+        }
+        if (sl >= 9 && sl < 13) W3_VSTORE(vd, sl - 9, vo[sl - 9]);
         if (sl >= 1 && sl < 5) W3_DMA_U(sl - 1, kgn, nxt);
         if (sl == 5) W3_DMA_PATCH(stn, cur);                       // stage kg + 2 over stage kg (transformed during kg - 1)
         __builtin_amdgcn_sched_barrier(0);
@@ -525,6 +548,8 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
 #undef W3_DMA_U
 #undef W3_TRANSFORM_READ
 #undef W3_VOUT
+#undef W3_VCOL
+#undef W3_VSTORE
 
   // ---- output transform.  This wave holds M[i][j] for i = 2 ph, 2 ph + 1.  Column sums of A^T M: s0[j] = m0j + m1j + m2j,
   // s1[j] = m1j - m2j - m3j: the ph = 0 wave contributes (m0j + m1j, m1j), the ph = 1 wave (m2j, -m2j - m3j); the row transform is
@@ -757,8 +782,9 @@ constexpr int W2_DPC = 2 * 2 * W2_T / 4;                 // gradient DMA pieces:
 constexpr int W2_DBUF = W2_DPC * 256;                    // floats per raw gradient buffer
 constexpr int W2_VBUF = 16 * W2_T * 64;                  // floats per transformed-input buffer
 
+template <int ABL>
 __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part,
-                                                      int N, int H, int W, int C, int Co, int nsb, int per, int nblk, int nsplit) {
+                                                      int N, int H, int W, int C, int Co, int nsb, int per, int nblk, int nsplit, int dbg) {
   __shared__ __attribute__((aligned(16))) float smem[2 * W2_PBUF + 3 * W2_DBUF + 2 * W2_VBUF];
   float* sP = smem;
   float* sD = smem + 2 * W2_PBUF;
@@ -798,13 +824,6 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
     dvoff[i] = static_cast<unsigned>(((pr * W + pc) * Co + 4 * (lane & 15)) * 4);
     dflag[i] = pc < 2 * ovl ? 1u : 0u;
   }
-#define W2_DMA(voff_, sbase_, ldsaddr_)                                                                              \
-  do {                                                                                                               \
-    unsigned keep_;                                                                                                  \
-    const unsigned m0v_ = __builtin_amdgcn_readfirstlane(ldsaddr_);                                                  \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"  \
-                 : "=&s"(keep_) : "v"(voff_), "s"(m0v_), "s"(sbase_) : "memory");                                    \
-  } while (0)
   // stage geometry (scalar): n, th, column block cbk -> bases and edge masks.  Kept as counters, advanced without divisions.
 #define W2_GEOM(n_, th_, cbk_, xb_, db_, pe_, de_)                                                                   \
   do {                                                                                                               \
@@ -819,19 +838,39 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
   do {                                                                                                               \
     if (++(cbk_) == NSW) { (cbk_) = 0; if (++(th_) == TH) { (th_) = 0; ++(n_); } }                                   \
   } while (0)
-  // patch piece i_ of the stage (xb_, pe_) -> sP[buf_]; gradient piece -> sD[buf_]
-#define W2_DMA_PATCH(i_, xb_, pe_, buf_)                                                                             \
+  // patch piece i_ of the stage (base xb_, zero-lane masks pm[] from W2_MASKS) -> sP[buf_]; gradient piece -> sD[buf_].  Branch-free and
+  // without VALU work at the issue site (a lone VALU instruction between two MFMAs costs ~17 cycles of matrix time): the lanes of
+  // mask_ are taken out of EXEC for the load and store zeros instead; the masks of all seven pieces are formed in one group per stage.
+  floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  asm volatile("" : "+v"(zero4));                         // opaque: kept in four registers instead of being re-formed at every use
+  const unsigned lanebase = lds0 + static_cast<unsigned>((w * 256 + lane * 4) * 4);
+#define W2_DMA_M(voff_, sbase_, ldsaddr_, mask_, zaddr_, zoff_)                                                      \
   do {                                                                                                               \
-    const unsigned la_ = lds0 + static_cast<unsigned>(((buf_) * W2_PBUF + (wu + 4 * (i_)) * 256) * 4);               \
-    if ((pflag[i_] & (pe_)) == 0) W2_DMA(pvoff[i_], xb_, la_);                                                       \
-    else if (!(pflag[i_] & 16u)) *reinterpret_cast<float4*>(sP + (buf_) * W2_PBUF + (wu + 4 * (i_)) * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f); \
+    unsigned keep_;                                                                                                  \
+    const unsigned m0v_ = __builtin_amdgcn_readfirstlane(ldsaddr_);                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_andn2_b64 exec, exec, %4\n\tglobal_load_lds_dwordx4 %1, %3\n\t" \
+                 "s_mov_b64 exec, %4\n\tds_write_b128 %5, %6 offset:%7\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"     \
+                 : "=&s"(keep_) : "v"(voff_), "s"(m0v_), "s"(sbase_), "s"(mask_), "v"(zaddr_), "v"(zero4), "n"(zoff_) : "memory"); \
   } while (0)
-#define W2_DMA_DY(i_, db_, de_, buf_)                                                                                \
+#define W2_MASKS(pe_, de_, pm_, dm_)                                                                                 \
+  do {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) pm_[i] = __builtin_amdgcn_ballot_w64((pflag[i] & (pe_) & 15u) != 0u); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) dm_[i] = __builtin_amdgcn_ballot_w64((dflag[i] & (de_)) != 0u);     \
+  } while (0)
+#define W2_DMA_PATCH(i_, xb_, pm_, buf_, zaddr_)                                                                     \
+  do {                                                                                                               \
+    if ((i_) < 4 || wu + 4 * (i_) < W2_PPC) {                                                                        \
+      const unsigned la_ = lds0 + static_cast<unsigned>(((buf_) * W2_PBUF + (wu + 4 * (i_)) * 256) * 4);             \
+      W2_DMA_M(pvoff[i_], xb_, la_, pm_[i_], zaddr_, (i_) * 4096);                                                   \
+    }                                                                                                                \
+  } while (0)
+#define W2_DMA_DY(i_, db_, dm_, buf_, zaddr_)                                                                        \
   do {                                                                                                               \
     const unsigned la_ = lds0 + static_cast<unsigned>((2 * W2_PBUF + (buf_) * W2_DBUF + (wu + 4 * (i_)) * 256) * 4); \
-    if ((dflag[i_] & (de_)) == 0) W2_DMA(dvoff[i_], db_, la_);                                                       \
-    else *reinterpret_cast<float4*>(sD + (buf_) * W2_DBUF + (wu + 4 * (i_)) * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f); \
+    W2_DMA_M(dvoff[i_], db_, la_, dm_[i_], zaddr_, (i_) * 4096);                                                     \
   } while (0)
+#define W2_ZP(buf_) (lanebase + static_cast<unsigned>((buf_) * W2_PBUF * 4))
+#define W2_ZD(buf_) (lanebase + static_cast<unsigned>((2 * W2_PBUF + (buf_) * W2_DBUF) * 4))
 
   // ---- transform task: channel pair cp = tid & 31, tile tl = tid >> 5 of the stage
   const int cp = tid & 31, tl = tid >> 5;
@@ -847,13 +886,16 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
   for (int p = 0; p < 16; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const unsigned long long t0c = (dbg & 256) ? __builtin_amdgcn_s_memtime() : 0ull, t0r = (dbg & 256) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   floatx2 d[4][4], T[4][4];
 #define W2_DREAD(ptr_, a_, b_) d[a_][b_] = *reinterpret_cast<const floatx2*>((ptr_) + ((a_) * W2_PW + (b_)) * 64)
 #define W2_TOP(i_, b_) T[i_][b_] = (i_) == 0 ? pk_sub(d[0][b_], d[2][b_]) : (i_) == 1 ? pk_add(d[1][b_], d[2][b_]) : (i_) == 2 ? pk_sub(d[2][b_], d[1][b_]) : pk_sub(d[1][b_], d[3][b_])
-#define W2_VOUT(dst_, i_, j_)                                                                                        \
-  *reinterpret_cast<floatx2*>((dst_) + (4 * (i_) + (j_)) * (W2_T * 64)) =                                            \
-      (j_) == 0 ? pk_sub(T[i_][0], T[i_][2]) : (j_) == 1 ? pk_add(T[i_][1], T[i_][2]) : (j_) == 2 ? pk_sub(T[i_][2], T[i_][1]) : pk_sub(T[i_][1], T[i_][3])
+#define W2_VCOL(i_, j_) \
+  ((j_) == 0 ? pk_sub(T[i_][0], T[i_][2]) : (j_) == 1 ? pk_add(T[i_][1], T[i_][2]) : (j_) == 2 ? pk_sub(T[i_][2], T[i_][1]) : pk_sub(T[i_][1], T[i_][3]))
+#define W2_VSTORE(dst_, i_, j_, v_) *reinterpret_cast<floatx2*>((dst_) + (4 * (i_) + (j_)) * (W2_T * 64)) = (v_)
+#define W2_VOUT(dst_, i_, j_) W2_VSTORE(dst_, i_, j_, W2_VCOL(i_, j_))
+  floatx2 vo[8];
   // gradient pixels of this lane's 4 tiles as two tile pairs q = 0, 1 (tiles 4 half + 2 q, + 1): y[a][b][q]
   floatx2 y[2][2][2], w1[2][2], w2[2][2];
   floatx2 z[2][4][2];                                       // rows of positions alternate between the two sets: z[row & 1][j][q]
@@ -883,17 +925,20 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
   }
   unsigned long long xb, db;
   unsigned pe, de;
+  unsigned long long pm[5], dm[2];
   W2_GEOM(n_a, th_a, cb_a, xb, db, pe, de);
+  W2_MASKS(pe, de, pm, dm);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) W2_DMA_PATCH(i, xb, pe, 0);
+  for (int i = 0; i < 5; ++i) W2_DMA_PATCH(i, xb, pm, 0, W2_ZP(0));
 #pragma unroll
-  for (int i = 0; i < 2; ++i) W2_DMA_DY(i, db, de, 0);
+  for (int i = 0; i < 2; ++i) W2_DMA_DY(i, db, dm, 0, W2_ZD(0));
   if (nst > 1) W2_ADVANCE(n_a, th_a, cb_a);
   W2_GEOM(n_a, th_a, cb_a, xb, db, pe, de);
+  W2_MASKS(pe, de, pm, dm);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) W2_DMA_PATCH(i, xb, pe, 1);
+  for (int i = 0; i < 5; ++i) W2_DMA_PATCH(i, xb, pm, 1, W2_ZP(1));
 #pragma unroll
-  for (int i = 0; i < 2; ++i) W2_DMA_DY(i, db, de, 1);
+  for (int i = 0; i < 2; ++i) W2_DMA_DY(i, db, dm, 1, W2_ZD(1));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
@@ -927,7 +972,9 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
     // fetch counters: stage k + 2 (clamped to the share's last stage: a redundant load into buffers nobody reads any more)
     if (k + 2 < nst) W2_ADVANCE(n_a, th_a, cb_a);
     W2_GEOM(n_a, th_a, cb_a, xb, db, pe, de);
+    W2_MASKS(pe, de, pm, dm);
     const int dnx = (k + 1) % 3, dft = (k + 2) % 3;
+    const unsigned zp = W2_ZP(cur), zd = W2_ZD(dft);
     const float* ps = sP + nxt * W2_PBUF + tsrc;           // raw patch of stage k + 1
     float* vd = sV + nxt * W2_VBUF + tdst;                 // V(k + 1)
     const float* ap = sV + cur * W2_VBUF + aoff;
@@ -942,28 +989,52 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
         const int sl = 4 * p + e;
         const floatx2 zq = z[(p >> 2) & 1][p & 3][e >> 1];
         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[p & 1][e], (e & 1) ? zq.y : zq.x, acc[p], 0, 0, 0);
-        if (p < 15) a4[(p + 1) & 1][e] = ap[((p + 1) * W2_T + e) * 64];
-        if (sl >= 1 && sl < 17) { const int q = sl - 1; W2_DREAD(ps, q >> 2, q & 3); }
-        if (sl >= 17 && sl < 33) { const int q = sl - 17; W2_TOP(q >> 2, q & 3); }
-        if (sl >= 33 && sl < 49) { const int q = sl - 33; W2_VOUT(vd, q >> 2, q & 3); }
+        if (p < 15 && !(ABL & 1) && (e & 1) == 0) {        // two operands per LDS instruction (ds_read2st64_b32)
+          a4[(p + 1) & 1][e] = ap[((p + 1) * W2_T + e) * 64];
+          a4[(p + 1) & 1][e + 1] = ap[((p + 1) * W2_T + e + 1) * 64];
+        }
+        // VALU work in groups (profiles/r04_mfma_fillers.txt: a lone VALU instruction between two MFMAs costs ~17 cycles of matrix
+        // time, one of a group of 8-16 costs ~6): raw reads one per slot, then all 16 row combinations at once, the column
+        // combinations 8 at a time with their LDS stores spread over the following slots
+        if (!(ABL & 2)) {
+          if (sl >= 1 && sl < 17) { const int q = sl - 1; W2_DREAD(ps, q >> 2, q & 3); }
+          if (sl == 20) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) W2_TOP(q >> 2, q & 3);
+          }
+          if (sl == 24 || sl == 34) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vo[q] = W2_VCOL((sl == 24 ? 0 : 2) + (q >> 2), q & 3);
+          }
+          if (sl >= 25 && sl < 33) { const int q = sl - 25; W2_VSTORE(vd, q >> 2, q & 3, vo[q]); }
+          if (sl >= 35 && sl < 43) { const int q = sl - 35; W2_VSTORE(vd, 2 + (q >> 2), q & 3, vo[q]); }
+        }
         // the next row of positions: rows 1..3 of this stage under rows 0..2; row 0 of the next stage, from its gradient pixels,
         // under row 3
-        if ((p & 3) == 0 && p < 12 && e < 2) { W2_ZROW(z[((p >> 2) + 1) & 1], (p >> 2) + 1, e); }
-        if (p == 12 && e == 0) { W2_YREAD(pyn); }
-        if (p == 13 && e < 2) {
+        if (!(ABL & 4)) {
+          if ((p & 3) == 0 && p < 12 && e == 0) { W2_ZROW(z[((p >> 2) + 1) & 1], (p >> 2) + 1, 0); W2_ZROW(z[((p >> 2) + 1) & 1], (p >> 2) + 1, 1); }
+          if (p == 12 && e == 0) { W2_YREAD(pyn); }
+          if (p == 13 && e == 2) {
 #pragma unroll
-          for (int b2 = 0; b2 < 2; ++b2) { w1[b2][e] = pk_add(y[0][b2][e], y[1][b2][e]); w2[b2][e] = pk_sub(y[0][b2][e], y[1][b2][e]); }
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+              for (int b2 = 0; b2 < 2; ++b2) { w1[b2][q] = pk_add(y[0][b2][q], y[1][b2][q]); w2[b2][q] = pk_sub(y[0][b2][q], y[1][b2][q]); }
+              W2_ZROW(z[0], 0, q);
+            }
+          }
         }
-        if (p == 14 && e < 2) { W2_ZROW(z[0], 0, e); }
-        if (sl >= 2 && sl < 7) W2_DMA_PATCH(sl - 2, xb, pe, cur);     // raw patch of stage k + 2 over the one transformed during k - 1
-        if (sl >= 7 && sl < 9) W2_DMA_DY(sl - 7, db, de, dft);
+        if (sl >= 2 && sl < 7 && !(dbg & 32)) W2_DMA_PATCH(sl - 2, xb, pm, cur, zp);     // raw patch of stage k + 2 over the one transformed during k - 1
+        if (sl >= 7 && sl < 9 && !(dbg & 32)) W2_DMA_DY(sl - 7, db, dm, dft, zd);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(dbg & 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(dbg & 128)) __syncthreads();
   }
-#undef W2_DMA
+#undef W2_DMA_M
+#undef W2_MASKS
+#undef W2_ZP
+#undef W2_ZD
 #undef W2_GEOM
 #undef W2_ADVANCE
 #undef W2_DMA_PATCH
@@ -971,6 +1042,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
 #undef W2_DREAD
 #undef W2_TOP
 #undef W2_VOUT
+#undef W2_VCOL
+#undef W2_VSTORE
 #undef W2_YREAD
 #undef W2_ZROW
   // accumulator register 4 q + r of position p = input channel c0 + 32 ci + 8 q + 4 half + r, output channel o0 + 32 coi + l31
@@ -981,6 +1054,11 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4*>(out + static_cast<size_t>(p) * Co * C + 8 * q) =
           make_float4(acc[p][4 * q + 0], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]);
+  if ((dbg & 256) && blk == 0 && split == nsplit - 1 && tid == 0) {     // ablation only: shader clocks / 100 MHz ticks of this workgroup
+    const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
+    unsigned* o = reinterpret_cast<unsigned*>(part + static_cast<size_t>(split) * 16 * Co * C);
+    o[0] = static_cast<unsigned>(t1c - t0c); o[1] = static_cast<unsigned>(t1r - t0r); o[2] = static_cast<unsigned>(nst);
+  }
 }
 
 // part [nsplit][16][Co][C]: the shares of every element are added in a fixed order (four interleaved chains, then pairwise) into
@@ -1075,10 +1153,12 @@ bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
   // 64-tile blocks of wino_fwd: 8 x 8 or 4 x 16, whichever wastes fewer tile slots at the image edges
   const long long w88 = static_cast<long long>((TH + 7) / 8) * ((TW + 7) / 8), w416 = static_cast<long long>((TH + 3) / 4) * ((TW + 15) / 16);
   const long long nb64 = (w416 < w88 ? w416 : w88) * N;
-  // Which kernel (measured, profiles/r04_wino_vs_miopen.txt): wino_fwd3 (two small workgroups per CU: bubbles filled, finer rounds, but
-  // the packed filters are fetched once per 32 tiles instead of 64) wins below ~1000 64-tile work items, wino_fwd above
+  // Which kernel (measured, profiles/r04_wino_vs_miopen.txt): wino_fwd (64-tile items, one per CU) is 10-17 % faster per tile once the
+  // chip is full; wino_fwd3 (32-tile items, two per CU) wins where wino_fwd would leave CUs idle: under ~200 items (64 items: 98 vs
+  // 129 us, 128: 55 vs 69), and when a second round would be at most half full (384 items: 247 vs 264 us)
   const int ver = wino_fwd_version();
-  p->v3 = ver == 3 || (C % 8) != 0 || (ver != 2 && nb64 * p->ncb < 1024);
+  const long long items = nb64 * p->ncb;
+  p->v3 = ver == 3 || (C % 8) != 0 || (ver != 2 && (items <= 192 || (items > 256 && items <= 384)));
   if (p->v3) {                                   // 32-tile blocks: 4 x 8 or 2 x 16
     const long long w48 = static_cast<long long>((TH + 3) / 4) * ((TW + 7) / 8), w216 = static_cast<long long>((TH + 1) / 2) * ((TW + 15) / 16);
     if (w216 < w48) { p->bh = 2; p->bw = 16; p->ntb = static_cast<int>(w216) * N; }
@@ -1171,10 +1251,18 @@ extern "C" int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const floa
   hipStream_t s = dbev_stream(stream);
   float* part = static_cast<float*>(workspace);
   DbevKt kt(DBEV_K_WINO_WGRAD, 32LL * N * (H / 2) * (W / 2) * Cin * Cout, s);      // whole entry (GEMMs + share sum + G^T . G)
-  if (p.v2)
-    hipLaunchKernelGGL(wino_wgrad2, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
-                       p.nsplit);
-  else
+  if (p.v2) {
+#define W2_GO(A_) hipLaunchKernelGGL(wino_wgrad2<A_>, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk, p.nsplit, wino_dbg())
+#ifdef DBEV_WINO_ABLATE                                     // dev builds: DBEV_WINO_DBG bits 9-11 drop the operand reads / the transform / Z
+    switch ((wino_dbg() >> 9) & 7) {
+      case 1: W2_GO(1); break; case 2: W2_GO(2); break; case 4: W2_GO(4); break; case 7: W2_GO(7); break; case 6: W2_GO(6); break;
+      default: W2_GO(0);
+    }
+#else
+    W2_GO(0);
+#endif
+#undef W2_GO
+  } else
     hipLaunchKernelGGL(wino_wgrad, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
                        p.nsplit);
   DBEV_LAUNCH_CHECK();

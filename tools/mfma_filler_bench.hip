@@ -86,7 +86,108 @@ void run(const char* name) {
   hipFree(out);
 }
 
+
+// Two waves per SIMD: does the VALU work of one wave hide under the MFMAs of the OTHER wave of the same SIMD?  NW waves per workgroup
+// (4: one per SIMD, 8: two per SIMD), 8 accumulators (128 registers) per lane either way, F v_pk_add_f32 after each MFMA.
+template <int F, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k2(float* __restrict__ out, int iters) {
+  const int tid = threadIdx.x;
+  floatx16 acc[8];
+  for (int p = 0; p < 8; ++p) for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  float a = 1.f + tid * 1e-6f, b = 2.f;
+  floatx2 g0 = {1.f, 2.f}, g1 = {3.f, 4.f}, g2 = {1.f, 2.f}, g3 = {3.f, 4.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      acc[s >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[s >> 2], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < F; ++i) {
+        if (i & 1) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(g0) : "v"(g1));
+        else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(g2) : "v"(g3));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float sacc = g0.x + g2.x;
+  for (int p = 0; p < 8; ++p) for (int r = 0; r < 16; ++r) sacc += acc[p][r];
+  if (sacc == 12345.678f) out[0] = sacc;
+}
+
+template <int F, int NW>
+void run2(const char* name) {
+  float* out;
+  hipMalloc(&out, 8);
+  const int iters = 600, grid = 256;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  k2<F, NW><<<grid, 64 * NW>>>(out, 10);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  k2<F, NW><<<grid, 64 * NW>>>(out, iters);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms;
+  hipEventElapsedTime(&ms, a, b);
+  const double flop = 2.0 * 32 * 32 * 2 * 32.0 * iters * NW * grid;
+  printf("%-44s F=%2d waves/SIMD=%d: %7.3f ms  %6.1f TFLOP/s\n", name, F, NW / 4, ms, flop / ms / 1e9);
+  hipFree(out);
+}
+
+// Clustering: the same number of v_pk_add_f32 per MFMA on average (F), issued as one group of F * EVERY after every EVERY-th MFMA
+// (8 independent register chains).
+template <int F, int EVERY>
+__global__ __launch_bounds__(256, 1) void k3(float* __restrict__ out, int iters) {
+  const int tid = threadIdx.x;
+  floatx16 acc[16];
+  for (int p = 0; p < 16; ++p) for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  float a = 1.f + tid * 1e-6f, b = 2.f;
+  floatx2 g[8], h = {3.f, 4.f};
+  for (int i = 0; i < 8; ++i) g[i] = floatx2{1.f * i, 2.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+      acc[s >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[s >> 2], 0, 0, 0);
+      if (s % EVERY == EVERY - 1) {
+#pragma unroll
+        for (int i = 0; i < F * EVERY; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(g[i & 7]) : "v"(h));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float sacc = 0.f;
+  for (int i = 0; i < 8; ++i) sacc += g[i].x;
+  for (int p = 0; p < 16; ++p) for (int r = 0; r < 16; ++r) sacc += acc[p][r];
+  if (sacc == 12345.678f) out[0] = sacc;
+}
+
+template <int F, int EVERY>
+void run3() {
+  float* out;
+  hipMalloc(&out, 8);
+  const int iters = 300, grid = 256;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  k3<F, EVERY><<<grid, 256>>>(out, 10);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  k3<F, EVERY><<<grid, 256>>>(out, iters);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms;
+  hipEventElapsedTime(&ms, a, b);
+  const double flop = 2.0 * 32 * 32 * 2 * 64.0 * iters * 4.0 * grid;
+  printf("k3: %d v_pk_add per MFMA on average, in groups of %3d every %2d MFMAs: %7.3f ms  %6.1f TFLOP/s\n", F, F * EVERY, EVERY, ms, flop / ms / 1e9);
+  hipFree(out);
+}
+
 int main() {
+  run3<1, 1>(); run3<1, 2>(); run3<1, 4>(); run3<1, 8>(); run3<1, 16>(); run3<1, 64>();
+  run3<2, 1>(); run3<2, 2>(); run3<2, 4>(); run3<2, 8>(); run3<2, 16>(); run3<2, 64>();
+  run2<0, 4>("k2 bare"); run2<0, 8>("k2 bare");
+  run2<1, 4>("k2 v_pk_add fillers"); run2<1, 8>("k2 v_pk_add fillers");
+  run2<2, 4>("k2 v_pk_add fillers"); run2<2, 8>("k2 v_pk_add fillers");
+  run2<4, 4>("k2 v_pk_add fillers"); run2<4, 8>("k2 v_pk_add fillers");
+  run2<8, 4>("k2 v_pk_add fillers"); run2<8, 8>("k2 v_pk_add fillers");
   run<0, 0, 0>("bare MFMAs");
   run<0, 0, 1>("bare MFMAs");
   run<2, 0, 0>("v_add_f32 fillers"); run<4, 0, 0>("v_add_f32 fillers"); run<6, 0, 0>("v_add_f32 fillers");
