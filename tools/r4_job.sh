@@ -1,14 +1,4 @@
-mkdir -p gpurun_out/r4
-R=/root/repo
-./tools/mfb_bin > gpurun_out/r4/mfma_fillers.txt 2>&1
-python tools/kbench_wino.py > gpurun_out/r4/wino_vs_miopen.txt 2>&1
-python tools/kbench_wino_v23.py > gpurun_out/r4/wino_v23.txt 2>&1
-cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $R/gpurun_out/r4/pmc_$c -- python $R/tools/kbench_wino_one.py 48 256 256 16 44 3 > /dev/null 2>&1
-  (cd $R; python tools/pmc_summary.py $(ls gpurun_out/r4/pmc_$c/*/*.db | head -1) wino > gpurun_out/r4/pmc_wino_$c.txt 2>&1; rm -rf gpurun_out/r4/pmc_$c)
-  rocprofv3 --pmc $c -d $R/gpurun_out/r4/pmc2_$c -- python $R/tools/kbench_wino_one.py 8 512 256 128 128 3 > /dev/null 2>&1
-  (cd $R; python tools/pmc_summary.py $(ls gpurun_out/r4/pmc2_$c/*/*.db | head -1) wino > gpurun_out/r4/pmc_wino2_$c.txt 2>&1; rm -rf gpurun_out/r4/pmc2_$c)
+for i in 1 2; do
+DBEV_HIP_LIB=$PWD/tools/libdbev_hip_base.so python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('base', d['ms_per_step'], d['roofline']['ms_per_step'], d['roofline']['other_hot_kernels']['c1x1_fwd']['ms_per_step'])"
+python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('new ', d['ms_per_step'], d['roofline']['ms_per_step'], d['roofline']['other_hot_kernels']['c1x1_fwd']['ms_per_step'])"
 done
-cd $R
-cat gpurun_out/r4/pmc_wino*_*.txt | grep "wino_fwd\|wino_wgrad2" | cut -c1-40,88-140
