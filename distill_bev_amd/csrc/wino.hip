@@ -29,10 +29,14 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+// Ablation switches (DBEV_WINO_DBG bits, dev builds with -DDBEV_WINO_ABLATE only: the product kernels carry no tests of them in their loops)
+#ifdef DBEV_WINO_ABLATE
+#define WN_DBG(bit_) (dbg & (bit_))
+#else
+#define WN_DBG(bit_) 0
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int WN_KP = 16;                       // channels per patch stage (two k groups of 8)
-constexpr int WN_PSTR = 20;                     // floats per patch pixel in LDS (16 + 4: keeps the b128 accesses aligned)
 constexpr int WN_UCHUNK = 16 * 2 * 64 * 4;      // floats of one (channel block, k group) of packed filters = 32 KB
 constexpr int W3_UCHUNK = 16 * 2 * 64 * 2;      // floats of one (channel block, k group of 4) of packed filters = 16 KB
 constexpr int W3_VBUF = 16 * 32 * 4;            // floats of one transformed-input buffer of wino_fwd3 = 8 KB
@@ -79,9 +83,6 @@ __global__ __launch_bounds__(256) void wino_filter_pack(const float* __restrict_
     out[(4 * i + 3) * 512] = u3;
   }
 }
-
-__device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 f4add(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // two fp32 additions / subtractions in ONE VALU instruction (hipcc splits a float2 expression into two v_add_f32; every VALU
 // instruction costs matrix time here, see below)
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
   }
   __syncthreads();
 
-  const int nkg_run = (dbg & 2) ? 1 : nkg;
+  const int nkg_run = WN_DBG(2) ? 1 : nkg;
   for (int kg = 0; kg < nkg_run; ++kg) {
     const int cur = kg & 1, nxt = cur ^ 1;
     // branch-free body: past the end the DMAs repeat the last chunk / stage into buffers nobody reads any more
@@ -273,13 +274,13 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
         }
         if (sl >= 25 && sl < 33) { const int q = sl - 25; WN_VSTORE(vd, q >> 2, q & 3, vo[q]); }
         if (sl >= 35 && sl < 43) { const int q = sl - 35; WN_VSTORE(vd, 2 + (q >> 2), q & 3, vo[q]); }
-        if (sl >= 2 && sl < 10 && !(dbg & 16)) WN_DMA_U(sl - 2, kgn, nxt);
-        if (sl >= 10 && sl < 13 && !(dbg & 8)) WN_DMA_PATCH(sl - 10, stn, cur);     // stage kg + 2 over stage kg (read during kg - 1)
+        if (sl >= 2 && sl < 10 && !WN_DBG(16)) WN_DMA_U(sl - 2, kgn, nxt);
+        if (sl >= 10 && sl < 13 && !WN_DBG(8)) WN_DMA_PATCH(sl - 10, stn, cur);     // stage kg + 2 over stage kg (read during kg - 1)
         __builtin_amdgcn_sched_barrier(0);
       }
       av = an; bv = bn;
     }
-    if (!(dbg & 4)) {
+    if (!WN_DBG(4)) {
       WN_WAIT_VM();
       __syncthreads();
     }
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
     }
     const float y00 = (s0[0] + s0[1]) + s0[2] + bco, y01 = (s0[1] - s0[2]) - s0[3] + bco;
     const float y10 = (s1r[0] + s1r[1]) + s1r[2] + bco, y11 = (s1r[1] - s1r[2]) - s1r[3] + bco;
-    if (th < TH && tw < TW && !(dbg & 1)) {
+    if (th < TH && tw < TW && !WN_DBG(1)) {
       float* yp = Y + (static_cast<size_t>(n * H + 2 * th) * W + 2 * tw) * Co + co;
       yp[0] = y00;
       yp[Co] = y01;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
   }
   __syncthreads();
 
-  const int nkg_run = (dbg & 2) ? 1 : nkg;
+  const int nkg_run = WN_DBG(2) ? 1 : nkg;
   for (int kg = 0; kg < nkg_run; ++kg) {
     const int cur = kg & 1, nxt = cur ^ 1;
     const int kgn = min(kg + 1, nkg - 1), stn = min(kg + 2, nkg - 1);       // past the end: redundant loads nobody reads
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
       const float y01 = ((s0[1] - s0[2]) - s0[3]) + xch[(r * 4 + 1) * 64 + lane] + bco;
       const float y10 = ((s1[0] + s1[1]) + s1[2]) + xch[(r * 4 + 2) * 64 + lane] + bco;
       const float y11 = ((s1[1] - s1[2]) - s1[3]) + xch[(r * 4 + 3) * 64 + lane] + bco;
-      if (th < TH && tw < TW && !(dbg & 1)) {
+      if (th < TH && tw < TW && !WN_DBG(1)) {
         float* yp = Y + (static_cast<size_t>(n * H + 2 * th) * W + 2 * tw) * Co + co;
         yp[0] = y00;
         yp[Co] = y01;
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
   for (int p = 0; p < 16; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-  const unsigned long long t0c = (dbg & 256) ? __builtin_amdgcn_s_memtime() : 0ull, t0r = (dbg & 256) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const unsigned long long t0c = WN_DBG(256) ? __builtin_amdgcn_s_memtime() : 0ull, t0r = WN_DBG(256) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   floatx2 d[4][4], T[4][4];
 #define W2_DREAD(ptr_, a_, b_) d[a_][b_] = *reinterpret_cast<const floatx2*>((ptr_) + ((a_) * W2_PW + (b_)) * 64)
@@ -1023,13 +1024,13 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
             }
           }
         }
-        if (sl >= 2 && sl < 7 && !(dbg & 32)) W2_DMA_PATCH(sl - 2, xb, pm, cur, zp);     // raw patch of stage k + 2 over the one transformed during k - 1
-        if (sl >= 7 && sl < 9 && !(dbg & 32)) W2_DMA_DY(sl - 7, db, dm, dft, zd);
+        if (sl >= 2 && sl < 7 && !WN_DBG(32)) W2_DMA_PATCH(sl - 2, xb, pm, cur, zp);     // raw patch of stage k + 2 over the one transformed during k - 1
+        if (sl >= 7 && sl < 9 && !WN_DBG(32)) W2_DMA_DY(sl - 7, db, dm, dft, zd);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (!(dbg & 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(dbg & 128)) __syncthreads();
+    if (!WN_DBG(64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!WN_DBG(128)) __syncthreads();
   }
 #undef W2_DMA_M
 #undef W2_MASKS
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4*>(out + static_cast<size_t>(p) * Co * C + 8 * q) =
           make_float4(acc[p][4 * q + 0], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]);
-  if ((dbg & 256) && blk == 0 && split == nsplit - 1 && tid == 0) {     // ablation only: shader clocks / 100 MHz ticks of this workgroup
+  if (WN_DBG(256) && blk == 0 && split == nsplit - 1 && tid == 0) {     // ablation only: shader clocks / 100 MHz ticks of this workgroup
     const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
     unsigned* o = reinterpret_cast<unsigned*>(part + static_cast<size_t>(split) * 16 * Co * C);
     o[0] = static_cast<unsigned>(t1c - t0c); o[1] = static_cast<unsigned>(t1r - t0r); o[2] = static_cast<unsigned>(nst);
