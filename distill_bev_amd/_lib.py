@@ -108,6 +108,7 @@ _SIGNATURES = {
     "dbev_gemm1x1_backward_weight": [_p, _p, _p, _ll, _i, _i, _i, _p, _sz, _p],
     "dbev_wino_filter_floats": [_i, _i],
     "dbev_wino_filter_pack": [_p, _ll, _ll, _ll, _ll, _i, _i, _i, _p, _p],
+    "dbev_wino_filter_pack_pair": [_p, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _p, _p, _p],
     "dbev_wino_conv3x3_stats_rows": [_i, _i, _i, _i, _i],
     "dbev_wino_conv3x3_forward_kernel": [_i, _i, _i, _i, _i],
     "dbev_wino_conv3x3_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -46,9 +46,8 @@ constexpr int W3_VBUF = 16 * 32 * 4;            // floats of one transformed-inp
 // mode 0 (forward):        reduction index k = c,  output index j = co, taps g[a][b] = w[co][c][a][b]
 // mode 1 (data gradient):  k = co, j = c, taps g[a][b] = w[co][c][2-a][2-b]
 // U[((jb * (K/8) + kg) * 16 + p) * 2 + ni][lane][e] = (G g G^T)[p] for k = 8 kg + 4 (lane >> 5) + e, j = 64 jb + 32 ni + (lane & 31)
-__global__ __launch_bounds__(256) void wino_filter_pack(const float* __restrict__ w, long long so, long long sc, long long sa,
-                                                        long long sb, int K, int J, int mode, float* __restrict__ U) {
-  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+__device__ __forceinline__ void wino_pack_elem(long long idx, const float* __restrict__ w, long long so, long long sc, long long sa,
+                                               long long sb, int K, int J, int mode, float* __restrict__ U) {
   const int nkg = K / 8;
   const long long total = static_cast<long long>(J / 64) * nkg * 512;
   if (idx >= total) return;
@@ -82,6 +81,11 @@ __global__ __launch_bounds__(256) void wino_filter_pack(const float* __restrict_
     out[(4 * i + 2) * 512] = u2;
     out[(4 * i + 3) * 512] = u3;
   }
+}
+
+__global__ __launch_bounds__(256) void wino_filter_pack(const float* __restrict__ w, long long so, long long sc, long long sa,
+                                                        long long sb, int K, int J, int mode, float* __restrict__ U) {
+  wino_pack_elem(static_cast<long long>(blockIdx.x) * 256 + threadIdx.x, w, so, sc, sa, sb, K, J, mode, U);
 }
 
 // two fp32 additions / subtractions in ONE VALU instruction (hipcc splits a float2 expression into two v_add_f32; every VALU
@@ -358,9 +362,8 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
 // U[((jb * (K/4) + kg) * 16 + p) * 2 + ni][lane][e] = (G g G^T)[p] for k = 4 kg + 2 (lane >> 5) + e, j = 64 jb + 32 ni + (lane & 31):
 // the B operand of position p, channel half ni, for two MFMA steps of a lane, is one ds_read_b64 of an image that LDS-DMA copies linearly
 
-__global__ __launch_bounds__(256) void wino_filter_pack3(const float* __restrict__ w, long long so, long long sc, long long sa,
-                                                         long long sb, int K, int J, int mode, float* __restrict__ U) {
-  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+__device__ __forceinline__ void wino_pack3_elem(long long idx, const float* __restrict__ w, long long so, long long sc, long long sa,
+                                                long long sb, int K, int J, int mode, float* __restrict__ U) {
   const int nkg = K / 4;
   const long long total = static_cast<long long>(J / 64) * nkg * 256;
   if (idx >= total) return;
@@ -394,6 +397,26 @@ __global__ __launch_bounds__(256) void wino_filter_pack3(const float* __restrict
     out[(4 * i + 2) * 256] = u2;
     out[(4 * i + 3) * 256] = u3;
   }
+}
+
+__global__ __launch_bounds__(256) void wino_filter_pack3(const float* __restrict__ w, long long so, long long sc, long long sa,
+                                                         long long sb, int K, int J, int mode, float* __restrict__ U) {
+  wino_pack3_elem(static_cast<long long>(blockIdx.x) * 256 + threadIdx.x, w, so, sc, sa, sb, K, J, mode, U);
+}
+
+// both directions of a layer in ONE launch (blockIdx.y = 0: forward filters, 1: data-gradient filters), each in the format of the
+// forward kernel that direction gets (fmt 2: wino_fwd, second half of its buffer; 3: wino_fwd3, first half; 0: not wanted)
+__global__ __launch_bounds__(256) void wino_filter_pack_pair(const float* __restrict__ w, long long so, long long sc, long long sa,
+                                                             long long sb, int Cout, int Cin, int fmt_fwd, int fmt_dgrad,
+                                                             float* __restrict__ Uf, float* __restrict__ Ud) {
+  const int mode = blockIdx.y;
+  const int fmt = mode ? fmt_dgrad : fmt_fwd;
+  if (fmt == 0) return;
+  const int K = mode ? Cout : Cin, J = mode ? Cin : Cout;
+  float* U = mode ? Ud : Uf;
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (fmt == 2) wino_pack_elem(idx, w, so, sc, sa, sb, K, J, mode, U + 16LL * K * J);
+  else wino_pack3_elem(idx, w, so, sc, sa, sb, K, J, mode, U);
 }
 
 __device__ __forceinline__ floatx2 pk_fma(floatx2 a, floatx2 b, floatx2 c) {       // a * b + c
@@ -1194,6 +1217,22 @@ extern "C" int dbev_wino_filter_pack(const float* weight, long long so, long lon
   if ((K % 8) == 0 && only != 1)
     hipLaunchKernelGGL(wino_filter_pack, dim3(dbev_ceil_div(one / 16, 256)), dim3(256), 0, dbev_stream(stream), weight, so, sc, sa, sb, K,
                        J, data_gradient, packed + one);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_wino_filter_pack_pair(const float* weight, long long so, long long sc, long long sa, long long sb, int Cout,
+                                          int Cin, int fwd_kernel, int dgrad_kernel, float* packed_fwd, float* packed_dgrad,
+                                          dbevStream_t stream) {
+  // fwd_kernel / dgrad_kernel: what dbev_wino_conv3x3_forward_kernel returns for the layer each pack will be applied to (2 / 3), 0: skip
+  const bool okf = fwd_kernel == 0 || ((fwd_kernel == 2 || fwd_kernel == 3) && packed_fwd != nullptr && dbev_wino_filter_floats(Cin, Cout) > 0 &&
+                                       (fwd_kernel == 3 || (Cin % 8) == 0));
+  const bool okd = dgrad_kernel == 0 || ((dgrad_kernel == 2 || dgrad_kernel == 3) && packed_dgrad != nullptr &&
+                                         dbev_wino_filter_floats(Cout, Cin) > 0 && (dgrad_kernel == 3 || (Cout % 8) == 0));
+  if (weight == nullptr || !okf || !okd || (fwd_kernel == 0 && dgrad_kernel == 0)) return DBEV_EINVAL;
+  const long long threads = static_cast<long long>(Cin) * Cout;                       // one per (reduction, output) channel pair
+  hipLaunchKernelGGL(wino_filter_pack_pair, dim3(dbev_ceil_div(threads, 256), 2), dim3(256), 0, dbev_stream(stream), weight, so, sc, sa,
+                     sb, Cout, Cin, fwd_kernel, dgrad_kernel, packed_fwd, packed_dgrad);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -75,6 +75,40 @@ def pack_filters(weight, data_gradient=False, for_input=None):
     return packed
 
 
+def packed_pair(weight, x_shape, want_dgrad):
+    """-> (forward pack, data-gradient pack or None) of `weight` for inputs of shape `x_shape` [N, C, H, W]: both directions come out
+    of ONE launch (dbev_wino_filter_pack_pair), each in the format of the kernel its direction gets, and stay attached to the weight
+    until it changes (version / storage) -- a layer's forward in the detached frame, its forward in the differentiated frame and its
+    data gradient share one pack per step."""
+    dev = L.require_cuda(weight)
+    N, C, H, W = (int(v) for v in x_shape)
+    Co = int(weight.shape[0])
+    want_dgrad = bool(want_dgrad) and C % 64 == 0
+    key = (weight._version, weight.data_ptr(), N, H, W)
+    hit = getattr(weight, "_dbev_wino_pair", None)
+    fwd = dgrad = None
+    if hit is not None and hit[0] == key:
+        fwd, dgrad = hit[1], hit[2]
+        if dgrad is not None or not want_dgrad:
+            return fwd, dgrad
+    fk = 0 if fwd is not None else int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, C, Co))
+    dk = int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, Co, C)) if want_dgrad else 0
+    if fwd is None:
+        if fk == 0:
+            raise L.DbevHipError(f"wino: unsupported layer {C} -> {Co} at {H} x {W}")
+        fwd = torch.empty((int(L.call("dbev_wino_filter_floats", C, Co)),), dtype=torch.float32, device=dev)
+    if dk:
+        dgrad = torch.empty((int(L.call("dbev_wino_filter_floats", Co, C)),), dtype=torch.float32, device=dev)
+    so, sc, sa, sb = weight.stride()
+    with torch.cuda.device(dev):
+        L.call("dbev_wino_filter_pack_pair", L.ptr(weight), so, sc, sa, sb, Co, C, fk, dk, L.ptr(fwd), L.ptr(dgrad), L.stream_ptr(dev))
+    try:
+        weight._dbev_wino_pair = (key, fwd, dgrad)
+    except AttributeError:                                  # a tensor type without instance attributes: no reuse, still correct
+        pass
+    return fwd, dgrad
+
+
 def stats_rows(x_shape, Cout):
     N, C, H, W = x_shape
     return int(L.call("dbev_wino_conv3x3_stats_rows", N, H, W, C, Cout))
@@ -104,7 +138,9 @@ class _Conv3x3Wino(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stats):
         Co = weight.shape[0]
-        out = conv_packed(x, pack_filters(weight, False, x.shape), Co, bias, stats)
+        U, ctx.dgrad_pack = packed_pair(weight, x.shape, ctx.needs_input_grad[0])
+        ctx.pack_key = (weight._version, weight.data_ptr())
+        out = conv_packed(x, U, Co, bias, stats)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         if stats:
@@ -119,7 +155,8 @@ class _Conv3x3Wino(Function):
         if ctx.needs_input_grad[0]:
             C = weight.shape[1]
             if C % 64 == 0:
-                gx = conv_packed(gy, pack_filters(weight, True, gy.shape), C)
+                Ud = ctx.dgrad_pack if ctx.pack_key == (weight._version, weight.data_ptr()) else None
+                gx = conv_packed(gy, Ud if Ud is not None else pack_filters(weight, True, gy.shape), C)
             else:                                          # e.g. a 16- or 32-channel input: the library's data gradient
                 gx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
@@ -167,18 +204,9 @@ class WinoConv2d(nn.Conv2d):
         if self.padding_mode == "zeros" and eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups) \
                 and worthwhile(x, self.out_channels):
             if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
-                return conv_packed(x, self._packed(), self.out_channels, self.bias)
+                return conv_packed(x, packed_pair(self.weight, x.shape, self.weight.requires_grad)[0], self.out_channels, self.bias)
             return conv3x3(x, self.weight, self.bias)
         return super().forward(x)
-
-    def _packed(self):
-        w = self.weight
-        key = (w._version, w.data_ptr(), str(w.device))
-        hit = self.__dict__.get("_dbev_wino_packed")
-        if hit is None or hit[0] != key:
-            hit = (key, pack_filters(w.detach(), False))
-            self.__dict__["_dbev_wino_packed"] = hit
-        return hit[1]
 
 
 def _wino_geometry(m):

@@ -731,6 +731,10 @@ int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, float* y_nhwc
  *                                   flags bit 0: pack the filters of the data gradient (K = Cout, J = Cin, taps rotated by 180
  *                                   degrees); bits 1-2: 0 both formats, 1 only wino_fwd3's, 2 only wino_fwd's (the caller asked
  *                                   dbev_wino_conv3x3_forward_kernel which kernel its layer gets)
+ *   dbev_wino_filter_pack_pair      the forward AND the data-gradient filters of one layer in one launch, each only in the format of
+ *                                   the kernel its direction gets: fwd_kernel / dgrad_kernel = dbev_wino_conv3x3_forward_kernel(...) of
+ *                                   (N, H, W, Cin, Cout) / (N, H, W, Cout, Cin), 0 = direction not wanted; buffers sized by
+ *                                   dbev_wino_filter_floats(Cin, Cout) / (Cout, Cin)
  *   dbev_wino_conv3x3_forward       x_nhwc f32[N, H, W, Cin] -> y_nhwc f32[N, H, W, Cout] (+ bias f32[Cout] or NULL); H, W even,
  *                                   Cin % 4 == 0, Cout % 64 == 0, fewer than 2^31 elements per tensor, H * W * Cin * 4 < 2^31.  stats_partial (may be NULL)
  *                                   f32[rows, 2, Cout], rows = dbev_wino_conv3x3_stats_rows(...): per tile block the sums of y and
@@ -745,6 +749,8 @@ int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, float* y_nhwc
 long long dbev_wino_filter_floats(int K, int J);
 int dbev_wino_filter_pack(const float* weight, long long so, long long sc, long long sa, long long sb, int Cout, int Cin,
                           int flags, float* packed, dbevStream_t stream);
+int dbev_wino_filter_pack_pair(const float* weight, long long so, long long sc, long long sa, long long sb, int Cout, int Cin,
+                              int fwd_kernel, int dgrad_kernel, float* packed_fwd, float* packed_dgrad, dbevStream_t stream);
 int dbev_wino_conv3x3_forward_kernel(int N, int H, int W, int Cin, int Cout);    /* 2 | 3: the forward kernel the layer gets; 0: unsupported */
 int dbev_wino_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout);
 int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc, float* stats_partial,

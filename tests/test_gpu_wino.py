@@ -100,6 +100,34 @@ def test_filter_pack_is_the_winograd_transform_of_each_filter():
             assert np.abs(packed.numpy() - U.numpy()[j, k, p]).max() <= 1e-6
 
 
+def test_paired_pack_matches_the_single_direction_packs_and_is_reused():
+    """dbev_wino_filter_pack_pair writes, in one launch, exactly what the two single-direction packs write in the slot of the kernel
+    each direction gets; the pair stays attached to the weight until its version changes"""
+    from distill_bev_amd import wino, _lib as L
+    for (N, C, Co, H, W) in [(2, 64, 128, 16, 16), (48, 64, 64, 16, 44), (1, 64, 64, 8, 8)]:
+        x, w, _ = _mk(N, C, Co, H, W, 21, False)
+        fwd, dg = wino.packed_pair(w, x.shape, True)
+        for pack, mode, K, J in ((fwd, False, C, Co), (dg, True, Co, C)):
+            ver = int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, K, J))
+            ref = wino.pack_filters(w, mode)
+            one = 16 * K * J
+            sl = slice(one, 2 * one) if ver == 2 else slice(0, one)
+            assert torch.equal(pack[sl], ref[sl])
+        again = wino.packed_pair(w, x.shape, True)
+        assert again[0] is fwd and again[1] is dg                       # same version: the attached pair
+        w.add_(1.0)                                                     # in-place update (the optimizer's): new version, new pack
+        f2, d2 = wino.packed_pair(w, x.shape, True)
+        assert f2 is not fwd and not torch.equal(f2[sl], fwd[sl])
+        y = wino.conv3x3(x, w)
+        assert torch.allclose(y, F.conv2d(x, w, None, 1, 1), atol=2e-5 * float(y.abs().max()))
+    # forward first without the data gradient, then the missing direction alone
+    x, w, _ = _mk(2, 64, 64, 16, 16, 22, False)
+    f, d = wino.packed_pair(w, x.shape, False)
+    assert d is None
+    f3, d3 = wino.packed_pair(w, x.shape, True)
+    assert f3 is f and d3 is not None
+
+
 @pytest.mark.parametrize("block", ["basic", "bottleneck"])
 def test_residual_blocks_on_the_winograd_kernels_match_the_stock_convolutions(block, monkeypatch):
     """use_wino_convs re-classes the 3x3 convolutions of a residual block (res_block.py:11-230); the block then runs the Winograd

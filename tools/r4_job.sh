@@ -1,11 +1,4 @@
-B=$PWD/tools/libdbev_hip_base.so
-for v in 2; do
-  DBEV_HIP_LIB=$B DBEV_WINO_FWD_V=$v python tools/kbench_wino_var.py 2>&1 | tail -1
-  DBEV_WINO_FWD_V=$v python tools/kbench_wino_var.py 2>&1 | tail -1
-  DBEV_HIP_LIB=$B DBEV_WINO_FWD_V=$v python tools/kbench_wino_var.py 2>&1 | tail -1
-  DBEV_WINO_FWD_V=$v python tools/kbench_wino_var.py 2>&1 | tail -1
-done
-for shp in "8 512 512 64 64" "48 256 256 16 44"; do
-  DBEV_HIP_LIB=$B python tools/kbench_wgrad_dbg.py $shp 2>&1 | tail -1
-  python tools/kbench_wgrad_dbg.py $shp 2>&1 | tail -1
+for i in 1 2; do
+(cd build_ab/head && python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('head', d['ms_per_step'], d['roofline']['ms_per_step'])")
+python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('new ', d['ms_per_step'], d['roofline']['ms_per_step'])"
 done
