@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
         const float a_ = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
         const float b_ = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, acc[p], 0, 0, 0);
-        if (e == 0 && p < 15) { an = ap[(p + 1) * 128]; bn = bp[(p + 1) * 128]; }
+        if (e == 0 && p < 15 && !WN_DBG(512)) { an = ap[(p + 1) * 128]; bn = bp[(p + 1) * 128]; }
+        if (!WN_DBG(1024)) {
         // the transform's VALU work in three groups (a lone VALU instruction between two MFMAs costs ~17 cycles of matrix time, one
         // of a group of 8-16 ~6: profiles/r04_mfma_fillers.txt); the LDS reads / writes around them one per slot
         if (sl >= 1 && sl < 17) { const int q = sl - 1; WN_DREAD(ps, q >> 2, q & 3); }
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
         }
         if (sl >= 25 && sl < 33) { const int q = sl - 25; WN_VSTORE(vd, q >> 2, q & 3, vo[q]); }
         if (sl >= 35 && sl < 43) { const int q = sl - 35; WN_VSTORE(vd, 2 + (q >> 2), q & 3, vo[q]); }
+        }
         if (sl >= 2 && sl < 10 && !WN_DBG(16)) WN_DMA_U(sl - 2, kgn, nxt);
         if (sl >= 10 && sl < 13 && !WN_DBG(8)) WN_DMA_PATCH(sl - 10, stn, cur);     // stage kg + 2 over stage kg (read during kg - 1)
         __builtin_amdgcn_sched_barrier(0);

@@ -1,4 +1,1 @@
-for i in 1 2; do
-(cd build_ab/head && python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('head', d['ms_per_step'], d['roofline']['ms_per_step'])")
-python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('new ', d['ms_per_step'], d['roofline']['ms_per_step'])"
-done
+for d in 0 4 24 512 1024 1536 1564 0; do DBEV_WINO_FWD_V=2 DBEV_WINO_DBG=$d python tools/kbench_wino_var.py 2>&1 | tail -1; done
