@@ -102,6 +102,11 @@ __device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ floatx2 pk_fma(floatx2 a, floatx2 b, floatx2 c) {       // a * b + c
+  floatx2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 // a wave-uniform 64-bit value the compiler cannot prove uniform -> SGPR pair (the scalar base of an LDS-DMA)
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
@@ -305,28 +310,75 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
   const int co = 64 * cb + 32 * ni + l31;
   const float bco = bias != nullptr ? bias[co] : 0.f;
   float s1 = 0.f, s2 = 0.f;
+  if (th0 + BH <= TH && tw0 + BW <= TW && !WN_DBG(1)) {
+    // The block lies inside the image (uniform test): no per-tile bounds tests.  Nothing overlaps this part -- every VALU instruction
+    // is paid in full -- so registers r, r + 1 (two tiles side by side) go through the transform as ONE packed operation each, and the
+    // four pixels of a tile are stored at ONE 32-bit offset from four scalar bases (pixel (0,0), (0,1), (1,0), (1,1) of the image).
+    static_assert(BW == 8 || BW == 16, "tile (row, column) of register r below");
+    unsigned long long yb[8];
+    yb[0] = uniform64(reinterpret_cast<unsigned long long>(Y + static_cast<size_t>(n) * H * W * Co));
+    yb[1] = yb[0] + static_cast<unsigned long long>(Co) * 4ull;
+    yb[2] = yb[0] + static_cast<unsigned long long>(W) * Co * 4ull;
+    yb[3] = yb[2] + static_cast<unsigned long long>(Co) * 4ull;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int t = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
-    const int tr = t / BW, tc = t - tr * BW;
-    const int th = th0 + tr, tw = tw0 + tc;
-    float s0[4], s1r[4];
+    for (int i = 0; i < 4; ++i) yb[4 + i] = yb[i] + static_cast<unsigned long long>(Co) * 8ull;
+    // scalar-base store: the compiler turns base + offset arithmetic on pointers into 64-bit VALU additions per store
+#define WN_ST(voff_, val_, sbase_) asm volatile("global_store_dword %0, %1, %2" :: "v"(voff_), "v"(val_), "s"(sbase_) : "memory")
+    // tile of register r: BW = 8: row 4 mi + (r >> 2), column (r & 3) + 4 half; BW = 16: row 2 mi + (r >> 3), column (r & 3) + 4 half + 8 ((r >> 2) & 1)
+    const int tr0 = (BW == 8 ? 4 : 2) * mi, tc0 = 4 * half;
+    const unsigned voff0 = static_cast<unsigned>(((2 * (th0 + tr0) * W + 2 * (tw0 + tc0)) * Co + co) * 4);
+    const unsigned rowstep = static_cast<unsigned>(2 * W * Co * 4), colstep = static_cast<unsigned>(2 * Co * 4);
+    const floatx2 b2 = {bco, bco};
+    floatx2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s0[j] = (acc[0 + j][r] + acc[4 + j][r]) + acc[8 + j][r];
-      s1r[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
-    }
-    const float y00 = (s0[0] + s0[1]) + s0[2] + bco, y01 = (s0[1] - s0[2]) - s0[3] + bco;
-    const float y10 = (s1r[0] + s1r[1]) + s1r[2] + bco, y11 = (s1r[1] - s1r[2]) - s1r[3] + bco;
-    if (th < TH && tw < TW && !WN_DBG(1)) {
-      float* yp = Y + (static_cast<size_t>(n * H + 2 * th) * W + 2 * tw) * Co + co;
-      yp[0] = y00;
-      yp[Co] = y01;
-      yp[static_cast<size_t>(W) * Co] = y10;
-      yp[static_cast<size_t>(W) * Co + Co] = y11;
+    for (int r = 0; r < 16; r += 2) {
+      const int dr = BW == 8 ? (r >> 2) : (r >> 3), dc = BW == 8 ? (r & 3) : (r & 3) + 8 * ((r >> 2) & 1);
+      floatx2 s0[4], s1r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const floatx2 a0 = {acc[0 + j][r], acc[0 + j][r + 1]}, a1 = {acc[4 + j][r], acc[4 + j][r + 1]};
+        const floatx2 a2 = {acc[8 + j][r], acc[8 + j][r + 1]}, a3 = {acc[12 + j][r], acc[12 + j][r + 1]};
+        s0[j] = pk_add(pk_add(a0, a1), a2);
+        s1r[j] = pk_sub(pk_sub(a1, a2), a3);
+      }
+      const floatx2 y00 = pk_add(pk_add(pk_add(s0[0], s0[1]), s0[2]), b2), y01 = pk_add(pk_sub(pk_sub(s0[1], s0[2]), s0[3]), b2);
+      const floatx2 y10 = pk_add(pk_add(pk_add(s1r[0], s1r[1]), s1r[2]), b2), y11 = pk_add(pk_sub(pk_sub(s1r[1], s1r[2]), s1r[3]), b2);
+      const unsigned vo = voff0 + dr * rowstep + dc * colstep;
+      WN_ST(vo, y00.x, yb[0]); WN_ST(vo, y00.y, yb[4]);              // bases 4..7: the tile one column to the right
+      WN_ST(vo, y01.x, yb[1]); WN_ST(vo, y01.y, yb[5]);
+      WN_ST(vo, y10.x, yb[2]); WN_ST(vo, y10.y, yb[6]);
+      WN_ST(vo, y11.x, yb[3]); WN_ST(vo, y11.y, yb[7]);
       if (STATS) {
-        s1 += (y00 + y01) + (y10 + y11);
-        s2 = fmaf(y00, y00, s2); s2 = fmaf(y01, y01, s2); s2 = fmaf(y10, y10, s2); s2 = fmaf(y11, y11, s2);
+        t1 = pk_add(t1, pk_add(pk_add(y00, y01), pk_add(y10, y11)));
+        t2 = pk_fma(y00, y00, t2); t2 = pk_fma(y01, y01, t2); t2 = pk_fma(y10, y10, t2); t2 = pk_fma(y11, y11, t2);
+      }
+    }
+    s1 = t1.x + t1.y; s2 = t2.x + t2.y;
+#undef WN_ST
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int tr = t / BW, tc = t - tr * BW;
+      const int th = th0 + tr, tw = tw0 + tc;
+      float s0[4], s1r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0[j] = (acc[0 + j][r] + acc[4 + j][r]) + acc[8 + j][r];
+        s1r[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
+      }
+      const float y00 = (s0[0] + s0[1]) + s0[2] + bco, y01 = (s0[1] - s0[2]) - s0[3] + bco;
+      const float y10 = (s1r[0] + s1r[1]) + s1r[2] + bco, y11 = (s1r[1] - s1r[2]) - s1r[3] + bco;
+      if (th < TH && tw < TW && !WN_DBG(1)) {
+        float* yp = Y + (static_cast<size_t>(n * H + 2 * th) * W + 2 * tw) * Co + co;
+        yp[0] = y00;
+        yp[Co] = y01;
+        yp[static_cast<size_t>(W) * Co] = y10;
+        yp[static_cast<size_t>(W) * Co + Co] = y11;
+        if (STATS) {
+          s1 += (y00 + y01) + (y10 + y11);
+          s2 = fmaf(y00, y00, s2); s2 = fmaf(y01, y01, s2); s2 = fmaf(y10, y10, s2); s2 = fmaf(y11, y11, s2);
+        }
       }
     }
   }
@@ -421,11 +473,6 @@ __global__ __launch_bounds__(256) void wino_filter_pack_pair(const float* __rest
   else wino_pack3_elem(idx, w, so, sc, sa, sb, K, J, mode, U);
 }
 
-__device__ __forceinline__ floatx2 pk_fma(floatx2 a, floatx2 b, floatx2 c) {       // a * b + c
-  floatx2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
 
 template <int BH, int BW, bool STATS>
 __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X, const float* __restrict__ U, const float* __restrict__ bias,

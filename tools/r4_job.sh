@@ -1,1 +1,5 @@
-for d in 0 4 24 512 1024 1536 1564 0; do DBEV_WINO_FWD_V=2 DBEV_WINO_DBG=$d python tools/kbench_wino_var.py 2>&1 | tail -1; done
+B=$PWD/tools/libdbev_hip_base.so
+for i in 1 2 3; do
+  DBEV_HIP_LIB=$B DBEV_WINO_FWD_V=2 python tools/kbench_wino_var.py 2>&1 | tail -1
+  DBEV_WINO_FWD_V=2 python tools/kbench_wino_var.py 2>&1 | tail -1
+done
