@@ -205,11 +205,7 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
   const int aoff = (32 * mi + l31) * 8 + 4 * half;
   const int boff = (ni * 64 + lane) * 4;
 
-  floatx16 acc[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  floatx16 acc[16];                                              // zeroed in the prologue, under the first DMA round trip
 
   floatx2 d[4][4], T[4][4];
 #define WN_DREAD(ptr_, a_, b_) d[a_][b_] = *reinterpret_cast<const floatx2*>((ptr_) + ((a_) * PW + (b_)) * 8)
@@ -231,6 +227,16 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
   for (int i = 0; i < 3; ++i) WN_DMA_PATCH(i, nkg > 1 ? 1 : 0, 1);
 #pragma unroll
   for (int i = 0; i < 8; ++i) WN_DMA_U(i, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);                             // the 256 accumulator writes go HERE: behind the DMA issue, under its latency
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                // (as asm: plain assignments are sunk to the first use, behind the wait)
+      float z;
+      asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));
+      acc[p][r] = z;
+    }
+  __builtin_amdgcn_sched_barrier(0);
   WN_WAIT_VM();
   __syncthreads();
   {
@@ -550,11 +556,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
   const int aoff = ((8 * ph) * 32 + l31) * 4 + 2 * half;
   const int boff = ((8 * ph) * 2 + ni) * 128 + lane * 2;
 
-  floatx16 acc[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  floatx16 acc[8];                                        // zeroed in the prologue, under the first DMA round trip
 
   floatx2 da[4], db[4], T[4];
 #define W3_TRANSFORM_READ(ps_, b_) do { da[b_] = *reinterpret_cast<const floatx2*>((ps_) + tsa + (b_) * 4); db[b_] = *reinterpret_cast<const floatx2*>((ps_) + tsb + (b_) * 4); } while (0)
@@ -569,6 +571,16 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
   W3_DMA_PATCH(nkg > 1 ? 1 : 0, 1);
 #pragma unroll
   for (int i = 0; i < 4; ++i) W3_DMA_U(i, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                // (as asm: plain assignments are sunk to the first use, behind the wait)
+      float z;
+      asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));
+      acc[p][r] = z;
+    }
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
@@ -954,11 +966,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
   const int aoff = (4 * half) * 64 + 32 * ci + l31;
   const int yoff = (2 * 4 * half) * 64 + 32 * coi + l31;
 
-  floatx16 acc[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  floatx16 acc[16];                                        // zeroed in the prologue, under the first DMA round trip
   const unsigned long long t0c = WN_DBG(256) ? __builtin_amdgcn_s_memtime() : 0ull, t0r = WN_DBG(256) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   floatx2 d[4][4], T[4][4];
@@ -1012,6 +1020,16 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
   for (int i = 0; i < 5; ++i) W2_DMA_PATCH(i, xb, pm, 1, W2_ZP(1));
 #pragma unroll
   for (int i = 0; i < 2; ++i) W2_DMA_DY(i, db, dm, 1, W2_ZD(1));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                // (as asm: plain assignments are sunk to the first use, behind the wait)
+      float z;
+      asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));
+      acc[p][r] = z;
+    }
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
