@@ -112,6 +112,7 @@ _SIGNATURES = {
     "dbev_wino_conv3x3_stats_rows": [_i, _i, _i, _i, _i],
     "dbev_wino_conv3x3_forward_kernel": [_i, _i, _i, _i, _i],
     "dbev_wino_conv3x3_forward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dbev_wino_conv3x3_forward_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dbev_wino_conv3x3_backward_weight_workspace_bytes": [_i, _i, _i, _i, _i],
     "dbev_wino_conv3x3_backward_weight": [_p, _p, _p, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, _p, _sz, _p],
     "dbev_range_voxel_coords": [_p, _i, _i, _p, _p, _i, _p, _p],

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
   float* sP = smem;
   float* sV = smem + 2 * PBUF;
   float* sU = sV + 2 * VBUF;
+  const bool relu = (dbg >> 16) & 1;                             // launch flag: ReLU on the output (the folded eval-mode norm + ReLU)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mi = w & 1, ni = w >> 1, half = lane >> 5, l31 = lane & 31;
   const int ncb = Co / 64;
@@ -347,8 +348,12 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
         s0[j] = pk_add(pk_add(a0, a1), a2);
         s1r[j] = pk_sub(pk_sub(a1, a2), a3);
       }
-      const floatx2 y00 = pk_add(pk_add(pk_add(s0[0], s0[1]), s0[2]), b2), y01 = pk_add(pk_sub(pk_sub(s0[1], s0[2]), s0[3]), b2);
-      const floatx2 y10 = pk_add(pk_add(pk_add(s1r[0], s1r[1]), s1r[2]), b2), y11 = pk_add(pk_sub(pk_sub(s1r[1], s1r[2]), s1r[3]), b2);
+      floatx2 y00 = pk_add(pk_add(pk_add(s0[0], s0[1]), s0[2]), b2), y01 = pk_add(pk_sub(pk_sub(s0[1], s0[2]), s0[3]), b2);
+      floatx2 y10 = pk_add(pk_add(pk_add(s1r[0], s1r[1]), s1r[2]), b2), y11 = pk_add(pk_sub(pk_sub(s1r[1], s1r[2]), s1r[3]), b2);
+      if (relu) {
+        y00.x = fmaxf(y00.x, 0.f); y00.y = fmaxf(y00.y, 0.f); y01.x = fmaxf(y01.x, 0.f); y01.y = fmaxf(y01.y, 0.f);
+        y10.x = fmaxf(y10.x, 0.f); y10.y = fmaxf(y10.y, 0.f); y11.x = fmaxf(y11.x, 0.f); y11.y = fmaxf(y11.y, 0.f);
+      }
       const unsigned vo = voff0 + dr * rowstep + dc * colstep;
       WN_ST(vo, y00.x, yb[0]); WN_ST(vo, y00.y, yb[4]);              // bases 4..7: the tile one column to the right
       WN_ST(vo, y01.x, yb[1]); WN_ST(vo, y01.y, yb[5]);
@@ -373,8 +378,9 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
         s0[j] = (acc[0 + j][r] + acc[4 + j][r]) + acc[8 + j][r];
         s1r[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
       }
-      const float y00 = (s0[0] + s0[1]) + s0[2] + bco, y01 = (s0[1] - s0[2]) - s0[3] + bco;
-      const float y10 = (s1r[0] + s1r[1]) + s1r[2] + bco, y11 = (s1r[1] - s1r[2]) - s1r[3] + bco;
+      float y00 = (s0[0] + s0[1]) + s0[2] + bco, y01 = (s0[1] - s0[2]) - s0[3] + bco;
+      float y10 = (s1r[0] + s1r[1]) + s1r[2] + bco, y11 = (s1r[1] - s1r[2]) - s1r[3] + bco;
+      if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
       if (th < TH && tw < TW && !WN_DBG(1)) {
         float* yp = Y + (static_cast<size_t>(n * H + 2 * th) * W + 2 * tw) * Co + co;
         yp[0] = y00;
@@ -492,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
   float* sP = smem;
   float* sV = smem + 2 * PBUF;
   float* sU = sV + 2 * W3_VBUF;
+  const bool relu = (dbg >> 16) & 1;                             // launch flag: ReLU on the output (the folded eval-mode norm + ReLU)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ni = w & 1, ph = w >> 1, half = lane >> 5, l31 = lane & 31;
   const int ncb = Co / 64;
@@ -665,10 +672,11 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
       float s0[4], s1[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s0[j] = acc[j][r] + acc[4 + j][r]; s1[j] = acc[4 + j][r]; }
-      const float y00 = ((s0[0] + s0[1]) + s0[2]) + xch[(r * 4 + 0) * 64 + lane] + bco;
-      const float y01 = ((s0[1] - s0[2]) - s0[3]) + xch[(r * 4 + 1) * 64 + lane] + bco;
-      const float y10 = ((s1[0] + s1[1]) + s1[2]) + xch[(r * 4 + 2) * 64 + lane] + bco;
-      const float y11 = ((s1[1] - s1[2]) - s1[3]) + xch[(r * 4 + 3) * 64 + lane] + bco;
+      float y00 = ((s0[0] + s0[1]) + s0[2]) + xch[(r * 4 + 0) * 64 + lane] + bco;
+      float y01 = ((s0[1] - s0[2]) - s0[3]) + xch[(r * 4 + 1) * 64 + lane] + bco;
+      float y10 = ((s1[0] + s1[1]) + s1[2]) + xch[(r * 4 + 2) * 64 + lane] + bco;
+      float y11 = ((s1[1] - s1[2]) - s1[3]) + xch[(r * 4 + 3) * 64 + lane] + bco;
+      if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
       if (th < TH && tw < TW && !WN_DBG(1)) {
         float* yp = Y + (static_cast<size_t>(n * H + 2 * th) * W + 2 * tw) * Co + co;
         yp[0] = y00;
@@ -1314,8 +1322,9 @@ extern "C" int dbev_wino_conv3x3_stats_rows(int N, int H, int W, int Cin, int Co
   return wino_plan(N, H, W, Cin, Cout, &p) ? p.ntb : 0;
 }
 
-extern "C" int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc,
-                                         float* stats_partial, int N, int H, int W, int Cin, int Cout, dbevStream_t stream) {
+extern "C" int dbev_wino_conv3x3_forward_act(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc,
+                                             float* stats_partial, int N, int H, int W, int Cin, int Cout, int relu,
+                                             dbevStream_t stream) {
   WinoPlan p;
   if (!wino_plan(N, H, W, Cin, Cout, &p) || x_nhwc == nullptr || packed == nullptr || y_nhwc == nullptr) return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
@@ -1324,10 +1333,10 @@ extern "C" int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packe
   DbevKt kt(DBEV_K_WINO_FWD, 32LL * N * (H / 2) * (W / 2) * Cin * Cout, s);
 #define WN_GO(BHV, BWV, ST)                                                                                                       \
   hipLaunchKernelGGL((wino_fwd<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
-                     Cin, Cout, p.ntb, wino_dbg())
+                     Cin, Cout, p.ntb, wino_dbg() | (relu ? 1 << 16 : 0))
 #define WN_GO3(BHV, BWV, ST)                                                                                                      \
   hipLaunchKernelGGL((wino_fwd3<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
-                     Cin, Cout, p.ntb, wino_dbg())
+                     Cin, Cout, p.ntb, wino_dbg() | (relu ? 1 << 16 : 0))
   if (p.v3) {
     if (p.bw == 8) { if (stats_partial != nullptr) WN_GO3(4, 8, true); else WN_GO3(4, 8, false); }
     else { if (stats_partial != nullptr) WN_GO3(2, 16, true); else WN_GO3(2, 16, false); }
@@ -1340,6 +1349,11 @@ extern "C" int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packe
 #undef WN_GO3
   DBEV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc,
+                                         float* stats_partial, int N, int H, int W, int Cin, int Cout, dbevStream_t stream) {
+  return dbev_wino_conv3x3_forward_act(x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, Cin, Cout, 0, stream);
 }
 
 extern "C" size_t dbev_wino_conv3x3_backward_weight_workspace_bytes(int N, int H, int W, int Cin, int Cout) {

@@ -173,7 +173,10 @@ class ConvModule(nn.Module):
             # a 3x3 convolution on the Winograd kernels hands the fused norm(+ReLU) behind it the batch statistics of its output
             # (no statistics pass); decided per call from the modules' types / modes and the tensor (wino.conv3x3_bn_ready)
             from .bn_act import BatchNormAct2d, bn_act
-            from .wino import conv3x3_bn_ready, conv3x3_stats
+            from .wino import conv3x3_bn_ready, conv3x3_stats, conv_norm_relu_eval, fold_ready
+            if fold_ready(self.conv, self.norm, x):          # frozen stack: convolution, eval-mode norm and ReLU in one launch
+                x = conv_norm_relu_eval(x, self.conv, self.norm)
+                return self.activate(x) if self.with_activation else x
             if type(self.norm) is BatchNormAct2d and conv3x3_bn_ready(self.conv, self.norm, x):
                 z, rows = conv3x3_stats(x, self.conv.weight, None)
                 x = bn_act(z, self.norm, None, True, pre=rows)

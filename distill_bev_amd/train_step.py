@@ -130,8 +130,9 @@ def accelerate_modules(detector):
     roots = [detector] + ([detector.teacher_model] if getattr(detector, "teacher_model", None) is not None else [])
     n_bn = sum(fuse_bn_relu_modules(r) for r in roots)
     detector.skinny_convs = sum(use_skinny_convs(r) for r in roots)    # final 64 -> 1..3 convs of the CenterHead branches
-    from .wino import use_wino_convs
+    from .wino import link_conv_norm_stacks, use_wino_convs
     detector.wino_convs = sum(use_wino_convs(r) for r in roots)        # 3x3 stride-1 convolutions: Winograd F(2x2, 3x3) on fp32 MFMA
+    detector.folded_norm_pairs = sum(link_conv_norm_stacks(r) for r in roots)   # conv -> eval norm -> ReLU of frozen stacks: one launch
     from .center_head import CenterHead
     from .head_batch import plan_branches
     detector.batched_branches = 0

@@ -117,7 +117,7 @@ def stats_rows(x_shape, Cout):
 COUNTERS = {"on": False, "launches": 0, "flops": 0, "bytes": 0}      # bench.py: algorithmic work of the forward / data-gradient launches
 
 
-def conv_packed(x, packed, Cout, bias=None, stats=False):
+def conv_packed(x, packed, Cout, bias=None, stats=False, relu=False):
     """one launch of the convolution kernel: x [N, C, H, W] channels-last, packed filters for C -> Cout.
     -> y (channels-last) or (y, partial statistics rows f32[rows, 2, Cout]) with stats=True"""
     dev = L.require_cuda(x, packed, bias)
@@ -129,9 +129,82 @@ def conv_packed(x, packed, Cout, bias=None, stats=False):
     y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     part = torch.empty((stats_rows(x.shape, Cout), 2, Cout), dtype=torch.float32, device=dev) if stats else None
     with torch.cuda.device(dev):
-        L.call("dbev_wino_conv3x3_forward", L.ptr(x), L.ptr(packed), L.ptr(bias), L.ptr(y), L.ptr(part), N, H, W, C, Cout,
-               L.stream_ptr(dev))
+        L.call("dbev_wino_conv3x3_forward_act", L.ptr(x), L.ptr(packed), L.ptr(bias), L.ptr(y), L.ptr(part), N, H, W, C, Cout,
+               int(bool(relu)), L.stream_ptr(dev))
     return (y, part) if stats else y
+
+
+# ---- convolution -> eval-mode norm -> ReLU of a frozen stack in one launch -----------------------------------------------------------
+def fold_ready(conv, norm, x):
+    """may `conv -> norm(+ReLU)` run as ONE Winograd launch with the norm folded in?  A re-classed 3x3 convolution followed by a fused
+    BatchNorm + ReLU module in EVAL mode (running statistics), nothing differentiable involved (the frozen teacher: second.py:60-78,
+    centerpoint_head.py:17-130), the input fit for the kernels."""
+    from . import bn_act as BA
+    if not (type(conv) is WinoConv2d and type(norm) is BA.BatchNormAct2d and BA._state["enabled"]):
+        return False
+    if norm.training or norm.running_mean is None or not norm.affine or norm.num_features != conv.out_channels:
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or norm.weight.requires_grad
+                                    or (conv.bias is not None and conv.bias.requires_grad)):
+        return False
+    return (conv.padding_mode == "zeros" and eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            and worthwhile(x, conv.out_channels))
+
+
+def conv_norm_relu_eval(x, conv, norm):
+    """relu(norm(conv(x))) for a `fold_ready` triple: the norm's scale goes into the filters before they are transformed and packed
+    (kept until the convolution's or the norm's tensors change), its shift (+ the scaled convolution bias) is the kernel's bias, the
+    ReLU its output flag -- no normalisation pass over the output."""
+    from . import bn_act as BA
+    dev = x.device
+    coef = BA._eval_coef(norm, dev)                          # scale | shift; a new tensor object whenever the norm's tensors change
+    w = conv.weight
+    N, _, H, W = x.shape
+    key = (w._version, w.data_ptr(), None if conv.bias is None else conv.bias._version, N, H, W)
+    hit = conv.__dict__.get("_dbev_wino_folded")
+    if hit is None or hit[0] != key or hit[1] is not coef:
+        Co = conv.out_channels
+        with torch.no_grad():
+            scale, shift = coef[:Co], coef[Co:]
+            wf = w.detach() * scale.view(Co, 1, 1, 1)
+            b = (shift if conv.bias is None else shift + conv.bias.detach() * scale).contiguous()
+            U = pack_filters(wf, False, x.shape)
+        hit = (key, coef, U, b)
+        conv.__dict__["_dbev_wino_folded"] = hit
+    return conv_packed(x, hit[2], conv.out_channels, hit[3], relu=True)
+
+
+class ConvNormSequential(nn.Sequential):
+    """nn.Sequential whose `3x3 convolution -> eval-mode norm + ReLU` neighbours run as one launch when `fold_ready`; every other
+    module, and every pair that is not ready (training mode, gradients), is called as nn.Sequential calls it.  Same children, same
+    state-dict keys (link_conv_norm_stacks re-classes in place)."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            if i + 1 < len(mods) and torch.is_tensor(x) and fold_ready(mods[i], mods[i + 1], x):
+                x = conv_norm_relu_eval(x, mods[i], mods[i + 1])
+                i += 2
+            else:
+                x = mods[i](x)
+                i += 1
+        return x
+
+
+def link_conv_norm_stacks(model):
+    """Re-class the plain nn.Sequential stacks that hold a (WinoConv2d, fused BatchNorm + ReLU) neighbour pair; returns how many pairs.
+    Run after bn_act.fuse_bn_relu_modules and use_wino_convs.  Idempotent."""
+    from . import bn_act as BA
+    n = 0
+    for mod in model.modules():
+        if type(mod) in (nn.Sequential, ConvNormSequential):
+            kids = list(mod._modules.values())
+            pairs = sum(1 for a, b in zip(kids, kids[1:]) if type(a) is WinoConv2d and type(b) is BA.BatchNormAct2d)
+            if pairs:
+                mod.__class__ = ConvNormSequential
+                n += pairs
+    return n
 
 
 class _Conv3x3Wino(Function):

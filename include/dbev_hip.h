@@ -739,6 +739,9 @@ int dbev_conv1x1_forward(const float* x_nhwc, const float* weight, float* y_nhwc
  *                                   Cin % 4 == 0, Cout % 64 == 0, fewer than 2^31 elements per tensor, H * W * Cin * 4 < 2^31.  stats_partial (may be NULL)
  *                                   f32[rows, 2, Cout], rows = dbev_wino_conv3x3_stats_rows(...): per tile block the sums of y and
  *                                   y^2 per channel (bias included), the partial-row layout of dbev_bn_act_train_forward_pre.
+ *   dbev_wino_conv3x3_forward_act   the same with relu != 0: max(y, 0) on the way out -- with the scale of an eval-mode BatchNorm folded into
+ *                                   the filters before packing and its shift passed as `bias`, conv -> norm -> ReLU of a frozen stack
+ *                                   (the CenterPoint teacher's SECOND / head: second.py:60-78) is this one launch
  *   For the data gradient call it with (x = grad_y, Cin <-> Cout swapped, the data_gradient pack).
  *   dbev_wino_conv3x3_backward_weight   grad_w[co][c][a][b] (element strides as for the pack) = sum over pixels, in the Winograd
  *                                   domain: G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G; workspace from ..._workspace_bytes, fixed
@@ -755,6 +758,8 @@ int dbev_wino_conv3x3_forward_kernel(int N, int H, int W, int Cin, int Cout);   
 int dbev_wino_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout);
 int dbev_wino_conv3x3_forward(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc, float* stats_partial,
                               int N, int H, int W, int Cin, int Cout, dbevStream_t stream);
+int dbev_wino_conv3x3_forward_act(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc, float* stats_partial,
+                                 int N, int H, int W, int Cin, int Cout, int relu, dbevStream_t stream);
 size_t dbev_wino_conv3x3_backward_weight_workspace_bytes(int N, int H, int W, int Cin, int Cout);   /* 0: unsupported geometry */
 int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const float* grad_y_nhwc, float* grad_weight, long long so, long long sc,
                                       long long sa, long long sb, int N, int H, int W, int Cin, int Cout, void* workspace,

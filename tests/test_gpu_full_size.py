@@ -53,6 +53,7 @@ def test_full_size_forward_finite_and_stable_then_one_optimizer_step(full):
     # groups (round 4: re-classing the 3x3 convolutions first silently disabled them), 3x3 convolutions on the Winograd kernels
     assert tr.detector.batched_branches >= 36, tr.detector.batched_branches      # (72: the teacher's head is planned as well)
     assert tr.detector.wino_convs >= 60, tr.detector.wino_convs
+    assert tr.detector.folded_norm_pairs >= 13, tr.detector.folded_norm_pairs      # the frozen teacher's SECOND stacks: conv -> norm -> ReLU in one launch
 
 
 def test_full_size_hand_written_ops_are_bit_reproducible(full):

@@ -128,6 +128,42 @@ def test_paired_pack_matches_the_single_direction_packs_and_is_reused():
     assert f3 is f and d3 is not None
 
 
+def test_frozen_conv_norm_relu_stack_is_one_launch_per_pair():
+    """conv -> eval-mode BatchNorm -> ReLU of a frozen nn.Sequential (the teacher's SECOND stages, second.py:60-78) with the norm folded into
+    the Winograd launch (wino.ConvNormSequential) == the three stock modules; in training mode / under autograd the stack runs unfolded"""
+    import torch.nn as nn
+    from distill_bev_amd import wino, bn_act, _lib as L
+    torch.manual_seed(3)
+    seq = nn.Sequential(nn.Conv2d(64, 64, 3, 2, 1, bias=False), nn.BatchNorm2d(64, eps=1e-3), nn.ReLU(inplace=True),
+                        nn.Conv2d(64, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64, eps=1e-3), nn.ReLU(inplace=True),
+                        nn.Conv2d(64, 128, 3, 1, 1, bias=True), nn.BatchNorm2d(128, eps=1e-3), nn.ReLU(inplace=True)).to(DEV)
+    for m in seq.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.normal_(); m.running_var.uniform_(0.5, 2.0); m.weight.data.normal_(1.0, 0.3); m.bias.data.normal_()
+    seq = seq.to(memory_format=torch.channels_last).eval()
+    import copy
+    ref = copy.deepcopy(seq)
+    assert bn_act.fuse_bn_relu_modules(seq) == 3 and wino.use_wino_convs(seq) == 2 and wino.link_conv_norm_stacks(seq) == 2
+    assert type(seq) is wino.ConvNormSequential and list(seq.state_dict()) == list(ref.state_dict())
+    x = torch.randn((8, 64, 128, 128), device=DEV).contiguous(memory_format=torch.channels_last)     # 64 x 64 behind the strided layer
+    with torch.no_grad():
+        y, yr = seq(x), ref(x)
+    assert y.shape == yr.shape and float((y - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
+    assert "_dbev_wino_folded" in seq[3].__dict__ and "_dbev_wino_folded" in seq[6].__dict__          # both pairs took the folded path
+    # a changed norm -> new coefficients -> new fold
+    with torch.no_grad():
+        seq[4].weight.mul_(0.5); ref[4].weight.mul_(0.5)
+        y, yr = seq(x), ref(x)
+    assert float((y - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
+    # training mode: batch statistics, no folding; gradients flow
+    seq.train(); ref.train()
+    xg = x.clone().requires_grad_(True)
+    out = seq(xg)
+    out.sum().backward()
+    outr = ref(x)
+    assert float((out.detach() - outr.detach()).abs().max()) <= 1e-4 * float(outr.detach().abs().max()) and xg.grad is not None
+
+
 @pytest.mark.parametrize("block", ["basic", "bottleneck"])
 def test_residual_blocks_on_the_winograd_kernels_match_the_stock_convolutions(block, monkeypatch):
     """use_wino_convs re-classes the 3x3 convolutions of a residual block (res_block.py:11-230); the block then runs the Winograd
