@@ -481,15 +481,15 @@ __global__ __launch_bounds__(256) void wino_filter_pack_pair(const float* __rest
   const int K = mode ? Cout : Cin, J = mode ? Cin : Cout;
   float* U = mode ? Ud : Uf;
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-  if (fmt == 2) wino_pack_elem(idx, w, so, sc, sa, sb, K, J, mode, U + 16LL * K * J);
-  else wino_pack3_elem(idx, w, so, sc, sa, sb, K, J, mode, U);
+  if (fmt == 2 || fmt == 6) wino_pack_elem(idx, w, so, sc, sa, sb, K, J, mode, U + 16LL * K * J);
+  if (fmt == 3 || fmt == 6) wino_pack3_elem(idx, w, so, sc, sa, sb, K, J, mode, U);
 }
 
 
 template <int BH, int BW, bool STATS>
 __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X, const float* __restrict__ U, const float* __restrict__ bias,
                                                     float* __restrict__ Y, float* __restrict__ partial, int N, int H, int W, int C,
-                                                    int Co, int ntb, int dbg) {
+                                                    int Co, int ntb, int dbg, int tb_first) {
   static_assert(BH * BW == 32, "32 tiles per workgroup");
   constexpr int PW = 2 * BW + 2, PH = 2 * BH + 2, NPIX = PW * PH;
   constexpr int NPC = (NPIX + 63) / 64;                    // patch DMA pieces: 64 pixels x 16 bytes (4 channels) = 1 KB
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
   const int ni = w & 1, ph = w >> 1, half = lane >> 5, l31 = lane & 31;
   const int ncb = Co / 64;
   const int L = xcd_block();
-  const int cb = L % ncb, tb = L / ncb;
+  const int cb = L % ncb, tb = L / ncb + tb_first;            // tb_first > 0: the tail of a layer whose full rounds wino_fwd ran
   if (tb >= ntb) return;
   const int TH = H >> 1, TW = W >> 1;
   const int NBW = (TW + BW - 1) / BW, NBH = (TH + BH - 1) / BH;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd3(const float* __restrict__ X,
     __syncthreads();
     if (tid < 128) {
       const int which = tid >> 6, c = tid & 63;
-      partial[(static_cast<size_t>(tb) * 2 + which) * Co + 64 * cb + c] = red[which * 64 + c];
+      partial[(static_cast<size_t>(tb - tb_first) * 2 + which) * Co + 64 * cb + c] = red[which * 64 + c];
     }
   }
 }
@@ -1238,7 +1238,11 @@ bool wino_wg_plan(int N, int H, int W, int C, int Co, WinoWgPlan* p) {
 
 int wino_dbg() { static const int v = getenv("DBEV_WINO_DBG") ? atoi(getenv("DBEV_WINO_DBG")) : 0; return v; }
 
-struct WinoPlan { int bh, bw, ntb, ncb, grid, v3; };
+struct WinoPlan {
+  int bh, bw, ntb, ncb, grid, v3;
+  int n2;                                      // > 0: hybrid -- wino_fwd runs tile blocks [0, n2) (whole rounds), wino_fwd3 the rest
+  int bh3, bw3, tb3_first, ntb3, grid3;        // the wino_fwd3 part of a hybrid launch (its 32-tile blocks from tb3_first on)
+};
 
 // DBEV_WINO_FWD_V = 2 / 3 forces one forward kernel (A/B runs); default 0: chosen per layer
 int wino_fwd_version() { static const int v = getenv("DBEV_WINO_FWD_V") ? atoi(getenv("DBEV_WINO_FWD_V")) : 0; return v; }
@@ -1267,6 +1271,29 @@ bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
   const long long g = static_cast<long long>(p->ntb) * p->ncb;
   if (g > 0x3fffffffLL) return false;
   p->grid = dbev_round_xcd(static_cast<int>(g));
+  // Hybrid: a layer whose last round of 64-tile items would be at most half full (2.25 rounds: the 48-image ResNet stages) pays a whole
+  // round for it.  wino_fwd then runs only the whole rounds (tile blocks [0, n2), n2 a multiple of a block row), and the remaining tile
+  // rows go to wino_fwd3 as 32-tile items, two per CU: <= 256 of them take ~0.58 of a round, <= 512 ~1.16 (profiles/r04_wino_vs_miopen.txt).
+  p->n2 = 0;
+  static const int hybrid_on = getenv("DBEV_WINO_HYBRID") ? atoi(getenv("DBEV_WINO_HYBRID")) : 1;
+  if (!p->v3 && ver == 0 && hybrid_on && (TH % p->bh) == 0) {
+    const int nbw = (TW + p->bw - 1) / p->bw;
+    const long long n2 = (items / DBEV_NUM_CU * DBEV_NUM_CU / p->ncb) / nbw * nbw;
+    const long long rem = nb64 - n2, halves = 2 * rem * p->ncb;
+    if (n2 > 0 && rem > 0 && halves <= 2 * DBEV_NUM_CU) {
+      const double t_v2 = static_cast<double>((items + DBEV_NUM_CU - 1) / DBEV_NUM_CU);
+      const double t_hy = static_cast<double>((n2 * p->ncb + DBEV_NUM_CU - 1) / DBEV_NUM_CU) + (halves <= DBEV_NUM_CU ? 0.58 : 1.16) + 0.06;
+      if (t_hy < 0.92 * t_v2) {              // measured: the model's 12 % at 2.25 rounds is 4 % in the layer, its 4 % at 8.25 rounds nothing
+        p->n2 = static_cast<int>(n2);
+        p->bh3 = p->bh / 2; p->bw3 = p->bw;
+        p->tb3_first = 2 * p->n2;                                  // block rows double, the row-major order of the blocks is kept
+        p->ntb3 = (TH / p->bh3) * nbw * N;
+        p->grid3 = dbev_round_xcd(static_cast<int>((p->ntb3 - p->tb3_first) * p->ncb));
+        p->grid = dbev_round_xcd(p->n2 * p->ncb);
+        p->ntb = p->n2;                                            // wino_fwd's bound: its blocks only
+      }
+    }
+  }
   return true;
 }
 
@@ -1300,10 +1327,11 @@ extern "C" int dbev_wino_filter_pack_pair(const float* weight, long long so, lon
                                           int Cin, int fwd_kernel, int dgrad_kernel, float* packed_fwd, float* packed_dgrad,
                                           dbevStream_t stream) {
   // fwd_kernel / dgrad_kernel: what dbev_wino_conv3x3_forward_kernel returns for the layer each pack will be applied to (2 / 3), 0: skip
-  const bool okf = fwd_kernel == 0 || ((fwd_kernel == 2 || fwd_kernel == 3) && packed_fwd != nullptr && dbev_wino_filter_floats(Cin, Cout) > 0 &&
+  const auto known = [](int k) { return k == 2 || k == 3 || k == 6; };             // 6: both formats (a hybrid launch)
+  const bool okf = fwd_kernel == 0 || (known(fwd_kernel) && packed_fwd != nullptr && dbev_wino_filter_floats(Cin, Cout) > 0 &&
                                        (fwd_kernel == 3 || (Cin % 8) == 0));
-  const bool okd = dgrad_kernel == 0 || ((dgrad_kernel == 2 || dgrad_kernel == 3) && packed_dgrad != nullptr &&
-                                         dbev_wino_filter_floats(Cout, Cin) > 0 && (dgrad_kernel == 3 || (Cout % 8) == 0));
+  const bool okd = dgrad_kernel == 0 || (known(dgrad_kernel) && packed_dgrad != nullptr && dbev_wino_filter_floats(Cout, Cin) > 0 &&
+                                         (dgrad_kernel == 3 || (Cout % 8) == 0));
   if (weight == nullptr || !okf || !okd || (fwd_kernel == 0 && dgrad_kernel == 0)) return DBEV_EINVAL;
   const long long threads = static_cast<long long>(Cin) * Cout;                       // one per (reduction, output) channel pair
   hipLaunchKernelGGL(wino_filter_pack_pair, dim3(dbev_ceil_div(threads, 256), 2), dim3(256), 0, dbev_stream(stream), weight, so, sc, sa,
@@ -1314,12 +1342,12 @@ extern "C" int dbev_wino_filter_pack_pair(const float* weight, long long so, lon
 
 extern "C" int dbev_wino_conv3x3_forward_kernel(int N, int H, int W, int Cin, int Cout) {
   WinoPlan p;
-  return wino_plan(N, H, W, Cin, Cout, &p) ? (p.v3 ? 3 : 2) : 0;
+  return wino_plan(N, H, W, Cin, Cout, &p) ? (p.v3 ? 3 : p.n2 > 0 ? 6 : 2) : 0;
 }
 
 extern "C" int dbev_wino_conv3x3_stats_rows(int N, int H, int W, int Cin, int Cout) {
   WinoPlan p;
-  return wino_plan(N, H, W, Cin, Cout, &p) ? p.ntb : 0;
+  return wino_plan(N, H, W, Cin, Cout, &p) ? (p.n2 > 0 ? p.n2 + (p.ntb3 - p.tb3_first) : p.ntb) : 0;
 }
 
 extern "C" int dbev_wino_conv3x3_forward_act(const float* x_nhwc, const float* packed, const float* bias, float* y_nhwc,
@@ -1336,17 +1364,26 @@ extern "C" int dbev_wino_conv3x3_forward_act(const float* x_nhwc, const float* p
                      Cin, Cout, p.ntb, wino_dbg() | (relu ? 1 << 16 : 0))
 #define WN_GO3(BHV, BWV, ST)                                                                                                      \
   hipLaunchKernelGGL((wino_fwd3<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
-                     Cin, Cout, p.ntb, wino_dbg() | (relu ? 1 << 16 : 0))
+                     Cin, Cout, p.ntb, wino_dbg() | (relu ? 1 << 16 : 0), 0)
+#define WN_GO3T(BHV, BWV, ST)                     /* the tail of a hybrid launch: blocks tb3_first.. , statistics rows behind wino_fwd's */ \
+  hipLaunchKernelGGL((wino_fwd3<BHV, BWV, ST>), dim3(p.grid3), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc,                        \
+                     stats_partial != nullptr ? stats_partial + static_cast<size_t>(p.n2) * 2 * Cout : nullptr, N, H, W, Cin, Cout,  \
+                     p.ntb3, wino_dbg() | (relu ? 1 << 16 : 0), p.tb3_first)
   if (p.v3) {
     if (p.bw == 8) { if (stats_partial != nullptr) WN_GO3(4, 8, true); else WN_GO3(4, 8, false); }
     else { if (stats_partial != nullptr) WN_GO3(2, 16, true); else WN_GO3(2, 16, false); }
   } else {
+    if (p.n2 > 0) {                                         // hybrid: the rows wino_fwd leaves (launched first: it owns fewer CUs per item)
+      if (p.bw3 == 8) { if (stats_partial != nullptr) WN_GO3T(4, 8, true); else WN_GO3T(4, 8, false); }
+      else { if (stats_partial != nullptr) WN_GO3T(2, 16, true); else WN_GO3T(2, 16, false); }
+    }
     packed += 16LL * Cin * Cout;                            // the second format of the packed buffer
     if (p.bw == 8) { if (stats_partial != nullptr) WN_GO(8, 8, true); else WN_GO(8, 8, false); }
     else { if (stats_partial != nullptr) WN_GO(4, 16, true); else WN_GO(4, 16, false); }
   }
 #undef WN_GO
 #undef WN_GO3
+#undef WN_GO3T
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -164,6 +164,31 @@ def test_frozen_conv_norm_relu_stack_is_one_launch_per_pair():
     assert float((out.detach() - outr.detach()).abs().max()) <= 1e-4 * float(outr.detach().abs().max()) and xg.grad is not None
 
 
+def test_hybrid_launch_whole_rounds_on_one_kernel_the_tail_on_the_other():
+    """576 work items = 2.25 rounds of 256 CUs: wino_fwd runs the whole rounds, wino_fwd3 the remaining tile rows (kernel code 6, both
+    filter formats); output, statistics rows and gradients as for any other layer"""
+    from distill_bev_amd import wino, _lib as L
+    N, C, Co, H, W = 48, 64, 256, 16, 44
+    assert int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, C, Co)) == 6
+    x, w, b = _mk(N, C, Co, H, W, 31, True)
+    y, part = wino.conv_packed(x, wino.pack_filters(w, False, x.shape), Co, b, stats=True)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * scale
+    assert part.shape[0] == wino.stats_rows(x.shape, Co)
+    s = part.double().sum(0)
+    assert torch.allclose(s[0], ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * scale)
+    assert torch.allclose(s[1], (ref ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * scale * scale)
+    xg = x.clone().requires_grad_(True)
+    wg = w.clone().requires_grad_(True)
+    wino.conv3x3(xg, wg, b).backward(torch.ones_like(y))
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(xr, wr, b.double(), 1, 1).backward(torch.ones_like(ref))
+    assert float((xg.grad.double() - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
+    assert float((wg.grad.double() - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max())
+
+
 @pytest.mark.parametrize("block", ["basic", "bottleneck"])
 def test_residual_blocks_on_the_winograd_kernels_match_the_stock_convolutions(block, monkeypatch):
     """use_wino_convs re-classes the 3x3 convolutions of a residual block (res_block.py:11-230); the block then runs the Winograd
