@@ -18,10 +18,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # against 3 x 553 648 128 B = 1 660 944 384 B algorithmic -> ratio 1.00005 (no over-fetch, no write amplification)
 MFMA_F32_PEAK_TF = 157.3          # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
 PMC_TRAFFIC = {"bn_apply_res_ratio": (540720.8 * 2 + 540672.0) * 1024 / (3 * 553648128.0),
-               # wino_fwd at 48 x 256 -> 256 x 16 x 44: FETCH_SIZE 66 702.5 KB x 2 + WRITE_SIZE 34 368.0 KB = 171.8 MB per launch against
-               # 73.9 MB algorithmic (x, y once + packed filters): the four 64-channel blocks of a tile block each fetch its patch
-               # (32-byte pieces; the x 2 read correction is the guide's for wide reads and is conservative here); writes = the output
-               "wino_fwd_ratio": (66702.5 * 2 + 34368.0) * 1024 / (4.0 * 48 * 16 * 44 * 512 + 4.0 * 16 * 256 * 256),
+               # the 3x3 layer 48 x 256 -> 256 x 16 x 44 (a hybrid launch: wino_fwd + wino_fwd3): FETCH_SIZE (49 592.2 + 19 068.0) KB x 2 +
+               # WRITE_SIZE (30 072 + 4 224) KB = 175.7 MB per layer against 73.9 MB algorithmic (x, y once + packed filters): the four
+               # 64-channel blocks of a tile block each fetch its patch (16- / 32-byte pieces; the x 2 read correction is the guide's for
+               # wide reads and is conservative here); writes = the output
+               "wino_fwd_ratio": ((49592.2 + 19068.0) * 2 + 30072.0 + 4224.0) * 1024 / (4.0 * 48 * 16 * 44 * 512 + 4.0 * 16 * 256 * 256),
                "wino_source": "profiles/r04_pmc_wino_FETCH_SIZE.txt (x2 gfx950 wide-read correction) + profiles/r04_pmc_wino_WRITE_SIZE.txt, "
                               "separate --pmc passes of wino_fwd at 48x256x16x44 -> 256; traffic = mean algorithmic bytes of the timed "
                               "launches x that measured ratio (not collected live)",
