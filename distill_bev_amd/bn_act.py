@@ -312,11 +312,15 @@ def _eval_coef(bn, dev):
 
 
 def invalidate_eval_coef(root):
-    """forget the kept eval-mode coefficients of every norm under `root`.  The cache follows version counters, which writes through
+    """forget the kept eval-mode coefficients of every norm under `root` (and the packed / folded Winograd filters of its convolutions).  The cache follows version counters, which writes through
     `.data` (EMA hooks, mmcv-style `.data` loads, collectives on `t.data`) do NOT move: code that updates norm tensors that way calls
     this afterwards (GradReducer's construction-time broadcast bumps the versions itself)."""
     for m in root.modules():
         m.__dict__.pop("_dbev_eval_coef", None)
+        m.__dict__.pop("_dbev_wino_folded", None)          # filters packed with a folded norm (wino.conv_norm_relu_eval)
+        w = getattr(m, "weight", None)
+        if w is not None and hasattr(w, "_dbev_wino_pair"):  # packed Winograd filters kept on the weight (wino.packed_pair)
+            del w._dbev_wino_pair
 
 
 def _infer(x, residual, bn, relu):

@@ -155,6 +155,12 @@ def test_frozen_conv_norm_relu_stack_is_one_launch_per_pair():
         seq[4].weight.mul_(0.5); ref[4].weight.mul_(0.5)
         y, yr = seq(x), ref(x)
     assert float((y - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
+    # writes through .data move no version counter: the documented remedy forgets the kept packs / folds
+    seq[3].weight.data.mul_(2.0); ref[3].weight.data.mul_(2.0)
+    bn_act.invalidate_eval_coef(seq)
+    with torch.no_grad():
+        y, yr = seq(x), ref(x)
+    assert float((y - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
     # training mode: batch statistics, no folding; gradients flow
     seq.train(); ref.train()
     xg = x.clone().requires_grad_(True)
