@@ -85,6 +85,8 @@ _SIGNATURES = {
     "dbev_grid_sample_bilinear_nhwc": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "dbev_maxpool3x3s2_forward": [_p, _i, _i, _i, _i, _p, _p, _p],
     "dbev_maxpool3x3s2_backward": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "dbev_channel_sum_workspace_bytes": [_ll, _i],
+    "dbev_channel_sum_nhwc": [_p, _ll, _i, _p, _p, _sz, _p],
     "dbev_depth_head_forward": [_p, _p, _p, _p, _ll, _i, _i, _p, _p, _p, _p],
     "dbev_spconv_build_workspace_bytes": [_i, _i, _p, _p, _i, _i],
     "dbev_spconv_outputs": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _sz, _p],
@@ -152,6 +154,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_spconv_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_kernel_timing_read": ctypes.c_int,
              "dbev_pillar_vfe_workspace_bytes": ctypes.c_size_t,
+             "dbev_channel_sum_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_workspace_bytes": ctypes.c_size_t,
              "dbev_lift_splat_workspace_bytes": ctypes.c_size_t,

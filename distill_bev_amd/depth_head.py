@@ -85,8 +85,10 @@ class _DepthHead(Function):
             t = prob * (g_prob - (g_prob * prob).sum(dim=1, keepdim=True))
             gz = t if gz is None else gz + t
         gz = gz.contiguous(memory_format=torch.channels_last)
-        gxn, gw, gb = torch.ops.aten.convolution_backward(gz, xn, conv_w, [conv_w.shape[0]], [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                          [True, True, True])
+        gxn, gw, _ = torch.ops.aten.convolution_backward(gz, xn, conv_w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [True, True, False])
+        from .colsum import channel_sum
+        gb = channel_sum(gz) if ctx.needs_input_grad[4] else None      # ATen's reduction takes ~95 us for this 59-channel map
         gxn = gxn.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev)

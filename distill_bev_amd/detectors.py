@@ -143,6 +143,15 @@ class DynamicCenterPoint(CenterPoint):
 
 
 # --------------------------------------------------------------------------------------
+def _conv_norm_relu(conv, norm, x):
+    """relu(norm(conv(x))).  In training mode the norm subtracts the batch mean, so the convolution's bias cancels: the library
+    convolution then runs without its separate bias pass and without the bias-gradient reduction (colsum.conv_bn_cancelled_bias)."""
+    from .colsum import BiasSumConv2d, cancelled_bias_ready, conv_bn_cancelled_bias
+    if type(conv) in (nn.Conv2d, BiasSumConv2d) and cancelled_bias_ready(conv, norm, x):
+        return conv_bn_cancelled_bias(conv, norm, x, lambda z: bn_act(z, norm, None, True))
+    return bn_act(conv(x), norm, None, True)
+
+
 class ThreeLayer(nn.Module):
     """bevdet_distill.py:99-132: three (conv + BN + ReLU) stages; the first one carries kernel/stride."""
 
@@ -158,9 +167,9 @@ class ThreeLayer(nn.Module):
         self.norm3 = nn.BatchNorm2d(out_features); self.act3 = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        x = bn_act(self.conv1(x), self.norm1, None, True)      # norm -> relu on the fused kernel when eligible
-        x = bn_act(self.conv2(x), self.norm2, None, True)
-        return bn_act(self.conv3(x), self.norm3, None, True)
+        x = _conv_norm_relu(self.conv1, self.norm1, x)         # norm -> relu on the fused kernel when eligible
+        x = _conv_norm_relu(self.conv2, self.norm2, x)
+        return _conv_norm_relu(self.conv3, self.norm3, x)
 
 
 class TwoLayer(nn.Module):
@@ -176,7 +185,7 @@ class TwoLayer(nn.Module):
         self.norm2 = nn.BatchNorm2d(out_features); self.act2 = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return bn_act(self.conv2(bn_act(self.conv1(x), self.norm1, None, True)), self.norm2, None, True)
+        return _conv_norm_relu(self.conv2, self.norm2, _conv_norm_relu(self.conv1, self.norm1, x))
 
 
 def load_checkpoint(module, path, what="model", allow_missing=False):

@@ -144,6 +144,8 @@ def accelerate_modules(detector):
     detector.batched_branches = 0
     if os.environ.get("DBEV_HEAD_BATCH", "1") != "0":
         detector.batched_branches = sum(plan_branches(m) for r in roots for m in r.modules() if isinstance(m, CenterHead))
+    from .colsum import use_bias_sum_convs
+    detector.bias_sum_convs = sum(use_bias_sum_convs(r) for r in roots)   # remaining nn.Conv2d(bias=True): bias gradient as one streaming pass
     n_up = 0
     for r in roots:
         for mod in r.modules():

@@ -236,7 +236,8 @@ class _Conv3x3Wino(Function):
         if ctx.needs_input_grad[1]:
             gw = weight_gradient(x, gy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3))
+            from .colsum import channel_sum
+            gb = channel_sum(gy)                           # one streaming pass, fixed order (csrc/colsum.hip)
         return gx, gw, gb, None
 
 

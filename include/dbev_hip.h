@@ -605,6 +605,17 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
                                dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Per-channel sum of a channels-last tensor, out[c] = sum over the M = N*H*W rows of x_nhwc[M, C]: the bias gradient of a convolution
+ * (replaces ATen's grad_output.sum((0, 2, 3)) inside convolution_backward for the nn.Conv2d(bias=True) layers of
+ * mmdet3d/models/necks/fpn.py:77-95, necks/view_transformer_mine.py:288-309, backbones/resnet.py:80-96 and the DCN offset
+ * convolution).  Any C (float4 lanes when C % 4 == 0); fixed summation order (per-workgroup partial rows in `workspace`, merged by a
+ * second launch): bit-reproducible.  workspace: dbev_channel_sum_workspace_bytes(M, C) bytes (0: unsupported size).
+ * ---------------------------------------------------------------------------------- */
+size_t dbev_channel_sum_workspace_bytes(long long M, int C);
+int dbev_channel_sum_nhwc(const float* x_nhwc, long long M, int C, float* out, void* workspace, size_t workspace_bytes,
+                          dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Depth head of the BEVDepth view transformer, forward (mmdet3d/models/necks/view_transformer_mine.py:300-309 self.dcn's
  * BatchNorm2d, :326 depth_digit = self.depthnet(depth_feat) (nn.Conv2d(c, D, 1), :291), :327 get_depth_dist = softmax(dim=1);
  * same in detectors/bevdet_distill_more.py:398-416): normalise -> 1x1 convolution -> softmax in one pass.

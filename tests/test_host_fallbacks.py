@@ -34,3 +34,18 @@ def test_forked_is_the_identity_without_the_fused_path_and_h2d_is_a_plain_copy_o
     assert torch.equal(L.h2d(t, "cpu"), t)
     like = L.h2d_like(torch.zeros(3, dtype=torch.float64), [1, 2, 3])
     assert like.dtype == torch.float64 and like.tolist() == [1.0, 2.0, 3.0]
+
+
+def test_bias_sum_conv_is_the_stock_module_on_the_host():
+    """colsum.BiasSumConv2d / the cancelled-bias path only engage for channels-last device tensors (no CPU compute in the product)"""
+    import torch
+    import torch.nn as nn
+    from distill_bev_amd.colsum import BiasSumConv2d, cancelled_bias_ready, use_bias_sum_convs
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Conv2d(4, 6, 3, 1, 1), nn.Conv2d(6, 2, 1, bias=False))
+    ref = nn.Conv2d(4, 6, 3, 1, 1)
+    ref.load_state_dict(m[0].state_dict())
+    assert use_bias_sum_convs(m) == 1 and type(m[0]) is BiasSumConv2d and type(m[1]) is nn.Conv2d
+    x = torch.randn(2, 4, 5, 5, requires_grad=True)
+    assert torch.equal(m[0](x), ref(x))
+    assert not cancelled_bias_ready(m[0], nn.BatchNorm2d(6), x)
