@@ -256,8 +256,15 @@ class _Conv1x1Stats(Function):
     @staticmethod
     def backward(ctx, gz, _gpart):
         x, w = ctx.saved_tensors
-        gx, gw, _ = torch.ops.aten.convolution_backward(gz.contiguous(memory_format=torch.channels_last), x, w, None, [1, 1], [0, 0],
-                                                        [1, 1], False, [0, 0], 1, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        gz = gz.contiguous(memory_format=torch.channels_last)
+        from .gemm_bf6 import data_gradient
+        gx = data_gradient(gz, w) if ctx.needs_input_grad[0] else None      # bf16x6 GEMM where it fills the chip, else the library
+        lib_x = ctx.needs_input_grad[0] and gx is None
+        gw = None
+        if lib_x or ctx.needs_input_grad[1]:
+            a, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                           [lib_x, ctx.needs_input_grad[1], False])
+            gx = a if lib_x else gx
         return gx, gw
 
 
@@ -270,7 +277,8 @@ def conv1x1_bn_ready(conv, bn, x):
     library than the hand-written kernel with the statistics in its epilogue -- measured (tools/kbench_c1x1.py,
     profiles/r03_conv1x1_vs_miopen.txt): the >= 300 k-pixel maps of the image backbone's first stage (64 <-> 256 channels, HBM-bound:
     conv + statistics 0.21 vs 0.30 ms); at stage 2 the two are even, from stage 3 on the library's kernels win."""
-    if not (_C1["enabled"] and _state["enabled"] and type(conv) is nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+    if not (_C1["enabled"] and _state["enabled"] and type(conv).__name__ in ("Conv2d", "Bf6Conv2d") and isinstance(conv, nn.Conv2d)
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None):
         return False
     if not (x.is_cuda and x.dtype == torch.float32 and _nhwc(x) and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
@@ -321,6 +329,8 @@ def invalidate_eval_coef(root):
         w = getattr(m, "weight", None)
         if w is not None and hasattr(w, "_dbev_wino_pair"):  # packed Winograd filters kept on the weight (wino.packed_pair)
             del w._dbev_wino_pair
+        if w is not None and hasattr(w, "_dbev_bf6_packs"):  # bf16 planes of a 1x1 filter (gemm_bf6.packed)
+            del w._dbev_bf6_packs
 
 
 def _infer(x, residual, bn, relu):

@@ -541,7 +541,7 @@ class BEVDepth4DDistill(CenterPoint):
         adapt = self.channel_wise_adaptations[index]
         # 'head' recipe (1x1-conv adaptation): GEMM + loss reductions in one MFMA kernel, no adapted tensor in memory
         fused = self.fused_adapt_mse and not dp["channel_mask"] and fused_adapt_eligible(adapt, student_feat, teacher_feat)
-        if (not fused and self.fused_adapt_mse and not dp["channel_mask"] and type(adapt) is nn.Conv2d and adapt.kernel_size == (1, 1)
+        if (not fused and self.fused_adapt_mse and not dp["channel_mask"] and type(adapt).__name__ in ("Conv2d", "BiasSumConv2d") and isinstance(adapt, nn.Conv2d) and adapt.kernel_size == (1, 1)
                 and getattr(self, "channels_last", False) and student_feat.is_cuda):
             L.note_fallback("adapt_mse", f"{adapt.in_channels}->{adapt.out_channels}, layouts {student_feat.stride()} / {teacher_feat.stride()}")
         if not fused:

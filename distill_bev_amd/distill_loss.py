@@ -307,7 +307,7 @@ class _FusedAdaptMSE(Function):
 
 def fused_adapt_eligible(conv, student_in, teacher_feat):
     """the 'head' recipe: nn.Conv2d(Cs, Ct, 1) with bias on channels-last fp32 features, Cs % 32 == Ct % 32 == 0"""
-    if type(conv) is not torch.nn.Conv2d or conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) \
+    if type(conv).__name__ not in ("Conv2d", "BiasSumConv2d") or not isinstance(conv, torch.nn.Conv2d) or conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) \
             or conv.groups != 1 or conv.bias is None or conv.dilation != (1, 1):
         return False
     if not (student_in.is_cuda and student_in.dtype == torch.float32 and _is_nhwc(student_in) and _is_nhwc(teacher_feat)):

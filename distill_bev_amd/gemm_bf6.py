@@ -1,0 +1,143 @@
+"""1x1 convolutions as fp32 GEMMs on the BF16 matrix cores at fp32 accuracy (csrc/gemm_bf6.hip, "bf16x6").
+
+Host-side mirror of what the reference reaches through ``nn.Conv2d(k=1)`` -> cuDNN in the bottlenecks and necks
+(mmdet3d/models/bricks/res_block.py:102-230, necks/fpn.py:10-204, necks/lss_fpn.py:10-72).  Every fp32 operand is split into three
+bf16 values (24 mantissa bits in three pieces), a product is the sum of the six partial products that matter -- each exact in fp32 --
+and the sums are kept in fp32: max |y - fp64| / max |y| = 2-4e-7 on the step's layers, at or BELOW the library's fp32 kernels
+(5e-7-1e-6; tests/test_gpu_gemm_bf6.py asserts it per shape).  On gfx950 the bf16 matrix pipe is 16 x as fast as the fp32 one, so six
+bf16 instructions replace eight fp32 ones in 0.38 of the time.
+
+``conv1x1(x, weight)`` is ``F.conv2d(x, weight)`` for channels-last fp32 device tensors with N*H*W % 128 == 0, Cin % 16 == 0,
+Cout % 64 == 0, differentiable: the data gradient is the same kernel on grad_y with the transposed weight view, the weight gradient
+stays the library's.  Layers that would leave half of the chip idle (fewer than `_MIN_ITEMS` output tiles) stay with the library."""
+import os
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib as L
+
+_ON = os.environ.get("DBEV_BF6", "1") != "0"
+_MIN_ITEMS = int(os.environ.get("DBEV_BF6_MIN_ITEMS", "448"))     # 128 x 128 (or 128 x 64) output tiles; two workgroups share a CU
+
+
+def _nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def shape_ok(M, K, N):
+    """can the kernels take Y[M, N] = X[M, K] W[N, K]^T, and does the launch fill the chip?"""
+    if M <= 0 or M % 128 or K % 16 or N % 64 or K <= 0 or N <= 0:
+        return False
+    bn = 128 if N % 128 == 0 else 64
+    return (M // 128) * (N // bn) >= _MIN_ITEMS
+
+
+def eligible(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1):
+    if not (_ON and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    if tuple(weight.shape[2:]) != (1, 1) or tuple(stride) != (1, 1) or tuple(padding) != (0, 0) or tuple(dilation) != (1, 1) or groups != 1:
+        return False
+    N, C, H, W = x.shape
+    return weight.shape[1] == C and _nhwc(x) and shape_ok(N * H * W, C, weight.shape[0])
+
+
+def packed(weight, transposed=False):
+    """the three bf16 planes of `weight` [Cout, Cin, 1, 1] in the kernel's LDS image order (dbev_gemm_bf16x6_pack), kept on the weight
+    until it changes.  transposed: for the data gradient (rows = input channels, reduction over the output channels)."""
+    dev = L.require_cuda(weight)
+    Co, Ci = int(weight.shape[0]), int(weight.shape[1])
+    key = (weight._version, weight.data_ptr())
+    cache = getattr(weight, "_dbev_bf6_packs", None)
+    if cache is None or cache[0] != key:
+        cache = (key, {})
+        try:
+            weight._dbev_bf6_packs = cache
+        except AttributeError:
+            pass
+    hit = cache[1].get(bool(transposed))
+    if hit is not None:
+        return hit
+    w2 = weight.detach().reshape(Co, Ci)                      # a view for both memory formats of a 1x1 filter
+    n, k = (Ci, Co) if transposed else (Co, Ci)
+    sn, sk = (w2.stride(1), w2.stride(0)) if transposed else (w2.stride(0), w2.stride(1))
+    nbytes = int(L.call("dbev_gemm_bf16x6_packed_bytes", n, k))
+    if nbytes == 0:
+        raise L.DbevHipError(f"gemm_bf6: unsupported weight {Co} x {Ci} (transposed={transposed})")
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dbev_gemm_bf16x6_pack", L.ptr(w2), sn, sk, n, k, L.ptr(buf), L.stream_ptr(dev))
+    cache[1][bool(transposed)] = buf
+    return buf
+
+
+def gemm(x, pack, Cout):
+    """x [N, K, H, W] channels-last -> [N, Cout, H, W] channels-last with the packed weight planes"""
+    dev = L.require_cuda(x, pack)
+    n, K, H, W = x.shape
+    y = torch.empty((n, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    with torch.cuda.device(dev):
+        L.call("dbev_gemm_bf16x6_forward", L.ptr(x), L.ptr(pack), L.ptr(y), n * H * W, K, Cout, K, L.stream_ptr(dev))
+    return y
+
+
+def data_gradient(gy, weight):
+    """grad_x of y = conv1x1(x, weight) from a channels-last grad_y, or None when the library should do it (shape / layout)"""
+    Co, Ci = int(weight.shape[0]), int(weight.shape[1])
+    if not (_ON and gy.is_cuda and gy.dtype == torch.float32 and _nhwc(gy) and shape_ok(gy.shape[0] * gy.shape[2] * gy.shape[3], Co, Ci)):
+        return None
+    return gemm(gy, packed(weight, True), Ci)
+
+
+class _Conv1x1Bf6(Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        y = gemm(x, packed(weight), int(weight.shape[0]))
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_x:
+            gx = data_gradient(gy, weight)
+        if need_w or (need_x and gx is None):
+            a, b, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                          [need_x and gx is None, need_w, False])
+            gx = a if gx is None else gx
+            gw = b
+        return gx, gw
+
+
+def conv1x1(x, weight):
+    """F.conv2d(x, weight) for an `eligible` pair"""
+    return _Conv1x1Bf6.apply(x, weight)
+
+
+class Bf6Conv2d(nn.Conv2d):
+    """nn.Conv2d (1x1, stride 1, no padding, no bias) whose forward and data gradient run on the bf16x6 GEMM when the input qualifies
+    (`eligible`); the stock convolution otherwise.  Same parameters and state-dict keys."""
+
+    def forward(self, x):
+        if self.bias is None and eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+                return gemm(x, packed(self.weight), self.out_channels)
+            return conv1x1(x, self.weight)
+        return super().forward(x)
+
+
+def use_bf6_convs(model):
+    """Re-class the bias-free 1x1 / stride-1 nn.Conv2d modules with Cin % 16 == 0 and Cout % 64 == 0; returns how many.  Idempotent."""
+    if not _ON:
+        return 0
+    n = 0
+    for m in model.modules():
+        if type(m) is nn.Conv2d and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) and m.dilation == (1, 1) \
+                and m.groups == 1 and m.bias is None and m.in_channels % 16 == 0 and m.out_channels % 64 == 0:
+            m.__class__ = Bf6Conv2d
+            n += 1
+    return n

@@ -144,6 +144,8 @@ def accelerate_modules(detector):
     detector.batched_branches = 0
     if os.environ.get("DBEV_HEAD_BATCH", "1") != "0":
         detector.batched_branches = sum(plan_branches(m) for r in roots for m in r.modules() if isinstance(m, CenterHead))
+    from .gemm_bf6 import use_bf6_convs
+    detector.bf6_convs = sum(use_bf6_convs(r) for r in roots)          # bias-free 1x1 convolutions: fp32 GEMM on the bf16 matrix cores (bf16x6)
     from .colsum import use_bias_sum_convs
     detector.bias_sum_convs = sum(use_bias_sum_convs(r) for r in roots)   # remaining nn.Conv2d(bias=True): bias gradient as one streaming pass
     n_up = 0

@@ -605,6 +605,19 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
                                dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * fp32 GEMM of a 1x1 convolution on the BF16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three bf16 values,
+ * six exact partial products per product, fp32 accumulation; csrc/gemm_bf6.hip).  Replaces cuDNN behind nn.Conv2d(k=1) of
+ * mmdet3d/models/bricks/res_block.py:102-230 / necks/fpn.py:10-204 like dbev_gemm1x1_forward does.
+ *   y[M, N] = x[M, K] * weight[N, K]^T,  x rows of x_row_stride floats, y row-major; M % 256 == 0, K % 32 == 0, N % 64 == 0.
+ * dbev_gemm_bf16x6_pack splits the weight (element (n, k) at weight[n * stride_n + k * stride_k]: the transposed view serves the data
+ * gradient) into `packed` (dbev_gemm_bf16x6_packed_bytes(N, K) bytes; 0: unsupported shape) once per weight version.
+ * ---------------------------------------------------------------------------------- */
+long long dbev_gemm_bf16x6_packed_bytes(int N, int K);
+int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long stride_k, int N, int K, void* packed, dbevStream_t stream);
+int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
+                             dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Per-channel sum of a channels-last tensor, out[c] = sum over the M = N*H*W rows of x_nhwc[M, C]: the bias gradient of a convolution
  * (replaces ATen's grad_output.sum((0, 2, 3)) inside convolution_backward for the nn.Conv2d(bias=True) layers of
  * mmdet3d/models/necks/fpn.py:77-95, necks/view_transformer_mine.py:288-309, backbones/resnet.py:80-96 and the DCN offset

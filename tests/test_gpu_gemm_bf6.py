@@ -1,0 +1,110 @@
+"""fp32 GEMM of the 1x1 convolutions on the bf16 matrix cores (csrc/gemm_bf6.hip, distill_bev_amd/gemm_bf6.py) vs the op the reference
+runs (nn.Conv2d(k=1) -> the library's fp32 convolution; res_block.py:102-230, necks/fpn.py:10-204).  The claim under test: fp32 accuracy
+-- the error against an fp64 GEMM is at or below the error of the library's own fp32 kernel on the same inputs (bound: 1.25 x the
+library's error + 1e-7 of the output scale), for the forward product and for both gradients the module hands back."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _mk(n, ci, co, h, w, seed, relu=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((n, ci, h, w), generator=g)
+    x = (torch.relu(x) if relu else x).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((co, ci, 1, 1), generator=g) / ci ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    return x, wt
+
+
+def _err(y, ref):
+    return float((y.double() - ref).abs().max()) / float(ref.abs().max())
+
+
+SHAPES = [(2, 16, 64, 8, 8),            # one chunk, one 64-column block
+          (4, 64, 256, 16, 16),         # 128-column blocks
+          (3, 48, 192, 16, 16),         # K = 3 chunks, N = 3 x 64
+          (2, 256, 64, 32, 16),         # 16 chunks: two flushes of the matrix accumulator
+          (1, 2048, 128, 16, 16),       # deep reduction (128 chunks)
+          (2, 1024, 512, 16, 8)]
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", SHAPES)
+def test_forward_is_as_exact_as_the_fp32_library_kernel(n, ci, co, h, w, monkeypatch):
+    from distill_bev_amd import gemm_bf6 as G
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    x, wt = _mk(n, ci, co, h, w, 11)
+    assert G.eligible(x, wt)
+    y = G.gemm(x, G.packed(wt), co)
+    lib = F.conv2d(x, wt)
+    ref = F.conv2d(x.double(), wt.double())
+    assert y.shape == lib.shape and y.is_contiguous(memory_format=torch.channels_last)
+    e, el = _err(y, ref), _err(lib, ref)
+    assert e <= 1.25 * el + 1e-7, (e, el)
+    assert e < 1e-6
+    assert torch.equal(y, G.gemm(x, G.packed(wt), co))           # deterministic
+
+
+def test_signed_inputs_and_extreme_magnitudes(monkeypatch):
+    """operands spanning 2^-60 ... 2^60: the split must not lose the small ones (every piece keeps its own exponent)"""
+    from distill_bev_amd import gemm_bf6 as G
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn((2, 64, 8, 8), generator=g) * torch.exp2(torch.randint(-60, 60, (2, 1, 8, 8), generator=g).float()))
+    x = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn((64, 64, 1, 1), generator=g).to(DEV)
+    y = G.gemm(x, G.packed(wt), 64)
+    ref = F.conv2d(x.double(), wt.double())
+    rowscale = ref.abs().amax(dim=1, keepdim=True).clamp(min=1e-300)
+    assert float(((y.double() - ref).abs() / rowscale).max()) < 2e-6     # relative to each pixel's own scale
+    z = G.gemm(torch.zeros_like(x), G.packed(wt), 64)
+    assert float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(4, 64, 256, 16, 16), (2, 256, 64, 32, 16), (2, 128, 128, 16, 16)])
+def test_module_gradients_vs_fp64(n, ci, co, h, w, monkeypatch):
+    from distill_bev_amd import gemm_bf6 as G
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    torch.manual_seed(7)
+    m = nn.Sequential(nn.Conv2d(ci, co, 1, bias=False)).to(DEV).to(memory_format=torch.channels_last)
+    assert G.use_bf6_convs(m) == 1 and type(m[0]) is G.Bf6Conv2d and G.use_bf6_convs(m) == 0
+    assert list(m.state_dict()) == ["0.weight"]
+    x, _ = _mk(n, ci, co, h, w, 5, relu=False)
+    xa = x.clone().requires_grad_(True)
+    y = m(xa)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd = x.double().requires_grad_(True)
+    wd = m[0].weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd)
+    yd.backward(gy.double())
+    # the library's fp32 gradients on the same inputs, for the bound
+    xl = x.clone().requires_grad_(True)
+    wl = m[0].weight.detach().clone().requires_grad_(True)
+    F.conv2d(xl, wl).backward(gy)
+    assert _err(y, yd.detach()) <= 1.25 * _err(F.conv2d(x, wl.detach()), yd.detach()) + 1e-7
+    assert _err(xa.grad, xd.grad) <= 1.25 * _err(xl.grad, xd.grad) + 1e-7
+    assert _err(m[0].weight.grad, wd.grad) <= 1.25 * _err(wl.grad, wd.grad) + 1e-7      # (the library's kernel: same bits)
+    with torch.no_grad():
+        assert torch.equal(m(x), y.detach())                     # the no-grad path runs the same kernel
+
+
+def test_small_layers_stay_with_the_library_and_packs_follow_the_weight():
+    from distill_bev_amd import gemm_bf6 as G
+    x, wt = _mk(1, 64, 64, 16, 16, 1)                            # two tiles: below _MIN_ITEMS
+    assert not G.eligible(x, wt)
+    m = nn.Conv2d(64, 64, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    m.__class__ = G.Bf6Conv2d
+    assert torch.equal(m(x), F.conv2d(x, m.weight))
+    p1 = G.packed(m.weight)
+    assert G.packed(m.weight) is p1
+    with torch.no_grad():
+        m.weight.mul_(2.0)                                       # version counter moves: a new pack
+    assert G.packed(m.weight) is not p1
+    from distill_bev_amd.bn_act import invalidate_eval_coef
+    p2 = G.packed(m.weight)
+    m.weight.data.mul_(0.5)                                      # a write the version counter does not see ...
+    invalidate_eval_coef(m)                                      # ... is followed by the documented invalidation
+    assert G.packed(m.weight) is not p2
