@@ -232,6 +232,21 @@ class DistillStep(_Base):
                 self.full_head_ms = (time.perf_counter() - t0) / 5 * 1e3
             finally:
                 del os.environ["DBEV_TEACHER_FULL_HEAD"]
+        # the same step with the 1x1 convolutions on the fp32 matrix cores only (the library's kernels) instead of the bf16x6 GEMM
+        # (same accuracy class, tests/test_gpu_gemm_bf6.py): 1 warm-up + 5 timed steps, outside the timed region
+        from distill_bev_amd import gemm_bf6
+        if gemm_bf6._ON:
+            gemm_bf6._ON = False
+            try:
+                self.step()
+                torch.cuda.synchronize(self.dev)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    self.step()
+                torch.cuda.synchronize(self.dev)
+                self.fp32_mfma_only_ms = (time.perf_counter() - t0) / 5 * 1e3
+            finally:
+                gemm_bf6._ON = True
         rt, rf = self._fam(roof)                    # seconds, Winograd-domain FLOPs (the log's work field) of the timed launches
         ach = rf / rt / 1e12
         other = {}
@@ -351,6 +366,14 @@ class DistillStep(_Base):
                                getattr(self.trainer.detector, "wino_convs", 0), __import__("distill_bev_amd.wino", fromlist=["x"])._MIN_WG),
                 "batched_head_branches": getattr(self.trainer.detector, "batched_branches", 0),
                 "ms_per_step_full_teacher_head": getattr(self, "full_head_ms", None),
+                # fp32 results throughout; the bias-free 1x1 convolutions' forward / data-gradient GEMMs form every fp32 product from
+                # six exact bf16 x bf16 partial products (three-way split of both operands) on the bf16 matrix cores, sums in fp32:
+                # error vs fp64 at or below the library's fp32 kernels (asserted per shape, tests/test_gpu_gemm_bf6.py).
+                # DBEV_BF6=0 keeps them on the library's fp32-MFMA kernels: that step time is measured beside the headline
+                "conv1x1": "fp32 GEMM as bf16x6 on the bf16 matrix cores (csrc/gemm_bf6.hip): %d modules re-classed, forward + data "
+                           "gradient of layers with >= %d output tiles; weight gradients and the other layers: MIOpen fp32" % (
+                               getattr(self.trainer.detector, "bf6_convs", 0), __import__("distill_bev_amd.gemm_bf6", fromlist=["x"])._MIN_ITEMS),
+                "ms_per_step_fp32_matrix_cores_only": getattr(self, "fp32_mfma_only_ms", None),
                 "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py"}
 
 

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "dbev_gemm_bf16x6_packed_bytes": [_i, _i],
     "dbev_gemm_bf16x6_pack": [_p, _ll, _ll, _i, _i, _p, _p],
     "dbev_gemm_bf16x6_forward": [_p, _p, _p, _ll, _i, _i, _i, _p],
+    "dbev_gemm_bf16x6_backward_weight_workspace_bytes": [_ll, _i, _i, _i],
+    "dbev_gemm_bf16x6_backward_weight": [_p, _p, _p, _ll, _i, _i, _i, _p, _sz, _p],
     "dbev_channel_sum_nhwc": [_p, _ll, _i, _p, _p, _sz, _p],
     "dbev_depth_head_forward": [_p, _p, _p, _p, _ll, _i, _i, _p, _p, _p, _p],
     "dbev_spconv_build_workspace_bytes": [_i, _i, _p, _p, _i, _i],
@@ -159,6 +161,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_pillar_vfe_workspace_bytes": ctypes.c_size_t,
              "dbev_channel_sum_workspace_bytes": ctypes.c_size_t,
              "dbev_gemm_bf16x6_packed_bytes": ctypes.c_longlong,
+             "dbev_gemm_bf16x6_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_workspace_bytes": ctypes.c_size_t,
              "dbev_lift_splat_workspace_bytes": ctypes.c_size_t,

@@ -257,14 +257,14 @@ class _Conv1x1Stats(Function):
     def backward(ctx, gz, _gpart):
         x, w = ctx.saved_tensors
         gz = gz.contiguous(memory_format=torch.channels_last)
-        from .gemm_bf6 import data_gradient
-        gx = data_gradient(gz, w) if ctx.needs_input_grad[0] else None      # bf16x6 GEMM where it fills the chip, else the library
-        lib_x = ctx.needs_input_grad[0] and gx is None
-        gw = None
-        if lib_x or ctx.needs_input_grad[1]:
-            a, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                           [lib_x, ctx.needs_input_grad[1], False])
+        from .gemm_bf6 import data_gradient, weight_gradient
+        gx = data_gradient(gz, w) if ctx.needs_input_grad[0] else None      # bf16x6 GEMMs where they apply, else the library
+        gw = weight_gradient(x, gz, w) if ctx.needs_input_grad[1] else None
+        lib_x, lib_w = ctx.needs_input_grad[0] and gx is None, ctx.needs_input_grad[1] and gw is None
+        if lib_x or lib_w:
+            a, b, _ = torch.ops.aten.convolution_backward(gz, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [lib_x, lib_w, False])
             gx = a if lib_x else gx
+            gw = b if lib_w else gw
         return gx, gw
 
 

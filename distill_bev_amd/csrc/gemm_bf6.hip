@@ -10,7 +10,7 @@
 // fp32 lanes -- VALU work issued between bf16 MFMAs costs ~2 cycles per instruction, so the split of the activation operand can be done
 // on the fly (5.5 VALU operations per element, amortised over the tile's columns).  The weights are split once per step by b6_pack.
 //
-//   Y[M, N] = X[M, K] * W[N, K]^T     X rows of x_stride floats, Y row-major, M % 256 == 0, K % 32 == 0, N % 64 == 0
+//   Y[M, N] = X[M, K] * W[N, K]^T     X rows of x_stride floats, Y row-major, M % 128 == 0, K % 64 == 0, N % 64 == 0
 //
 // Workgroup = 8 waves (two per SIMD), tile 256 rows x BN columns (BN = 128: waves 4 x 2, wave tile 64 x 64; BN = 64: waves 8 x 1, wave
 // tile 32 x 64), reduction in chunks of 32, double-buffered in LDS as three bf16 planes per operand ([plane][row][32 k], the four 16-byte
@@ -22,6 +22,13 @@
 #include <stdlib.h>
 
 namespace {
+
+// ablation switches (dev builds with -DDBEV_BF6_ABLATE, DBEV_BF6_DBG bits: 1 no global fetch, 2 no split / LDS staging, 4 no barrier, 8 no stores)
+#ifdef DBEV_BF6_ABLATE
+#define B6_DBG(bit_) (dbg & (bit_))
+#else
+#define B6_DBG(bit_) 0
+#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -64,6 +71,8 @@ __global__ __launch_bounds__(256) void b6_pack(const float* __restrict__ w, long
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 // (a, b) -> three dwords of two bf16 each (round to nearest even, v_cvt_pk_bf16_f32): a = p0.lo + p1.lo + p2.lo up to 2^-25 |a|
 __device__ __forceinline__ void b6_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
@@ -80,10 +89,19 @@ __device__ __forceinline__ void b6_split2(float a, float b, unsigned& p0, unsign
   p2 = *reinterpret_cast<unsigned*>(&h);
 }
 
+__device__ __forceinline__ unsigned long long b6_uniform64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 // LDS image of a chunk (16 reduction steps): [plane 3][row][2 units of 8 bf16], unit u of row r in slot u ^ ((r >> 3) & 1)
-template <int BN, int OCC, int FL>
+// The reduction runs in groups of FOUR chunks (K % 64 == 0): the matrix pipe accumulates a group from zero (the first instruction of
+// a tile takes the constant 0 as its addend), then the group's sum is added to `tot` by the VALU in round-to-nearest -- the error of a
+// long chain of matrix instructions on one accumulator grows with its length (1.8e-6 of the output scale at K = 2048 against 4.8e-7
+// for the fp32 kernels), with 24-instruction chains it is 2-3e-7 at every K.
+template <int BN, int OCC>
 __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, const unsigned short* __restrict__ Wp,
-                                                   float* __restrict__ Y, int M, int K, int N, int xs) {
+                                                   float* __restrict__ Y, int M, int K, int N, int xs, int dbg) {
   constexpr int WN = BN / 64, WM = 4 / WN, TM = B6_BM / WM / 32;            // waves along N / M, 32-row tiles per wave
   constexpr int APL = B6_BM * 32, BPL = BN * 32;                            // bytes of one plane of a chunk
   constexpr int ABUF = 3 * APL, BBUF = 3 * BPL;
@@ -102,24 +120,28 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
   const int m0 = mb * B6_BM, n0 = nb * BN;
   const int nkc = K / B6_KC;
 
-  // activation fetch: float4 f = tid + 256 i of the chunk (128 rows x 4 float4): row f / 4, floats 4 (f % 4) .. + 3
+  // activation fetch: thread = (row tid >> 2 and that row + 64, floats 4 (tid & 3) .. + 3 of the chunk); scalar base + 32-bit offsets
   const int row0 = tid >> 2, row1 = 64 + (tid >> 2), c4 = tid & 3;
-  const float* xrow0 = X + static_cast<size_t>(m0 + row0) * xs + 4 * c4;
-  const float* xrow1 = X + static_cast<size_t>(m0 + row1) * xs + 4 * c4;
+  typedef const __attribute__((address_space(1))) float* gfloat_p;      // (a pointer rebuilt from integers is generic: flat loads)
+  typedef const __attribute__((address_space(1))) uintx4* guint4_p;
+  const gfloat_p xb = reinterpret_cast<gfloat_p>(b6_uniform64(reinterpret_cast<unsigned long long>(X + static_cast<size_t>(m0) * xs)));
+  const unsigned xo0 = static_cast<unsigned>(row0 * xs + 4 * c4), xo1 = static_cast<unsigned>(row1 * xs + 4 * c4);
   const int aoff0 = row0 * 32 + (((c4 >> 1) ^ ((row0 >> 3) & 1)) * 16) + (c4 & 1) * 8;
   const int aoff1 = row1 * 32 + (((c4 >> 1) ^ ((row1 >> 3) & 1)) * 16) + (c4 & 1) * 8;
-  const uint4* wsrc = reinterpret_cast<const uint4*>(Wp) + static_cast<size_t>(nb) * nkc * BV + tid;
+  const guint4_p wsrc = reinterpret_cast<guint4_p>(b6_uniform64(reinterpret_cast<unsigned long long>(
+      reinterpret_cast<const uintx4*>(Wp) + static_cast<size_t>(nb) * nkc * BV)));
   // two chunks in flight in registers (set q = chunk & 1); named scalars: indexed arrays of these end up in scratch memory
-  float4 xa0_0, xa0_1, xa1_0, xa1_1;
-  uint4 wb0_0, wb0_1 = make_uint4(0, 0, 0, 0), wb0_2 = make_uint4(0, 0, 0, 0), wb1_0, wb1_1 = make_uint4(0, 0, 0, 0), wb1_2 = make_uint4(0, 0, 0, 0);
+  floatx4 xa0_0, xa0_1, xa1_0, xa1_1;
+  uintx4 wb0_0, wb0_1 = {0, 0, 0, 0}, wb0_2 = {0, 0, 0, 0}, wb1_0, wb1_1 = {0, 0, 0, 0}, wb1_2 = {0, 0, 0, 0};
 #define B6_FETCH(q_, kc_)                                                                                            \
   do {                                                                                                               \
-    xa##q_##_0 = *reinterpret_cast<const float4*>(xrow0 + (kc_) * B6_KC);                                            \
-    xa##q_##_1 = *reinterpret_cast<const float4*>(xrow1 + (kc_) * B6_KC);                                            \
-    const uint4* ws_ = wsrc + static_cast<size_t>(kc_) * BV;                                                         \
-    wb##q_##_0 = ws_[0];                                                                                             \
-    if (BV == 768 || tid < 128) wb##q_##_1 = ws_[256];                                                               \
-    if (BV == 768) wb##q_##_2 = ws_[512];                                                                            \
+    const gfloat_p xc_ = xb + (kc_) * B6_KC;                                                                         \
+    xa##q_##_0 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo0);                      \
+    xa##q_##_1 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo1);                      \
+    const guint4_p ws_ = wsrc + static_cast<size_t>(kc_) * BV;                                                       \
+    wb##q_##_0 = ws_[tid];                                                                                           \
+    if (BV == 768 || tid < 128) wb##q_##_1 = ws_[tid + 256];                                                         \
+    if (BV == 768) wb##q_##_2 = ws_[tid + 512];                                                                      \
   } while (0)
 #define B6_SPLIT_STORE(v_, off_)                                                                                     \
   do {                                                                                                               \
@@ -135,25 +157,21 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
     unsigned char* a_ = sA + (buf_) * ABUF;                                                                          \
     B6_SPLIT_STORE(xa##q_##_0, aoff0);                                                                               \
     B6_SPLIT_STORE(xa##q_##_1, aoff1);                                                                               \
-    uint4* b_ = reinterpret_cast<uint4*>(sB + (buf_) * BBUF) + tid;                                                  \
+    uintx4* b_ = reinterpret_cast<uintx4*>(sB + (buf_) * BBUF) + tid;                                                \
     b_[0] = wb##q_##_0;                                                                                              \
     if (BV == 768 || tid < 128) b_[256] = wb##q_##_1;                                                                \
     if (BV == 768) b_[512] = wb##q_##_2;                                                                             \
   } while (0)
 
-  // acc: what the MFMAs accumulate into; every FL chunks it is added to `tot` by the VALU (round to nearest) and restarted from zero:
-  // the matrix pipe's accumulation error grows with the number of instructions chained on one accumulator (measured 1.8e-6 of the
-  // output scale at K = 2048 against 4.8e-7 for the fp32 kernels; with FL = 8, i.e. 48 chained instructions, 2-5e-7 at every K)
-  floatx16 acc[TM][2], tot[FL > 0 ? TM : 1][2];
+  floatx16 acc[TM][2], tot[TM][2];
+  const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; if (FL > 0) tot[a][b][r] = 0.f; }
+    for (int b = 0; b < 2; ++b) tot[a][b] = zero16;
 
   B6_FETCH(0, 0);
-  if (nkc > 1) B6_FETCH(1, 1);
+  B6_FETCH(1, 1);                                                        // nkc >= 4
   B6_STAGE(0, 0);
   __syncthreads();
   // operand addresses of this lane (the chunk is ONE MFMA reduction step: unit = half)
@@ -169,42 +187,39 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
     baddr[b] = row * 32 + ((half ^ ((row >> 3) & 1)) * 16);
   }
 
-#define B6_CHUNK(q_)                                                                                                 \
+  // chunk j of a group: registers of set j & 1 hold chunk kc + 1's operands when it starts ... (q_ = j & 1, cur_ = LDS buffer j & 1)
+#define B6_CHUNK(j_, first_)                                                                                         \
   do {                                                                                                               \
-    const int cur = kc & 1;                                                                                          \
-    const unsigned char* a_ = sA + cur * ABUF;                                                                       \
-    const unsigned char* b_ = sB + cur * BBUF;                                                                       \
+    const int kc = g + (j_);                                                                                         \
+    const unsigned char* a_ = sA + ((j_) & 1) * ABUF;                                                                \
+    const unsigned char* b_ = sB + ((j_) & 1) * BBUF;                                                                \
     bf16x8 af[TM][3], bf[2][3];                                                                                      \
     _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                    \
       _Pragma("unroll") for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const bf16x8*>(a_ + p * APL + aaddr[a]); \
     _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                     \
       _Pragma("unroll") for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8*>(b_ + p * BPL + baddr[b]); \
-    /* chunk kc + 1 (registers, set 1 - q_) -> the other LDS buffer under the MFMAs; chunk kc + 2 -> registers, set q_ */ \
-    if (kc + 1 < nkc) { if ((q_) == 0) B6_STAGE(1, cur ^ 1); else B6_STAGE(0, cur ^ 1); }                            \
-    if (kc + 2 < nkc) { if ((q_) == 0) B6_FETCH(0, kc + 2); else B6_FETCH(1, kc + 2); }                              \
-    _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                    \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                 \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], acc[a][b], 0, 0, 0);                 \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], acc[a][b], 0, 0, 0);                 \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], acc[a][b], 0, 0, 0);                 \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], acc[a][b], 0, 0, 0);                 \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], acc[a][b], 0, 0, 0);                 \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);                 \
-      }                                                                                                              \
-    if (FL > 0 && (kc % FL) == FL - 1) {                                                                             \
+    /* chunk kc + 1 (registers, other set) -> the other LDS buffer; chunk kc + 2 -> registers, this set */           \
+    if (kc + 1 < nkc && !B6_DBG(2)) { if (((j_) & 1) == 0) B6_STAGE(1, 1); else B6_STAGE(0, 0); }                    \
+    if (kc + 2 < nkc && !B6_DBG(1)) { if (((j_) & 1) == 0) B6_FETCH(0, kc + 2); else B6_FETCH(1, kc + 2); }          \
+    /* the six partial products, smallest first; consecutive instructions go to DIFFERENT accumulator tiles (a dependent    \
+       instruction waits for the whole pass count of its predecessor) */                                             \
+    _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                   \
+      const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, pb = t == 0 || t == 3 || t == 5 ? 0 : (t == 1 || t == 4) ? 1 : 2; \
       _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                  \
         _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                 \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) { tot[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }       \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][pa], bf[b][pb], (first_) && t == 0 ? zero16 : acc[a][b], 0, 0, 0); \
     }                                                                                                                \
-    __syncthreads();                                                                                                 \
+    if (!B6_DBG(4)) __syncthreads();                                                                                 \
   } while (0)
-  // chunk kc's registers were fetched into set kc & 1; the loop body is written for both parities so that every register
-  // array index is a compile-time constant
-  for (int kc = 0; kc < nkc; kc += 2) {
-    B6_CHUNK(0);
-    ++kc;
-    if (kc < nkc) B6_CHUNK(1);
-    --kc;
+  for (int g = 0; g < nkc; g += 4) {
+    B6_CHUNK(0, true);
+    B6_CHUNK(1, false);
+    B6_CHUNK(2, false);
+    B6_CHUNK(3, false);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) tot[a][b] += acc[a][b];
   }
 #undef B6_CHUNK
 #undef B6_FETCH
@@ -217,21 +232,187 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
     for (int b = 0; b < 2; ++b) {
       float* y = Y + static_cast<size_t>(m0 + (wm * TM + a) * 32 + 4 * half) * N + n0 + (wn * 2 + b) * 32 + l31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) y[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N] = FL > 0 ? tot[a][b][r] + acc[a][b][r] : acc[a][b][r];
+      for (int r = 0; r < 16; ++r)
+        if (!B6_DBG(8) || tot[a][b][r] == 12345.678f) y[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N] = tot[a][b][r];
     }
+}
+
+// ---- weight gradient: dW[Co, Ci] = sum_m GY[m, Co] * X[m, Ci] --------------------------------------------------------------------
+// Both operands are activations: both are split on the fly.  The reduction index is the pixel index m, which is the SLOW index of both
+// channels-last tensors, while an MFMA lane wants 8 consecutive reduction steps of one row -- so a thread fetches an 8 (pixels) x 4
+// (channels) block (8 float4, coalesced along the channels), and each of its 4 channels' 8 values is exactly one 16-byte fragment
+// piece per plane: the transposition happens in registers, the LDS image [plane][channel row][32 m] is written by ds_write_b128.
+// Workgroup = 4 waves (2 x 2), tile 128 (Co) x 128 (Ci), chunks of 32 pixels (two reduction steps), one LDS buffer (48 KB: two
+// workgroups per CU), threads 0-127 stage the gradient operand, 128-255 the input operand.  The pixel range is cut into `nsplit` shares
+// (one workgroup each per tile), partial sums [nsplit][Co][Ci] are merged by b6_wsum in a fixed order: bit-reproducible, no atomics,
+// no zero-fill launch.
+constexpr int B6W_KC = 32;
+
+__global__ __launch_bounds__(256, 2) void b6_wgrad(const float* __restrict__ GY, const float* __restrict__ X, float* __restrict__ part,
+                                                   int M, int Co, int Ci, int xs, int rows_per_split, int nsplit) {
+  constexpr int PL = 128 * 64;                                              // bytes of one plane of one operand
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * PL];
+  unsigned char* sA = smem;                                                 // gradient operand: rows = output channels
+  unsigned char* sB = smem + 3 * PL;                                        // input operand: rows = input channels
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = w & 1, wn = w >> 1;
+  const int tiles_n = Ci / 128, tiles = (Co / 128) * tiles_n;
+  const int L = xcd_block();
+  const int tile = L % tiles, split = L / tiles;
+  if (split >= nsplit) return;
+  const int co0 = (tile / tiles_n) * 128, ci0 = (tile % tiles_n) * 128;
+  const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  const int nch = (mend - mbeg) / B6W_KC;
+
+  // staging role of this thread
+  const bool isB = tid >= 128;
+  const int st = tid & 127, mg = st >> 5, cq = st & 31;                     // pixels 8 mg .. + 7 of the chunk, channels 4 cq .. + 3
+  const float* src = isB ? X + static_cast<size_t>(mbeg + 8 * mg) * xs + ci0 + 4 * cq
+                         : GY + static_cast<size_t>(mbeg + 8 * mg) * Co + co0 + 4 * cq;
+  const int sstride = isB ? xs : Co;
+  unsigned char* sdst = (isB ? sB : sA);
+  int soff[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int row = 4 * cq + c;
+    soff[c] = row * 64 + ((mg ^ ((row >> 2) & 3)) * 16);
+  }
+  floatx4 v0, v1, v2, v3, v4, v5, v6, v7;
+#define B6W_FETCH(ch_)                                                                                               \
+  do {                                                                                                               \
+    const float* p_ = src + static_cast<size_t>(ch_) * B6W_KC * sstride;                                             \
+    v0 = *reinterpret_cast<const floatx4*>(p_);                                                                      \
+    v1 = *reinterpret_cast<const floatx4*>(p_ + sstride);                                                            \
+    v2 = *reinterpret_cast<const floatx4*>(p_ + 2 * sstride);                                                        \
+    v3 = *reinterpret_cast<const floatx4*>(p_ + 3 * sstride);                                                        \
+    v4 = *reinterpret_cast<const floatx4*>(p_ + 4 * sstride);                                                        \
+    v5 = *reinterpret_cast<const floatx4*>(p_ + 5 * sstride);                                                        \
+    v6 = *reinterpret_cast<const floatx4*>(p_ + 6 * sstride);                                                        \
+    v7 = *reinterpret_cast<const floatx4*>(p_ + 7 * sstride);                                                        \
+  } while (0)
+  // channel c_ of the block: 8 pixel values -> one 16-byte piece per plane
+#define B6W_STAGE1(c_)                                                                                               \
+  do {                                                                                                               \
+    unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;                                                         \
+    b6_split2(v0[c_], v1[c_], a0, a1, a2);                                                                           \
+    b6_split2(v2[c_], v3[c_], b0, b1, b2);                                                                           \
+    b6_split2(v4[c_], v5[c_], c0, c1, c2);                                                                           \
+    b6_split2(v6[c_], v7[c_], d0, d1, d2);                                                                           \
+    *reinterpret_cast<uintx4*>(sdst + soff[c_]) = uintx4{a0, b0, c0, d0};                                            \
+    *reinterpret_cast<uintx4*>(sdst + PL + soff[c_]) = uintx4{a1, b1, c1, d1};                                       \
+    *reinterpret_cast<uintx4*>(sdst + 2 * PL + soff[c_]) = uintx4{a2, b2, c2, d2};                                   \
+  } while (0)
+
+  floatx16 acc[2][2], tot[2][2];
+  const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { tot[a][b] = zero16; acc[a][b] = zero16; }
+  int aaddr[2][2], baddr[2][2];                                             // [tile][reduction step]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int ra = (wm * 2 + a) * 32 + l31, rb = (wn * 2 + a) * 32 + l31, u = 2 * s2 + half;
+      aaddr[a][s2] = ra * 64 + ((u ^ ((ra >> 2) & 3)) * 16);
+      baddr[a][s2] = rb * 64 + ((u ^ ((rb >> 2) & 3)) * 16);
+    }
+
+  if (nch > 0) B6W_FETCH(0);
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();                                        // everybody has read the previous chunk's fragments
+    B6W_STAGE1(0); B6W_STAGE1(1); B6W_STAGE1(2); B6W_STAGE1(3);
+    __syncthreads();
+    if (ch + 1 < nch) B6W_FETCH(ch + 1);
+    const bool first = (ch & 3) == 0;                       // groups of four chunks = 48 chained instructions per accumulator
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          af[a][p] = *reinterpret_cast<const bf16x8*>(sA + p * PL + aaddr[a][s2]);
+          bf[a][p] = *reinterpret_cast<const bf16x8*>(sB + p * PL + baddr[a][s2]);
+        }
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, pb = t == 0 || t == 3 || t == 5 ? 0 : (t == 1 || t == 4) ? 1 : 2;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][pa], bf[b][pb], acc[a][b], 0, 0, 0);
+      }
+    }
+    if ((ch & 3) == 3 || ch + 1 == nch) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { tot[a][b] += acc[a][b]; acc[a][b] = zero16; }
+    }
+    (void)first;
+  }
+#undef B6W_FETCH
+#undef B6W_STAGE1
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float* o = part + (static_cast<size_t>(split) * Co + co0 + (wm * 2 + a) * 32 + 4 * half) * Ci + ci0 + (wn * 2 + b) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * Ci] = tot[a][b][r];
+    }
+}
+
+// dW = sum of the shares, four interleaved chains then pairwise (fixed order)
+__global__ __launch_bounds__(256) void b6_wsum(const float* __restrict__ part, int nsplit, long long plane, float* __restrict__ out) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= plane) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* ps = part + idx;
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    s0 += ps[(s + 0) * plane];
+    s1 += ps[(s + 1) * plane];
+    s2 += ps[(s + 2) * plane];
+    s3 += ps[(s + 3) * plane];
+  }
+  for (; s < nsplit; ++s) s0 += ps[s * plane];
+  out[idx] = (s0 + s1) + (s2 + s3);
+}
+
+struct B6WPlan { int nsplit, rows, grid; };
+
+bool b6w_plan(long long M, int Ci, int Co, int xs, B6WPlan* p) {
+  if (M <= 0 || (M % B6W_KC) || M > 0x7fffffffLL || Ci <= 0 || (Ci % 128) || Co <= 0 || (Co % 128) || xs < Ci || (xs % 4)) return false;
+  const int tiles = (Co / 128) * (Ci / 128);
+  long long ns = (2 * DBEV_NUM_CU) / tiles;                  // two workgroups per CU, one round
+  const long long chunks = M / B6W_KC;
+  if (ns > chunks / 8) ns = chunks / 8;                      // a share reduces at least 8 chunks
+  if (ns < 1) ns = 1;
+  long long per = (chunks + ns - 1) / ns;
+  per = (per + 3) / 4 * 4;                                   // whole groups of four chunks
+  ns = (chunks + per - 1) / per;
+  p->nsplit = static_cast<int>(ns);
+  p->rows = static_cast<int>(per * B6W_KC);
+  p->grid = dbev_round_xcd(tiles * p->nsplit);
+  return true;
 }
 
 int b6_bn(int N) { return (N % 128) == 0 ? 128 : 64; }
 
 bool b6_ok(long long M, int K, int N, int xs) {
-  return M > 0 && (M % B6_BM) == 0 && M <= 0x7fffffffLL && K > 0 && (K % B6_KC) == 0 && N > 0 && (N % 64) == 0 && xs >= K && (xs % 4) == 0 &&
+  return M > 0 && (M % B6_BM) == 0 && M <= 0x7fffffffLL && K > 0 && (K % 64) == 0 && N > 0 && (N % 64) == 0 && xs >= K && (xs % 4) == 0 &&
          M * static_cast<long long>(xs > N ? xs : N) < (1LL << 40);
 }
 
 }  // namespace
 
 extern "C" long long dbev_gemm_bf16x6_packed_bytes(int N, int K) {
-  if (N <= 0 || K <= 0 || (N % 64) || (K % B6_KC)) return 0;
+  if (N <= 0 || K <= 0 || (N % 64) || (K % 64)) return 0;
   return 3LL * N * K * 2;
 }
 
@@ -253,14 +434,37 @@ extern "C" int dbev_gemm_bf16x6_forward(const float* x, const void* packed, floa
   const int bn = b6_bn(N);
   const int grid = dbev_round_xcd((m / B6_BM) * (N / bn));
   DbevKt kt(DBEV_K_GEMM1X1_FWD, 2LL * M * K * N, s);
-  static const int occ = getenv("DBEV_BF6_OCC") ? atoi(getenv("DBEV_BF6_OCC")) : 2;
   const unsigned short* pw = static_cast<const unsigned short*>(packed);
-  static const int fl = getenv("DBEV_BF6_FLUSH") ? atoi(getenv("DBEV_BF6_FLUSH")) : 8;
-#define B6_GO(BNV, OV, FV) hipLaunchKernelGGL((b6_fwd<BNV, OV, FV>), dim3(grid), dim3(256), 0, s, x, pw, y, m, K, N, x_row_stride)
-  if (bn == 128) { if (fl == 0) B6_GO(128, 2, 0); else if (fl == 4) B6_GO(128, 2, 4); else B6_GO(128, 2, 8); }
-  else { if (fl == 0) B6_GO(64, 2, 0); else if (fl == 4) B6_GO(64, 2, 4); else B6_GO(64, 2, 8); }
-  (void)occ;
+  static const int dbg = getenv("DBEV_BF6_DBG") ? atoi(getenv("DBEV_BF6_DBG")) : 0;
+#define B6_GO(BNV) hipLaunchKernelGGL((b6_fwd<BNV, 2>), dim3(grid), dim3(256), 0, s, x, pw, y, m, K, N, x_row_stride, dbg)
+  if (bn == 128) B6_GO(128); else B6_GO(64);
 #undef B6_GO
   DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t dbev_gemm_bf16x6_backward_weight_workspace_bytes(long long M, int Cin, int Cout, int x_row_stride) {
+  B6WPlan p;
+  if (!b6w_plan(M, Cin, Cout, x_row_stride, &p)) return 0;
+  return static_cast<size_t>(p.nsplit) * Cin * Cout * sizeof(float);
+}
+
+extern "C" int dbev_gemm_bf16x6_backward_weight(const float* x, const float* grad_y, float* grad_weight, long long M, int Cin, int Cout,
+                                                int x_row_stride, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  B6WPlan p;
+  if (!b6w_plan(M, Cin, Cout, x_row_stride, &p) || x == nullptr || grad_y == nullptr || grad_weight == nullptr || workspace == nullptr ||
+      workspace_bytes < static_cast<size_t>(p.nsplit) * Cin * Cout * sizeof(float))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  DbevKt kt(DBEV_K_GEMM1X1_WGRAD, 2LL * M * Cin * Cout, s);
+  hipLaunchKernelGGL(b6_wgrad, dim3(p.grid), dim3(256), 0, s, grad_y, x, p.nsplit > 1 ? part : grad_weight, static_cast<int>(M), Cout, Cin,
+                     x_row_stride, p.rows, p.nsplit);
+  DBEV_LAUNCH_CHECK();
+  if (p.nsplit > 1) {
+    const long long plane = static_cast<long long>(Cin) * Cout;
+    hipLaunchKernelGGL(b6_wsum, dim3(dbev_ceil_div(plane, 256)), dim3(256), 0, s, part, p.nsplit, plane, grad_weight);
+    DBEV_LAUNCH_CHECK();
+  }
   return 0;
 }

@@ -7,9 +7,9 @@ and the sums are kept in fp32: max |y - fp64| / max |y| = 2-4e-7 on the step's l
 (5e-7-1e-6; tests/test_gpu_gemm_bf6.py asserts it per shape).  On gfx950 the bf16 matrix pipe is 16 x as fast as the fp32 one, so six
 bf16 instructions replace eight fp32 ones in 0.38 of the time.
 
-``conv1x1(x, weight)`` is ``F.conv2d(x, weight)`` for channels-last fp32 device tensors with N*H*W % 128 == 0, Cin % 16 == 0,
+``conv1x1(x, weight)`` is ``F.conv2d(x, weight)`` for channels-last fp32 device tensors with N*H*W % 128 == 0, Cin % 64 == 0,
 Cout % 64 == 0, differentiable: the data gradient is the same kernel on grad_y with the transposed weight view, the weight gradient
-stays the library's.  Layers that would leave half of the chip idle (fewer than `_MIN_ITEMS` output tiles) stay with the library."""
+its own kernel (both operands split on the fly; channel counts that are multiples of 128, the library's otherwise).  Layers that would leave half of the chip idle (fewer than `_MIN_ITEMS` output tiles) stay with the library."""
 import os
 
 import torch
@@ -19,7 +19,9 @@ from torch.autograd import Function
 from . import _lib as L
 
 _ON = os.environ.get("DBEV_BF6", "1") != "0"
-_MIN_ITEMS = int(os.environ.get("DBEV_BF6_MIN_ITEMS", "448"))     # 128 x 128 (or 128 x 64) output tiles; two workgroups share a CU
+_WGRAD = os.environ.get("DBEV_BF6_WGRAD", "1") != "0"
+_MIN_ITEMS = int(os.environ.get("DBEV_BF6_MIN_ITEMS", "448"))
+_MIN_WGRAD_ROWS = 4096                                           # below: a handful of chunks per share, the library's kernel     # 128 x 128 (or 128 x 64) output tiles; two workgroups share a CU
 
 
 def _nhwc(t):
@@ -28,7 +30,7 @@ def _nhwc(t):
 
 def shape_ok(M, K, N):
     """can the kernels take Y[M, N] = X[M, K] W[N, K]^T, and does the launch fill the chip?"""
-    if M <= 0 or M % 128 or K % 16 or N % 64 or K <= 0 or N <= 0:
+    if M <= 0 or M % 128 or K % 64 or N % 64 or K <= 0 or N <= 0:
         return False
     bn = 128 if N % 128 == 0 else 64
     return (M // 128) * (N // bn) >= _MIN_ITEMS
@@ -90,6 +92,25 @@ def data_gradient(gy, weight):
     return gemm(gy, packed(weight, True), Ci)
 
 
+def weight_gradient(x, gy, weight):
+    """grad_weight of y = conv1x1(x, weight) (dbev_gemm_bf16x6_backward_weight: both operands split on the fly, fixed summation order),
+    with `weight`'s strides, or None when the library should do it (channel counts not multiples of 128, layout)"""
+    Co, Ci = int(weight.shape[0]), int(weight.shape[1])
+    if not (_ON and _WGRAD and x.is_cuda and x.dtype == torch.float32 and gy.dtype == torch.float32 and _nhwc(x) and _nhwc(gy)
+            and Ci % 128 == 0 and Co % 128 == 0):
+        return None
+    M = x.shape[0] * x.shape[2] * x.shape[3]
+    nbytes = int(L.call("dbev_gemm_bf16x6_backward_weight_workspace_bytes", M, Ci, Co, Ci))
+    if nbytes == 0 or M < _MIN_WGRAD_ROWS:
+        return None
+    dev = x.device
+    gw2 = torch.empty((Co, Ci), dtype=torch.float32, device=dev)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dbev_gemm_bf16x6_backward_weight", L.ptr(x), L.ptr(gy), L.ptr(gw2), M, Ci, Co, Ci, L.ptr(ws), nbytes, L.stream_ptr(dev))
+    return gw2.view(Co, Ci, 1, 1)                           # [Co, Ci] in memory: contiguous in both memory formats of a 1x1 filter
+
+
 class _Conv1x1Bf6(Function):
     @staticmethod
     def forward(ctx, x, weight):
@@ -105,11 +126,14 @@ class _Conv1x1Bf6(Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if need_x:
             gx = data_gradient(gy, weight)
-        if need_w or (need_x and gx is None):
+        if need_w:
+            gw = weight_gradient(x, gy, weight)
+        lib_x, lib_w = need_x and gx is None, need_w and gw is None
+        if lib_x or lib_w:
             a, b, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                          [need_x and gx is None, need_w, False])
-            gx = a if gx is None else gx
-            gw = b
+                                                          [lib_x, lib_w, False])
+            gx = a if lib_x else gx
+            gw = b if lib_w else gw
         return gx, gw
 
 
@@ -131,13 +155,13 @@ class Bf6Conv2d(nn.Conv2d):
 
 
 def use_bf6_convs(model):
-    """Re-class the bias-free 1x1 / stride-1 nn.Conv2d modules with Cin % 16 == 0 and Cout % 64 == 0; returns how many.  Idempotent."""
+    """Re-class the bias-free 1x1 / stride-1 nn.Conv2d modules with Cin % 64 == 0 and Cout % 64 == 0; returns how many.  Idempotent."""
     if not _ON:
         return 0
     n = 0
     for m in model.modules():
         if type(m) is nn.Conv2d and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) and m.dilation == (1, 1) \
-                and m.groups == 1 and m.bias is None and m.in_channels % 16 == 0 and m.out_channels % 64 == 0:
+                and m.groups == 1 and m.bias is None and m.in_channels % 64 == 0 and m.out_channels % 64 == 0:
             m.__class__ = Bf6Conv2d
             n += 1
     return n

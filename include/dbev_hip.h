@@ -608,7 +608,7 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
  * fp32 GEMM of a 1x1 convolution on the BF16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three bf16 values,
  * six exact partial products per product, fp32 accumulation; csrc/gemm_bf6.hip).  Replaces cuDNN behind nn.Conv2d(k=1) of
  * mmdet3d/models/bricks/res_block.py:102-230 / necks/fpn.py:10-204 like dbev_gemm1x1_forward does.
- *   y[M, N] = x[M, K] * weight[N, K]^T,  x rows of x_row_stride floats, y row-major; M % 256 == 0, K % 32 == 0, N % 64 == 0.
+ *   y[M, N] = x[M, K] * weight[N, K]^T,  x rows of x_row_stride floats, y row-major; M % 128 == 0, K % 64 == 0, N % 64 == 0.
  * dbev_gemm_bf16x6_pack splits the weight (element (n, k) at weight[n * stride_n + k * stride_k]: the transposed view serves the data
  * gradient) into `packed` (dbev_gemm_bf16x6_packed_bytes(N, K) bytes; 0: unsupported shape) once per weight version.
  * ---------------------------------------------------------------------------------- */
@@ -616,6 +616,12 @@ long long dbev_gemm_bf16x6_packed_bytes(int N, int K);
 int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long stride_k, int N, int K, void* packed, dbevStream_t stream);
 int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
                              dbevStream_t stream);
+/* weight gradient of the same layer, grad_weight[Cout, Cin] = sum_m grad_y[m, Cout] * x[m, Cin] (both operands split on the fly,
+ * shares of the pixel range merged in a fixed order: bit-reproducible, no zero-fill launch, no atomics); M % 32 == 0,
+ * Cin % 128 == 0, Cout % 128 == 0; workspace: dbev_gemm_bf16x6_backward_weight_workspace_bytes bytes (0: unsupported shape). */
+size_t dbev_gemm_bf16x6_backward_weight_workspace_bytes(long long M, int Cin, int Cout, int x_row_stride);
+int dbev_gemm_bf16x6_backward_weight(const float* x, const float* grad_y, float* grad_weight, long long M, int Cin, int Cout,
+                                     int x_row_stride, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Per-channel sum of a channels-last tensor, out[c] = sum over the M = N*H*W rows of x_nhwc[M, C]: the bias gradient of a convolution

@@ -23,11 +23,11 @@ def _err(y, ref):
     return float((y.double() - ref).abs().max()) / float(ref.abs().max())
 
 
-SHAPES = [(2, 16, 64, 8, 8),            # one chunk, one 64-column block
+SHAPES = [(2, 64, 64, 8, 8),            # one group of four chunks, one 64-column block
           (4, 64, 256, 16, 16),         # 128-column blocks
-          (3, 48, 192, 16, 16),         # K = 3 chunks, N = 3 x 64
-          (2, 256, 64, 32, 16),         # 16 chunks: two flushes of the matrix accumulator
-          (1, 2048, 128, 16, 16),       # deep reduction (128 chunks)
+          (3, 192, 192, 16, 16),        # three groups, N = 3 x 64
+          (2, 256, 64, 32, 16),         # four groups of the matrix accumulator
+          (1, 2048, 128, 16, 16),       # deep reduction (32 groups)
           (2, 1024, 512, 16, 8)]
 
 
@@ -52,7 +52,7 @@ def test_signed_inputs_and_extreme_magnitudes(monkeypatch):
     from distill_bev_amd import gemm_bf6 as G
     monkeypatch.setattr(G, "_MIN_ITEMS", 1)
     g = torch.Generator().manual_seed(3)
-    x = (torch.randn((2, 64, 8, 8), generator=g) * torch.exp2(torch.randint(-60, 60, (2, 1, 8, 8), generator=g).float()))
+    x = (torch.randn((2, 64, 8, 8), generator=g) * torch.exp2(torch.randint(-60, 60, (2, 1, 8, 8), generator=g).float()))   # K = 64
     x = x.to(DEV).contiguous(memory_format=torch.channels_last)
     wt = torch.randn((64, 64, 1, 1), generator=g).to(DEV)
     y = G.gemm(x, G.packed(wt), 64)
@@ -63,10 +63,13 @@ def test_signed_inputs_and_extreme_magnitudes(monkeypatch):
     assert float(z.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n,ci,co,h,w", [(4, 64, 256, 16, 16), (2, 256, 64, 32, 16), (2, 128, 128, 16, 16)])
+@pytest.mark.parametrize("n,ci,co,h,w", [(4, 64, 256, 16, 16), (2, 256, 64, 32, 16), (2, 128, 128, 16, 16), (3, 256, 384, 16, 24),
+                                         (2, 1024, 128, 8, 16)])
 def test_module_gradients_vs_fp64(n, ci, co, h, w, monkeypatch):
+    """forward, data gradient and (channel counts that are multiples of 128) weight gradient on the bf16x6 kernels"""
     from distill_bev_amd import gemm_bf6 as G
     monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    monkeypatch.setattr(G, "_MIN_WGRAD_ROWS", 1)
     torch.manual_seed(7)
     m = nn.Sequential(nn.Conv2d(ci, co, 1, bias=False)).to(DEV).to(memory_format=torch.channels_last)
     assert G.use_bf6_convs(m) == 1 and type(m[0]) is G.Bf6Conv2d and G.use_bf6_convs(m) == 0
@@ -86,7 +89,12 @@ def test_module_gradients_vs_fp64(n, ci, co, h, w, monkeypatch):
     F.conv2d(xl, wl).backward(gy)
     assert _err(y, yd.detach()) <= 1.25 * _err(F.conv2d(x, wl.detach()), yd.detach()) + 1e-7
     assert _err(xa.grad, xd.grad) <= 1.25 * _err(xl.grad, xd.grad) + 1e-7
-    assert _err(m[0].weight.grad, wd.grad) <= 1.25 * _err(wl.grad, wd.grad) + 1e-7      # (the library's kernel: same bits)
+    assert _err(m[0].weight.grad, wd.grad) <= 1.25 * _err(wl.grad, wd.grad) + 1e-7
+    assert m[0].weight.grad.shape == m[0].weight.shape
+    if ci % 128 == 0 and co % 128 == 0:                           # the bf16x6 weight gradient ran: fixed summation order
+        g1 = G.weight_gradient(x, gy, m[0].weight)
+        assert g1 is not None and torch.equal(g1, G.weight_gradient(x, gy, m[0].weight))
+        assert torch.equal(g1.reshape(co, ci), m[0].weight.grad.reshape(co, ci))
     with torch.no_grad():
         assert torch.equal(m(x), y.detach())                     # the no-grad path runs the same kernel
 
@@ -108,3 +116,17 @@ def test_small_layers_stay_with_the_library_and_packs_follow_the_weight():
     m.weight.data.mul_(0.5)                                      # a write the version counter does not see ...
     invalidate_eval_coef(m)                                      # ... is followed by the documented invalidation
     assert G.packed(m.weight) is not p2
+
+
+def test_weight_gradient_full_size_share_merge(monkeypatch):
+    """a ResNet stage-3 layer at the step's size: 33 792 pixels in 32 shares (dbev_gemm_bf16x6_backward_weight + the share sum)"""
+    from distill_bev_amd import gemm_bf6 as G
+    g = torch.Generator().manual_seed(9)
+    x = torch.relu(torch.randn((48, 256, 16, 44), generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((48, 1024, 16, 44), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros((1024, 256, 1, 1), device=DEV)
+    gw = G.weight_gradient(x, gy, w)
+    lib = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    ref = gy.permute(0, 2, 3, 1).reshape(-1, 1024).double().t() @ x.permute(0, 2, 3, 1).reshape(-1, 256).double()
+    e, el = _err(gw.reshape(1024, 256), ref), _err(lib.reshape(1024, 256), ref)
+    assert e <= 1.25 * el + 1e-7 and e < 1e-6, (e, el)

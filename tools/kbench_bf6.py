@@ -56,3 +56,22 @@ for (n, ci, co, h, w_) in SHAPES:
         t3 = float("nan")
     tp = tm(lambda: pack(w2))
     print(f"{str((n, ci, co, h, w_)):32s} {gf:6.1f} | {t1:8.1f} {gf / t1 * 1e3:6.1f} | {t2:8.1f} {gf / t2 * 1e3:6.1f} | {t3:8.1f} | {e1:.2e} / {e2:.2e}   pack {tp:.1f} us")
+
+print("\nweight gradient: shape | bf16x6 us  TF | miopen us | err bf16x6 / miopen vs fp64")
+from distill_bev_amd import gemm_bf6 as G
+for (n, ci, co, h, w_) in [s for s in SHAPES if s[1] % 128 == 0 and s[2] % 128 == 0]:
+    g = torch.Generator().manual_seed(ci + co)
+    x = torch.relu(torch.randn((n, ci, h, w_), generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((n, co, h, w_), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros((co, ci, 1, 1), device=dev).contiguous(memory_format=torch.channels_last)
+    lib = lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    a = G.weight_gradient(x, gy, w)
+    b = lib()
+    step = max(1, (n * h * w_) // 65536)
+    # fp64 reference of the full sum is affordable: [M, co]^T [M, ci]
+    ref = gy.permute(0, 2, 3, 1).reshape(-1, co).double().t() @ x.permute(0, 2, 3, 1).reshape(-1, ci).double()
+    sc = float(ref.abs().max())
+    e1, e2 = float((a.reshape(co, ci).double() - ref).abs().max()) / sc, float((b.reshape(co, ci).double() - ref).abs().max()) / sc
+    gf = 2.0 * n * h * w_ * ci * co / 1e9
+    t1, t2 = tm(lambda: G.weight_gradient(x, gy, w)), tm(lib)
+    print(f"{str((n, ci, co, h, w_)):32s} | {t1:8.1f} {gf / t1 * 1e3:6.1f} | {t2:8.1f} | {e1:.2e} / {e2:.2e}")
