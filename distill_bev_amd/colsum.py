@@ -81,10 +81,16 @@ class BiasSumConv2d(nn.Conv2d):
     tensor and gradients are recorded; the stock module otherwise.  Same parameters and state-dict keys."""
 
     def forward(self, x):
-        if (self.bias is not None and self.padding_mode == "zeros" and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda
-                and x.dtype == torch.float32 and _nhwc(x) and x.numel() > 0 and not isinstance(self.padding, str)
-                and (x.requires_grad or self.weight.requires_grad or self.bias.requires_grad)):
-            return _BiasConv.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if (self.bias is not None and self.padding_mode == "zeros" and torch.is_tensor(x) and x.is_cuda
+                and x.dtype == torch.float32 and _nhwc(x) and x.numel() > 0 and not isinstance(self.padding, str)):
+            from . import gemm_bf6 as G                       # a 1x1 layer the bf16x6 GEMM takes: its kernels + this module's bias handling
+            grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or self.bias.requires_grad)
+            if G.eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+                if grad:
+                    return G.conv1x1(x, self.weight, self.bias)
+                return G.gemm(x, G.packed(self.weight), self.out_channels).add_(self.bias.view(1, -1, 1, 1))
+            if grad:
+                return _BiasConv.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         return super().forward(x)
 
 
@@ -128,7 +134,12 @@ def conv_bn_cancelled_bias(conv, bn, x, bn_call):
     they update the running statistics through raw pointers and save neither of them, the library's BatchNorm saves both for its
     backward (a later in-place update raises) -- there the convolution keeps its bias."""
     from . import bn_act as BA
-    z = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    from . import gemm_bf6 as G
+    if G.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
+        z = G.conv1x1(x, conv.weight) if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad) \
+            else G.gemm(x, G.packed(conv.weight), conv.out_channels)
+    else:
+        z = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if not BA.eligible(z, bn):
         return bn_call(z.add_(conv.bias.view(1, -1, 1, 1)))          # conv(x) as ATen computes it
     if torch.is_grad_enabled() and conv.bias.requires_grad:

@@ -64,6 +64,12 @@ def modulated_deform_conv2d_raw(x, offset_mask, weight, bias, stride=1, padding=
         N, KC, Ho, Wo = cols.shape
         y = F.linear(cols.permute(0, 2, 3, 1).reshape(-1, KC), w.view(Co, KC), bias)
         return y.view(N, Ho, Wo, Co).permute(0, 3, 1, 2)
+    from . import gemm_bf6 as G
+    if G.eligible(cols, w):                                               # the contraction over (k, c): a 1x1 layer of the bf16x6 GEMM
+        if torch.is_grad_enabled() and (cols.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)):
+            return G.conv1x1(cols, w, bias)
+        y = G.gemm(cols, G.packed(w), Co)
+        return y if bias is None else y.add_(bias.view(1, -1, 1, 1))
     return F.conv2d(cols, w, bias)
 
 

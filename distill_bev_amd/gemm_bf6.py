@@ -113,8 +113,10 @@ def weight_gradient(x, gy, weight):
 
 class _Conv1x1Bf6(Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, bias):
         y = gemm(x, packed(weight), int(weight.shape[0]))
+        if bias is not None:
+            y.add_(bias.view(1, -1, 1, 1))                    # the separate bias pass ATen runs behind the library's convolution
         ctx.save_for_backward(x, weight)
         return y
 
@@ -122,7 +124,7 @@ class _Conv1x1Bf6(Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
-        gx = gw = None
+        gx = gw = gb = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if need_x:
             gx = data_gradient(gy, weight)
@@ -134,12 +136,15 @@ class _Conv1x1Bf6(Function):
                                                           [lib_x, lib_w, False])
             gx = a if lib_x else gx
             gw = b if lib_w else gw
-        return gx, gw
+        if ctx.needs_input_grad[2]:
+            from .colsum import channel_sum
+            gb = channel_sum(gy)
+        return gx, gw, gb
 
 
-def conv1x1(x, weight):
-    """F.conv2d(x, weight) for an `eligible` pair"""
-    return _Conv1x1Bf6.apply(x, weight)
+def conv1x1(x, weight, bias=None):
+    """F.conv2d(x, weight, bias) for an `eligible` pair (bias: added in a separate pass, its gradient by colsum.channel_sum)"""
+    return _Conv1x1Bf6.apply(x, weight, bias)
 
 
 class Bf6Conv2d(nn.Conv2d):
