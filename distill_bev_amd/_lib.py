@@ -321,6 +321,28 @@ def touched(*tensors):
             torch.autograd.graph.increment_version(t)
 
 
+_VERSION_HOOK = []
+
+
+def ensure_param_version_hook():
+    """Everything this package keeps per weight (packed Winograd filters, bf16 planes of the 1x1 filters, eval-mode norm coefficients)
+    is keyed on the tensor's version counter -- and torch's FUSED optimizers (torch.optim.AdamW(fused=True), the one train_step.Trainer
+    uses) update the parameters without moving it (measured: `_version` 0 -> 0 across `step()`, CPU and GPU; foreach / single-tensor
+    implementations do move it).  A stale pack would make every step after the first run its forward pass on the step-0 weights.  One
+    global optimizer post-step hook bumps the counters of the parameters the step had gradients for.  Idempotent."""
+    if _VERSION_HOOK:
+        return
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+
+    def _bump(optimizer, args, kwargs):
+        for group in optimizer.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    torch.autograd.graph.increment_version(p)
+
+    _VERSION_HOOK.append(register_optimizer_step_post_hook(_bump))
+
+
 def h2d(t, device):
     """CPU tensor -> device without stalling the host on the GPU queue: a copy from PAGEABLE memory blocks until everything queued
     before it has run (the host then sits idle for most of a step); staged through the pinned-memory cache the copy is asynchronous

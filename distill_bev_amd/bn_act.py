@@ -22,6 +22,8 @@ from torch.autograd import Function
 
 from . import _lib as L
 
+L.ensure_param_version_hook()          # fused optimizers do not move `_version`; the kept packs / coefficients follow it
+
 _state = {"enabled": os.environ.get("DBEV_FUSED_BN", "1") != "0",
           "fork": os.environ.get("DBEV_BN_FORK", "1") != "0"}      # residual-block outputs carry a second handle (see _BNActTrain.forward)
 

@@ -18,6 +18,8 @@ from torch.autograd import Function
 
 from . import _lib as L
 
+L.ensure_param_version_hook()          # fused optimizers do not move `_version`; the kept packs / coefficients follow it
+
 _ON = os.environ.get("DBEV_BF6", "1") != "0"
 _WGRAD = os.environ.get("DBEV_BF6_WGRAD", "1") != "0"
 _MIN_ITEMS = int(os.environ.get("DBEV_BF6_MIN_ITEMS", "448"))

@@ -15,6 +15,8 @@ from torch.autograd import Function
 
 from . import _lib as L
 
+L.ensure_param_version_hook()          # fused optimizers do not move `_version`; the kept packs / coefficients follow it
+
 # Work items (64-tile blocks x 64-channel blocks) a layer must offer before the Winograd kernels take it -- measured
 # (tools/kbench_wino.py, profiles/r04_wino_vs_miopen.txt): with the two-workgroups-per-CU kernel for small grids, 64 items run at 0.9 x
 # the library's kernel, 128 at 1.7 x, 384 at 1.3 x, larger layers at 1.6-2.2 x.

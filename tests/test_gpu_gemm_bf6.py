@@ -130,3 +130,28 @@ def test_weight_gradient_full_size_share_merge(monkeypatch):
     ref = gy.permute(0, 2, 3, 1).reshape(-1, 1024).double().t() @ x.permute(0, 2, 3, 1).reshape(-1, 256).double()
     e, el = _err(gw.reshape(1024, 256), ref), _err(lib.reshape(1024, 256), ref)
     assert e <= 1.25 * el + 1e-7 and e < 1e-6, (e, el)
+
+
+def test_packs_follow_a_fused_optimizer_step(monkeypatch):
+    """torch.optim.AdamW(fused=True) -- the Trainer's optimizer -- updates weights without moving `_version`; the kept bf16 planes and
+    Winograd packs must still follow the new weights (the post-step hook of _lib.ensure_param_version_hook)"""
+    from distill_bev_amd import gemm_bf6 as G
+    from distill_bev_amd import wino
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    monkeypatch.setattr(wino, "_MIN_WG", 1)
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Conv2d(64, 64, 1, bias=False), nn.Conv2d(64, 64, 3, padding=1, bias=False)).to(DEV).to(memory_format=torch.channels_last)
+    assert G.use_bf6_convs(m) == 1 and wino.use_wino_convs(m) == 1
+    opt = torch.optim.AdamW(m.parameters(), lr=0.05, fused=True)
+    x = torch.randn((4, 64, 16, 16), device=DEV).contiguous(memory_format=torch.channels_last)
+    for _ in range(2):
+        y = m(x)
+        ref = F.conv2d(F.conv2d(x.double(), m[0].weight.detach().double()), m[1].weight.detach().double(), padding=1)
+        assert float((y.detach().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max()), "forward ran on stale packed weights"
+        opt.zero_grad(set_to_none=True)
+        y.square().mean().backward()
+        opt.step()
+    with torch.no_grad():                                        # the no-grad paths keep packs too
+        y = m(x)
+        ref = F.conv2d(F.conv2d(x.double(), m[0].weight.double()), m[1].weight.double(), padding=1)
+        assert float((y.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())

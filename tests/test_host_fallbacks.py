@@ -49,3 +49,20 @@ def test_bias_sum_conv_is_the_stock_module_on_the_host():
     x = torch.randn(2, 4, 5, 5, requires_grad=True)
     assert torch.equal(m[0](x), ref(x))
     assert not cancelled_bias_ready(m[0], nn.BatchNorm2d(6), x)
+
+
+def test_fused_optimizer_steps_move_the_version_counter():
+    """torch's fused AdamW leaves `_version` alone; every kept pack of this package follows it (the global post-step hook of _lib)"""
+    import torch
+    from distill_bev_amd import _lib as L
+    from distill_bev_amd import wino  # noqa: F401  (importing the package's cache holders installs the hook)
+    L.ensure_param_version_hook()
+    p = torch.nn.Parameter(torch.randn(8, 8))
+    q = torch.nn.Parameter(torch.randn(4))                      # no gradient: not updated, not bumped
+    opt = torch.optim.AdamW([p, q], lr=1e-3, fused=True)
+    p.grad = torch.randn_like(p)
+    v0, w0, before = p._version, q._version, p.detach().clone()
+    opt.step()
+    assert not torch.equal(before, p.detach())
+    assert p._version > v0 and q._version == w0
+    assert len(L._VERSION_HOOK) == 1
