@@ -8,15 +8,16 @@
 // v_mfma_f32_32x32x2_f32 (tools/mfma_bf16_bench.hip: 32.8 vs 64.7 cycles per instruction of 16 vs 2 reduction steps), so six bf16
 // instructions do the work of eight fp32 ones in 0.38 of the time, and -- unlike under the fp32 instruction, which occupies the SIMD's
 // fp32 lanes -- VALU work issued between bf16 MFMAs costs ~2 cycles per instruction, so the split of the activation operand can be done
-// on the fly (5.5 VALU operations per element, amortised over the tile's columns).  The weights are split once per step by b6_pack.
+// on the fly (4.5 VALU operations per element, amortised over the tile's columns).  The weights are split once per step by b6_pack.
 //
 //   Y[M, N] = X[M, K] * W[N, K]^T     X rows of x_stride floats, Y row-major, M % 128 == 0, K % 64 == 0, N % 64 == 0
 //
-// Workgroup = 8 waves (two per SIMD), tile 256 rows x BN columns (BN = 128: waves 4 x 2, wave tile 64 x 64; BN = 64: waves 8 x 1, wave
-// tile 32 x 64), reduction in chunks of 32, double-buffered in LDS as three bf16 planes per operand ([plane][row][32 k], the four 16-byte
-// units of a row XOR-swizzled by (row >> 2) & 3: the 16 lanes of a ds_read_b128 service group hit 16 distinct bank quads).  Per chunk and
-// wave: 12 (BN = 64: 9) ds_read_b128 per reduction step of 16, 48 (24) MFMAs, the next chunk's activations fetched into registers
-// under them, split and written to the other buffer behind them, one barrier.
+// Forward / data gradient (b6_fwd): workgroup = 4 waves, tile 128 rows x BN columns (BN = 128: waves 2 x 2, wave tile 64 x 64; BN = 64:
+// waves 4 x 1, wave tile 32 x 64), two workgroups per CU; reduction in chunks of 16 (ONE MFMA reduction step), double-buffered in LDS as
+// three bf16 planes per operand ([plane][row][16 k], the two 16-byte units of a row swapped for rows with bit 3 set: the 16 lanes of a
+// ds_read_b128 service group hit 16 distinct bank quads, SQ_LDS_BANK_CONFLICT = 0).  Per chunk and wave: 12 (9) ds_read_b128, 24 (12)
+// MFMAs -- consecutive ones on different accumulator tiles --, the activations of two chunks ahead fetched into registers, those of
+// the next chunk split and written to the other buffer, one barrier.  Weight gradient (b6_wgrad): see there.
 #include "common.h"
 
 #include <stdlib.h>
