@@ -164,6 +164,11 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        # the same metric with every GEMM on the fp32 matrix cores (config.conv1x1: DBEV_BF6=0), measured outside the timed region on this
+        # rank -- for a reader who wants the headline without the bf16x6 products
+        alt = line["config"].get("ms_per_step_fp32_matrix_cores_only")
+        if alt:
+            line["value_fp32_matrix_cores_only"] = wl.units_per_step * world / (alt * 1e-3)
     if dist.is_initialized():
         dist.destroy_process_group()
     _flush_c_stdio()

@@ -24,7 +24,7 @@
 
 namespace {
 
-// ablation switches (dev builds with -DDBEV_BF6_ABLATE, DBEV_BF6_DBG bits: 1 no global fetch, 2 no split / LDS staging, 4 no barrier, 8 no stores)
+// ablation switches (dev builds with -DDBEV_BF6_ABLATE, DBEV_BF6_DBG bits: 1 no global fetch, 2 no split / LDS staging, 4 no barrier, 8 no stores, 16 clock probe)
 #ifdef DBEV_BF6_ABLATE
 #define B6_DBG(bit_) (dbg & (bit_))
 #else
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
 #pragma unroll
     for (int b = 0; b < 2; ++b) tot[a][b] = zero16;
 
+  const unsigned long long t0c = B6_DBG(16) ? __builtin_amdgcn_s_memtime() : 0ull, t0r = B6_DBG(16) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   B6_FETCH(0, 0);
   B6_FETCH(1, 1);                                                        // nkc >= 4
   B6_STAGE(0, 0);
@@ -236,6 +237,11 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
       for (int r = 0; r < 16; ++r)
         if (!B6_DBG(8) || tot[a][b][r] == 12345.678f) y[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N] = tot[a][b][r];
     }
+  if (B6_DBG(16) && blockIdx.x == 0 && tid == 0) {          // ablation only: shader clocks / 100 MHz ticks of this workgroup -> y[0..1]
+    const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
+    reinterpret_cast<unsigned*>(Y)[0] = static_cast<unsigned>(t1c - t0c);
+    reinterpret_cast<unsigned*>(Y)[1] = static_cast<unsigned>(t1r - t0r);
+  }
 }
 
 // ---- weight gradient: dW[Co, Ci] = sum_m GY[m, Co] * X[m, Ci] --------------------------------------------------------------------
