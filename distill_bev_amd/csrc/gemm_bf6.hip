@@ -249,32 +249,39 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
 // channels-last tensors, while an MFMA lane wants 8 consecutive reduction steps of one row -- so a thread fetches an 8 (pixels) x 4
 // (channels) block (8 float4, coalesced along the channels), and each of its 4 channels' 8 values is exactly one 16-byte fragment
 // piece per plane: the transposition happens in registers, the LDS image [plane][channel row][32 m] is written by ds_write_b128.
-// Workgroup = 4 waves (2 x 2), tile 128 (Co) x 128 (Ci), chunks of 32 pixels (two reduction steps), one LDS buffer (48 KB: two
+// Workgroup = 4 waves (2 x 2), tile 128 (or 64) Co x 128 (or 64) Ci, chunks of 32 pixels (two reduction steps), one LDS buffer (48 KB: two
 // workgroups per CU), threads 0-127 stage the gradient operand, 128-255 the input operand.  The pixel range is cut into `nsplit` shares
 // (one workgroup each per tile), partial sums [nsplit][Co][Ci] are merged by b6_wsum in a fixed order: bit-reproducible, no atomics,
 // no zero-fill launch.
 constexpr int B6W_KC = 32;
 
+// TA / TB: rows of the gradient-side / input-side tile (128 or 64 output / input channels); wave tile TA/2 x TB/2
+template <int TA, int TB>
 __global__ __launch_bounds__(256, 2) void b6_wgrad(const float* __restrict__ GY, const float* __restrict__ X, float* __restrict__ part,
                                                    int M, int Co, int Ci, int xs, int rows_per_split, int nsplit) {
-  constexpr int PL = 128 * 64;                                              // bytes of one plane of one operand
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * PL];
+  constexpr int PLA = TA * 64, PLB = TB * 64;                               // bytes of one plane of each operand
+  constexpr int NA = TA / 64, NB = TB / 64;                                 // 32-row tiles per wave
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PLA + 3 * PLB];
   unsigned char* sA = smem;                                                 // gradient operand: rows = output channels
-  unsigned char* sB = smem + 3 * PL;                                        // input operand: rows = input channels
+  unsigned char* sB = smem + 3 * PLA;                                       // input operand: rows = input channels
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = w & 1, wn = w >> 1;
-  const int tiles_n = Ci / 128, tiles = (Co / 128) * tiles_n;
+  const int tiles_n = Ci / TB, tiles = (Co / TA) * tiles_n;
   const int L = xcd_block();
   const int tile = L % tiles, split = L / tiles;
   if (split >= nsplit) return;
-  const int co0 = (tile / tiles_n) * 128, ci0 = (tile % tiles_n) * 128;
+  const int co0 = (tile / tiles_n) * TA, ci0 = (tile % tiles_n) * TB;
   const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
   const int nch = (mend - mbeg) / B6W_KC;
 
   // staging role of this thread
   const bool isB = tid >= 128;
-  const int st = tid & 127, mg = st >> 5, cq = st & 31;                     // pixels 8 mg .. + 7 of the chunk, channels 4 cq .. + 3
+  const int st = tid & 127;
+  const int tw = isB ? TB : TA;                                             // a 64-wide operand is staged by 64 of the 128 threads
+  const bool stage = st < tw;
+  const int mg = tw == 128 ? st >> 5 : (st >> 4) & 3, cq = tw == 128 ? st & 31 : st & 15;   // pixels 8 mg .. + 7 of the chunk, channels 4 cq .. + 3
+  const int PL = isB ? PLB : PLA;
   const float* src = isB ? X + static_cast<size_t>(mbeg + 8 * mg) * xs + ci0 + 4 * cq
                          : GY + static_cast<size_t>(mbeg + 8 * mg) * Co + co0 + 4 * cq;
   const int sstride = isB ? xs : Co;
@@ -288,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad(const float* __restrict__ GY,
   floatx4 v0, v1, v2, v3, v4, v5, v6, v7;
 #define B6W_FETCH(ch_)                                                                                               \
   do {                                                                                                               \
+    if (!stage) break;                                                                                               \
     const float* p_ = src + static_cast<size_t>(ch_) * B6W_KC * sstride;                                             \
     v0 = *reinterpret_cast<const floatx4*>(p_);                                                                      \
     v1 = *reinterpret_cast<const floatx4*>(p_ + sstride);                                                            \
@@ -301,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad(const float* __restrict__ GY,
   // channel c_ of the block: 8 pixel values -> one 16-byte piece per plane
 #define B6W_STAGE1(c_)                                                                                               \
   do {                                                                                                               \
+    if (!stage) break;                                                                                               \
     unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;                                                         \
     b6_split2(v0[c_], v1[c_], a0, a1, a2);                                                                           \
     b6_split2(v2[c_], v3[c_], b0, b1, b2);                                                                           \
@@ -311,21 +320,27 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad(const float* __restrict__ GY,
     *reinterpret_cast<uintx4*>(sdst + 2 * PL + soff[c_]) = uintx4{a2, b2, c2, d2};                                   \
   } while (0)
 
-  floatx16 acc[2][2], tot[2][2];
+  floatx16 acc[NA][NB], tot[NA][NB];
   const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) { tot[a][b] = zero16; acc[a][b] = zero16; }
-  int aaddr[2][2], baddr[2][2];                                             // [tile][reduction step]
+    for (int b = 0; b < NB; ++b) { tot[a][b] = zero16; acc[a][b] = zero16; }
+  int aaddr[NA][2], baddr[NB][2];                                           // [tile][reduction step]
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int u = 2 * s2 + half;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int ra = (wm * 2 + a) * 32 + l31, rb = (wn * 2 + a) * 32 + l31, u = 2 * s2 + half;
+    for (int a = 0; a < NA; ++a) {
+      const int ra = (wm * NA + a) * 32 + l31;
       aaddr[a][s2] = ra * 64 + ((u ^ ((ra >> 2) & 3)) * 16);
-      baddr[a][s2] = rb * 64 + ((u ^ ((rb >> 2) & 3)) * 16);
     }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int rb = (wn * NB + b) * 32 + l31;
+      baddr[b][s2] = rb * 64 + ((u ^ ((rb >> 2) & 3)) * 16);
+    }
+  }
 
   if (nch > 0) B6W_FETCH(0);
   for (int ch = 0; ch < nch; ++ch) {
@@ -336,39 +351,39 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad(const float* __restrict__ GY,
     const bool first = (ch & 3) == 0;                       // groups of four chunks = 48 chained instructions per accumulator
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 af[2][3], bf[2][3];
+      bf16x8 af[NA][3], bf[NB][3];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          af[a][p] = *reinterpret_cast<const bf16x8*>(sA + p * PL + aaddr[a][s2]);
-          bf[a][p] = *reinterpret_cast<const bf16x8*>(sB + p * PL + baddr[a][s2]);
-        }
+        for (int a = 0; a < NA; ++a) af[a][p] = *reinterpret_cast<const bf16x8*>(sA + p * PLA + aaddr[a][s2]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bf[b][p] = *reinterpret_cast<const bf16x8*>(sB + p * PLB + baddr[b][s2]);
+      }
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
         const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, pb = t == 0 || t == 3 || t == 5 ? 0 : (t == 1 || t == 4) ? 1 : 2;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < NB; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][pa], bf[b][pb], acc[a][b], 0, 0, 0);
       }
     }
     if ((ch & 3) == 3 || ch + 1 == nch) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { tot[a][b] += acc[a][b]; acc[a][b] = zero16; }
+        for (int b = 0; b < NB; ++b) { tot[a][b] += acc[a][b]; acc[a][b] = zero16; }
     }
     (void)first;
   }
 #undef B6W_FETCH
 #undef B6W_STAGE1
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      float* o = part + (static_cast<size_t>(split) * Co + co0 + (wm * 2 + a) * 32 + 4 * half) * Ci + ci0 + (wn * 2 + b) * 32 + l31;
+    for (int b = 0; b < NB; ++b) {
+      float* o = part + (static_cast<size_t>(split) * Co + co0 + (wm * NA + a) * 32 + 4 * half) * Ci + ci0 + (wn * NB + b) * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * Ci] = tot[a][b][r];
     }
@@ -391,11 +406,13 @@ __global__ __launch_bounds__(256) void b6_wsum(const float* __restrict__ part, i
   out[idx] = (s0 + s1) + (s2 + s3);
 }
 
-struct B6WPlan { int nsplit, rows, grid; };
+struct B6WPlan { int nsplit, rows, grid, ta, tb; };
 
 bool b6w_plan(long long M, int Ci, int Co, int xs, B6WPlan* p) {
-  if (M <= 0 || (M % B6W_KC) || M > 0x7fffffffLL || Ci <= 0 || (Ci % 128) || Co <= 0 || (Co % 128) || xs < Ci || (xs % 4)) return false;
-  const int tiles = (Co / 128) * (Ci / 128);
+  if (M <= 0 || (M % B6W_KC) || M > 0x7fffffffLL || Ci <= 0 || (Ci % 64) || Co <= 0 || (Co % 64) || xs < Ci || (xs % 4)) return false;
+  p->ta = (Co % 128) == 0 ? 128 : 64;
+  p->tb = (Ci % 128) == 0 ? 128 : 64;
+  const int tiles = (Co / p->ta) * (Ci / p->tb);
   long long ns = (2 * DBEV_NUM_CU) / tiles;                  // two workgroups per CU, one round
   const long long chunks = M / B6W_KC;
   if (ns > chunks / 8) ns = chunks / 8;                      // a share reduces at least 8 chunks
@@ -465,8 +482,12 @@ extern "C" int dbev_gemm_bf16x6_backward_weight(const float* x, const float* gra
   hipStream_t s = dbev_stream(stream);
   float* part = static_cast<float*>(workspace);
   DbevKt kt(DBEV_K_GEMM1X1_WGRAD, 2LL * M * Cin * Cout, s);
-  hipLaunchKernelGGL(b6_wgrad, dim3(p.grid), dim3(256), 0, s, grad_y, x, p.nsplit > 1 ? part : grad_weight, static_cast<int>(M), Cout, Cin,
-                     x_row_stride, p.rows, p.nsplit);
+#define B6W_GO(TAV, TBV)                                                                                                          \
+  hipLaunchKernelGGL((b6_wgrad<TAV, TBV>), dim3(p.grid), dim3(256), 0, s, grad_y, x, p.nsplit > 1 ? part : grad_weight,           \
+                     static_cast<int>(M), Cout, Cin, x_row_stride, p.rows, p.nsplit)
+  if (p.ta == 128) { if (p.tb == 128) B6W_GO(128, 128); else B6W_GO(128, 64); }
+  else { if (p.tb == 128) B6W_GO(64, 128); else B6W_GO(64, 64); }
+#undef B6W_GO
   DBEV_LAUNCH_CHECK();
   if (p.nsplit > 1) {
     const long long plane = static_cast<long long>(Cin) * Cout;

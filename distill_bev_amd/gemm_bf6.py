@@ -9,7 +9,7 @@ bf16 instructions replace eight fp32 ones in 0.38 of the time.
 
 ``conv1x1(x, weight)`` is ``F.conv2d(x, weight)`` for channels-last fp32 device tensors with N*H*W % 128 == 0, Cin % 64 == 0,
 Cout % 64 == 0, differentiable: the data gradient is the same kernel on grad_y with the transposed weight view, the weight gradient
-its own kernel (both operands split on the fly; channel counts that are multiples of 128, the library's otherwise).  Layers that would leave half of the chip idle (fewer than `_MIN_ITEMS` output tiles) stay with the library."""
+its own kernel (both operands split on the fly).  Layers that would leave half of the chip idle (fewer than `_MIN_ITEMS` output tiles) stay with the library."""
 import os
 
 import torch
@@ -96,10 +96,10 @@ def data_gradient(gy, weight):
 
 def weight_gradient(x, gy, weight):
     """grad_weight of y = conv1x1(x, weight) (dbev_gemm_bf16x6_backward_weight: both operands split on the fly, fixed summation order),
-    with `weight`'s strides, or None when the library should do it (channel counts not multiples of 128, layout)"""
+    with `weight`'s strides, or None when the library should do it (channel counts not multiples of 64, layout)"""
     Co, Ci = int(weight.shape[0]), int(weight.shape[1])
     if not (_ON and _WGRAD and x.is_cuda and x.dtype == torch.float32 and gy.dtype == torch.float32 and _nhwc(x) and _nhwc(gy)
-            and Ci % 128 == 0 and Co % 128 == 0):
+            and Ci % 64 == 0 and Co % 64 == 0):
         return None
     M = x.shape[0] * x.shape[2] * x.shape[3]
     nbytes = int(L.call("dbev_gemm_bf16x6_backward_weight_workspace_bytes", M, Ci, Co, Ci))

@@ -618,7 +618,7 @@ int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long 
                              dbevStream_t stream);
 /* weight gradient of the same layer, grad_weight[Cout, Cin] = sum_m grad_y[m, Cout] * x[m, Cin] (both operands split on the fly,
  * shares of the pixel range merged in a fixed order: bit-reproducible, no zero-fill launch, no atomics); M % 32 == 0,
- * Cin % 128 == 0, Cout % 128 == 0; workspace: dbev_gemm_bf16x6_backward_weight_workspace_bytes bytes (0: unsupported shape). */
+ * Cin % 64 == 0, Cout % 64 == 0; workspace: dbev_gemm_bf16x6_backward_weight_workspace_bytes bytes (0: unsupported shape). */
 size_t dbev_gemm_bf16x6_backward_weight_workspace_bytes(long long M, int Cin, int Cout, int x_row_stride);
 int dbev_gemm_bf16x6_backward_weight(const float* x, const float* grad_y, float* grad_weight, long long M, int Cin, int Cout,
                                      int x_row_stride, void* workspace, size_t workspace_bytes, dbevStream_t stream);

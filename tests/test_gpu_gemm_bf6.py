@@ -64,9 +64,9 @@ def test_signed_inputs_and_extreme_magnitudes(monkeypatch):
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(4, 64, 256, 16, 16), (2, 256, 64, 32, 16), (2, 128, 128, 16, 16), (3, 256, 384, 16, 24),
-                                         (2, 1024, 128, 8, 16)])
+                                         (2, 1024, 128, 8, 16), (2, 64, 64, 32, 32), (2, 192, 320, 16, 16)])
 def test_module_gradients_vs_fp64(n, ci, co, h, w, monkeypatch):
-    """forward, data gradient and (channel counts that are multiples of 128) weight gradient on the bf16x6 kernels"""
+    """forward, data gradient and weight gradient (all four tile shapes: 128 / 64 output x 128 / 64 input channels) on the bf16x6 kernels"""
     from distill_bev_amd import gemm_bf6 as G
     monkeypatch.setattr(G, "_MIN_ITEMS", 1)
     monkeypatch.setattr(G, "_MIN_WGRAD_ROWS", 1)
@@ -91,7 +91,7 @@ def test_module_gradients_vs_fp64(n, ci, co, h, w, monkeypatch):
     assert _err(xa.grad, xd.grad) <= 1.25 * _err(xl.grad, xd.grad) + 1e-7
     assert _err(m[0].weight.grad, wd.grad) <= 1.25 * _err(wl.grad, wd.grad) + 1e-7
     assert m[0].weight.grad.shape == m[0].weight.shape
-    if ci % 128 == 0 and co % 128 == 0:                           # the bf16x6 weight gradient ran: fixed summation order
+    if ci % 64 == 0 and co % 64 == 0:                             # the bf16x6 weight gradient ran (128- or 64-wide tiles): fixed summation order
         g1 = G.weight_gradient(x, gy, m[0].weight)
         assert g1 is not None and torch.equal(g1, G.weight_gradient(x, gy, m[0].weight))
         assert torch.equal(g1.reshape(co, ci), m[0].weight.grad.reshape(co, ci))
