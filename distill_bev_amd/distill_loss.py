@@ -299,9 +299,20 @@ class _FusedAdaptMSE(Function):
         with torch.cuda.device(dev):
             L.call("dbev_adapt_mse_backward_ds", L.ptr(D), L.ptr(gE), L.ptr(z(gEfp)), L.ptr(z(gP)), L.ptr(cc), B, H * W, Ct,
                    L.ptr(dS), L.stream_ptr(dev))
-        # the convolution gradients are plain GEMMs on dS: MIOpen's NHWC fp32 MFMA kernels
-        dx, dw, db = torch.ops.aten.convolution_backward(dS, x, weight, [Ct], [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                         [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]])
+        # the convolution gradients are plain GEMMs on dS: the bf16x6 kernels where they apply (gemm_bf6), MIOpen's fp32 kernels
+        # otherwise; the bias gradient is a column sum of dS (colsum)
+        from . import colsum, gemm_bf6 as G
+        nx, nw, nb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        nhwc = dS.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)
+        dx = G.data_gradient(dS, weight) if nx and nhwc else None
+        dw = G.weight_gradient(x, dS, weight) if nw and nhwc else None
+        db = colsum.channel_sum(dS) if nb and nhwc else None
+        lx, lw, lb = nx and dx is None, nw and dw is None, nb and db is None
+        if lx or lw or lb:
+            a, b, c = torch.ops.aten.convolution_backward(dS, x, weight, [Ct], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [lx, lw, lb])
+            dx, dw, db = (a if lx else dx), (b if lw else dw), (c if lb else db)
+        if dw is not None and dw.shape != weight.shape:
+            dw = dw.view(weight.shape)
         return dx, dw, db, None, None
 
 
