@@ -31,6 +31,10 @@ namespace {
 #define B6_DBG(bit_) 0
 #endif
 
+#ifndef B6_NT
+#define B6_NT 0
+#endif
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -235,7 +239,10 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
       float* y = Y + static_cast<size_t>(m0 + (wm * TM + a) * 32 + 4 * half) * N + n0 + (wn * 2 + b) * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (!B6_DBG(8) || tot[a][b][r] == 12345.678f) y[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N] = tot[a][b][r];
+        if (!B6_DBG(8) || tot[a][b][r] == 12345.678f) {
+          if (B6_NT) __builtin_nontemporal_store(tot[a][b][r], y + static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N);
+          else y[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N] = tot[a][b][r];
+        }
     }
   if (B6_DBG(16) && blockIdx.x == 0 && tid == 0) {          // ablation only: shader clocks / 100 MHz ticks of this workgroup -> y[0..1]
     const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
