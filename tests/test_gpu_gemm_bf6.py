@@ -155,3 +155,47 @@ def test_packs_follow_a_fused_optimizer_step(monkeypatch):
         y = m(x)
         ref = F.conv2d(F.conv2d(x.double(), m[0].weight.double()), m[1].weight.double(), padding=1)
         assert float((y.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+def test_biased_layers_and_the_dcn_contraction_take_the_same_kernels(monkeypatch):
+    """colsum.BiasSumConv2d (1x1 with bias), colsum.conv_bn_cancelled_bias and dcn.modulated_deform_conv2d_raw hand eligible GEMMs to
+    the bf16x6 kernels: outputs and gradients against the same calls with the path switched off (the library's fp32 kernels)"""
+    from distill_bev_amd import colsum, dcn
+    from distill_bev_amd import gemm_bf6 as G
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    monkeypatch.setattr(G, "_MIN_WGRAD_ROWS", 1)
+    torch.manual_seed(2)
+    conv = nn.Conv2d(128, 192, 1).to(DEV).to(memory_format=torch.channels_last)
+    conv.__class__ = colsum.BiasSumConv2d
+    x = torch.randn((2, 128, 16, 16), device=DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((2, 192, 16, 16), device=DEV).contiguous(memory_format=torch.channels_last)
+
+    def run(on):
+        monkeypatch.setattr(G, "_ON", on)
+        xa = x.clone().requires_grad_(True)
+        conv.zero_grad(set_to_none=True)
+        y = conv(xa)
+        y.backward(gy)
+        return y.detach(), xa.grad, conv.weight.grad.clone(), conv.bias.grad.clone()
+
+    a, b = run(True), run(False)
+    ref = F.conv2d(x.double(), conv.weight.detach().double(), conv.bias.detach().double())
+    assert _err(a[0], ref) <= 1.25 * _err(b[0], ref) + 1e-7
+    for u, v in zip(a[1:], b[1:]):
+        assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max())
+    with torch.no_grad():
+        monkeypatch.setattr(G, "_ON", True)
+        assert torch.equal(conv(x), a[0])
+    # DCNv2: 3x3 deformable convolution 64 -> 64 whose column contraction (K = 576) is a 1x1 layer
+    w = (torch.randn((64, 64, 3, 3), device=DEV) / 24.0).requires_grad_(True)
+    xd = torch.randn((2, 64, 16, 16), device=DEV).contiguous(memory_format=torch.channels_last)
+    om = (0.5 * torch.randn((2, 27, 16, 16), device=DEV)).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(G, "_ON", on)
+        xr = xd.clone().requires_grad_(True)
+        y = dcn.modulated_deform_conv2d_raw(xr, om, w, None)
+        gx, gw = torch.autograd.grad(y, (xr, w), torch.ones_like(y))
+        outs.append((y.detach(), gx, gw))
+    for u, v in zip(*outs):
+        assert float((u - v).abs().max()) <= 3e-6 * float(v.abs().max())
