@@ -88,7 +88,7 @@ class BiasSumConv2d(nn.Conv2d):
             if G.eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
                 if grad:
                     return G.conv1x1(x, self.weight, self.bias)
-                return G.gemm(x, G.packed(self.weight), self.out_channels).add_(self.bias.view(1, -1, 1, 1))
+                return G.product(x, self.weight).add_(self.bias.view(1, -1, 1, 1))
             if grad:
                 return _BiasConv.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         return super().forward(x)
@@ -137,7 +137,7 @@ def conv_bn_cancelled_bias(conv, bn, x, bn_call):
     from . import gemm_bf6 as G
     if G.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
         z = G.conv1x1(x, conv.weight) if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad) \
-            else G.gemm(x, G.packed(conv.weight), conv.out_channels)
+            else G.product(x, conv.weight)
     else:
         z = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if not BA.eligible(z, bn):

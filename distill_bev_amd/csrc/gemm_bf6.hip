@@ -433,7 +433,8 @@ bool b6w_plan(long long M, int Ci, int Co, int xs, B6WPlan* p) {
   return true;
 }
 
-int b6_bn(int N) { return (N % 128) == 0 ? 128 : 64; }
+// tile_n: 128 / 64 columns per workgroup tile; 0 = 128 when N allows it (64 gives twice the workgroups: layers with few rows)
+int b6_bn(int N, int tile_n) { return (tile_n == 64 || (N % 128) != 0) ? 64 : 128; }
 
 bool b6_ok(long long M, int K, int N, int xs) {
   return M > 0 && (M % B6_BM) == 0 && M <= 0x7fffffffLL && K > 0 && (K % 64) == 0 && N > 0 && (N % 64) == 0 && xs >= K && (xs % 4) == 0 &&
@@ -447,22 +448,26 @@ extern "C" long long dbev_gemm_bf16x6_packed_bytes(int N, int K) {
   return 3LL * N * K * 2;
 }
 
-extern "C" int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long stride_k, int N, int K, void* packed,
+extern "C" int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long stride_k, int N, int K, int tile_n, void* packed,
                                      dbevStream_t stream) {
-  if (dbev_gemm_bf16x6_packed_bytes(N, K) == 0 || weight == nullptr || packed == nullptr) return DBEV_EINVAL;
+  if (dbev_gemm_bf16x6_packed_bytes(N, K) == 0 || weight == nullptr || packed == nullptr || (tile_n != 0 && tile_n != 64 && tile_n != 128) ||
+      (tile_n == 128 && (N % 128) != 0))
+    return DBEV_EINVAL;
   const long long threads = static_cast<long long>(N) * (K / 8);
   hipLaunchKernelGGL(b6_pack, dim3(dbev_ceil_div(threads, 256)), dim3(256), 0, dbev_stream(stream), weight, stride_n, stride_k, N, K,
-                     b6_bn(N), static_cast<unsigned short*>(packed));
+                     b6_bn(N, tile_n), static_cast<unsigned short*>(packed));
   DBEV_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
-                                        dbevStream_t stream) {
-  if (!b6_ok(M, K, N, x_row_stride) || x == nullptr || packed == nullptr || y == nullptr) return DBEV_EINVAL;
+                                        int tile_n, dbevStream_t stream) {
+  if (!b6_ok(M, K, N, x_row_stride) || x == nullptr || packed == nullptr || y == nullptr || (tile_n != 0 && tile_n != 64 && tile_n != 128) ||
+      (tile_n == 128 && (N % 128) != 0))
+    return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   const int m = static_cast<int>(M);
-  const int bn = b6_bn(N);
+  const int bn = b6_bn(N, tile_n);
   const int grid = dbev_round_xcd((m / B6_BM) * (N / bn));
   DbevKt kt(DBEV_K_GEMM1X1_FWD, 2LL * M * K * N, s);
   const unsigned short* pw = static_cast<const unsigned short*>(packed);

@@ -68,7 +68,7 @@ def modulated_deform_conv2d_raw(x, offset_mask, weight, bias, stride=1, padding=
     if G.eligible(cols, w):                                               # the contraction over (k, c): a 1x1 layer of the bf16x6 GEMM
         if torch.is_grad_enabled() and (cols.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)):
             return G.conv1x1(cols, w, bias)
-        y = G.gemm(cols, G.packed(w), Co)
+        y = G.product(cols, w)
         return y if bias is None else y.add_(bias.view(1, -1, 1, 1))
     return F.conv2d(cols, w, bias)
 

@@ -30,12 +30,19 @@ def _nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
 
+def tile_n(M, N):
+    """columns of a workgroup tile for Y[M, N]: 128 when that already gives `_MIN_ITEMS` tiles (or N % 128 != 0 -> 64), else 64 -- the
+    8 x 22 maps of the last ResNet stage have 66 row blocks"""
+    if N % 128:
+        return 64
+    return 128 if (M // 128) * (N // 128) >= _MIN_ITEMS else 64
+
+
 def shape_ok(M, K, N):
     """can the kernels take Y[M, N] = X[M, K] W[N, K]^T, and does the launch fill the chip?"""
     if M <= 0 or M % 128 or K % 64 or N % 64 or K <= 0 or N <= 0:
         return False
-    bn = 128 if N % 128 == 0 else 64
-    return (M // 128) * (N // bn) >= _MIN_ITEMS
+    return (M // 128) * (N // tile_n(M, N)) >= _MIN_ITEMS
 
 
 def eligible(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1):
@@ -47,7 +54,7 @@ def eligible(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1
     return weight.shape[1] == C and _nhwc(x) and shape_ok(N * H * W, C, weight.shape[0])
 
 
-def packed(weight, transposed=False):
+def packed(weight, transposed=False, tn=128):
     """the three bf16 planes of `weight` [Cout, Cin, 1, 1] in the kernel's LDS image order (dbev_gemm_bf16x6_pack), kept on the weight
     until it changes.  transposed: for the data gradient (rows = input channels, reduction over the output channels)."""
     dev = L.require_cuda(weight)
@@ -60,7 +67,9 @@ def packed(weight, transposed=False):
             weight._dbev_bf6_packs = cache
         except AttributeError:
             pass
-    hit = cache[1].get(bool(transposed))
+    if (Ci if transposed else Co) % 128:
+        tn = 64
+    hit = cache[1].get((bool(transposed), tn))
     if hit is not None:
         return hit
     w2 = weight.detach().reshape(Co, Ci)                      # a view for both memory formats of a 1x1 filter
@@ -71,19 +80,29 @@ def packed(weight, transposed=False):
         raise L.DbevHipError(f"gemm_bf6: unsupported weight {Co} x {Ci} (transposed={transposed})")
     buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        L.call("dbev_gemm_bf16x6_pack", L.ptr(w2), sn, sk, n, k, L.ptr(buf), L.stream_ptr(dev))
-    cache[1][bool(transposed)] = buf
+        L.call("dbev_gemm_bf16x6_pack", L.ptr(w2), sn, sk, n, k, tn, L.ptr(buf), L.stream_ptr(dev))
+    cache[1][(bool(transposed), tn)] = buf
     return buf
 
 
-def gemm(x, pack, Cout):
-    """x [N, K, H, W] channels-last -> [N, Cout, H, W] channels-last with the packed weight planes"""
+def gemm(x, pack, Cout, tn):
+    """x [N, K, H, W] channels-last -> [N, Cout, H, W] channels-last with weight planes packed for tile width `tn` (`product` pairs
+    the pack and the launch)"""
     dev = L.require_cuda(x, pack)
     n, K, H, W = x.shape
     y = torch.empty((n, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     with torch.cuda.device(dev):
-        L.call("dbev_gemm_bf16x6_forward", L.ptr(x), L.ptr(pack), L.ptr(y), n * H * W, K, Cout, K, L.stream_ptr(dev))
+        L.call("dbev_gemm_bf16x6_forward", L.ptr(x), L.ptr(pack), L.ptr(y), n * H * W, K, Cout, K,
+               int(tn), L.stream_ptr(dev))
     return y
+
+
+def product(x, weight, transposed=False):
+    """x [N, K, H, W] channels-last times the 1x1 filter `weight` [Cout, Cin, 1, 1] (transposed: its transpose, the data gradient's
+    operand) -> channels-last; no autograd.  The tile width follows the layer's row count (`tile_n`), the pack is made for it."""
+    cout = int(weight.shape[1 if transposed else 0])
+    tn = tile_n(x.shape[0] * x.shape[2] * x.shape[3], cout)
+    return gemm(x, packed(weight, transposed, tn), cout, tn)
 
 
 def data_gradient(gy, weight):
@@ -91,7 +110,7 @@ def data_gradient(gy, weight):
     Co, Ci = int(weight.shape[0]), int(weight.shape[1])
     if not (_ON and gy.is_cuda and gy.dtype == torch.float32 and _nhwc(gy) and shape_ok(gy.shape[0] * gy.shape[2] * gy.shape[3], Co, Ci)):
         return None
-    return gemm(gy, packed(weight, True), Ci)
+    return product(gy, weight, True)
 
 
 def weight_gradient(x, gy, weight):
@@ -116,7 +135,7 @@ def weight_gradient(x, gy, weight):
 class _Conv1x1Bf6(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        y = gemm(x, packed(weight), int(weight.shape[0]))
+        y = product(x, weight)
         if bias is not None:
             y.add_(bias.view(1, -1, 1, 1))                    # the separate bias pass ATen runs behind the library's convolution
         ctx.save_for_backward(x, weight)
@@ -156,7 +175,7 @@ class Bf6Conv2d(nn.Conv2d):
     def forward(self, x):
         if self.bias is None and eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
             if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
-                return gemm(x, packed(self.weight), self.out_channels)
+                return product(x, self.weight)
             return conv1x1(x, self.weight)
         return super().forward(x)
 

@@ -610,11 +610,14 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
  * mmdet3d/models/bricks/res_block.py:102-230 / necks/fpn.py:10-204 like dbev_gemm1x1_forward does.
  *   y[M, N] = x[M, K] * weight[N, K]^T,  x rows of x_row_stride floats, y row-major; M % 128 == 0, K % 64 == 0, N % 64 == 0.
  * dbev_gemm_bf16x6_pack splits the weight (element (n, k) at weight[n * stride_n + k * stride_k]: the transposed view serves the data
- * gradient) into `packed` (dbev_gemm_bf16x6_packed_bytes(N, K) bytes; 0: unsupported shape) once per weight version.
+ * gradient) into `packed` (dbev_gemm_bf16x6_packed_bytes(N, K) bytes; 0: unsupported shape) once per weight version.  tile_n: columns
+ * of a workgroup tile, the SAME value for the pack and the launches that use it: 0 = 128 when N % 128 == 0 else 64; 64 doubles the
+ * workgroups of a layer with few rows.
  * ---------------------------------------------------------------------------------- */
 long long dbev_gemm_bf16x6_packed_bytes(int N, int K);
-int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long stride_k, int N, int K, void* packed, dbevStream_t stream);
-int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
+int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long stride_k, int N, int K, int tile_n, void* packed,
+                          dbevStream_t stream);
+int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride, int tile_n,
                              dbevStream_t stream);
 /* weight gradient of the same layer, grad_weight[Cout, Cin] = sum_m grad_y[m, Cout] * x[m, Cin] (both operands split on the fly,
  * shares of the pixel range merged in a fixed order: bit-reproducible, no zero-fill launch, no atomics); M % 32 == 0,

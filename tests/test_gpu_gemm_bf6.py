@@ -37,14 +37,14 @@ def test_forward_is_as_exact_as_the_fp32_library_kernel(n, ci, co, h, w, monkeyp
     monkeypatch.setattr(G, "_MIN_ITEMS", 1)
     x, wt = _mk(n, ci, co, h, w, 11)
     assert G.eligible(x, wt)
-    y = G.gemm(x, G.packed(wt), co)
+    y = G.product(x, wt)
     lib = F.conv2d(x, wt)
     ref = F.conv2d(x.double(), wt.double())
     assert y.shape == lib.shape and y.is_contiguous(memory_format=torch.channels_last)
     e, el = _err(y, ref), _err(lib, ref)
     assert e <= 1.25 * el + 1e-7, (e, el)
     assert e < 1e-6
-    assert torch.equal(y, G.gemm(x, G.packed(wt), co))           # deterministic
+    assert torch.equal(y, G.product(x, wt))           # deterministic
 
 
 def test_signed_inputs_and_extreme_magnitudes(monkeypatch):
@@ -55,11 +55,11 @@ def test_signed_inputs_and_extreme_magnitudes(monkeypatch):
     x = (torch.randn((2, 64, 8, 8), generator=g) * torch.exp2(torch.randint(-60, 60, (2, 1, 8, 8), generator=g).float()))   # K = 64
     x = x.to(DEV).contiguous(memory_format=torch.channels_last)
     wt = torch.randn((64, 64, 1, 1), generator=g).to(DEV)
-    y = G.gemm(x, G.packed(wt), 64)
+    y = G.product(x, wt)
     ref = F.conv2d(x.double(), wt.double())
     rowscale = ref.abs().amax(dim=1, keepdim=True).clamp(min=1e-300)
     assert float(((y.double() - ref).abs() / rowscale).max()) < 2e-6     # relative to each pixel's own scale
-    z = G.gemm(torch.zeros_like(x), G.packed(wt), 64)
+    z = G.product(torch.zeros_like(x), wt)
     assert float(z.abs().max()) == 0.0
 
 
@@ -199,3 +199,18 @@ def test_biased_layers_and_the_dcn_contraction_take_the_same_kernels(monkeypatch
         outs.append((y.detach(), gx, gw))
     for u, v in zip(*outs):
         assert float((u - v).abs().max()) <= 3e-6 * float(v.abs().max())
+
+
+def test_few_rows_take_64_column_tiles():
+    """the 8 x 22 maps of the last ResNet stage (66 row blocks): 64-column tiles double the workgroups; pack and launch agree on the width"""
+    from distill_bev_amd import gemm_bf6 as G
+    assert G.tile_n(8448, 512) == 64 and G.tile_n(33792, 1024) == 128 and G.tile_n(8448, 192) == 64
+    assert G.shape_ok(8448, 2048, 512) and not G.shape_ok(8448, 2048, 256)
+    x, wt = _mk(48, 2048, 512, 8, 22, 4)
+    y = G.product(x, wt)
+    ref = F.conv2d(x.double(), wt.double())
+    e, el = _err(y, ref), _err(F.conv2d(x, wt), ref)
+    assert e <= 1.25 * el + 1e-7 and e < 1e-6, (e, el)
+    gx = G.data_gradient(y, wt)                                 # [M, 512] x [512, 2048]: 128-column tiles, the transposed pack
+    refg = F.conv_transpose2d(y.double(), wt.double())
+    assert gx is not None and _err(gx, refg) < 1e-6

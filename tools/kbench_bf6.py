@@ -16,16 +16,17 @@ def tm(f, n=20):
     for _ in range(n): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
+TN = [0]            # tile width of the pack / launch pair (set per shape below)
 def pack(w2):      # w2 [N, K]
     N, K = w2.shape
     nb = int(L.call("dbev_gemm_bf16x6_packed_bytes", N, K))
     p = torch.empty((nb,), dtype=torch.uint8, device=dev)
-    L.call("dbev_gemm_bf16x6_pack", L.ptr(w2), w2.stride(0), w2.stride(1), N, K, L.ptr(p), L.stream_ptr(dev))
+    L.call("dbev_gemm_bf16x6_pack", L.ptr(w2), w2.stride(0), w2.stride(1), N, K, TN[0], L.ptr(p), L.stream_ptr(dev))
     return p
 def gemm(x, p, N):
     n, K, H, W = x.shape
     y = torch.empty((n, N, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-    L.call("dbev_gemm_bf16x6_forward", L.ptr(x), L.ptr(p), L.ptr(y), n * H * W, K, N, K, L.stream_ptr(dev))
+    L.call("dbev_gemm_bf16x6_forward", L.ptr(x), L.ptr(p), L.ptr(y), n * H * W, K, N, K, TN[0], L.stream_ptr(dev))
     return y
 SHAPES = [(48, 64, 256, 64, 176), (48, 256, 64, 64, 176), (48, 128, 512, 32, 88), (48, 512, 128, 32, 88), (48, 256, 1024, 16, 44),
           (48, 1024, 256, 16, 44), (48, 512, 2048, 8, 22), (48, 2048, 512, 8, 22), (48, 1024, 512, 16, 44), (8, 256, 256, 128, 128),
@@ -37,6 +38,8 @@ for (n, ci, co, h, w_) in SHAPES:
     x = torch.relu(torch.randn((n, ci, h, w_), generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn((co, ci, 1, 1), generator=g) / ci ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
     w2 = w.reshape(co, ci)
+    from distill_bev_amd.gemm_bf6 import tile_n
+    TN[0] = tile_n(n * h * w_, co)
     p = pack(w2)
     y = gemm(x, p, co)
     ym = F.conv2d(x, w)
