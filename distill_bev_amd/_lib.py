@@ -88,6 +88,7 @@ _SIGNATURES = {
     "dbev_channel_sum_workspace_bytes": [_ll, _i],
     "dbev_gemm_bf16x6_packed_bytes": [_i, _i],
     "dbev_gemm_bf16x6_pack": [_p, _ll, _ll, _i, _i, _i, _p, _p],
+    "dbev_gemm_bf16x6_pack_pair": [_p, _ll, _ll, _i, _i, _i, _p, _i, _p, _p],
     "dbev_gemm_bf16x6_forward": [_p, _p, _p, _ll, _i, _i, _i, _i, _p],
     "dbev_gemm_bf16x6_backward_weight_workspace_bytes": [_ll, _i, _i, _i],
     "dbev_gemm_bf16x6_backward_weight": [_p, _p, _p, _ll, _i, _i, _i, _p, _sz, _p],

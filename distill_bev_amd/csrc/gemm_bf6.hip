@@ -48,10 +48,9 @@ __device__ __forceinline__ unsigned b6_rne(float x) {                    // bf16
 // ---- weight split + packing: W element (n, k) at w[n * sn + k * sk] -> planes in the LDS image order -----------------------------
 // packed (bf16 elements): ((((nb * nkc + kc) * 3 + plane) * BN + row) * 16) + (u ^ ((row >> 3) & 1)) * 8 + i,  n = nb BN + row,
 // k = 16 kc + 8 u + i
-__global__ __launch_bounds__(256) void b6_pack(const float* __restrict__ w, long long sn, long long sk, int N, int K, int BN,
-                                               unsigned short* __restrict__ out) {
-  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;      // (n, k unit of 8)
-  const int nk8 = K / 8;
+__device__ __forceinline__ void b6_pack_elem(long long idx, const float* __restrict__ w, long long sn, long long sk, int N, int K, int BN,
+                                             unsigned short* __restrict__ out) {
+  const int nk8 = K / 8;                                                              // idx = (n, k unit of 8)
   if (idx >= static_cast<long long>(N) * nk8) return;
   const int n = static_cast<int>(idx / nk8), k8 = static_cast<int>(idx % nk8);
   const int nb = n / BN, row = n % BN, kc = k8 / 2, u = k8 % 2, nkc = K / B6_KC;
@@ -72,6 +71,20 @@ __global__ __launch_bounds__(256) void b6_pack(const float* __restrict__ w, long
     unsigned short* o = out + ((((static_cast<long long>(nb) * nkc + kc) * 3 + pl) * BN + row) * 16) + ((u ^ ((row >> 3) & 1)) * 8);
     *reinterpret_cast<uint4*>(o) = make_uint4(pk[pl][0], pk[pl][1], pk[pl][2], pk[pl][3]);
   }
+}
+
+__global__ __launch_bounds__(256) void b6_pack(const float* __restrict__ w, long long sn, long long sk, int N, int K, int BN,
+                                               unsigned short* __restrict__ out) {
+  b6_pack_elem(static_cast<long long>(blockIdx.x) * 256 + threadIdx.x, w, sn, sk, N, K, BN, out);
+}
+
+// both orientations of a [Co, Ci] filter in one launch: blockIdx.y = 0 the forward planes (rows = output channels), 1 the data
+// gradient's (rows = input channels, reduction over the output channels)
+__global__ __launch_bounds__(256) void b6_pack_pair(const float* __restrict__ w, long long so, long long sc, int Co, int Ci, int bn_f,
+                                                    unsigned short* __restrict__ out_f, int bn_t, unsigned short* __restrict__ out_t) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (blockIdx.y == 0) b6_pack_elem(idx, w, so, sc, Co, Ci, bn_f, out_f);
+  else b6_pack_elem(idx, w, sc, so, Ci, Co, bn_t, out_t);
 }
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -456,6 +469,20 @@ extern "C" int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, lo
   const long long threads = static_cast<long long>(N) * (K / 8);
   hipLaunchKernelGGL(b6_pack, dim3(dbev_ceil_div(threads, 256)), dim3(256), 0, dbev_stream(stream), weight, stride_n, stride_k, N, K,
                      b6_bn(N, tile_n), static_cast<unsigned short*>(packed));
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_gemm_bf16x6_pack_pair(const float* weight, long long stride_o, long long stride_c, int Cout, int Cin, int tile_fwd,
+                                          void* packed_fwd, int tile_dgrad, void* packed_dgrad, dbevStream_t stream) {
+  const auto okt = [](int t, int n) { return t == 0 || t == 64 || (t == 128 && (n % 128) == 0); };
+  if (dbev_gemm_bf16x6_packed_bytes(Cout, Cin) == 0 || dbev_gemm_bf16x6_packed_bytes(Cin, Cout) == 0 || weight == nullptr ||
+      packed_fwd == nullptr || packed_dgrad == nullptr || !okt(tile_fwd, Cout) || !okt(tile_dgrad, Cin))
+    return DBEV_EINVAL;
+  const long long threads = static_cast<long long>(Cout) * Cin / 8;                  // the same count for both orientations
+  hipLaunchKernelGGL(b6_pack_pair, dim3(dbev_ceil_div(threads, 256), 2), dim3(256), 0, dbev_stream(stream), weight, stride_o, stride_c, Cout,
+                     Cin, b6_bn(Cout, tile_fwd), static_cast<unsigned short*>(packed_fwd), b6_bn(Cin, tile_dgrad),
+                     static_cast<unsigned short*>(packed_dgrad));
   DBEV_LAUNCH_CHECK();
   return 0;
 }

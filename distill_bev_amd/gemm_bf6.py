@@ -85,6 +85,33 @@ def packed(weight, transposed=False, tn=128):
     return buf
 
 
+def pack_both(weight, M):
+    """forward and data-gradient planes of `weight` for a layer of M rows in ONE launch (dbev_gemm_bf16x6_pack_pair), into the cache
+    `packed` reads -- called where both will be needed (a differentiated forward whose data gradient the kernels take)"""
+    Co, Ci = int(weight.shape[0]), int(weight.shape[1])
+    tf, tt = tile_n(M, Co), tile_n(M, Ci)
+    key = (weight._version, weight.data_ptr())
+    cache = getattr(weight, "_dbev_bf6_packs", None)
+    if cache is not None and cache[0] == key and (False, tf) in cache[1] and (True, tt) in cache[1]:
+        return
+    if cache is None or cache[0] != key:
+        cache = (key, {})
+        try:
+            weight._dbev_bf6_packs = cache
+        except AttributeError:
+            return                                            # no place to keep them: `packed` packs one at a time
+    dev = L.require_cuda(weight)
+    w2 = weight.detach().reshape(Co, Ci)
+    nf, nt = int(L.call("dbev_gemm_bf16x6_packed_bytes", Co, Ci)), int(L.call("dbev_gemm_bf16x6_packed_bytes", Ci, Co))
+    if nf == 0 or nt == 0:
+        return
+    bf, bt = torch.empty((nf,), dtype=torch.uint8, device=dev), torch.empty((nt,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dbev_gemm_bf16x6_pack_pair", L.ptr(w2), w2.stride(0), w2.stride(1), Co, Ci, tf, L.ptr(bf), tt, L.ptr(bt), L.stream_ptr(dev))
+    cache[1][(False, tf)] = bf
+    cache[1][(True, tt)] = bt
+
+
 def gemm(x, pack, Cout, tn):
     """x [N, K, H, W] channels-last -> [N, Cout, H, W] channels-last with weight planes packed for tile width `tn` (`product` pairs
     the pack and the launch)"""
@@ -135,6 +162,9 @@ def weight_gradient(x, gy, weight):
 class _Conv1x1Bf6(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
+        M = x.shape[0] * x.shape[2] * x.shape[3]
+        if ctx.needs_input_grad[0] and shape_ok(M, int(weight.shape[0]), int(weight.shape[1])):
+            pack_both(weight, M)                              # the data gradient will want the transposed planes: one launch for both
         y = product(x, weight)
         if bias is not None:
             y.add_(bias.view(1, -1, 1, 1))                    # the separate bias pass ATen runs behind the library's convolution

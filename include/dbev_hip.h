@@ -617,6 +617,10 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
 long long dbev_gemm_bf16x6_packed_bytes(int N, int K);
 int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long stride_k, int N, int K, int tile_n, void* packed,
                           dbevStream_t stream);
+/* both orientations of a [Cout, Cin] filter (element (o, c) at weight[o * stride_o + c * stride_c]) in ONE launch: the forward planes
+ * (N = Cout, K = Cin, tile_fwd) and the data gradient's (N = Cin, K = Cout, tile_dgrad) */
+int dbev_gemm_bf16x6_pack_pair(const float* weight, long long stride_o, long long stride_c, int Cout, int Cin, int tile_fwd,
+                               void* packed_fwd, int tile_dgrad, void* packed_dgrad, dbevStream_t stream);
 int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride, int tile_n,
                              dbevStream_t stream);
 /* weight gradient of the same layer, grad_weight[Cout, Cin] = sum_m grad_y[m, Cout] * x[m, Cin] (both operands split on the fly,
