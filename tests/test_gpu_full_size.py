@@ -54,6 +54,8 @@ def test_full_size_forward_finite_and_stable_then_one_optimizer_step(full):
     assert tr.detector.batched_branches >= 36, tr.detector.batched_branches      # (72: the teacher's head is planned as well)
     assert tr.detector.wino_convs >= 60, tr.detector.wino_convs
     assert tr.detector.folded_norm_pairs >= 13, tr.detector.folded_norm_pairs      # the frozen teacher's SECOND stacks: conv -> norm -> ReLU in one launch
+    assert tr.detector.bf6_convs >= 30, tr.detector.bf6_convs                      # bias-free 1x1 layers on the bf16x6 GEMM (34 in this recipe)
+    assert tr.detector.bias_sum_convs >= 10, tr.detector.bias_sum_convs            # the remaining nn.Conv2d(bias=True) modules
 
 
 def test_full_size_hand_written_ops_are_bit_reproducible(full):
