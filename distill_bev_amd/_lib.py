@@ -90,6 +90,8 @@ _SIGNATURES = {
     "dbev_gemm_bf16x6_pack": [_p, _ll, _ll, _i, _i, _i, _p, _p],
     "dbev_gemm_bf16x6_pack_pair": [_p, _ll, _ll, _i, _i, _i, _p, _i, _p, _p],
     "dbev_gemm_bf16x6_forward": [_p, _p, _p, _ll, _i, _i, _i, _i, _p],
+    "dbev_gemm_bf16x6_forward_stats": [_p, _p, _p, _p, _ll, _i, _i, _i, _i, _p],
+    "dbev_gemm_bf16x6_stats_rows": [_ll],
     "dbev_gemm_bf16x6_backward_weight_workspace_bytes": [_ll, _i, _i, _i],
     "dbev_gemm_bf16x6_backward_weight": [_p, _p, _p, _ll, _i, _i, _i, _p, _sz, _p],
     "dbev_channel_sum_nhwc": [_p, _ll, _i, _p, _p, _sz, _p],
@@ -176,7 +178,7 @@ _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_dcnv2_col2im_workspace_bytes": ctypes.c_size_t,
              "dbev_abs_mean_maps_nhwc_workspace_bytes": ctypes.c_size_t,
              "dbev_fgd_masked_mse_nhwc_workspace_bytes": ctypes.c_size_t}
-_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows", "dbev_wino_conv3x3_stats_rows", "dbev_wino_conv3x3_forward_kernel", "dbev_gemm1x1_stats_rows"}
+_NO_CHECK = set(_RESTYPES) | {"dbev_adapt_mse_map_slices", "dbev_conv1x1_stats_rows", "dbev_wino_conv3x3_stats_rows", "dbev_wino_conv3x3_forward_kernel", "dbev_gemm1x1_stats_rows", "dbev_gemm_bf16x6_stats_rows"}
 
 
 class DbevHipError(RuntimeError):

@@ -117,9 +117,11 @@ __device__ __forceinline__ unsigned long long b6_uniform64(unsigned long long v)
 // a tile takes the constant 0 as its addend), then the group's sum is added to `tot` by the VALU in round-to-nearest -- the error of a
 // long chain of matrix instructions on one accumulator grows with its length (1.8e-6 of the output scale at K = 2048 against 4.8e-7
 // for the fp32 kernels), with 24-instruction chains it is 2-3e-7 at every K.
-template <int BN, int OCC>
+// STATS: the per-channel sums of y and y^2 of the tile (the BatchNorm statistics of the output: `partial` f32[M / 128][2][N], rows in
+// bn_finalize's layout, merged there in fp64) leave the accumulators in the epilogue -- no statistics pass over y
+template <int BN, int OCC, bool STATS>
 __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, const unsigned short* __restrict__ Wp,
-                                                   float* __restrict__ Y, int M, int K, int N, int xs, int dbg) {
+                                                   float* __restrict__ Y, float* __restrict__ partial, int M, int K, int N, int xs, int dbg) {
   constexpr int WN = BN / 64, WM = 4 / WN, TM = B6_BM / WM / 32;            // waves along N / M, 32-row tiles per wave
   constexpr int APL = B6_BM * 32, BPL = BN * 32;                            // bytes of one plane of a chunk
   constexpr int ABUF = 3 * APL, BBUF = 3 * BPL;
@@ -257,6 +259,33 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
           else y[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N] = tot[a][b][r];
         }
     }
+  if (STATS) {
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = tot[a][b][r]; s1[b] += v; s2[b] = fmaf(v, v, s2[b]); }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { s1[b] += __shfl_xor(s1[b], 32); s2[b] += __shfl_xor(s2[b], 32); }
+    float* red = reinterpret_cast<float*>(smem);                             // [which 2][wm][BN]; the loop ended on a barrier
+    if (half == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        red[(0 * WM + wm) * BN + (wn * 2 + b) * 32 + l31] = s1[b];
+        red[(1 * WM + wm) * BN + (wn * 2 + b) * 32 + l31] = s2[b];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid % BN;
+      float s = red[(which * WM) * BN + c];
+#pragma unroll
+      for (int j = 1; j < WM; ++j) s += red[(which * WM + j) * BN + c];      // fixed order
+      partial[(static_cast<size_t>(mb) * 2 + which) * N + n0 + c] = s;
+    }
+  }
   if (B6_DBG(16) && blockIdx.x == 0 && tid == 0) {          // ablation only: shader clocks / 100 MHz ticks of this workgroup -> y[0..1]
     const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
     reinterpret_cast<unsigned*>(Y)[0] = static_cast<unsigned>(t1c - t0c);
@@ -487,8 +516,10 @@ extern "C" int dbev_gemm_bf16x6_pack_pair(const float* weight, long long stride_
   return 0;
 }
 
-extern "C" int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
-                                        int tile_n, dbevStream_t stream) {
+extern "C" int dbev_gemm_bf16x6_stats_rows(long long M) { return (M > 0 && (M % B6_BM) == 0 && M <= 0x7fffffffLL) ? static_cast<int>(M / B6_BM) : 0; }
+
+extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed, float* y, float* stats_partial, long long M, int K, int N,
+                                              int x_row_stride, int tile_n, dbevStream_t stream) {
   if (!b6_ok(M, K, N, x_row_stride) || x == nullptr || packed == nullptr || y == nullptr || (tile_n != 0 && tile_n != 64 && tile_n != 128) ||
       (tile_n == 128 && (N % 128) != 0))
     return DBEV_EINVAL;
@@ -497,13 +528,19 @@ extern "C" int dbev_gemm_bf16x6_forward(const float* x, const void* packed, floa
   const int bn = b6_bn(N, tile_n);
   const int grid = dbev_round_xcd((m / B6_BM) * (N / bn));
   DbevKt kt(DBEV_K_GEMM1X1_FWD, 2LL * M * K * N, s);
-  const unsigned short* pw = static_cast<const unsigned short*>(packed);
   static const int dbg = getenv("DBEV_BF6_DBG") ? atoi(getenv("DBEV_BF6_DBG")) : 0;
-#define B6_GO(BNV) hipLaunchKernelGGL((b6_fwd<BNV, 2>), dim3(grid), dim3(256), 0, s, x, pw, y, m, K, N, x_row_stride, dbg)
-  if (bn == 128) B6_GO(128); else B6_GO(64);
+  const unsigned short* pw = static_cast<const unsigned short*>(packed);
+#define B6_GO(BNV, ST) hipLaunchKernelGGL((b6_fwd<BNV, 2, ST>), dim3(grid), dim3(256), 0, s, x, pw, y, stats_partial, m, K, N, x_row_stride, dbg)
+  if (bn == 128) { if (stats_partial != nullptr) B6_GO(128, true); else B6_GO(128, false); }
+  else { if (stats_partial != nullptr) B6_GO(64, true); else B6_GO(64, false); }
 #undef B6_GO
   DBEV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
+                                        int tile_n, dbevStream_t stream) {
+  return dbev_gemm_bf16x6_forward_stats(x, packed, y, nullptr, M, K, N, x_row_stride, tile_n, stream);
 }
 
 extern "C" size_t dbev_gemm_bf16x6_backward_weight_workspace_bytes(long long M, int Cin, int Cout, int x_row_stride) {

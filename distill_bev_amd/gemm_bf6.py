@@ -22,6 +22,7 @@ L.ensure_param_version_hook()          # fused optimizers do not move `_version`
 
 _ON = os.environ.get("DBEV_BF6", "1") != "0"
 _WGRAD = os.environ.get("DBEV_BF6_WGRAD", "1") != "0"
+_STATS = os.environ.get("DBEV_BF6_STATS", "1") != "0"         # BatchNorm statistics from the forward kernel's epilogue (nets._conv1x1_stats)
 _MIN_ITEMS = int(os.environ.get("DBEV_BF6_MIN_ITEMS", "448"))
 _MIN_WGRAD_ROWS = 4096                                           # below: a handful of chunks per share, the library's kernel     # 128 x 128 (or 128 x 64) output tiles; two workgroups share a CU
 
@@ -112,24 +113,25 @@ def pack_both(weight, M):
     cache[1][(True, tt)] = bt
 
 
-def gemm(x, pack, Cout, tn):
+def gemm(x, pack, Cout, tn, stats=False):
     """x [N, K, H, W] channels-last -> [N, Cout, H, W] channels-last with weight planes packed for tile width `tn` (`product` pairs
-    the pack and the launch)"""
+    the pack and the launch); stats: also the partial BatchNorm statistics rows f32[M / 128, 2, Cout] of the output (kernel epilogue)"""
     dev = L.require_cuda(x, pack)
     n, K, H, W = x.shape
+    M = n * H * W
     y = torch.empty((n, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    part = torch.empty((int(L.call("dbev_gemm_bf16x6_stats_rows", M)), 2, Cout), dtype=torch.float32, device=dev) if stats else None
     with torch.cuda.device(dev):
-        L.call("dbev_gemm_bf16x6_forward", L.ptr(x), L.ptr(pack), L.ptr(y), n * H * W, K, Cout, K,
-               int(tn), L.stream_ptr(dev))
-    return y
+        L.call("dbev_gemm_bf16x6_forward_stats", L.ptr(x), L.ptr(pack), L.ptr(y), L.ptr(part), M, K, Cout, K, int(tn), L.stream_ptr(dev))
+    return (y, part) if stats else y
 
 
-def product(x, weight, transposed=False):
+def product(x, weight, transposed=False, stats=False):
     """x [N, K, H, W] channels-last times the 1x1 filter `weight` [Cout, Cin, 1, 1] (transposed: its transpose, the data gradient's
     operand) -> channels-last; no autograd.  The tile width follows the layer's row count (`tile_n`), the pack is made for it."""
     cout = int(weight.shape[1 if transposed else 0])
     tn = tile_n(x.shape[0] * x.shape[2] * x.shape[3], cout)
-    return gemm(x, packed(weight, transposed, tn), cout, tn)
+    return gemm(x, packed(weight, transposed, tn), cout, tn, stats)
 
 
 def data_gradient(gy, weight):
@@ -161,18 +163,22 @@ def weight_gradient(x, gy, weight):
 
 class _Conv1x1Bf6(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, stats=False):
         M = x.shape[0] * x.shape[2] * x.shape[3]
         if ctx.needs_input_grad[0] and shape_ok(M, int(weight.shape[0]), int(weight.shape[1])):
             pack_both(weight, M)                              # the data gradient will want the transposed planes: one launch for both
+        ctx.save_for_backward(x, weight)
+        if stats:                                             # (bias-free layers in front of a training-mode norm)
+            y, part = product(x, weight, stats=True)
+            ctx.mark_non_differentiable(part)
+            return y, part
         y = product(x, weight)
         if bias is not None:
             y.add_(bias.view(1, -1, 1, 1))                    # the separate bias pass ATen runs behind the library's convolution
-        ctx.save_for_backward(x, weight)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpart=None):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = gb = None
@@ -190,7 +196,12 @@ class _Conv1x1Bf6(Function):
         if ctx.needs_input_grad[2]:
             from .colsum import channel_sum
             gb = channel_sum(gy)
-        return gx, gw, gb
+        return gx, gw, gb, None
+
+
+def conv1x1_stats(x, weight):
+    """-> (F.conv2d(x, weight), partial statistics rows of the output) for an `eligible` pair: bn_act(..., pre=rows) skips its statistics pass"""
+    return _Conv1x1Bf6.apply(x, weight, None, True)
 
 
 def conv1x1(x, weight, bias=None):

@@ -27,6 +27,20 @@ from .registry import (MODELS, ConvModule, build_activation_layer, build_conv_la
                        build_upsample_layer, register_conv)
 
 
+def _conv1x1_stats(conv, bn, x):
+    """a bottleneck's 1x1 convolution -> (z, partial statistics rows of z or None): the fp32-MFMA GEMM with the statistics in its
+    epilogue on the first stage's large maps (conv1x1_bn_ready), the bf16x6 GEMM with the same epilogue where it takes the layer"""
+    if conv1x1_bn_ready(conv, bn, x):
+        return conv1x1_stats(conv, x)
+    from . import bn_act as BA
+    from . import gemm_bf6 as G
+    if (G._STATS and conv.bias is None and G.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            and BA._state["enabled"] and type(bn) in BA._BN_TYPES and bn.affine and bn.training and bn.momentum is not None
+            and bn.running_mean is not None and BA._channels_ok(conv.out_channels)):
+        return G.conv1x1_stats(x, conv.weight)                # (also without autograd: the detached frame)
+    return conv(x), None
+
+
 def _conv_stats(conv, bn, x):
     """(conv(x), partial statistics rows or None): the Winograd 3x3 kernel's epilogue takes the following norm's batch statistics"""
     if conv3x3_bn_ready(conv, bn, x):
@@ -126,15 +140,15 @@ class Bottleneck(nn.Module):
         n1, n3 = getattr(self, self.norm1_name), getattr(self, self.norm3_name)
         xi = forked(x)             # second handle of the previous block's output for the identity branch (see BasicBlock._fused)
         # 1x1 convolutions of the large maps: fp32-MFMA GEMM with the norm's batch statistics in its epilogue (no statistics pass)
-        z1, p1 = conv1x1_stats(self.conv1, x) if conv1x1_bn_ready(self.conv1, n1, x) else (self.conv1(x), None)
+        z1, p1 = _conv1x1_stats(self.conv1, n1, x)
         out = bn_act(z1, n1, None, True, pre=p1)
         n2 = getattr(self, self.norm2_name)
         z2, p2 = _conv_stats(self.conv2, n2, out)
         out = bn_act(z2, n2, None, True, pre=p2)
-        z3, p3 = conv1x1_stats(self.conv3, out) if conv1x1_bn_ready(self.conv3, n3, out) else (self.conv3(out), None)
+        z3, p3 = _conv1x1_stats(self.conv3, n3, out)
         ds = split_downsample(self.downsample)
         if ds is not None:
-            zd, pd = conv1x1_stats(ds[0], xi) if conv1x1_bn_ready(ds[0], ds[1], xi) else (ds[0](xi), None)
+            zd, pd = _conv1x1_stats(ds[0], ds[1], xi)
             return bn_act_dual(z3, n3, zd, ds[1], True, pre=p3, pre_d=pd, fork=True)
         identity = xi if self.downsample is None else self.downsample(xi)
         return bn_act(z3, n3, identity, True, pre=p3, fork=True)

@@ -617,6 +617,11 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
 long long dbev_gemm_bf16x6_packed_bytes(int N, int K);
 int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long stride_k, int N, int K, int tile_n, void* packed,
                           dbevStream_t stream);
+/* the same launch with the BatchNorm statistics of y in its epilogue: stats_partial f32[dbev_gemm_bf16x6_stats_rows(M)][2][N] = per
+ * 128-row block the column sums of y and y^2 (bn_finalize's partial-row layout: dbev_bn_act_train_forward_pre(..., pre rows)); NULL: none */
+int dbev_gemm_bf16x6_stats_rows(long long M);
+int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed, float* y, float* stats_partial, long long M, int K, int N,
+                                   int x_row_stride, int tile_n, dbevStream_t stream);
 /* both orientations of a [Cout, Cin] filter (element (o, c) at weight[o * stride_o + c * stride_c]) in ONE launch: the forward planes
  * (N = Cout, K = Cin, tile_fwd) and the data gradient's (N = Cin, K = Cout, tile_dgrad) */
 int dbev_gemm_bf16x6_pack_pair(const float* weight, long long stride_o, long long stride_c, int Cout, int Cin, int tile_fwd,

@@ -214,3 +214,31 @@ def test_few_rows_take_64_column_tiles():
     gx = G.data_gradient(y, wt)                                 # [M, 512] x [512, 2048]: 128-column tiles, the transposed pack
     refg = F.conv_transpose2d(y.double(), wt.double())
     assert gx is not None and _err(gx, refg) < 1e-6
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(4, 64, 256, 16, 16), (2, 256, 64, 32, 16), (48, 2048, 512, 8, 22)])
+def test_statistics_rows_from_the_epilogue(n, ci, co, h, w, monkeypatch):
+    """conv1x1_stats: the partial (sum y, sum y^2) rows per 128-row block equal the column sums of the output it wrote, and a
+    training-mode norm fed with them (bn_act(..., pre=rows)) gives what it gives when it takes its own statistics pass"""
+    from distill_bev_amd import gemm_bf6 as G
+    from distill_bev_amd.bn_act import bn_act
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    x, wt = _mk(n, ci, co, h, w, 21)
+    y, part = G.conv1x1_stats(x, wt)
+    M = n * h * w
+    assert part.shape == (M // 128, 2, co) and torch.equal(y, G.product(x, wt))
+    y2 = y.permute(0, 2, 3, 1).reshape(M // 128, 128, co).double()
+    assert float((part[:, 0].double() - y2.sum(1)).abs().max()) <= 1e-5 * float(y2.abs().sum(1).max())
+    assert float((part[:, 1].double() - (y2 * y2).sum(1)).abs().max()) <= 1e-5 * float((y2 * y2).sum(1).max())
+    torch.manual_seed(1)
+    bn_a, bn_b = nn.BatchNorm2d(co).to(DEV).train(), nn.BatchNorm2d(co).to(DEV).train()
+    oa, ob = bn_act(y, bn_a, None, True, pre=part), bn_act(y, bn_b, None, True)
+    assert float((oa - ob).abs().max()) <= 2e-5 * max(1.0, float(ob.abs().max()))
+    assert float((bn_a.running_var - bn_b.running_var).abs().max()) < 1e-5 and float((bn_a.running_mean - bn_b.running_mean).abs().max()) < 1e-6
+    # differentiable: the second output carries no gradient
+    xa = x.clone().requires_grad_(True)
+    wa = wt.clone().requires_grad_(True)
+    ya, pa = G.conv1x1_stats(xa, wa)
+    assert not pa.requires_grad
+    gx, gw = torch.autograd.grad(ya, (xa, wa), torch.ones_like(ya))
+    assert gx.shape == x.shape and gw.shape == wt.shape
