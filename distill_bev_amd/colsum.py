@@ -129,22 +129,26 @@ def cancelled_bias_ready(conv, bn, x):
 
 
 def conv_bn_cancelled_bias(conv, bn, x, bn_call):
-    """bn_call(z) for z = conv(x) WITHOUT its bias (see the module docstring); bn_call runs the norm (+ activation) on z and updates
+    """bn_call(z) for z = conv(x) WITHOUT its bias (see the module docstring); bn_call(z[, statistics rows]) runs the norm (+ activation) on z and updates
     bn.running_mean with mean(z), which is then moved by momentum * bias.  Only in front of the fused norm kernels (bn_act.eligible):
     they update the running statistics through raw pointers and save neither of them, the library's BatchNorm saves both for its
     backward (a later in-place update raises) -- there the convolution keeps its bias."""
     from . import bn_act as BA
     from . import gemm_bf6 as G
+    part = None
     if G.eligible(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
-        z = G.conv1x1(x, conv.weight) if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad) \
-            else G.product(x, conv.weight)
+        if G._STATS and BA._channels_ok(conv.out_channels) and BA._state["enabled"] and type(bn) in BA._BN_TYPES and bn.affine:
+            z, part = G.conv1x1_stats(x, conv.weight)               # the norm's statistics from the GEMM's epilogue
+        else:
+            z = G.conv1x1(x, conv.weight) if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad) \
+                else G.product(x, conv.weight)
     else:
         z = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if not BA.eligible(z, bn):
         return bn_call(z.add_(conv.bias.view(1, -1, 1, 1)))          # conv(x) as ATen computes it
     if torch.is_grad_enabled() and conv.bias.requires_grad:
         z = _ZeroBiasGrad.apply(z, conv.bias)
-    y = bn_call(z)
+    y = bn_call(z) if part is None else bn_call(z, part)
     with torch.no_grad():
         bn.running_mean.add_(conv.bias.detach(), alpha=float(bn.momentum))
     return y

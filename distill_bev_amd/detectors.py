@@ -148,7 +148,7 @@ def _conv_norm_relu(conv, norm, x):
     convolution then runs without its separate bias pass and without the bias-gradient reduction (colsum.conv_bn_cancelled_bias)."""
     from .colsum import BiasSumConv2d, cancelled_bias_ready, conv_bn_cancelled_bias
     if type(conv) in (nn.Conv2d, BiasSumConv2d) and cancelled_bias_ready(conv, norm, x):
-        return conv_bn_cancelled_bias(conv, norm, x, lambda z: bn_act(z, norm, None, True))
+        return conv_bn_cancelled_bias(conv, norm, x, lambda z, pre=None: bn_act(z, norm, None, True, pre=pre))
     return bn_act(conv(x), norm, None, True)
 
 
