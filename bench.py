@@ -112,13 +112,20 @@ def main():
     wl.begin_timed()
     from distill_bev_amd import _lib as _L
     _L.fallback_reset()                          # ledger of torch-path fallbacks of the fused ops, over the timed region
+    # one event per step boundary on the launch stream (no synchronisation inside the timed region): the per-step GPU times behind
+    # the wall-clock figure -- the board's power state moves a single 20-step average by ~5 % box to box and run to run, the
+    # median over blocks of steps says how much of `ms_per_step` is that
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         wl.step()
+        marks[i + 1].record()
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,6 +157,10 @@ def main():
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": 1e3 * dt / steps,
+            # rank 0's per-step GPU time between the step-boundary events of the SAME timed region: median, and the means of
+            # (up to) four consecutive blocks of steps
+            "ms_per_step_median": float(np.median(per_step)) if per_step else None,
+            "ms_per_step_blocks": [float(np.mean(b)) for b in np.array_split(np.asarray(per_step), min(4, max(steps, 1))) if len(b)],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -169,6 +180,13 @@ def main():
         alt = line["config"].get("ms_per_step_fp32_matrix_cores_only")
         if alt:
             line["value_fp32_matrix_cores_only"] = wl.units_per_step * world / (alt * 1e-3)
+        # ... and with all 36 branch stacks of the frozen teacher's head evaluated as the reference does (the default skips the 30
+        # whose outputs nothing reads; identical losses)
+        alt = line["config"].get("ms_per_step_full_teacher_head")
+        if alt:
+            line["value_full_teacher_head"] = wl.units_per_step * world / (alt * 1e-3)
+        if line["ms_per_step_median"]:
+            line["value_median_step"] = wl.units_per_step * world / (line["ms_per_step_median"] * 1e-3)
     if dist.is_initialized():
         dist.destroy_process_group()
     _flush_c_stdio()

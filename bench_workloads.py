@@ -17,6 +17,15 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # bn_apply<true,true> at 48x256x64x176: FETCH_SIZE 540 702.1 KB x 2 + WRITE_SIZE 540 672.0 KB = 1 661 029 786 B per launch
 # against 3 x 553 648 128 B = 1 660 944 384 B algorithmic -> ratio 1.00005 (no over-fetch, no write amplification)
 MFMA_F32_PEAK_TF = 157.3          # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TF = 2516.8        # v_mfma_f32_32x32x16_bf16 dense: 256 CUs x 4 SIMDs x 32768 FLOP / 32 cycles x 2.4 GHz (guide: "~2.5 PF dense")
+BF16X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0      # an fp32-equivalent FLOP of the bf16x6 GEMMs costs six bf16 matrix FLOPs
+# kernels whose event-log work field is FLOPs, not bytes: name -> (peak TFLOP/s, what the peak is, what the FLOPs count)
+FLOP_LOGGED = {"wino_fwd": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "winograd"),
+               "wino_wgrad": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "winograd"),
+               "g1_fwd": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "fp32"),
+               "g1_wgrad": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "fp32"),
+               "b6_fwd": (BF16X6_PEAK_TF, "bf16 MFMA dense peak / 6 (2516.8 / 6)", "fp32_equivalent"),
+               "b6_wgrad": (BF16X6_PEAK_TF, "bf16 MFMA dense peak / 6 (2516.8 / 6)", "fp32_equivalent")}
 PMC_TRAFFIC = {"bn_apply_res_ratio": (540720.8 * 2 + 540672.0) * 1024 / (3 * 553648128.0),
                # the 3x3 layer 48 x 256 -> 256 x 16 x 44 (a hybrid launch: wino_fwd + wino_fwd3): FETCH_SIZE (49 592.2 + 19 068.0) KB x 2 +
                # WRITE_SIZE (30 072 + 4 224) KB = 175.7 MB per layer against 73.9 MB algorithmic (x, y once + packed filters): the four
@@ -29,6 +38,16 @@ PMC_TRAFFIC = {"bn_apply_res_ratio": (540720.8 * 2 + 540672.0) * 1024 / (3 * 553
                "source": "profiles/r03_pmc_FETCH_SIZE.txt (x2 gfx950 wide-read correction) + profiles/r03_pmc_WRITE_SIZE.txt, separate "
                          "--pmc passes at the kernel's largest shape (48x256x64x176); traffic = algorithmic bytes of the timed "
                          "launches x that measured ratio (not collected live)"}
+
+
+def assert_fracs(obj, path="roofline"):
+    """no fraction of a peak above 1 anywhere in the line: such a row would mean a wrong unit (round 4: FLOPs printed as bytes)"""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if k.startswith("frac") and isinstance(v, (int, float)):
+                assert 0.0 <= v <= 1.0, f"{path}.{k} = {v}: a fraction of a peak cannot exceed 1 (unit mix-up?)"
+            else:
+                assert_fracs(v, path + "." + str(k))
 
 
 def _grid():
@@ -149,10 +168,10 @@ class DistillStep(_Base):
     default_steps = 20
     default_warmup = 5
     N_POINTS = 240000
-    # `roofline` reports the hand-written kernel that takes the most TIME in the step: the apply pass of the fused
-    # BatchNorm + residual + ReLU (bn_apply<true, *>, 48 launches per step over 69 ... 554 MB activations), bracketed
-    # per LAUNCH by the library's kernel event log inside the timed region; the rest of the bn_* family and every
-    # other hand-written entry point are measured the same way in extra steps after it (`other_hot_kernels`).
+    # `roofline` reports the hand-written kernel that takes the most TIME in the step: the Winograd forward / data-gradient kernel
+    # (wino_fwd*, ~120 launches per step), bracketed per LAUNCH by the library's kernel event log inside the timed region; every other
+    # logged kernel (wino_wgrad, b6_*, the bn_* family, ...) and the remaining hand-written entry points are measured the same way in
+    # extra steps after it (`other_hot_kernels`: FLOP-logged kernels against their matrix-pipe peak, the rest against HBM).
     ROOF_KERNEL = "wino_fwd"
     ROOF_KERNEL_NAME = "wino_fwd"
     EXTRA_INSTRUMENTED_STEPS = 3
@@ -252,17 +271,20 @@ class DistillStep(_Base):
         other = {}
         for k, recs in sorted(fam.items()):         # per KERNEL: work and time summed over the launches of the extra steps
             kt, kb = self._fam(recs)
-            if k.startswith("wino"):                # MFMA-bound kernels: the work field holds FLOPs
-                other[k] = {"launches_per_step": len(recs) / n_extra, "ms_per_step": kt * 1e3 / n_extra,
-                            "winograd_TFLOP_per_step": kb / 1e12 / n_extra, "achieved_TFLOPs": kb / kt / 1e12,
-                            "frac_of_fp32_mfma_peak": kb / kt / 1e12 / MFMA_F32_PEAK_TF,
-                            "direct_conv_equivalent_TFLOPs": 2.25 * kb / kt / 1e12}
-                continue
-            other[k] = {"launches_per_step": len(recs) / n_extra, "ms_per_step": kt * 1e3 / n_extra,
-                        "algorithmic_GB_per_step": kb / 1e9 / n_extra, "achieved_GBps": kb / kt / 1e9,
-                        "frac": kb / kt / 1e9 / HBM_PEAK_GBS}
+            row = {"launches_per_step": len(recs) / n_extra, "ms_per_step": kt * 1e3 / n_extra}
+            if k in FLOP_LOGGED:                    # matrix-pipe kernels: the log's work field holds FLOPs (see FLOP_LOGGED)
+                peak, peak_name, what = FLOP_LOGGED[k]
+                row.update({"bound": "mfma", what + "_TFLOP_per_step": kb / 1e12 / n_extra, "achieved_TFLOPs": kb / kt / 1e12,
+                            "peak_TFLOPs": peak, "peak": peak_name, "frac": kb / kt / 1e12 / peak})
+                if k.startswith("wino"):
+                    row["direct_conv_equivalent_TFLOPs"] = 2.25 * kb / kt / 1e12
+            else:                                   # streaming kernels: algorithmic HBM bytes
+                row.update({"bound": "hbm", "algorithmic_GB_per_step": kb / 1e9 / n_extra, "achieved_GBps": kb / kt / 1e9,
+                            "frac": kb / kt / 1e9 / HBM_PEAK_GBS})
+            other[k] = row
         bn_t = sum(v["ms_per_step"] for k, v in other.items() if k.startswith("bn_"))
         bn_b = sum(v["algorithmic_GB_per_step"] for k, v in other.items() if k.startswith("bn_"))
+        b6 = {k: v for k, v in other.items() if k.startswith("b6_")}
         for k, v in t.items():                      # per ENTRY POINT (may launch several kernels)
             if v:
                 other[k] = {"avg_us": float(np.mean(v)) * 1e3, "launches_per_step": len(v) / n_extra,
@@ -283,7 +305,7 @@ class DistillStep(_Base):
             c["frac"] = c["achieved_GBps"] / HBM_PEAK_GBS
         nl = len(roof)
         alg_bytes = wc["bytes"] / max(wc["launches"], 1)
-        return {"bound": "mfma",
+        out = {"bound": "mfma",
                 "kernel": "wino_fwd (3x3 stride-1 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: forward and data "
                           "gradient of the ResNet / BEV-encoder / head / SECOND 3x3 layers; csrc/wino.hip) -- the hand-written kernel "
                           "with the largest share of the step; one event pair per launch in the timed region",
@@ -300,9 +322,18 @@ class DistillStep(_Base):
                 "bn_family": {"ms_per_step": bn_t, "algorithmic_GB_per_step": bn_b,
                               "achieved_GBps": bn_b / (bn_t * 1e-3) if bn_t else None,
                               "frac": bn_b / (bn_t * 1e-3) / HBM_PEAK_GBS if bn_t else None},
-                "other_hot_kernels_note": "per-kernel rows (bn_*, wino_*, c1x1_fwd): the library's kernel event log; dbev_* rows: "
+                "b6_family": {"ms_per_step": sum(v["ms_per_step"] for v in b6.values()),
+                              "fp32_equivalent_TFLOP_per_step": sum(v["fp32_equivalent_TFLOP_per_step"] for v in b6.values()),
+                              "achieved_TFLOPs": (sum(v["fp32_equivalent_TFLOP_per_step"] for v in b6.values())
+                                                  / max(sum(v["ms_per_step"] for v in b6.values()) * 1e-3, 1e-12)),
+                              "peak_TFLOPs": BF16X6_PEAK_TF,
+                              "frac": (sum(v["fp32_equivalent_TFLOP_per_step"] for v in b6.values())
+                                       / max(sum(v["ms_per_step"] for v in b6.values()) * 1e-3, 1e-12) / BF16X6_PEAK_TF)} if b6 else None,
+                "other_hot_kernels_note": "per-kernel rows (bn_*, wino_*, b6_*, c1x1_fwd): the library's kernel event log; dbev_* rows: "
                 "HIP-event brackets of whole ABI entry points; both over %d extra steps run AFTER the timed region" % n_extra,
                 "other_hot_kernels": other}
+        assert_fracs(out)
+        return out
 
     def cpu_baseline(self):
         """The same training step with the reference's op sequence on the host cores

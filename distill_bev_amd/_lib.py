@@ -257,7 +257,7 @@ def call(name, *args, alg_bytes=0):
 
 KERNEL_IDS = {"bn_stats": 1, "bn_finalize": 2, "bn_apply": 3, "bn_apply_res": 4, "bn_bwd_reduce": 5, "bn_bwd_reduce_y": 6,
               "bn_bwd_finalize": 7, "bn_bwd_dx": 8, "bn_bwd_dx_res": 9, "sp_conv_fwd": 10, "msda_fwd": 11, "msda_bwd_sample": 12,
-              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15, "wino_fwd": 16, "wino_wgrad": 17, "g1_fwd": 18, "g1_wgrad": 19}        # DBEV_K_* of include/dbev_hip.h
+              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15, "wino_fwd": 16, "wino_wgrad": 17, "g1_fwd": 18, "g1_wgrad": 19, "b6_fwd": 20, "b6_wgrad": 21}        # DBEV_K_* of include/dbev_hip.h
 
 
 def kernel_timing(which):
@@ -344,6 +344,43 @@ def ensure_param_version_hook():
                     torch.autograd.graph.increment_version(p)
 
     _VERSION_HOOK.append(register_optimizer_step_post_hook(_bump))
+
+
+# ---- debug guard of everything kept per weight ---------------------------------------------------------------------------------------
+# DBEV_CHECK_PACKS=N (N >= 1): every N-th REUSE of a kept derivative of a weight -- packed Winograd filters (wino.packed_pair, the folded
+# conv + norm packs), bf16 planes of a 1x1 filter (gemm_bf6.packed), eval-mode norm coefficients (bn_act._eval_coef) -- re-reads the live
+# source tensors and compares their fingerprint with the one taken when the derivative was made; a mismatch means the weight was written
+# without its version counter moving (a `.data` write, an EMA hook, a non-torch optimizer, a collective on `t.data`) and raises instead of
+# silently running the forward on stale weights.  Costs a reduction over the weight and a host read-back per check: a debug mode.
+CHECK_PACKS = int(os.environ.get("DBEV_CHECK_PACKS", "0") or 0)
+_check_calls = [0]
+
+
+def fingerprint(*tensors):
+    """device f64[2 n]: (sum, sum of squares) of each source tensor, or None when the guard is off"""
+    if not CHECK_PACKS:
+        return None
+    parts = []
+    for t in tensors:
+        if t is not None:
+            d = t.detach().double()
+            parts += [d.sum(), (d * d).sum()]
+    return torch.stack(parts) if parts else None
+
+
+def check_fingerprint(fp, what, *tensors):
+    """called where a kept derivative is about to be reused; every CHECK_PACKS-th call compares `fp` with the live tensors"""
+    if not CHECK_PACKS or fp is None:
+        return
+    _check_calls[0] += 1
+    if _check_calls[0] % CHECK_PACKS:
+        return
+    now = fingerprint(*tensors)
+    if now is None or now.shape != fp.shape or not torch.equal(fp.nan_to_num(), now.nan_to_num()):
+        raise DbevHipError(f"DBEV_CHECK_PACKS: the kept {what} is STALE -- its source tensor changed without its version counter moving "
+                           "(a .data write, an EMA hook, a custom optimizer?).  Write through the tensor itself (p.copy_ / "
+                           "torch.autograd.graph.increment_version(p)) or call distill_bev_amd.bn_act.invalidate_eval_coef(model) after "
+                           "such updates.")
 
 
 def h2d(t, device):

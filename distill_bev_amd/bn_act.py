@@ -316,8 +316,10 @@ def _eval_coef(bn, dev):
         with torch.cuda.device(dev):
             L.call("dbev_bn_infer_coef", L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                    float(bn.eps), bn.num_features, L.ptr(coef), L.stream_ptr(dev))
-        hit = (key, coef)
+        hit = (key, coef, L.fingerprint(bn.weight, bn.bias, bn.running_mean, bn.running_var))
         bn.__dict__["_dbev_eval_coef"] = hit
+    else:
+        L.check_fingerprint(hit[2], "eval-mode norm coefficients", bn.weight, bn.bias, bn.running_mean, bn.running_var)
     return hit[1]
 
 

@@ -88,6 +88,8 @@ extern "C" const char* dbev_kernel_name(int kid) {
     case DBEV_K_WINO_WGRAD: return "wino_wgrad";
     case DBEV_K_GEMM1X1_FWD: return "g1_fwd";
     case DBEV_K_GEMM1X1_WGRAD: return "g1_wgrad";
+    case DBEV_K_B6_FWD: return "b6_fwd";
+    case DBEV_K_B6_WGRAD: return "b6_wgrad";
     default: return "?";
   }
 }

@@ -42,7 +42,10 @@ constexpr int B6_BM = 128, B6_KC = 16;
 
 __device__ __forceinline__ unsigned b6_rne(float x) {                    // bf16(x), round to nearest even, as the upper half of a dword
   const unsigned u = __float_as_uint(x);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  const unsigned r = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  // a finite x above the largest bf16 (|x| > 3.3895e38) would round to inf and leave a NaN remainder: keep the truncated piece
+  // there (the later pieces absorb the remainder exactly, as for every other x).  inf / NaN inputs pass through unchanged.
+  return ((r & 0x7f800000u) == 0x7f800000u && (u & 0x7f800000u) != 0x7f800000u) ? (u & 0xffff0000u) : r;
 }
 
 // ---- weight split + packing: W element (n, k) at w[n * sn + k * sk] -> planes in the LDS image order -----------------------------
@@ -97,6 +100,14 @@ __device__ __forceinline__ void b6_split2(float a, float b, unsigned& p0, unsign
   floatx2 v = {a, b};
   bf16x2 h = __builtin_convertvector(v, bf16x2);
   p0 = *reinterpret_cast<unsigned*>(&h);
+  // a FINITE value above the largest bf16 (|x| > 3.3895e38) rounds to inf and would leave a NaN remainder where the library's fp32
+  // GEMM returns a finite result: keep the truncated leading piece there (the later pieces absorb the remainder exactly).  One
+  // max + compare per pair on the common path; inf / NaN inputs are left to propagate.
+  if (__builtin_expect(fmaxf(fabsf(a), fabsf(b)) >= 3.3895314e38f, 0)) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    if ((ua & 0x7f800000u) != 0x7f800000u && (p0 & 0x00007f80u) == 0x00007f80u) p0 = (p0 & 0xffff0000u) | (ua >> 16);
+    if ((ub & 0x7f800000u) != 0x7f800000u && (p0 & 0x7f800000u) == 0x7f800000u) p0 = (p0 & 0x0000ffffu) | (ub & 0xffff0000u);
+  }
   floatx2 f = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
   v = v - f;                                                           // exact
   h = __builtin_convertvector(v, bf16x2);
@@ -527,7 +538,7 @@ extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed
   const int m = static_cast<int>(M);
   const int bn = b6_bn(N, tile_n);
   const int grid = dbev_round_xcd((m / B6_BM) * (N / bn));
-  DbevKt kt(DBEV_K_GEMM1X1_FWD, 2LL * M * K * N, s);
+  DbevKt kt(DBEV_K_B6_FWD, 2LL * M * K * N, s);                  // the log's work field: fp32-equivalent FLOPs
   static const int dbg = getenv("DBEV_BF6_DBG") ? atoi(getenv("DBEV_BF6_DBG")) : 0;
   const unsigned short* pw = static_cast<const unsigned short*>(packed);
 #define B6_GO(BNV, ST) hipLaunchKernelGGL((b6_fwd<BNV, 2, ST>), dim3(grid), dim3(256), 0, s, x, pw, y, stats_partial, m, K, N, x_row_stride, dbg)
@@ -557,7 +568,7 @@ extern "C" int dbev_gemm_bf16x6_backward_weight(const float* x, const float* gra
     return DBEV_EINVAL;
   hipStream_t s = dbev_stream(stream);
   float* part = static_cast<float*>(workspace);
-  DbevKt kt(DBEV_K_GEMM1X1_WGRAD, 2LL * M * Cin * Cout, s);
+  DbevKt kt(DBEV_K_B6_WGRAD, 2LL * M * Cin * Cout, s);
 #define B6W_GO(TAV, TBV)                                                                                                          \
   hipLaunchKernelGGL((b6_wgrad<TAV, TBV>), dim3(p.grid), dim3(256), 0, s, grad_y, x, p.nsplit > 1 ? part : grad_weight,           \
                      static_cast<int>(M), Cout, Cin, x_row_stride, p.rows, p.nsplit)

@@ -1250,7 +1250,9 @@ int wino_fwd_version() { static const int v = getenv("DBEV_WINO_FWD_V") ? atoi(g
 bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
   if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C % 4) || Co <= 0 || (Co % 64)) return false;
   if (static_cast<long long>(N) * H * W * (C > Co ? C : Co) >= 0x7fffffffLL) return false;      // 32-bit element offsets
-  if (static_cast<long long>(H) * W * C * 4 >= 0x7fffffffLL) return false;                       // 32-bit byte offsets inside an image (LDS-DMA)
+  // 32-bit BYTE offsets inside an image: the input side (LDS-DMA) and the output side (store offsets of the fast path, and the
+  // data-gradient launch where the roles of C and Co swap) -- mirrors wino.eligible() for direct C-ABI callers
+  if (static_cast<long long>(H) * W * (C > Co ? C : Co) * 4 >= 0x7fffffffLL) return false;
   const int TH = H / 2, TW = W / 2;
   p->ncb = Co / 64;
   // 64-tile blocks of wino_fwd: 8 x 8 or 4 x 16, whichever wastes fewer tile slots at the image edges

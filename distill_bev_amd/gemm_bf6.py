@@ -63,11 +63,13 @@ def packed(weight, transposed=False, tn=128):
     key = (weight._version, weight.data_ptr())
     cache = getattr(weight, "_dbev_bf6_packs", None)
     if cache is None or cache[0] != key:
-        cache = (key, {})
+        cache = (key, {}, L.fingerprint(weight))
         try:
             weight._dbev_bf6_packs = cache
         except AttributeError:
             pass
+    else:
+        L.check_fingerprint(cache[2], "bf16 planes of a 1x1 filter", weight)
     if (Ci if transposed else Co) % 128:
         tn = 64
     hit = cache[1].get((bool(transposed), tn))
@@ -96,7 +98,7 @@ def pack_both(weight, M):
     if cache is not None and cache[0] == key and (False, tf) in cache[1] and (True, tt) in cache[1]:
         return
     if cache is None or cache[0] != key:
-        cache = (key, {})
+        cache = (key, {}, L.fingerprint(weight))
         try:
             weight._dbev_bf6_packs = cache
         except AttributeError:

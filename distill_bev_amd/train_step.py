@@ -162,6 +162,20 @@ def accelerate_modules(detector):
     return n_bn, n_up
 
 
+def to_channels_last(detector):
+    """Put a built, on-device detector (student + hidden teacher) into the layout bench.py times: channels-last weights of the dense
+    2-D convolution modules, then `accelerate_modules`.  -> (fused norm+ReLU pairs, swapped upsample modules)"""
+    # OIHW weights of the dense 2-D convolution modules only: Module.to(memory_format=) would also re-stride the sparse
+    # layers' [ky, kx, Cin, Cout] / 5-D weights, whose kernels view them in their own layout
+    from .dcn import ModulatedDeformConv2dPack
+    for root in (detector, getattr(detector, "teacher_model", None)):
+        for m in (root.modules() if root is not None else ()):
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, ModulatedDeformConv2dPack)) and m.weight.dim() == 4:
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    detector.channels_last = True
+    return accelerate_modules(detector)
+
+
 def _flat_view(g):
     """1-D view of a dense gradient in MEMORY order; falls back to a logical-order copy for exotic strides (the copy is
     then written back through the same mapping)."""
@@ -223,7 +237,11 @@ class GradReducer:
         # all-reduce started AT ONCE, from inside backward -- but strictly in bucket order, so every rank issues the same sequence
         # of collectives whatever order (or subset) of gradients its own batch produced.  Buckets holding a parameter without a
         # gradient on this rank simply wait for all_reduce_grads(), which flushes the rest in the same order.
-        self.overlap = (os.environ.get("DBEV_DDP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        # Default OFF (round 5): the ordering / bit-identity of the overlapped path is covered by the 2-rank tests, but whether launching
+        # the collectives from the autograd thread helps on xGMI has never been measured on N > 1 GPUs (the 8-GPU node has not been
+        # available to this project) -- the exposed all-reduce of 217 MB is ~1-2 % of the step, the simple path is the default until a
+        # measurement says otherwise.  DBEV_DDP_OVERLAP=1 (or overlap=True) turns it on.
+        self.overlap = (os.environ.get("DBEV_DDP_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
         self._bucket_of = {id(p): i for i, bucket in enumerate(self.buckets) for p in bucket}
         self._seen = [set() for _ in self.buckets]
         self._fired, self._pending, self.fired_in_backward = 0, [], 0
@@ -237,6 +255,17 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self.reset()
+
+    def dirty(self):
+        """state left behind by a step that did not reach all_reduce_grads() (an exception between backward and the reduction, a
+        loop that skips a step on a non-finite loss)"""
+        return bool(self._pending) or self._fired > 0 or any(self._seen)
+
+    def reset(self):
+        """forget an aborted step: wait for the collectives it started (every rank started the same ones -- they were issued in
+        bucket order), drop their results, clear the per-bucket bookkeeping.  Trainer.step() calls it before every forward, so a
+        step that raised (or was skipped) after its backward cannot poison the next one; every rank must skip the same steps."""
         for work, *_ in self._pending:
             work.wait()
         self._pending = []
@@ -276,7 +305,8 @@ class GradReducer:
             # the bucket was packed (or the parameter counted) by an earlier backward of this step: the state machine is one
             # backward per all_reduce_grads() -- anything else would silently average a stale bucket
             raise RuntimeError("GradReducer: a second gradient arrived for a parameter before all_reduce_grads(); wrap the extra "
-                               "backward passes of a gradient-accumulation step in reducer.no_sync()")
+                               "backward passes of a gradient-accumulation step in reducer.no_sync(), or call reducer.reset() after "
+                               "abandoning a step between its backward and all_reduce_grads()")
         self._seen[i].add(id(p))
         if i == self._fired:
             n0 = self._fired
@@ -386,15 +416,7 @@ class Trainer:
         self.detector = model.to(device)
         self.detector.train()
         if channels_last:
-            # OIHW weights of the dense 2-D convolution modules only: Module.to(memory_format=) would also re-stride the sparse
-            # layers' [ky, kx, Cin, Cout] / 5-D weights, whose kernels view them in their own layout
-            from .dcn import ModulatedDeformConv2dPack
-            for root in (self.detector, getattr(self.detector, "teacher_model", None)):
-                for m in (root.modules() if root is not None else ()):
-                    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, ModulatedDeformConv2dPack)) and m.weight.dim() == 4:
-                        m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
-            self.detector.channels_last = True
-            self.fused_bn_relu, self.swapped_upsample = accelerate_modules(self.detector)
+            self.fused_bn_relu, self.swapped_upsample = to_channels_last(self.detector)
         self.wrapper = _TrainWrapper(self.detector)
         self.world_size = world_size
         self.reducer = None
@@ -430,6 +452,8 @@ class Trainer:
             self.reducer = None
 
     def step(self, batch):
+        if self.reducer is not None and self.reducer.dirty():
+            self.reducer.reset()                 # the previous step was abandoned after (part of) its backward
         losses = self.module(**batch)
         loss = parse_losses(losses)
         self.optimizer.zero_grad(set_to_none=True)

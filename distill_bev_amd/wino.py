@@ -90,6 +90,7 @@ def packed_pair(weight, x_shape, want_dgrad):
     hit = getattr(weight, "_dbev_wino_pair", None)
     fwd = dgrad = None
     if hit is not None and hit[0] == key:
+        L.check_fingerprint(hit[3], "Winograd filter pack", weight)
         fwd, dgrad = hit[1], hit[2]
         if dgrad is not None or not want_dgrad:
             return fwd, dgrad
@@ -105,7 +106,7 @@ def packed_pair(weight, x_shape, want_dgrad):
     with torch.cuda.device(dev):
         L.call("dbev_wino_filter_pack_pair", L.ptr(weight), so, sc, sa, sb, Co, C, fk, dk, L.ptr(fwd), L.ptr(dgrad), L.stream_ptr(dev))
     try:
-        weight._dbev_wino_pair = (key, fwd, dgrad)
+        weight._dbev_wino_pair = (key, fwd, dgrad, L.fingerprint(weight))
     except AttributeError:                                  # a tensor type without instance attributes: no reuse, still correct
         pass
     return fwd, dgrad
@@ -171,8 +172,10 @@ def conv_norm_relu_eval(x, conv, norm):
             wf = w.detach() * scale.view(Co, 1, 1, 1)
             b = (shift if conv.bias is None else shift + conv.bias.detach() * scale).contiguous()
             U = pack_filters(wf, False, x.shape)
-        hit = (key, coef, U, b)
+        hit = (key, coef, U, b, L.fingerprint(w, conv.bias))
         conv.__dict__["_dbev_wino_folded"] = hit
+    else:
+        L.check_fingerprint(hit[4], "folded convolution + norm filter pack", w, conv.bias)
     return conv_packed(x, hit[2], conv.out_channels, hit[3], relu=True)
 
 

@@ -53,7 +53,7 @@ enum {
   DBEV_K_BN_STATS = 1, DBEV_K_BN_FINALIZE, DBEV_K_BN_APPLY, DBEV_K_BN_APPLY_RES, DBEV_K_BN_BWD_REDUCE,
   DBEV_K_BN_BWD_REDUCE_Y, DBEV_K_BN_BWD_FINALIZE, DBEV_K_BN_BWD_DX, DBEV_K_BN_BWD_DX_RES, DBEV_K_SPCONV_FWD,
   DBEV_K_MSDA_FWD, DBEV_K_MSDA_BWD_SAMPLE, DBEV_K_MSDA_GV_GATHER, DBEV_K_ADAPT_MSE_FWD, DBEV_K_CONV1X1_FWD, DBEV_K_WINO_FWD, DBEV_K_WINO_WGRAD,
-  DBEV_K_GEMM1X1_FWD, DBEV_K_GEMM1X1_WGRAD, DBEV_K_COUNT
+  DBEV_K_GEMM1X1_FWD, DBEV_K_GEMM1X1_WGRAD, DBEV_K_B6_FWD, DBEV_K_B6_WGRAD, DBEV_K_COUNT
 };
 int dbev_kernel_timing_enable(int mask);
 int dbev_kernel_timing_read(int* kernel_id, float* ms, long long* algorithmic_bytes, int cap);

@@ -337,3 +337,57 @@ def test_grad_reducer_rejects_a_second_backward_and_accumulates_under_no_sync(tm
         for a, b in zip(r["accum"], r["ref"]):
             assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
     assert all(torch.equal(a, b) for a, b in zip(r0["accum"], r1["accum"]))
+
+
+# ---- an abandoned step (backward ran, all_reduce_grads() did not) must not poison the next one -----------------------------------
+def _abort_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from distill_bev_amd.train_step import GradReducer
+    torch.manual_seed(0)
+    net = nn.Sequential(*[nn.Linear(32, 32) for _ in range(4)], nn.Linear(32, 1))
+    params = list(net.parameters())
+    red = GradReducer(params, bucket_mb=0.005, overlap=True)
+    xs = [torch.randn(8, 32, generator=torch.Generator().manual_seed(40 + 2 * rank + i)) for i in range(2)]
+    res = {}
+    net(xs[0]).square().mean().backward()        # step 1: backward started collectives from the hooks ... and is abandoned here
+    res["dirty_after_abort"] = red.dirty()
+    res["pending_after_abort"] = len(red._pending)
+    red.reset()                                  # what Trainer.step() does at the start of the next step
+    res["dirty_after_reset"] = red.dirty()
+    for p in params:
+        p.grad = None
+    net(xs[1]).square().mean().backward()        # step 2 must neither raise nor average stale buckets
+    red.all_reduce_grads()
+    res["grads"] = [p.grad.clone() for p in params]
+    red.close()
+    ref = []
+    for p in params:
+        p.grad = None
+    net(xs[1]).square().mean().backward()
+    for p in params:
+        g = p.grad.clone() / world
+        dist.all_reduce(g)
+        ref.append(g)
+    res["ref"] = ref
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_reset_after_an_abandoned_step(tmp_path):
+    """a step that stops between backward and all_reduce_grads() (an OOM the loop catches, a skipped non-finite loss)
+    leaves fired buckets and pending collectives behind; `reset()` (called by Trainer.step before every forward when `dirty()`)
+    waits for and drops them, and the next step reduces exactly its own gradients."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "abort.pt")
+    mp.spawn(_abort_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out, weights_only=False)
+    for r in (r0, r1):
+        assert r["dirty_after_abort"] is True and r["pending_after_abort"] >= 1 and r["dirty_after_reset"] is False
+        for a, b in zip(r["grads"], r["ref"]):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert all(torch.equal(a, b) for a, b in zip(r0["grads"], r1["grads"]))

@@ -62,13 +62,46 @@ def _groups(losses):
             "kd_head": [k for k in losses if k.endswith("head_head")]}
 
 
-@pytest.mark.parametrize("aligned", [False, True])
-def test_bevdepth4d_distill_forward_train_vs_reference_fixture(aligned):
+@pytest.mark.parametrize("mode", ["as_is", "aligned", "accelerated"])
+def test_bevdepth4d_distill_forward_train_vs_reference_fixture(mode):
+    """accelerated (round 5): the aligned pass on the product AS bench.py BUILDS IT -- channels-last weights + `accelerate_modules`
+    (train_step.to_channels_last: fused norm + ReLU modules, Winograd / bf16x6 / bias-sum convolution classes, batched head branches,
+    folded frozen stacks, HIP upsampling) with the size thresholds of the hand-written convolution kernels forced to zero
+    (tests/_variants.forced_kernels), so that every layer of this small recipe the kernels CAN take (the 64-channel 3x3 layers of the
+    BEV encoder / BEV neck / teacher SECOND) runs on them, forward and backward; same bounds as the aligned pass, and the kernel event
+    log must show the Winograd forward / weight-gradient kernels and the fused norm kernels."""
+    import contextlib
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _variants as V
+    aligned, accelerated = mode != "as_is", mode == "accelerated"
+    with contextlib.ExitStack() as stack:
+        if accelerated:
+            stack.enter_context(V.forced_kernels())
+            from distill_bev_amd import _lib as L
+            L.kernel_timing_read()
+            L.kernel_timing(True)
+            stack.callback(L.kernel_timing, False)
+        _fixture_pass(aligned, accelerated)
+        if accelerated:
+            ran = {k: len(v) for k, v in L.kernel_timing_read().items()}
+            print("kernels", ran)
+            assert ran.get("wino_fwd", 0) >= 4 and ran.get("wino_wgrad", 0) >= 1, ran
+            assert any(k.startswith("bn_apply") for k in ran) and any(k.startswith("bn_bwd_dx") for k in ran), ran
+
+
+def _fixture_pass(aligned, accelerated):
     from distill_bev_amd.center_head import LiDARBoxes
     fx = np.load(os.path.join(GOLD, "bevdepth_step.npz"))
     dev = torch.device("cuda:0")
     model = _build(fx, dev)
     assert model.training and not model.teacher_model.training
+    if accelerated:
+        from distill_bev_amd.train_step import to_channels_last
+        n_bn, n_up = to_channels_last(model)
+        print("rewired: fused norm pairs", n_bn, "upsample", n_up, "wino", model.wino_convs, "folded", model.folded_norm_pairs,
+              "bf6", model.bf6_convs, "bias-sum", model.bias_sum_convs, "batched branches", model.batched_branches,
+              "skinny", model.skinny_convs)
+        assert n_bn >= 10 and model.wino_convs >= 4 and model.bias_sum_convs >= 4
     vt = model.img_view_transformer
     splat, calls = vt.lift_splat_cameras, []
 

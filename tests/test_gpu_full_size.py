@@ -194,6 +194,103 @@ def test_full_size_lift_splat_vs_fp64_oracle_on_one_sample_frame(full):
     assert err < 1e-4
 
 
+def _grad_step(tr, batch):
+    """forward + backward of the whole step on the trainer's current weights (no clip, no optimizer step)
+    -> (losses, {parameter name: gradient clone}, total gradient norm = the clip's input, {buffer name: running statistic clone})"""
+    from distill_bev_amd.train_step import parse_losses
+    det = tr.detector
+    for p in tr.params:
+        p.grad = None
+    losses = det.forward_train(**batch)
+    parse_losses(losses).backward()
+    grads = {n: p.grad.detach().clone() for n, p in det.named_parameters() if p.grad is not None}
+    gnorm = float(torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.double()) for g in grads.values()])))
+    stats = {k: v.detach().clone() for k, v in det.state_dict().items() if "running_" in k}
+    return {k: float(v.detach()) for k, v in losses.items()}, grads, gnorm, stats
+
+
+def test_full_size_hand_written_dense_kernels_vs_library_path_one_step(full):
+    """The configuration bench.py times against ITSELF with the round-4 / round-5 dense kernels switched off: the bs-8 batch once
+    with the defaults (Winograd 3x3 with statistics epilogues, bf16x6 1x1 GEMMs forward / data / weight gradient, fused norm +
+    residual + ReLU kernels with forked block outputs, cancelled convolution biases, folded frozen stacks) and once with
+    tests/_variants.library_path (MIOpen convolutions, torch BatchNorm / ReLU, ATen bias passes) on the SAME weights, buffers and
+    batch.  Reference op sequence: bevdet_distill_more.py:457-522 on plain nn modules.  Compared: all 47 losses, the total gradient
+    norm (what the clip sees), the gradients next to the losses, the BatchNorm running statistics after the step."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _variants as V
+    tr, batch, dev = full
+    det = tr.detector
+    sd0 = {k: v.detach().clone() for k, v in det.state_dict().items()}
+    (la, ga, na, sa), ran = V.kernels_ran(lambda: _grad_step(tr, batch))
+    print("kernels of the default step:", ran)
+    for k in ("wino_fwd", "wino_wgrad", "b6_fwd", "b6_wgrad"):
+        assert ran.get(k, 0) >= 20, (k, ran)
+    assert any(k.startswith("bn_apply") for k in ran) and any(k.startswith("bn_bwd_dx") for k in ran)
+    det.load_state_dict(sd0)                                             # in place: version counters move, kept packs are re-derived
+    with V.library_path():
+        (lb, gb, nb, sb), ran_b = V.kernels_ran(lambda: _grad_step(tr, batch))
+    assert not any(k.startswith(("wino", "b6_", "g1_", "bn_", "c1x1")) for k in ran_b), ran_b
+    det.load_state_dict(sd0)
+    assert set(la) == set(lb) and len(la) == 47
+    rows = sorted(((abs(la[k] - lb[k]) / max(abs(lb[k]), 1e-3), k, la[k], lb[k]) for k in la), reverse=True)
+    for r in rows[:6]:
+        print("%.2e  %-45s kernels %.6g  library %.6g" % r)
+    for rel, k, a, b in rows:
+        # heat-map focal terms and the thresholded false-positive mask (sigmoid(teacher heat map) > 0.1 per cell) sit on gates
+        assert rel <= (1e-3 if ("heatmap" in k or "kd_fp" in k) else 1e-4), (k, a, b)
+    print("total gradient norm: kernels %.6g  library %.6g  rel %.2e" % (na, nb, abs(na - nb) / nb))
+    assert abs(na - nb) <= 1e-3 * nb
+    near = ["channel_wise_adaptations.2.weight", "spatial_wise_adaptations.2.weight", "pts_bbox_head.shared_conv.conv.weight",
+            "img_bev_encoder_neck.conv.0.weight", "img_view_transformer.depthnet.weight"]
+    for n in near:
+        if n in ga:
+            e = float((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-20))
+            print("grad rel-L2 %-48s %.3e" % (n, e))
+            assert e <= 2e-3, (n, e)
+    worst = max(((float((sa[k] - sb[k]).abs().max() / sb[k].abs().max().clamp_min(1e-6)), k) for k in sa))
+    print("running statistics after one step, worst rel-Linf:", worst)
+    assert worst[0] <= 1e-5, worst
+
+
+def test_full_size_five_step_loss_trajectory_kernels_vs_library_path():
+    """Five optimizer steps from the same seed, once with the defaults and once on tests/_variants.library_path: the loss
+    trajectories agree step by step.  (The class of bug a one-step comparison cannot see: every step after the first running its
+    forward on step-0 weights because a kept weight pack did not follow the optimizer -- f60be45 -- shows up here as a trajectory
+    that stops moving with the library's.)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _variants as V
+    from distill_bev_amd.train_step import Trainer, build_model, make_batch
+    dev = torch.device("cuda:0")
+    traj = []
+    for lib in (False, True):
+        model, cfg = build_model(seed=0, allow_synthetic_teacher=True)
+        tr = Trainer(model, cfg, dev, world_size=1, channels_last=True)
+        batch = make_batch(B, np.random.default_rng(1234), dev, n_points=N_POINTS)
+        ls = []
+        for _ in range(5):
+            if lib:
+                with V.library_path():
+                    loss, _l = tr.step(batch)
+            else:
+                loss, _l = tr.step(batch)
+            ls.append(float(loss))
+        traj.append(ls)
+        tr.close()
+        del tr, model, batch
+        torch.cuda.empty_cache()
+    a, b = traj
+    print("loss trajectory, kernels:", a)
+    print("loss trajectory, library:", b)
+    assert all(np.isfinite(a)) and all(np.isfinite(b))
+    assert abs(a[0] - b[0]) <= 1e-4 * abs(b[0])
+    # the optimizer moves the loss by far more than the two paths differ: steps 1-4 follow the library's trajectory
+    for i in range(1, 5):
+        assert abs(a[i] - b[i]) <= 2e-2 * abs(b[i]), (i, a, b)
+        assert abs(a[i] - a[i - 1]) > 10 * abs(a[i] - b[i]) or abs(a[i] - b[i]) <= 1e-3 * abs(b[i]), (i, a, b)
+
+
 def test_full_size_bevformer_distillation_step():
     """BASELINE configs[4] at the size `bench.py --workload bevformer_distill` times (queue of 4 frames x 6 cameras x 928 x 1600,
     200 x 200 BEV queries, 900 object queries, 400 k virtual points through the sparse encoder): the losses of two forward passes

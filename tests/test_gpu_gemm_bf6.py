@@ -242,3 +242,34 @@ def test_statistics_rows_from_the_epilogue(n, ci, co, h, w, monkeypatch):
     assert not pa.requires_grad
     gx, gw = torch.autograd.grad(ya, (xa, wa), torch.ones_like(ya))
     assert gx.shape == x.shape and gw.shape == wt.shape
+
+
+def test_huge_finite_values_stay_finite_and_non_finite_inputs_propagate(monkeypatch):
+    """a finite fp32 value above the largest bf16 (3.3895e38 < |x| <= 3.4028e38) must not become inf / NaN in the split
+    (activations: split on the fly in b6_fwd / b6_wgrad; weights: b6_pack) -- the library's fp32 GEMM returns a finite result there;
+    inf / NaN inputs still reach the output as non-finite values (a training loop's non-finite check must keep working)."""
+    from distill_bev_amd import gemm_bf6 as G
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    monkeypatch.setattr(G, "_MIN_WGRAD_ROWS", 1)
+    big = 3.4e38
+    x = torch.zeros((2, 64, 8, 8), device=DEV).contiguous(memory_format=torch.channels_last)
+    x[0, 3, 1, 1], x[1, 5, 2, 2], x[0, 7, 4, 4] = big, -big, 1.5
+    wt = torch.zeros((64, 64, 1, 1), device=DEV)
+    wt[2, 3], wt[2, 5], wt[4, 7], wt[6, 7] = 0.25, 0.5, big, -big          # huge activation x small weight, small activation x huge weight
+    y = G.product(x, wt)
+    ref = F.conv2d(x.double(), wt.double())
+    assert bool(torch.isfinite(y).all())
+    nz = ref != 0
+    assert int(nz.sum()) == 4
+    assert float(((y.double() - ref)[nz] / ref[nz]).abs().max()) < 1e-6
+    # weight gradient (both operands split on the fly): dW[o, c] = sum_m gy[m, o] x[m, c]
+    gy = torch.zeros((2, 64, 8, 8), device=DEV).contiguous(memory_format=torch.channels_last)
+    gy[0, 9, 1, 1] = 0.5
+    gw = G.weight_gradient(x, gy, wt)
+    assert gw is not None and bool(torch.isfinite(gw).all())
+    assert abs(float(gw[9, 3, 0, 0]) / (0.5 * big) - 1.0) < 1e-6
+    # non-finite inputs propagate
+    x2 = x.clone(); x2[0, 3, 1, 1] = float("inf")
+    assert not bool(torch.isfinite(G.product(x2, wt)[0, :, 1, 1]).all())
+    x3 = x.clone(); x3[0, 3, 1, 1] = float("nan")
+    assert bool(torch.isnan(G.product(x3, wt)[0, 2, 1, 1]))

@@ -89,3 +89,49 @@ def test_channels_last_fused_norm_act_step_matches_unfused_op_sequence():
         rel = abs(a - b) / max(abs(a), 1e-3)
         # same bounds as above: fp32 round-off of ~190 normalisation layers through a random-init network
         assert rel < (1e-2 if "kd_fp" in k or "kd_bg_feat_loss_head" in k else 3e-3), (k, a, b)
+
+
+def test_forced_hand_written_dense_kernels_step_matches_library_path():
+    """The bench configuration's module tree at this test's reduced image size, with the size thresholds of the Winograd / bf16x6
+    kernels forced to zero (tests/_variants.forced_kernels: at 64 x 176 every layer is below them, so without the forcing this size
+    never reaches the kernels), against the same weights and batch on tests/_variants.library_path: every loss of the step, the
+    gradients next to the losses, and the kernel event log must show that the forward, data-gradient and weight-gradient kernels of
+    both families ran."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _variants as V
+    from distill_bev_amd.train_step import Trainer, build_model, make_batch, parse_losses
+    dev = torch.device("cuda:0")
+    model, cfg = build_model(cfg_options=dict(OPTS), seed=5, allow_synthetic_teacher=True)
+    tr = Trainer(model, cfg, dev, channels_last=True)
+    det = tr.detector
+    batch = make_batch(2, np.random.default_rng(11), dev, n_points=20000, input_size=(64, 176))
+    sd0 = {k: v.detach().clone() for k, v in det.state_dict().items()}
+
+    def run():
+        for p in tr.params:
+            p.grad = None
+        losses = det.forward_train(**batch)
+        parse_losses(losses).backward()
+        return {k: float(v.detach()) for k, v in losses.items()}, {n: p.grad.detach().clone() for n, p in det.named_parameters()
+                                                                   if p.grad is not None}
+    with V.forced_kernels():
+        (lf, gf), ran = V.kernels_ran(run)
+    print("kernels:", ran)
+    for k in ("wino_fwd", "wino_wgrad", "b6_fwd", "b6_wgrad"):
+        assert ran.get(k, 0) >= 8, (k, ran)
+    det.load_state_dict(sd0)
+    with V.library_path():
+        (lu, gu), ran_u = V.kernels_ran(run)
+    assert not any(k.startswith(("wino", "b6_", "g1_", "bn_")) for k in ran_u), ran_u
+    assert set(lf) == set(lu) and len(lf) == 47
+    rows = sorted(((abs(lf[k] - lu[k]) / max(abs(lu[k]), 1e-3), k, lf[k], lu[k]) for k in lf), reverse=True)
+    for r in rows[:6]:
+        print("%.2e  %-45s kernels %.6g  library %.6g" % r)
+    for rel, k, a, b in rows:
+        assert rel < (1e-2 if "kd_fp" in k or "kd_bg_feat_loss_head" in k else 3e-3), (k, a, b)      # the bounds of the tests above
+    for name in ("channel_wise_adaptations.2.weight", "spatial_wise_adaptations.2.weight", "pts_bbox_head.shared_conv.conv.weight"):
+        e = float((gf[name] - gu[name]).norm() / gu[name].norm().clamp(min=1e-12))
+        print("grad rel-L2 diff %-48s %.3e" % (name, e))
+        assert e < 3e-2, (name, e)
