@@ -304,6 +304,247 @@ __global__ __launch_bounds__(256, OCC) void b6_fwd(const float* __restrict__ X, 
   }
 }
 
+// ---- b6_fwd2 (round 5): the same tile, LDS image and accumulation scheme as b6_fwd, software-pipelined -----------------------------
+// What b6_fwd loses (rocprof + ISA, round 5): the compiler runs a chunk's 24 MFMAs back to back and the staging of the next chunk
+// (split, LDS writes, fetch) AFTER them, so a wave alternates ~770 matrix cycles with ~700 cycles of everything else and the two
+// waves of a SIMD cover each other to 54 %; the split's exact subtractions and the group sums came out as v_pk_add_f32, which costs
+// ~13 extra cycles each beside bf16 MFMAs (MI355X_MICROARCH.md, "anti-lever"); and the weight planes made a round trip through 12
+// VGPRs.  Here: (1) the chunk body is ONE basic block (out-of-range prefetches are clamped, not branched around) whose instruction
+// order is prescribed by sched_group_barrier: operand reads first, then one MFMA / a few VALU / now and then an LDS write or a fetch;
+// (2) scalar v_sub_f32 / v_add_f32 (scalar source + -fno-slp-vectorize for this file); (3) the packed weight chunk goes global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4), two chunks ahead into a ring of four buffers -- no registers, no ds_write, and its landing is
+// implied by the wait the activation split needs anyway; (4) a finite |x| above the largest bf16 is clamped for the LEADING piece only
+// (v_med3_f32; the remainder pieces absorb the difference exactly), inf / NaN still propagate.
+// (plain scalar C++ -- the file is compiled with -fno-slp-vectorize so that adjacent scalar operations stay v_sub_f32 / v_add_f32.
+// NOT inline asm: the hazard recogniser does not see inline asm as a VALU instruction and would leave out the wait states a VALU
+// read of an MFMA result needs -- measured: the group sums read the accumulators before the matrix pipe had written them.)
+__device__ __forceinline__ float b6_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float b6_add(float a, float b) { return a + b; }
+constexpr float B6_BF16_MAX = 3.3895313892515355e38f;               // 0x7f7f0000
+
+__device__ __forceinline__ void b6_split2s(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  floatx2 v = {__builtin_amdgcn_fmed3f(a, B6_BF16_MAX, -B6_BF16_MAX), __builtin_amdgcn_fmed3f(b, B6_BF16_MAX, -B6_BF16_MAX)};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  p0 = *reinterpret_cast<unsigned*>(&h);
+  float ra = b6_sub(a, __uint_as_float(p0 << 16)), rb = b6_sub(b, __uint_as_float(p0 & 0xffff0000u));      // exact
+  v = floatx2{ra, rb};
+  h = __builtin_convertvector(v, bf16x2);
+  p1 = *reinterpret_cast<unsigned*>(&h);
+  ra = b6_sub(ra, __uint_as_float(p1 << 16));
+  rb = b6_sub(rb, __uint_as_float(p1 & 0xffff0000u));
+  v = floatx2{ra, rb};
+  h = __builtin_convertvector(v, bf16x2);
+  p2 = *reinterpret_cast<unsigned*>(&h);
+}
+
+#define B6_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier((mask_), (n_), 0)
+
+template <int BN, bool STATS>
+__global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, const unsigned short* __restrict__ Wp,
+                                                  float* __restrict__ Y, float* __restrict__ partial, int M, int K, int N, int xs) {
+  constexpr int WN = BN / 64, WM = 4 / WN, TM = B6_BM / WM / 32;            // waves along N / M, 32-row tiles per wave
+  constexpr int APL = B6_BM * 32, BPL = BN * 32;                            // bytes of one plane of a chunk
+  constexpr int ABUF = 3 * APL, BBUF = 3 * BPL;                             // 12288, 12288 / 6144
+  constexpr int NDMA = BBUF / 1024;                                          // 64-lane x 16-byte DMA instructions per chunk: 12 / 6
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // sA[2][ABUF] | sB[4][BBUF]
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * ABUF;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = w % WM, wn = w / WM;
+  const int nblk = N / BN;
+  const int L = xcd_block();
+  const int nb = L % nblk, mb = L / nblk;
+  if (mb >= M / B6_BM) return;
+  const int m0 = mb * B6_BM, n0 = nb * BN;
+  const int nkc = K / B6_KC;
+
+  const int row0 = tid >> 2, row1 = 64 + (tid >> 2), c4 = tid & 3;
+  typedef const __attribute__((address_space(1))) float* gfloat_p;
+  const gfloat_p xb = reinterpret_cast<gfloat_p>(b6_uniform64(reinterpret_cast<unsigned long long>(X + static_cast<size_t>(m0) * xs)));
+  const unsigned xo0 = static_cast<unsigned>(row0 * xs + 4 * c4), xo1 = static_cast<unsigned>(row1 * xs + 4 * c4);
+  const int aoff0 = row0 * 32 + (((c4 >> 1) ^ ((row0 >> 3) & 1)) * 16) + (c4 & 1) * 8;
+  const int aoff1 = row1 * 32 + (((c4 >> 1) ^ ((row1 >> 3) & 1)) * 16) + (c4 & 1) * 8;
+  // weight chunks of this column block: LDS-DMA, wave w copies the 1 KB pieces w, w + 4, w + 8 (BN = 128) / piece w and a quarter
+  // of the last two (BN = 64: 32 lanes) of the 12 KB / 6 KB chunk image
+  const unsigned long long wsrc = b6_uniform64(reinterpret_cast<unsigned long long>(Wp) + static_cast<unsigned long long>(nb) * nkc * BBUF);
+  typedef __attribute__((address_space(3))) unsigned char* lds_p;
+  const unsigned ldsB = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_p)sB)));
+  const unsigned dvoff = lane * 16;
+#define B6_DMA(sbase_, ldsaddr_)                                                                                     \
+  do {                                                                                                               \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(dvoff), "s"(ldsaddr_), "s"(sbase_) : "memory");                                \
+  } while (0)
+#define B6_DMA_HALF(sbase_, ldsaddr_)                                                                                \
+  do {                                                                                                               \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffffffff\n\tglobal_load_lds_dwordx4 %1, %3\n\t" \
+                 "s_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"                                                            \
+                 : "=&s"(keep_) : "v"(dvoff), "s"(ldsaddr_), "s"(sbase_) : "memory");                                \
+  } while (0)
+  // chunk kc_ (clamped) -> ring slot slot_
+#define B6_DMA_CHUNK(kc_, slot_)                                                                                     \
+  do {                                                                                                               \
+    const int kq_ = (kc_) < nkc ? (kc_) : nkc - 1;                                                                   \
+    const unsigned long long sb_ = wsrc + static_cast<unsigned long long>(kq_) * BBUF;                               \
+    const unsigned la_ = ldsB + (slot_) * BBUF;                                                                      \
+    if (NDMA == 12) {                                                                                                \
+      B6_DMA(sb_ + w * 1024, la_ + w * 1024);                                                                        \
+      B6_DMA(sb_ + (w + 4) * 1024, la_ + (w + 4) * 1024);                                                            \
+      B6_DMA(sb_ + (w + 8) * 1024, la_ + (w + 8) * 1024);                                                            \
+    } else {                                                                                                         \
+      B6_DMA(sb_ + w * 1024, la_ + w * 1024);                                                                        \
+      B6_DMA_HALF(sb_ + 4096 + w * 512, la_ + 4096 + w * 512);                                                      \
+    }                                                                                                                \
+  } while (0)
+  floatx4 xa0_0, xa0_1, xa1_0, xa1_1;                                    // raw activations of two chunks in flight
+#define B6_LOADA(q_, kc_)                                                                                            \
+  do {                                                                                                               \
+    const int kq_ = (kc_) < nkc ? (kc_) : nkc - 1;                                                                   \
+    const gfloat_p xc_ = xb + kq_ * B6_KC;                                                                           \
+    xa##q_##_0 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo0);                      \
+    xa##q_##_1 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo1);                      \
+  } while (0)
+#define B6_SPLIT_STORE2(v_, off_)                                                                                    \
+  do {                                                                                                               \
+    unsigned p0a, p1a, p2a, p0b, p1b, p2b;                                                                           \
+    b6_split2s((v_).x, (v_).y, p0a, p1a, p2a);                                                                       \
+    b6_split2s((v_).z, (v_).w, p0b, p1b, p2b);                                                                       \
+    *reinterpret_cast<uint2*>(a_ + (off_)) = make_uint2(p0a, p0b);                                                   \
+    *reinterpret_cast<uint2*>(a_ + APL + (off_)) = make_uint2(p1a, p1b);                                             \
+    *reinterpret_cast<uint2*>(a_ + 2 * APL + (off_)) = make_uint2(p2a, p2b);                                         \
+  } while (0)
+#define B6_STAGEA(q_, buf_)                                                                                          \
+  do {                                                                                                               \
+    unsigned char* a_ = sA + (buf_) * ABUF;                                                                          \
+    B6_SPLIT_STORE2(xa##q_##_0, aoff0);                                                                              \
+    B6_SPLIT_STORE2(xa##q_##_1, aoff1);                                                                              \
+  } while (0)
+
+  floatx16 acc[TM][2];
+  float tot[TM][2][16];
+  const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[a][b][r] = 0.f;
+
+  // prologue: weights of chunks 0, 1 on their way, activations of chunks 0 (staged), 1, 2 (registers)
+  B6_DMA_CHUNK(0, 0);
+  B6_DMA_CHUNK(1, 1);
+  B6_LOADA(0, 0);
+  B6_LOADA(1, 1);
+  B6_STAGEA(0, 0);
+  B6_LOADA(0, 2);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                       // the four activation loads may stay in flight; both DMAs landed
+  __syncthreads();
+  int aaddr[TM], baddr[2];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int row = (wm * TM + a) * 32 + l31;
+    aaddr[a] = row * 32 + ((half ^ ((row >> 3) & 1)) * 16);
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int row = (wn * 2 + b) * 32 + l31;
+    baddr[b] = row * 32 + ((half ^ ((row >> 3) & 1)) * 16);
+  }
+
+  // chunk j_ of a group (kc = g + j_): LDS buffers A[j_ & 1], B[j_]; raw activations: set (j_ + 1) & 1 = chunk kc + 1 (staged here,
+  // then refilled with chunk kc + 3), the other set = chunk kc + 2
+#define B6_CHUNK2(j_, first_, last_)                                                                                 \
+  do {                                                                                                               \
+    const int kc = g + (j_);                                                                                         \
+    const unsigned char* ar_ = sA + ((j_) & 1) * ABUF;                                                               \
+    const unsigned char* br_ = sB + (j_) * BBUF;                                                                     \
+    bf16x8 af[TM][3], bf[2][3];                                                                                      \
+    _Pragma("unroll") for (int p = 2; p >= 0; --p) {                                                                  \
+      _Pragma("unroll") for (int a = 0; a < TM; ++a) af[a][p] = *reinterpret_cast<const bf16x8*>(ar_ + p * APL + aaddr[a]); \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) bf[b][p] = *reinterpret_cast<const bf16x8*>(br_ + p * BPL + baddr[b]); \
+    }                                                                                                                \
+    if (((j_) & 1) == 0) B6_STAGEA(1, 1); else B6_STAGEA(0, 0);                                                      \
+    B6_DMA_CHUNK(kc + 2, ((j_) + 2) & 3);                                                                            \
+    if (((j_) & 1) == 0) B6_LOADA(1, kc + 3); else B6_LOADA(0, kc + 3);                                              \
+    _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                   \
+      const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, pb = t == 0 || t == 3 || t == 5 ? 0 : (t == 1 || t == 4) ? 1 : 2; \
+      _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                  \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                 \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][pa], bf[b][pb], (first_) && t == 0 ? zero16 : acc[a][b], 0, 0, 0); \
+    }                                                                                                                \
+    if (last_) {                                                                                                     \
+      _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                  \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                 \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) tot[a][b][r] = b6_add(tot[a][b][r], acc[a][b][r]);           \
+    }                                                                                                                \
+    /* prescribed order: the operand reads, then MFMA / VALU / (LDS write | fetch) rounds */                        \
+    B6_SGB(0x100, 3 * TM + 6);                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 12 * TM; ++i) {                                                             \
+      B6_SGB(0x008, 1);                                                                                              \
+      B6_SGB(0x002, TM == 2 ? 3 : 6);                                                                                \
+      /* the plane stores follow their split (26 / 52 VALU instructions in), the refill of the register set follows its last reader */ \
+      if (TM == 2 ? (i == 9 || i == 11 || i == 18 || i == 20) : (i == 4 || i == 5 || i == 9 || i == 10)) B6_SGB(0x200, 1); \
+      if (i == 12 * TM - 3 || i == 12 * TM - 2) B6_SGB(0x020, 1);                                                    \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    __syncthreads();                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);            /* nothing moves across a chunk boundary (register-only work would: the next chunk's split) */ \
+  } while (0)
+  for (int g = 0; g < nkc; g += 4) {
+    B6_CHUNK2(0, true, false);
+    B6_CHUNK2(1, false, false);
+    B6_CHUNK2(2, false, false);
+    B6_CHUNK2(3, false, true);
+  }
+#undef B6_CHUNK2
+#undef B6_STAGEA
+#undef B6_SPLIT_STORE2
+#undef B6_LOADA
+#undef B6_DMA_CHUNK
+#undef B6_DMA_HALF
+#undef B6_DMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped prefetches of the last chunks: no DMA may outlive the workgroup's LDS
+  // accumulator register r = row (r & 3) + 8 (r >> 2) + 4 half of the 32 x 32 tile, column l31
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float* y = Y + static_cast<size_t>(m0 + (wm * TM + a) * 32 + 4 * half) * N + n0 + (wn * 2 + b) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N] = tot[a][b][r];
+    }
+  if (STATS) {
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = tot[a][b][r]; s1[b] += v; s2[b] = fmaf(v, v, s2[b]); }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { s1[b] += __shfl_xor(s1[b], 32); s2[b] += __shfl_xor(s2[b], 32); }
+    float* red = reinterpret_cast<float*>(smem);                             // [which 2][wm][BN]; the loop ended on a barrier
+    if (half == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        red[(0 * WM + wm) * BN + (wn * 2 + b) * 32 + l31] = s1[b];
+        red[(1 * WM + wm) * BN + (wn * 2 + b) * 32 + l31] = s2[b];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid % BN;
+      float s = red[(which * WM) * BN + c];
+#pragma unroll
+      for (int j = 1; j < WM; ++j) s += red[(which * WM + j) * BN + c];      // fixed order
+      partial[(static_cast<size_t>(mb) * 2 + which) * N + n0 + c] = s;
+    }
+  }
+}
+
 // ---- weight gradient: dW[Co, Ci] = sum_m GY[m, Co] * X[m, Ci] --------------------------------------------------------------------
 // Both operands are activations: both are split on the fly.  The reduction index is the pixel index m, which is the SLOW index of both
 // channels-last tensors, while an MFMA lane wants 8 consecutive reduction steps of one row -- so a thread fetches an 8 (pixels) x 4
@@ -541,6 +782,24 @@ extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed
   DbevKt kt(DBEV_K_B6_FWD, 2LL * M * K * N, s);                  // the log's work field: fp32-equivalent FLOPs
   static const int dbg = getenv("DBEV_BF6_DBG") ? atoi(getenv("DBEV_BF6_DBG")) : 0;
   const unsigned short* pw = static_cast<const unsigned short*>(packed);
+  static const int ver = getenv("DBEV_BF6_V") ? atoi(getenv("DBEV_BF6_V")) : 2;          // 1: the round-4 kernel (A/B runs)
+  if (ver == 2) {
+#define B6_GO2(BNV, ST)                                                                                                            \
+  do {                                                                                                                             \
+    constexpr int lds_ = 2 * 3 * B6_BM * 32 + 4 * 3 * BNV * 32;                                                                    \
+    static bool once_ = false;                                                                                                     \
+    if (!once_) {                                                                                                                  \
+      DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b6_fwd2<BNV, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
+      once_ = true;                                                                                                                \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((b6_fwd2<BNV, ST>), dim3(grid), dim3(256), lds_, s, x, pw, y, stats_partial, m, K, N, x_row_stride);        \
+  } while (0)
+    if (bn == 128) { if (stats_partial != nullptr) B6_GO2(128, true); else B6_GO2(128, false); }
+    else { if (stats_partial != nullptr) B6_GO2(64, true); else B6_GO2(64, false); }
+#undef B6_GO2
+    DBEV_LAUNCH_CHECK();
+    return 0;
+  }
 #define B6_GO(BNV, ST) hipLaunchKernelGGL((b6_fwd<BNV, 2, ST>), dim3(grid), dim3(256), 0, s, x, pw, y, stats_partial, m, K, N, x_row_stride, dbg)
   if (bn == 128) { if (stats_partial != nullptr) B6_GO(128, true); else B6_GO(128, false); }
   else { if (stats_partial != nullptr) B6_GO(64, true); else B6_GO(64, false); }
