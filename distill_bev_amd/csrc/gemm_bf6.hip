@@ -507,15 +507,7 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
 #undef B6_DMA_HALF
 #undef B6_DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped prefetches of the last chunks: no DMA may outlive the workgroup's LDS
-  // accumulator register r = row (r & 3) + 8 (r >> 2) + 4 half of the 32 x 32 tile, column l31
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      float* y = Y + static_cast<size_t>(m0 + (wm * TM + a) * 32 + 4 * half) * N + n0 + (wn * 2 + b) * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) y[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * N] = tot[a][b][r];
-    }
+  __syncthreads();                                           // ... nor land in the LDS another wave re-uses for its output tile below
   if (STATS) {
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
@@ -541,6 +533,29 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
 #pragma unroll
       for (int j = 1; j < WM; ++j) s += red[(which * WM + j) * BN + c];      // fixed order
       partial[(static_cast<size_t>(mb) * 2 + which) * N + n0 + c] = s;
+    }
+  }
+  // output: the accumulator layout (register r = row (r & 3) + 8 (r >> 2) + 4 half of a 32 x 32 tile, column l31) is transposed through
+  // the wave's own 16 KB (8 KB) of LDS so that a lane stores 16 consecutive bytes and an instruction covers 256-byte row segments:
+  // 16 (8) global_store_dwordx4 per lane instead of 64 (32) global_store_dword -- the scalar stores were issue-bound (rocprof: the
+  // K = 64 layers of the first stage wrote at 3.5 TB/s)
+  {
+    if (STATS) __syncthreads();                                              // `red` shares the front of the LDS
+    float* tw = reinterpret_cast<float*>(smem) + w * (TM * 32 * 64);         // [TM * 32 rows][64 columns] of this wave
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tw[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + b * 32 + l31] = tot[a][b][r];
+    // (the wave reads only what it wrote itself: the compiler's lgkmcnt wait orders the two phases)
+    const int rr = lane >> 4, c4q = lane & 15;                               // 4 rows per instruction, 16 lanes x float4 per row
+    float* yb = Y + static_cast<size_t>(m0 + wm * TM * 32) * N + n0 + wn * 64 + 4 * c4q;
+#pragma unroll
+    for (int i = 0; i < TM * 8; ++i) {
+      const int row = 4 * i + rr;
+      const floatx4 v = *reinterpret_cast<const floatx4*>(tw + row * 64 + 4 * c4q);
+      *reinterpret_cast<floatx4*>(yb + static_cast<size_t>(row) * N) = v;
     }
   }
 }
@@ -690,6 +705,167 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad(const float* __restrict__ GY,
     }
 }
 
+// ---- b6_wgrad2 (round 5): the weight gradient software-pipelined like b6_fwd2 ------------------------------------------------------
+// b6_wgrad stages a 32-pixel chunk into ONE LDS buffer between two barriers: the split of both operands (208 VALU instructions per
+// thread, v_pk_add_f32 among them) and the 48 MFMAs of a wave never overlap inside a workgroup.  Here: chunks of 16 pixels (one
+// reduction step), two LDS buffers, one barrier per chunk; every thread splits 8 pixels x 2 channels of one operand (104 VALU, scalar)
+// UNDER the chunk's 24 MFMAs in an order prescribed by sched_group_barrier; raw values fetched two chunks ahead (8 x 8-byte loads per
+// thread, a wave covers 512-byte row segments).  Groups of 8 chunks = 48 chained MFMAs per accumulator, as before.  M % 128 == 0.
+template <int TA, int TB>
+__global__ __launch_bounds__(256, 2) void b6_wgrad2(const float* __restrict__ GY, const float* __restrict__ X, float* __restrict__ part,
+                                                    int M, int Co, int Ci, int xs, int rows_per_split, int nsplit) {
+  constexpr int PLA = TA * 32, PLB = TB * 32;                               // bytes of one plane of each operand (16 pixels)
+  constexpr int NA = TA / 64, NB = TB / 64;                                 // 32-row tiles per wave
+  constexpr int BUF = 3 * PLA + 3 * PLB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = w & 1, wn = w >> 1;
+  const int tiles_n = Ci / TB, tiles = (Co / TA) * tiles_n;
+  const int L = xcd_block();
+  const int tile = L % tiles, split = L / tiles;
+  if (split >= nsplit) return;
+  const int co0 = (tile / tiles_n) * TA, ci0 = (tile % tiles_n) * TB;
+  const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  const int nch = (mend - mbeg) / B6_KC;                                    // a multiple of 8
+
+  // staging role: operand (gradient rows = output channels | input rows = input channels), pixel group pg (8 pixels), channel pair cp
+  const bool isB = tid >= TA;
+  const int st = isB ? tid - TA : tid;
+  const bool stage = (TA + TB == 256) || st < (isB ? TB : TA);      // 128 x 128 tiles: every thread stages (no branch in the chunk body)
+  const int pg = st & 1, cp = st >> 1;                                      // (consecutive lanes: the two pixel groups of one channel pair)
+  const int sstride = isB ? xs : Co;
+  const float* src = (isB ? X + ci0 : GY + co0) + static_cast<size_t>(mbeg + 8 * pg) * sstride + 2 * cp;
+  unsigned char* sbase = smem + (isB ? 3 * PLA : 0);
+  const int PL = isB ? PLB : PLA;
+  int soff[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int row = 2 * cp + c;
+    soff[c] = row * 32 + ((pg ^ ((row >> 3) & 1)) * 16);
+  }
+  floatx2 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;      // two chunks in flight
+#define B6W2_LOAD(q_, ch_)                                                                                           \
+  do {                                                                                                               \
+    const int cq_ = (ch_) < nch ? (ch_) : nch - 1;                                                                   \
+    const float* p_ = src + static_cast<size_t>(cq_) * B6_KC * sstride;                                              \
+    if (stage) {                                                                                                     \
+      r##q_##0 = *reinterpret_cast<const floatx2*>(p_);                                                              \
+      r##q_##1 = *reinterpret_cast<const floatx2*>(p_ + sstride);                                                    \
+      r##q_##2 = *reinterpret_cast<const floatx2*>(p_ + 2 * sstride);                                                \
+      r##q_##3 = *reinterpret_cast<const floatx2*>(p_ + 3 * sstride);                                                \
+      r##q_##4 = *reinterpret_cast<const floatx2*>(p_ + 4 * sstride);                                                \
+      r##q_##5 = *reinterpret_cast<const floatx2*>(p_ + 5 * sstride);                                                \
+      r##q_##6 = *reinterpret_cast<const floatx2*>(p_ + 6 * sstride);                                                \
+      r##q_##7 = *reinterpret_cast<const floatx2*>(p_ + 7 * sstride);                                                \
+    }                                                                                                                \
+  } while (0)
+  // channel c_ of the pair: its 8 pixel values -> one 16-byte piece per plane
+#define B6W2_STAGE1(q_, c_, dst_)                                                                                    \
+  do {                                                                                                               \
+    unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;                                                         \
+    b6_split2s(r##q_##0[c_], r##q_##1[c_], a0, a1, a2);                                                              \
+    b6_split2s(r##q_##2[c_], r##q_##3[c_], b0, b1, b2);                                                              \
+    b6_split2s(r##q_##4[c_], r##q_##5[c_], c0, c1, c2);                                                              \
+    b6_split2s(r##q_##6[c_], r##q_##7[c_], d0, d1, d2);                                                              \
+    *reinterpret_cast<uintx4*>((dst_) + soff[c_]) = uintx4{a0, b0, c0, d0};                                          \
+    *reinterpret_cast<uintx4*>((dst_) + PL + soff[c_]) = uintx4{a1, b1, c1, d1};                                     \
+    *reinterpret_cast<uintx4*>((dst_) + 2 * PL + soff[c_]) = uintx4{a2, b2, c2, d2};                                 \
+  } while (0)
+#define B6W2_STAGE(q_, buf_)                                                                                         \
+  do {                                                                                                               \
+    if (stage) {                                                                                                     \
+      unsigned char* d_ = sbase + (buf_) * BUF;                                                                      \
+      B6W2_STAGE1(q_, 0, d_);                                                                                        \
+      B6W2_STAGE1(q_, 1, d_);                                                                                        \
+    }                                                                                                                \
+  } while (0)
+
+  floatx16 acc[NA][NB];
+  float tot[NA][NB][16];
+  const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[a][b][r] = 0.f;
+  int aaddr[NA], baddr[NB];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    const int ra = (wm * NA + a) * 32 + l31;
+    aaddr[a] = ra * 32 + ((half ^ ((ra >> 3) & 1)) * 16);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int rb = (wn * NB + b) * 32 + l31;
+    baddr[b] = 3 * PLA + rb * 32 + ((half ^ ((rb >> 3) & 1)) * 16);
+  }
+
+  B6W2_LOAD(a, 0);
+  B6W2_LOAD(b, 1);
+  B6W2_STAGE(a, 0);
+  B6W2_LOAD(a, 2);
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+  // chunk j_ of a group (ch = g + j_): LDS buffer j_ & 1; raw set (j_ + 1) & 1 = chunk ch + 1 (staged here, then refilled with ch + 3)
+#define B6W2_CHUNK(j_, first_, last_)                                                                                \
+  do {                                                                                                               \
+    const int ch = g + (j_);                                                                                         \
+    const unsigned char* rd_ = smem + ((j_) & 1) * BUF;                                                              \
+    bf16x8 af[NA][3], bf[NB][3];                                                                                     \
+    _Pragma("unroll") for (int p = 2; p >= 0; --p) {                                                                  \
+      _Pragma("unroll") for (int a = 0; a < NA; ++a) af[a][p] = *reinterpret_cast<const bf16x8*>(rd_ + p * PLA + aaddr[a]); \
+      _Pragma("unroll") for (int b = 0; b < NB; ++b) bf[b][p] = *reinterpret_cast<const bf16x8*>(rd_ + p * PLB + baddr[b]); \
+    }                                                                                                                \
+    if (((j_) & 1) == 0) { B6W2_STAGE(b, 1); B6W2_LOAD(b, ch + 3); } else { B6W2_STAGE(a, 0); B6W2_LOAD(a, ch + 3); } \
+    _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                   \
+      const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, pb = t == 0 || t == 3 || t == 5 ? 0 : (t == 1 || t == 4) ? 1 : 2; \
+      _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                  \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][pa], bf[b][pb], (first_) && t == 0 ? zero16 : acc[a][b], 0, 0, 0); \
+    }                                                                                                                \
+    if (last_) {                                                                                                     \
+      _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                  \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) tot[a][b][r] = b6_add(tot[a][b][r], acc[a][b][r]);           \
+    }                                                                                                                \
+    B6_SGB(0x100, 3 * (NA + NB));                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 6 * NA * NB; ++i) {                                                         \
+      B6_SGB(0x008, 1);                                                                                              \
+      B6_SGB(0x002, NA * NB == 4 ? 5 : (NA * NB == 2 ? 10 : 20));                                                    \
+      if (i == 6 * NA * NB / 2 - 2 || i == 6 * NA * NB / 2 || i == 6 * NA * NB / 2 + 2) B6_SGB(0x200, 1);            \
+      if (i >= 6 * NA * NB - 4 && i < 6 * NA * NB - 1) B6_SGB(0x200, 1);                                             \
+      if (i == 6 * NA * NB - 2 || i == 6 * NA * NB - 1) B6_SGB(0x020, 4);                                            \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    __syncthreads();                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  } while (0)
+  for (int g = 0; g < nch; g += 8) {
+    B6W2_CHUNK(0, true, false);
+    B6W2_CHUNK(1, false, false);
+    B6W2_CHUNK(2, false, false);
+    B6W2_CHUNK(3, false, false);
+    B6W2_CHUNK(4, false, false);
+    B6W2_CHUNK(5, false, false);
+    B6W2_CHUNK(6, false, false);
+    B6W2_CHUNK(7, false, true);
+  }
+#undef B6W2_CHUNK
+#undef B6W2_STAGE
+#undef B6W2_STAGE1
+#undef B6W2_LOAD
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float* o = part + (static_cast<size_t>(split) * Co + co0 + (wm * NA + a) * 32 + 4 * half) * Ci + ci0 + (wn * NB + b) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[static_cast<size_t>((r & 3) + 8 * (r >> 2)) * Ci] = tot[a][b][r];
+    }
+}
+
 // dW = sum of the shares, four interleaved chains then pairwise (fixed order)
 __global__ __launch_bounds__(256) void b6_wsum(const float* __restrict__ part, int nsplit, long long plane, float* __restrict__ out) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
@@ -828,9 +1004,15 @@ extern "C" int dbev_gemm_bf16x6_backward_weight(const float* x, const float* gra
   hipStream_t s = dbev_stream(stream);
   float* part = static_cast<float*>(workspace);
   DbevKt kt(DBEV_K_B6_WGRAD, 2LL * M * Cin * Cout, s);
+  static const int ver = getenv("DBEV_BF6_WV") ? atoi(getenv("DBEV_BF6_WV")) : 2;         // 1: the round-4 kernel (A/B runs)
+  const bool v2 = ver == 2 && (M % 128) == 0 && (p.rows % 128) == 0;
 #define B6W_GO(TAV, TBV)                                                                                                          \
-  hipLaunchKernelGGL((b6_wgrad<TAV, TBV>), dim3(p.grid), dim3(256), 0, s, grad_y, x, p.nsplit > 1 ? part : grad_weight,           \
-                     static_cast<int>(M), Cout, Cin, x_row_stride, p.rows, p.nsplit)
+  do {                                                                                                                            \
+    if (v2) hipLaunchKernelGGL((b6_wgrad2<TAV, TBV>), dim3(p.grid), dim3(256), 0, s, grad_y, x, p.nsplit > 1 ? part : grad_weight, \
+                               static_cast<int>(M), Cout, Cin, x_row_stride, p.rows, p.nsplit);                                   \
+    else hipLaunchKernelGGL((b6_wgrad<TAV, TBV>), dim3(p.grid), dim3(256), 0, s, grad_y, x, p.nsplit > 1 ? part : grad_weight,    \
+                            static_cast<int>(M), Cout, Cin, x_row_stride, p.rows, p.nsplit);                                      \
+  } while (0)
   if (p.ta == 128) { if (p.tb == 128) B6W_GO(128, 128); else B6W_GO(128, 64); }
   else { if (p.tb == 128) B6W_GO(64, 128); else B6W_GO(64, 64); }
 #undef B6W_GO

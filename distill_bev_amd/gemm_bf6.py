@@ -24,6 +24,7 @@ _ON = os.environ.get("DBEV_BF6", "1") != "0"
 _WGRAD = os.environ.get("DBEV_BF6_WGRAD", "1") != "0"
 _STATS = os.environ.get("DBEV_BF6_STATS", "1") != "0"         # BatchNorm statistics from the forward kernel's epilogue (nets._conv1x1_stats)
 _MIN_ITEMS = int(os.environ.get("DBEV_BF6_MIN_ITEMS", "448"))
+_WGRAD_LIB_ROWS = int(os.environ.get("DBEV_BF6_WGRAD_LIB_ROWS", "262144"))
 _MIN_WGRAD_ROWS = 4096                                           # below: a handful of chunks per share, the library's kernel     # 128 x 128 (or 128 x 64) output tiles; two workgroups share a CU
 
 
@@ -154,6 +155,10 @@ def weight_gradient(x, gy, weight):
     M = x.shape[0] * x.shape[2] * x.shape[3]
     nbytes = int(L.call("dbev_gemm_bf16x6_backward_weight_workspace_bytes", M, Ci, Co, Ci))
     if nbytes == 0 or M < _MIN_WGRAD_ROWS:
+        return None
+    if min(Ci, Co) <= 64 and M >= _WGRAD_LIB_ROWS:
+        # the 64 <-> 256 layers of the first ResNet stage (540 k pixels): HBM-bound, and the library's kernel streams them faster
+        # (190 vs 215 us, profiles/r05_gemm_bf6_vs_miopen.txt)
         return None
     dev = x.device
     gw2 = torch.empty((Co, Ci), dtype=torch.float32, device=dev)
