@@ -168,6 +168,89 @@ def weight_gradient(x, gy, weight):
     return gw2.view(Co, Ci, 1, 1)                           # [Co, Ci] in memory: contiguous in both memory formats of a 1x1 filter
 
 
+# ---- stride-2 1x1 convolutions: subsample + GEMM (csrc/stride2.hip) -------------------------------------------------------------------
+_S2 = os.environ.get("DBEV_BF6_S2", "1") != "0"
+
+
+def eligible_s2(x, weight, stride=(2, 2), padding=(0, 0), dilation=(1, 1), groups=1):
+    """can `F.conv2d(x, weight, stride=2)` (1x1, no padding) run as subsample + bf16x6 GEMM?  channels-last fp32, H and W even, the
+    GEMM's own shape rules on the subsampled pixels"""
+    if not (_ON and _S2 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    if tuple(weight.shape[2:]) != (1, 1) or tuple(stride) != (2, 2) or tuple(padding) != (0, 0) or tuple(dilation) != (1, 1) or groups != 1:
+        return False
+    N, C, H, W = x.shape
+    return weight.shape[1] == C and H % 2 == 0 and W % 2 == 0 and _nhwc(x) and shape_ok(N * (H // 2) * (W // 2), C, weight.shape[0])
+
+
+def subsample2(x):
+    """x[:, :, ::2, ::2] of a channels-last tensor as a contiguous channels-last tensor (one streaming pass)"""
+    dev = L.require_cuda(x)
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    with torch.cuda.device(dev):
+        L.call("dbev_subsample2_nhwc", L.ptr(x), L.ptr(y), N, H, W, C, L.stream_ptr(dev))
+    return y
+
+
+def upsample2_zero(g, H, W):
+    """the data gradient of subsample2: g [N, C, H/2, W/2] channels-last -> [N, C, H, W] with g at the even pixels and zeros elsewhere"""
+    dev = L.require_cuda(g)
+    N, C = g.shape[:2]
+    gx = torch.empty((N, C, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    with torch.cuda.device(dev):
+        L.call("dbev_upsample2_zero_nhwc", L.ptr(g), L.ptr(gx), N, H, W, C, L.stream_ptr(dev))
+    return gx
+
+
+class _Conv1x1S2Bf6(Function):
+    """F.conv2d(x, weight, stride=2) for a bias-free 1x1 filter (`eligible_s2`): the subsampled pixels are saved for the weight
+    gradient instead of x (a quarter of the bytes)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, stats=False):
+        xs = subsample2(x)
+        M = xs.shape[0] * xs.shape[2] * xs.shape[3]
+        if ctx.needs_input_grad[0] and shape_ok(M, int(weight.shape[0]), int(weight.shape[1])):
+            pack_both(weight, M)
+        ctx.save_for_backward(xs, weight)
+        ctx.hw = (int(x.shape[2]), int(x.shape[3]))
+        if stats:
+            y, part = product(xs, weight, stats=True)
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return product(xs, weight)
+
+    @staticmethod
+    def backward(ctx, gy, _gpart=None):
+        xs, weight = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gxs = data_gradient(gy, weight) if need_x else None
+        if need_w:
+            gw = weight_gradient(xs, gy, weight)
+        lib_x, lib_w = need_x and gxs is None, need_w and gw is None
+        if lib_x or lib_w:                                    # the library's (stride-1) kernels on the subsampled pixels
+            a, b, _ = torch.ops.aten.convolution_backward(gy, xs, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                          [lib_x, lib_w, False])
+            gxs = a.contiguous(memory_format=torch.channels_last) if lib_x else gxs
+            gw = b if lib_w else gw
+        if need_x:
+            gx = upsample2_zero(gxs, *ctx.hw)
+        return gx, gw, None
+
+
+def conv1x1_s2(x, weight):
+    """F.conv2d(x, weight, stride=2) for an `eligible_s2` pair, differentiable"""
+    return _Conv1x1S2Bf6.apply(x, weight, False)
+
+
+def conv1x1_s2_stats(x, weight):
+    """-> (F.conv2d(x, weight, stride=2), partial statistics rows of the output)"""
+    return _Conv1x1S2Bf6.apply(x, weight, True)
+
+
 class _Conv1x1Bf6(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stats=False):
@@ -217,25 +300,30 @@ def conv1x1(x, weight, bias=None):
 
 
 class Bf6Conv2d(nn.Conv2d):
-    """nn.Conv2d (1x1, stride 1, no padding, no bias) whose forward and data gradient run on the bf16x6 GEMM when the input qualifies
-    (`eligible`); the stock convolution otherwise.  Same parameters and state-dict keys."""
+    """nn.Conv2d (1x1, stride 1 or 2, no padding, no bias) whose forward and gradients run on the bf16x6 GEMM when the input qualifies
+    (`eligible` / `eligible_s2`: stride 2 = subsample + GEMM); the stock convolution otherwise.  Same parameters and state-dict keys."""
 
     def forward(self, x):
         if self.bias is None and eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
             if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
                 return product(x, self.weight)
             return conv1x1(x, self.weight)
+        if self.bias is None and self.stride == (2, 2) and eligible_s2(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+                return product(subsample2(x), self.weight)
+            return conv1x1_s2(x, self.weight)
         return super().forward(x)
 
 
 def use_bf6_convs(model):
-    """Re-class the bias-free 1x1 / stride-1 nn.Conv2d modules with Cin % 64 == 0 and Cout % 64 == 0; returns how many.  Idempotent."""
+    """Re-class the bias-free 1x1 nn.Conv2d modules (stride 1, or stride 2: the `downsample` convolutions) with Cin % 64 == 0 and
+    Cout % 64 == 0; returns how many.  Idempotent."""
     if not _ON:
         return 0
     n = 0
     for m in model.modules():
-        if type(m) is nn.Conv2d and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) and m.dilation == (1, 1) \
-                and m.groups == 1 and m.bias is None and m.in_channels % 64 == 0 and m.out_channels % 64 == 0:
+        if type(m) is nn.Conv2d and m.kernel_size == (1, 1) and m.stride in ((1, 1), (2, 2)) and m.padding == (0, 0) \
+                and m.dilation == (1, 1) and m.groups == 1 and m.bias is None and m.in_channels % 64 == 0 and m.out_channels % 64 == 0:
             m.__class__ = Bf6Conv2d
             n += 1
     return n

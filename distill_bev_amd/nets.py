@@ -37,6 +37,11 @@ def _conv1x1_stats(conv, bn, x):
             and BA._state["enabled"] and type(bn) in BA._BN_TYPES and bn.affine and bn.training and bn.momentum is not None
             and bn.running_mean is not None and BA._channels_ok(conv.out_channels)):
         return G.conv1x1_stats(x, conv.weight)                # (also without autograd: the detached frame)
+    if (G._STATS and conv.bias is None and tuple(conv.stride) == (2, 2)
+            and G.eligible_s2(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            and BA._state["enabled"] and type(bn) in BA._BN_TYPES and bn.affine and bn.training and bn.momentum is not None
+            and bn.running_mean is not None and BA._channels_ok(conv.out_channels)):
+        return G.conv1x1_s2_stats(x, conv.weight)             # the stride-2 `downsample` convolution: subsample + GEMM + statistics
     if conv1x1_bn_ready(conv, bn, x):
         return conv1x1_stats(conv, x)
     return conv(x), None

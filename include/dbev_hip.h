@@ -636,6 +636,17 @@ int dbev_gemm_bf16x6_backward_weight(const float* x, const float* grad_y, float*
                                      int x_row_stride, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Stride-2 1x1 convolutions as subsample + GEMM (the `downsample` branch of a stage-first bottleneck: nn.Conv2d(k = 1, stride = 2),
+ * mmdet ResNet make_res_layer / mmdet3d/models/bricks/res_block.py:102-230; replaces the library's strided implicit GEMM).
+ *   dbev_subsample2_nhwc:      y[n, ho, wo, :] = x[n, 2 ho, 2 wo, :]            x f32[N, H, W, C] channels-last -> y f32[N, H/2, W/2, C]
+ *   dbev_upsample2_zero_nhwc:  gx[n, 2 ho, 2 wo, :] = g[n, ho, wo, :], every other pixel of gx = 0 (the data gradient of the
+ *                              subsample; one pass, every element of gx written once)   g f32[N, H/2, W/2, C] -> gx f32[N, H, W, C]
+ * H, W even, C % 4 == 0 (DBEV_EINVAL otherwise); N, H, W are those of the FULL-resolution tensor in both calls.
+ * ---------------------------------------------------------------------------------- */
+int dbev_subsample2_nhwc(const float* x, float* y, int N, int H, int W, int C, dbevStream_t stream);
+int dbev_upsample2_zero_nhwc(const float* g, float* gx, int N, int H, int W, int C, dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Per-channel sum of a channels-last tensor, out[c] = sum over the M = N*H*W rows of x_nhwc[M, C]: the bias gradient of a convolution
  * (replaces ATen's grad_output.sum((0, 2, 3)) inside convolution_backward for the nn.Conv2d(bias=True) layers of
  * mmdet3d/models/necks/fpn.py:77-95, necks/view_transformer_mine.py:288-309, backbones/resnet.py:80-96 and the DCN offset

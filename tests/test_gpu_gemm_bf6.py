@@ -273,3 +273,58 @@ def test_huge_finite_values_stay_finite_and_non_finite_inputs_propagate(monkeypa
     assert not bool(torch.isfinite(G.product(x2, wt)[0, :, 1, 1]).all())
     x3 = x.clone(); x3[0, 3, 1, 1] = float("nan")
     assert bool(torch.isnan(G.product(x3, wt)[0, 2, 1, 1]))
+
+
+# ---- stride-2 1x1 convolutions: subsample + GEMM (csrc/stride2.hip) -------------------------------------------------------------------
+def test_subsample2_and_its_gradient_are_bit_exact():
+    """dbev_subsample2_nhwc == x[:, :, ::2, ::2]; dbev_upsample2_zero_nhwc == its autograd gradient (values at the even pixels, zeros
+    elsewhere, every element written)"""
+    from distill_bev_amd import gemm_bf6 as G
+    g = torch.Generator().manual_seed(5)
+    for (n, c, h, w) in [(2, 64, 8, 12), (3, 256, 16, 44), (1, 4, 2, 2), (2, 128, 6, 10)]:
+        x = torch.randn((n, c, h, w), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        y = G.subsample2(x)
+        assert y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, x[:, :, ::2, ::2])
+        gy = torch.randn((n, c, h // 2, w // 2), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        gx = G.upsample2_zero(gy, h, w)
+        ref = torch.zeros_like(x)
+        ref[:, :, ::2, ::2] = gy
+        assert gx.is_contiguous(memory_format=torch.channels_last) and torch.equal(gx, ref)
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(4, 64, 128, 16, 32), (2, 256, 512, 16, 16), (3, 128, 64, 32, 16)])
+def test_stride2_module_vs_fp64(n, ci, co, h, w, monkeypatch):
+    """Bf6Conv2d(stride=2): forward, data gradient (zeros at the skipped pixels) and weight gradient vs fp64 F.conv2d(stride=2) -- the
+    `downsample` convolution of a stage-first bottleneck (res_block.py:102-230); error bound of the stride-1 layers"""
+    from distill_bev_amd import gemm_bf6 as G
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    monkeypatch.setattr(G, "_MIN_WGRAD_ROWS", 1)
+    x, wt = _mk(n, ci, co, h, w, 23, relu=False)
+    conv = nn.Conv2d(ci, co, 1, stride=2, bias=False).to(DEV)
+    conv.weight.data.copy_(wt)
+    assert G.use_bf6_convs(conv) == 1 and type(conv) is G.Bf6Conv2d
+    assert G.eligible_s2(x, conv.weight)
+    xg = x.clone().requires_grad_(True)
+    y = conv(xg)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).to(DEV).contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    xd = x.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    yr = F.conv2d(xd, wd, stride=2)
+    yr.backward(gy.double())
+    lib = F.conv2d(x, conv.weight, stride=2)
+    e, el = _err(y.detach(), yr.detach()), _err(lib.detach(), yr.detach())
+    assert e <= 1.25 * el + 1e-7 and e < 1e-6, (e, el)
+    assert _err(xg.grad, xd.grad) < 1e-6 and _err(conv.weight.grad, wd.grad) < 2e-6
+    assert float(xg.grad[:, :, 1::2, :].abs().max()) == 0.0 and float(xg.grad[:, :, :, 1::2].abs().max()) == 0.0
+    with torch.no_grad():
+        assert torch.equal(conv(x), y.detach())               # the no-grad route (detached frame): same kernels
+    # statistics epilogue of the strided layer = statistics of its output
+    z, part = G.conv1x1_s2_stats(x, conv.weight)
+    assert torch.equal(z, y.detach())
+    s1 = part[:, 0].double().sum(0)
+    assert torch.allclose(s1, z.double().sum((0, 2, 3)), rtol=1e-6, atol=1e-4)
+    # odd sizes stay with the library
+    xo = x[:, :, : h - 1].contiguous(memory_format=torch.channels_last)
+    assert not G.eligible_s2(xo, conv.weight)
+    assert torch.allclose(conv(xo), F.conv2d(xo, conv.weight, stride=2), rtol=1e-4, atol=1e-5)
