@@ -239,7 +239,8 @@ class DistillStep(_Base):
         n_extra = self.steps_timed
         # the reference-shaped variant of the same step: all 36 branch stacks of the frozen teacher's head (the default prunes
         # the 30 whose outputs nothing reads -- identical losses); 1 warm-up + 5 timed steps, outside the timed region
-        if os.environ.get("DBEV_TEACHER_FULL_HEAD") != "1":
+        plain = os.environ.get("DBEV_BENCH_PLAIN") == "1"       # profiling runs: no variant legs behind the timed region
+        if os.environ.get("DBEV_TEACHER_FULL_HEAD") != "1" and not plain:
             os.environ["DBEV_TEACHER_FULL_HEAD"] = "1"
             try:
                 self.step()
@@ -254,7 +255,7 @@ class DistillStep(_Base):
         # the same step with the 1x1 convolutions on the fp32 matrix cores only (the library's kernels) instead of the bf16x6 GEMM
         # (same accuracy class, tests/test_gpu_gemm_bf6.py): 1 warm-up + 5 timed steps, outside the timed region
         from distill_bev_amd import gemm_bf6
-        if gemm_bf6._ON:
+        if gemm_bf6._ON and not plain:
             gemm_bf6._ON = False
             try:
                 self.step()

@@ -1048,7 +1048,12 @@ def make_bevformer_step():
     print({k: float(v) for k, v in losses.items()})
 
 
-def make_bevdepth_step():
+def make_bevdepth_step_wide():
+    """the same step with the wide BEV encoder of standins.distill_cfg(wide=True) -> bevdepth_step_wide.npz"""
+    make_bevdepth_step(wide=True)
+
+
+def make_bevdepth_step(wide=False):
     """BEVDepth4DDistill.forward_train of the reference -- the north-star step -- with the reference's OWN class hierarchy
     (bevdet_distill_more.py:334-522 on bevdet_distill.py / bevdet.py / centerpoint.py / dynamic_centerpoint.py / mvx_two_stage.py),
     built through its own constructors from the small recipe of standins.py: two-frame image encoding, SE + DCN depth net,
@@ -1062,7 +1067,7 @@ def make_bevdepth_step():
     more, REG = R.bevdepth_detectors()
     rng = np.random.default_rng(71)
     g = torch.Generator().manual_seed(71)
-    cfg = S.distill_cfg(S.teacher_cfg())
+    cfg = S.distill_cfg(S.teacher_cfg(), wide=wide)
     cfg = R._ConfigDict({k: (R._ConfigDict(v) if isinstance(v, dict) else v) for k, v in cfg.items()})
     cfg["train_cfg"] = R._ConfigDict(pts=R._ConfigDict(cfg["train_cfg"]["pts"]))
     t = cfg["teacher_config"]["model"]
@@ -1073,6 +1078,11 @@ def make_bevdepth_step():
 
     _randomize_bevdepth(model, g)
     _randomize_bevdepth(teacher, g)
+    if wide:                                      # weights / buffers on the fp16 grid: the fixture stores them as float16, exactly
+        for m_ in (model, teacher):
+            for t_ in list(m_.parameters()) + list(m_.buffers()):
+                if t_.is_floating_point() and t_.numel() > 64:
+                    t_.data = t_.data.half().float()
     model.train()
     assert not teacher.training
     B, N = 2, 6
@@ -1085,6 +1095,8 @@ def make_bevdepth_step():
     vt = model.img_view_transformer
     pool = vt.voxel_pooling
     vt.voxel_pooling = lambda *a, **k: (pooled.append(pool(*a, **k)), pooled[-1])[1]
+    sd_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd_teacher = {k: v.detach().clone() for k, v in teacher.state_dict().items()}
     torch.manual_seed(5)
     losses = model.forward_train(points=batch["points"], img_metas=None, gt_bboxes_3d=[R.LiDARBoxesStub(b) for b in batch["boxes"]],
                                  gt_labels_3d=[torch.from_numpy(l) for l in batch["labels"]], img_inputs=batch["img_inputs"])
@@ -1092,8 +1104,12 @@ def make_bevdepth_step():
     total = sum(v for v in losses.values())
     names = ["img_backbone.conv.weight", "img_neck.lateral_convs.1.conv.weight", "img_view_transformer.extra_depthnet.layers.0.0.conv1.weight",
              "img_view_transformer.dcn.0.weight", "img_view_transformer.depthnet.bias", "pre_process_net.layers.0.0.conv2.weight",
-             "img_bev_encoder_backbone.layers.0.0.conv1.weight", "img_bev_encoder_backbone.layers.2.1.bn2.weight",
+             "img_bev_encoder_backbone.layers.0.0.conv1.weight",
+             "img_bev_encoder_backbone.layers.1.0.bn3.weight" if wide else "img_bev_encoder_backbone.layers.2.1.bn2.weight",
              "img_bev_encoder_neck.up2.1.weight", "pts_bbox_head.task_heads.2.heatmap.1.bias", "channel_wise_adaptations.1.weight"]
+    if wide:                                      # the 1x1 / 3x3 layers of the reference's Bottleneck blocks
+        names += ["img_bev_encoder_backbone.layers.0.0.conv3.weight", "img_bev_encoder_backbone.layers.0.1.conv1.weight",
+                  "img_bev_encoder_backbone.layers.0.1.conv2.weight", "img_bev_encoder_neck.conv.3.weight"]
     params = dict(model.named_parameters())
     grads = torch.autograd.grad(total, [params[n] for n in names], retain_graph=True)
     # ... and of the 38 losses other than the six heat-map focal terms: those six are ~100x larger than the rest at a random
@@ -1120,14 +1136,29 @@ def make_bevdepth_step():
     gg["grad_depth__depthnet_bias"] = torch.autograd.grad(losses["loss_depth"], params["img_view_transformer.depthnet.bias"],
                                                           retain_graph=True)[0].numpy()
     imgs, rots, trans, intrins, post_rots, post_trans, dgt = batch["img_inputs"]
-    _save("bevdepth_step.npz", imgs=imgs.numpy().astype(np.float16), rots=rots.numpy(), trans=trans.numpy(), intrins=intrins.numpy(), post_rots=post_rots.numpy(),
+    _save("bevdepth_step_wide.npz" if wide else "bevdepth_step.npz", imgs=imgs.numpy().astype(np.float16), rots=rots.numpy(), trans=trans.numpy(), intrins=intrins.numpy(), post_rots=post_rots.numpy(),
           post_trans=post_trans.numpy(), depth_gt=dgt.numpy(), **{f"points{b}": batch["points"][b].numpy() for b in range(B)},
           **{f"gt_boxes{b}": batch["boxes"][b] for b in range(B)}, **{f"gt_labels{b}": batch["labels"][b] for b in range(B)},
           **_flat_losses("loss__", losses), **{"grad__" + n.replace(".", "__"): gr.numpy() for n, gr in zip(names, grads)},
           **{"gradnh__" + n.replace(".", "__"): gr.numpy() for n, gr in zip(names, grads_nh) if gr is not None},
-          **gg, pooled0=pooled[0].detach().numpy(), pooled1=pooled[1].detach().numpy(), **_sd("model__", model), **_sd("teacher__", teacher))
+          **gg, pooled0=pooled[0].detach().numpy(), pooled1=pooled[1].detach().numpy(), **_sd16("model__", model, wide, sd_model),
+          **_sd16("teacher__", teacher, wide, sd_teacher))
     print({k: len(v) for k, v in groups.items()})
     print(len(losses), {k: round(float(v), 5) for k, v in losses.items()})
+
+
+def _sd16(prefix, module, wide, before):
+    """state dict as _sd() would save it -- for the wide fixture from the snapshot taken BEFORE the forward pass, floating tensors that
+    sit on the fp16 grid stored as float16 (exact)"""
+    if not wide:
+        return _sd(prefix, module)
+    out = {}
+    for k, v in before.items():
+        a = v.detach().cpu()
+        if a.is_floating_point() and torch.equal(a.half().float(), a.float()):
+            a = a.half()
+        out[prefix + k.replace(".", "__")] = a.numpy()
+    return out
 
 
 def _randomize_bevdepth(module, gen):
@@ -1173,7 +1204,7 @@ def _bevdepth_batch(B, N, H, W, rng, g):
 
 SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgmask": make_fgmask, "center": make_center,
             "fgd": make_fgd, "shift_depth": make_shift_depth, "centerloss": make_centerloss, "pfn": make_pfn,
-            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map, "bevformer_step": make_bevformer_step, "bevdepth_step": make_bevdepth_step,
+            "second": make_second, "bevformer": make_bevformer, "bevformer_fgd": make_bevformer_fgd, "depth_map": make_depth_map, "bevformer_step": make_bevformer_step, "bevdepth_step": make_bevdepth_step, "bevdepth_step_wide": make_bevdepth_step_wide,
             "dynvoxel": make_dynvoxel, "student_dense": make_student_dense}
 
 if __name__ == "__main__":

@@ -66,8 +66,25 @@ def teacher_cfg():
         train_cfg=train_cfg(128, T_VOXEL, 4), test_cfg=None))
 
 
-def distill_cfg(teacher):
-    """student: 2 frames x 6 cameras of 64 x 176 -> 32 x 32 BEV (24 channels per frame) -> BEV encoder -> 32 channels at 32 x 32"""
+def distill_cfg(teacher, wide=False):
+    """student: 2 frames x 6 cameras of 64 x 176 -> 32 x 32 BEV (24 channels per frame) -> BEV encoder -> 32 channels at 32 x 32.
+    wide=True (round 5, bevdepth_step_wide.npz): the same step with a BEV encoder of the reference's OWN Bottleneck blocks
+    (bricks/res_block.py:102-230 through backbones/resnet.py block_type='BottleNeck') at 64 / 256 channels and a 512 -> 64 BEV neck,
+    i.e. channel counts the product's hand-written dense kernels take (1x1 layers: multiples of 64 -> bf16x6 GEMMs with statistics
+    epilogues, 3x3 stride-1 layers with 64 outputs -> Winograd): the detector-level reference for those kernels."""
+    cfg = _distill_cfg(teacher)
+    if wide:
+        cfg["pre_process"] = dict(type="ResNetForBEVDet", numC_input=32, num_layer=[1], num_channels=[32], stride=[1], backbone_output_ids=[0])
+        cfg["img_view_transformer"]["numC_Trans"] = 32
+        cfg["img_bev_encoder_backbone"] = dict(type="ResNetForBEVDet", numC_input=64, num_layer=[2, 1], num_channels=[256, 64],
+                                               stride=[2, 2], block_type="BottleNeck")      # (a narrow second stage keeps the fixture small)
+        cfg["img_bev_encoder_neck"] = dict(type="FPN_LSS", in_channels=256 + 64, out_channels=32, scale_factor=2, input_feature_index=(0, 1))
+        cfg["distill_params"]["student_channels"] = [256, 32]
+        cfg["distill_params"]["adaptation_type"] = ["1x1conv", "1x1conv"]
+    return cfg
+
+
+def _distill_cfg(teacher):
     return dict(
         type="BEVDepth4DDistill", teacher_config=teacher, teacher_ckpt=None, self_ckpt=None, inherit_head=False, distill_type="fgd",
         aligned=True, detach=True, before=True, interpolation_mode="bilinear",

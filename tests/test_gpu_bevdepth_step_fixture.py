@@ -9,6 +9,12 @@ split by loss group.  Here the product detector is built from the SAME recipe,
 loads the reference's two state dicts strict, and runs the step on the HIP path (lift-splat, DCNv2, dynamic voxelization,
 pillar scatter, FG masks, CenterHead targets + loss, FGD terms).
 
+Round 5 adds tests/golden/bevdepth_step_wide.npz (make_golden.py bevdepth_step_wide): the same step of the reference with a BEV encoder
+of its own Bottleneck blocks at 64 / 256 channels (standins.distill_cfg(wide=True)) -- channel counts the bf16x6 1x1 GEMMs and the
+Winograd 3x3 kernels take -- and two more passes per fixture: `accelerated` = the product as bench.py builds it (channels-last +
+accelerate_modules) with the kernels' size thresholds forced to zero; on the wide fixture the accelerated product is also compared
+with the plain product directly (losses 2e-5, gradients 1e-4 of their norm; measured 5e-6).
+
 Two passes:
 * as is: the 44 losses to 1e-3 (measured 3e-5), the two pooled BEV maps to 1e-3 of their norm (measured 2e-5: the reference
   pools through a cumulative sum over all frustum points, the product sums each cell directly -- DESIGN.md §4).
@@ -42,17 +48,22 @@ sys.path.insert(0, GOLD)
 pytestmark = pytest.mark.gpu
 
 
-def _build(fx, dev):
+def _t(a):
+    t = torch.from_numpy(a)
+    return t.float() if t.dtype == torch.float16 else t          # (the wide fixture stores fp16-grid weights as float16, exactly)
+
+
+def _build(fx, dev, wide=False):
     import standins as S
     from distill_bev_amd import detectors  # noqa: F401
     from distill_bev_amd.registry import MODELS, build_detector
     for cls in S.STANDINS.values():
         MODELS.register_module(module=cls, force=True)
-    model = build_detector(S.distill_cfg(S.teacher_cfg()))
-    sd = {k[7:].replace("__", "."): torch.from_numpy(fx[k]) for k in fx.files if k.startswith("model__")}
+    model = build_detector(S.distill_cfg(S.teacher_cfg(), wide=wide))
+    sd = {k[7:].replace("__", "."): _t(fx[k]) for k in fx.files if k.startswith("model__")}
     missing, unexpected = model.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
-    tsd = {k[9:].replace("__", "."): torch.from_numpy(fx[k]) for k in fx.files if k.startswith("teacher__")}
+    tsd = {k[9:].replace("__", "."): _t(fx[k]) for k in fx.files if k.startswith("teacher__")}
     model.teacher_model.load_state_dict(tsd, strict=True)
     return model.to(dev).train()
 
@@ -62,7 +73,7 @@ def _groups(losses):
             "kd_head": [k for k in losses if k.endswith("head_head")]}
 
 
-@pytest.mark.parametrize("mode", ["as_is", "aligned", "accelerated"])
+@pytest.mark.parametrize("mode", ["as_is", "aligned", "accelerated", "wide_aligned", "wide_accelerated"])
 def test_bevdepth4d_distill_forward_train_vs_reference_fixture(mode):
     """accelerated (round 5): the aligned pass on the product AS bench.py BUILDS IT -- channels-last weights + `accelerate_modules`
     (train_step.to_channels_last: fused norm + ReLU modules, Winograd / bf16x6 / bias-sum convolution classes, batched head branches,
@@ -73,7 +84,9 @@ def test_bevdepth4d_distill_forward_train_vs_reference_fixture(mode):
     import contextlib
     sys.path.insert(0, os.path.dirname(__file__))
     import _variants as V
-    aligned, accelerated = mode != "as_is", mode == "accelerated"
+    wide = mode.startswith("wide_")                 # bevdepth_step_wide.npz: the reference's Bottleneck BEV encoder at 64 / 256 channels,
+    mode = mode[5:] if wide else mode               # where the accelerated pass also runs the bf16x6 1x1 GEMMs (forward, both gradients,
+    aligned, accelerated = mode != "as_is", mode == "accelerated"         # statistics epilogues) -- standins.distill_cfg(wide=True)
     with contextlib.ExitStack() as stack:
         if accelerated:
             stack.enter_context(V.forced_kernels())
@@ -81,19 +94,33 @@ def test_bevdepth4d_distill_forward_train_vs_reference_fixture(mode):
             L.kernel_timing_read()
             L.kernel_timing(True)
             stack.callback(L.kernel_timing, False)
-        _fixture_pass(aligned, accelerated)
+        res = _fixture_pass(aligned, accelerated, wide)
         if accelerated:
             ran = {k: len(v) for k, v in L.kernel_timing_read().items()}
             print("kernels", ran)
             assert ran.get("wino_fwd", 0) >= 4 and ran.get("wino_wgrad", 0) >= 1, ran
             assert any(k.startswith("bn_apply") for k in ran) and any(k.startswith("bn_bwd_dx") for k in ran), ran
+            if wide:
+                assert ran.get("b6_fwd", 0) >= 8 and ran.get("b6_wgrad", 0) >= 4, ran
+    if accelerated and wide:
+        # ... and the accelerated product against the plain product (library convolutions, torch norms) on the same fixture: the hand-written
+        # kernels move NOTHING beyond fp32 round-off -- losses to 2e-5, every gradient along the step to 1e-4 of its norm
+        ref = _fixture_pass(True, False, True)
+        for k in ref["losses"]:
+            assert abs(res["losses"][k] - ref["losses"][k]) <= 2e-5 * abs(ref["losses"][k]) + 1e-7, (k, res["losses"][k], ref["losses"][k])
+        worst = 0.0
+        for n, g in ref["grad"].items():
+            e = float((res["grad"][n] - g).norm() / g.norm().clamp_min(1e-20))
+            worst = max(worst, e)
+            assert e <= 1e-4, (n, e)
+        print("accelerated vs plain product: worst gradient rel-L2", worst)
 
 
-def _fixture_pass(aligned, accelerated):
+def _fixture_pass(aligned, accelerated, wide=False):
     from distill_bev_amd.center_head import LiDARBoxes
-    fx = np.load(os.path.join(GOLD, "bevdepth_step.npz"))
+    fx = np.load(os.path.join(GOLD, "bevdepth_step_wide.npz" if wide else "bevdepth_step.npz"))
     dev = torch.device("cuda:0")
-    model = _build(fx, dev)
+    model = _build(fx, dev, wide)
     assert model.training and not model.teacher_model.training
     if accelerated:
         from distill_bev_amd.train_step import to_channels_last
@@ -143,6 +170,7 @@ def _fixture_pass(aligned, accelerated):
         gr = torch.autograd.grad(v, tb, retain_graph=True, allow_unused=True)
         g = torch.cat([(t if t is not None else torch.zeros_like(p)).reshape(-1) for t, p in zip(gr, tb)])
         errs[k] = rel(g, torch.from_numpy(fx[key]))
+    out = {"grad": {}, "gradnh": {}, "terms": {}}
     tight = [k for k, e in errs.items() if e <= 1e-4]
     print("terms", len(errs), "tight", len(tight), "loose", {k: e for k, e in errs.items() if e > 1e-4})
     term_report = (len(errs), len(tight), max(errs.values()))
@@ -151,7 +179,7 @@ def _fixture_pass(aligned, accelerated):
     # gradient by loss group
     bad = []
     names = [k[6:].replace("__", ".") for k in fx.files if k.startswith("grad__")]
-    assert len(names) == 11
+    assert len(names) == (15 if wide else 11)
     grads = torch.autograd.grad(sum(losses.values()), [params[n] for n in names], retain_graph=True)
     smooth = sum(v for k, v in losses.items() if not k.endswith("loss_heatmap"))
     grads_nh = torch.autograd.grad(smooth, [params[n] for n in names], retain_graph=True, allow_unused=True)
@@ -160,10 +188,13 @@ def _fixture_pass(aligned, accelerated):
         key = "gradnh__" + n.replace(".", "__")
         en = rel(gn, torch.from_numpy(fx[key])) if key in fx.files else 0.0
         print(n, e, en)
-        if e > (2e-2 if aligned else 1e-1) or en > (5e-4 if aligned else 1e-1):
+        out["grad"][n], out["gradnh"][n] = g.detach().cpu(), (None if gn is None else gn.detach().cpu())
+        if e > (2e-2 if aligned else 1e-1) or en > ((2e-3 if wide else 5e-4) if aligned else 1e-1):
             bad.append((n, e, en))
     w0 = params["img_bev_encoder_backbone.layers.0.0.conv1.weight"]
     gbar = dict(det=2e-2, kd_backbone=1e-4, kd_head=1e-3) if aligned else dict(det=1e-1, kd_backbone=1e-3, kd_head=1e-1)
+    if wide:
+        gbar = dict(det=2e-2, kd_backbone=1e-3, kd_head=1e-2)
     for gname, keys in _groups(losses).items():
         g = torch.autograd.grad(sum(losses[k] for k in keys), w0, retain_graph=True)[0]
         e = rel(g, torch.from_numpy(fx["gradgroup__" + gname]))
@@ -178,8 +209,15 @@ def _fixture_pass(aligned, accelerated):
     if e > 1e-4:
         bad.append(("depth", e))
     print("REPORT", aligned, term_report, bad)
-    if aligned:
+    if aligned and wide:
+        # the wide recipe's Bottleneck stack (norms over 128-512 values behind 64-channel 1x1 layers) amplifies the CPU-vs-GPU rounding
+        # of the convolutions in front of it ~10x more than the narrow one: every term to 3e-2 (measured 1.8e-4 ... 1.6e-2, the SAME
+        # figures to four digits for the plain and the accelerated product -- which are compared with each other directly below)
+        assert term_report[0] == 43 and term_report[2] <= 3e-2, (term_report, errs)
+    elif aligned:
         assert term_report[0] == 43 and term_report[1] >= 34 and term_report[2] <= 3e-2, (term_report, errs)
     else:
         assert term_report[0] == 43 and term_report[2] <= 1.5e-1, (term_report, errs)
     assert not bad, bad
+    out["losses"] = got
+    return out
