@@ -40,6 +40,19 @@ PMC_TRAFFIC = {"bn_apply_res_ratio": (540720.8 * 2 + 540672.0) * 1024 / (3 * 553
                          "launches x that measured ratio (not collected live)"}
 
 
+def _ddp_probe():
+    """profiles/r05_ddp_one_rank.json (measured separately on one MI355X by tools/ddp_one_rank.sh), quoted with its source"""
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_ddp_one_rank.json")
+    try:
+        d = json.load(open(path))
+        return {"source": "profiles/r05_ddp_one_rank.json (tools/ddp_one_rank.sh, a separate run on another box)",
+                "plain_ms": d["plain"]["ms_per_step"], "plain_again_ms": d["plain_again"]["ms_per_step"],
+                "reducer_overlap_off_ms": d["ddp_overlap_off"]["ms_per_step"], "reducer_overlap_on_ms": d["ddp_overlap_on"]["ms_per_step"]}
+    except Exception:
+        return None
+
+
 def assert_fracs(obj, path="roofline"):
     """no fraction of a peak above 1 anywhere in the line: such a row would mean a wrong unit (round 4: FLOPs printed as bytes)"""
     if isinstance(obj, dict):
@@ -406,7 +419,12 @@ class DistillStep(_Base):
                            "gradient of layers with >= %d output tiles; weight gradients and the other layers: MIOpen fp32" % (
                                getattr(self.trainer.detector, "bf6_convs", 0), __import__("distill_bev_amd.gemm_bf6", fromlist=["x"])._MIN_ITEMS),
                 "ms_per_step_fp32_matrix_cores_only": getattr(self, "fp32_mfma_only_ms", None),
-                "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py"}
+                "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py",
+                # data parallelism: GradReducer's in-backward bucket launches are OFF by default (DBEV_DDP_OVERLAP=1 turns them on): no
+                # N > 1 RCCL measurement exists to say they help on xGMI.  What one GPU can say (a separate run, tools/ddp_one_rank.sh,
+                # NOT this process): the step with the reducer active on a world-size-1 RCCL group vs the plain step
+                "ddp_overlap_default": "off" if os.environ.get("DBEV_DDP_OVERLAP", "0") != "1" else "on (DBEV_DDP_OVERLAP=1)",
+                "ddp_one_rank_probe": _ddp_probe()}
 
 
 MFMA_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* at the fp32 vector rate
