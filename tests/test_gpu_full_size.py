@@ -322,6 +322,21 @@ def test_full_size_bevformer_distillation_step():
         x, y = float(a[k].detach()), float(b[k].detach())
         assert np.isfinite(x) and np.isfinite(y), k
         assert abs(x - y) <= 1e-4 * max(abs(x), 1e-3), (k, x, y)
+    # round 5: the same forward on tests/_variants.library_path (MIOpen convolutions, torch norms; the deformable attentions and the sparse
+    # convolutions have no library counterpart and stay) -- a VALUE check of the full-size configs[4] step, not only finiteness:
+    # every loss of the hand-written dense path against the library path on the same weights, buffers and random draws
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _variants as V
+    tr.detector.load_state_dict(bufs, strict=False)
+    np.random.seed(0); torch.manual_seed(0)
+    with V.library_path():
+        c = tr.detector.forward_train(**batch)
+    tr.detector.load_state_dict(bufs, strict=False)
+    rows = sorted(((abs(float(a[k].detach()) - float(c[k].detach())) / max(abs(float(c[k].detach())), 1e-3), k) for k in a), reverse=True)
+    print("bevformer full-size, kernels vs library path, worst losses:", rows[:4])
+    for rel, k in rows:
+        assert rel <= 2e-3, (k, float(a[k].detach()), float(c[k].detach()))        # (Hungarian matching is discrete; measured <= 4e-6)
     L.fallback_reset()
     w0 = [p.detach().clone() for p in tr.params[:4]]
     loss, _ = tr.step(batch)
