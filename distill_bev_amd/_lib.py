@@ -151,6 +151,11 @@ _SIGNATURES = {
                                        _ll, _i, _p, _i, _p, _i, _p, _sz, _p],
     "dbev_bn_dual_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
     "dbev_bn_dual_backward2": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_act_train_forward_mask": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _ll, _i, _p, _i, _p, _p, _sz, _p],
+    "dbev_bn_act_backward3": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
+    "dbev_bn_dual_train_forward_mask": [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p,
+                                        _ll, _i, _p, _i, _p, _i, _p, _p, _sz, _p],
+    "dbev_bn_dual_backward3": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _sz, _p],
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_wino_filter_floats": ctypes.c_longlong,

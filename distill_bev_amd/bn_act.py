@@ -25,7 +25,10 @@ from . import _lib as L
 L.ensure_param_version_hook()          # fused optimizers do not move `_version`; the kept packs / coefficients follow it
 
 _state = {"enabled": os.environ.get("DBEV_FUSED_BN", "1") != "0",
-          "fork": os.environ.get("DBEV_BN_FORK", "1") != "0"}      # residual-block outputs carry a second handle (see _BNActTrain.forward)
+          "fork": os.environ.get("DBEV_BN_FORK", "1") != "0",      # residual-block outputs carry a second handle (see _BNActTrain.forward)
+          # round 5: a residual norm's forward writes its ReLU gate as one byte per four channels and the two backward passes read
+          # that instead of the saved output (16 x fewer bytes on the largest tensors of the step); 0: read the output as before
+          "gate_mask": os.environ.get("DBEV_BN_GATE_MASK", "1") != "0"}
 
 
 @contextlib.contextmanager
@@ -115,14 +118,18 @@ class _BNActTrain(Function):
         coef = torch.empty((2 * C,), dtype=torch.float32, device=dev)
         nbytes = L.lib().dbev_bn_act_workspace_bytes(M, C)
         ws = torch.empty((nbytes + 12 * C,), dtype=torch.uint8, device=dev)
+        need_y = relu and residual is not None
+        # the backward of a residual norm needs the output only for the ReLU gate: one byte per four channels instead
+        gmask = (torch.empty((M * C // 4,), dtype=torch.uint8, device=dev)
+                 if need_y and _state["gate_mask"] and any(ctx.needs_input_grad[:4]) else None)
         with torch.cuda.device(dev):
-            L.call("dbev_bn_act_train_forward_pre", L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
+            L.call("dbev_bn_act_train_forward_mask", L.ptr(x), L.ptr(residual), L.ptr(weight), L.ptr(bias),
                    L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), float(momentum or 0.0), float(eps), int(relu), L.ptr(y),
                    L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), M, C, L.ptr(pre), 0 if pre is None else pre.shape[0],
-                   L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+                   L.ptr(gmask), L.ptr(ws), ws.numel(), L.stream_ptr(dev),
                    alg_bytes=4 * M * C * (3 + (residual is not None) - (pre is not None)))     # x (stats), x (apply) [+ res] + y
         L.touched(running_mean, running_var, nbt)
-        need_y = relu and residual is not None
+        ctx.gmask = gmask
         y2 = _alias(y) if fork else None
         # both handles of a forked output are SAVED (whether or not the backward reads y): they share one storage but have separate
         # version counters, so an in-place op on either handle (`feat += ...`, `relu_`) would silently change what the other handle's
@@ -153,9 +160,10 @@ class _BNActTrain(Function):
         nbytes = L.lib().dbev_bn_act_workspace_bytes(M, C)
         ws = torch.empty((nbytes + 12 * C,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.call("dbev_bn_act_backward2", L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(y), L.ptr(weight), L.ptr(save_mean),
-                   L.ptr(save_invstd), L.ptr(coef), int(relu), L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), M, C,
-                   L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+            gm = ctx.gmask if need_y else None
+            L.call("dbev_bn_act_backward3", L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(y if gm is None else gm), int(gm is not None),
+                   L.ptr(weight), L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), int(relu), L.ptr(dx), L.ptr(dres), L.ptr(dgamma),
+                   L.ptr(dbeta), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
                    alg_bytes=4 * M * C * (5 + 3 * (dres is not None) + 2 * (dy2 is not None)))   # dy [+ dy2], x twice each + dx [+ y twice + dres]
         if has_res and not relu:                    # without ReLU the residual branch receives the incoming gradient itself
             dres = dy if dy2 is None else dy + dy2
@@ -174,12 +182,15 @@ class _BNDualTrain(Function):
         stats = torch.empty((8, C), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift of both norms
         nbytes = L.lib().dbev_bn_dual_workspace_bytes(M, C)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        gmask = (torch.empty((M * C // 4,), dtype=torch.uint8, device=dev)
+                 if relu and _state["gate_mask"] and any(ctx.needs_input_grad[:4]) else None)     # see _BNActTrain.forward
+        ctx.gmask = gmask
         with torch.cuda.device(dev):
-            L.call("dbev_bn_dual_train_forward_pre", L.ptr(x), L.ptr(xd), L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
+            L.call("dbev_bn_dual_train_forward_mask", L.ptr(x), L.ptr(xd), L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
                    float(mom or 0.0), float(eps), L.ptr(wd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), L.ptr(nbtd), float(momd or 0.0),
                    float(epsd), int(relu), L.ptr(y), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2:4]), L.ptr(stats[4]),
                    L.ptr(stats[5]), L.ptr(stats[6:8]), M, C, L.ptr(pre), 0 if pre is None else pre.shape[0], L.ptr(pre_d),
-                   0 if pre_d is None else pre_d.shape[0], L.ptr(ws), ws.numel(), L.stream_ptr(dev),
+                   0 if pre_d is None else pre_d.shape[0], L.ptr(gmask), L.ptr(ws), ws.numel(), L.stream_ptr(dev),
                    alg_bytes=4 * M * C * (5 - (pre is not None) - (pre_d is not None)))
         L.touched(rm, rv, nbt, rmd, rvd, nbtd)
         y2 = _alias(y) if fork else None
@@ -205,7 +216,9 @@ class _BNDualTrain(Function):
         nbytes = L.lib().dbev_bn_dual_workspace_bytes(M, C)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            L.call("dbev_bn_dual_backward2", L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(xd), L.ptr(y), L.ptr(w), L.ptr(stats[0]),
+            gm = ctx.gmask if relu else None
+            L.call("dbev_bn_dual_backward3", L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(xd), L.ptr(y if gm is None else gm), int(gm is not None),
+                   L.ptr(w), L.ptr(stats[0]),
                    L.ptr(stats[1]), L.ptr(wd), L.ptr(stats[4]), L.ptr(stats[5]), int(relu), L.ptr(dx), L.ptr(dxd), L.ptr(g[0]),
                    L.ptr(g[1]), L.ptr(g[2]), L.ptr(g[3]), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
                    alg_bytes=4 * M * C * (10 + 2 * (dy2 is not None)))

@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ par
 template <bool RES, bool RELU, bool RAFF = false>
 __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, const float4* __restrict__ res,
                                                 const float* __restrict__ coef, float4* __restrict__ y, BnGeom g,
-                                                const float* __restrict__ rcoef, int rev, BnFin fin, BnFin fin_d) {
+                                                const float* __restrict__ rcoef, int rev, BnFin fin, BnFin fin_d,
+                                                unsigned char* __restrict__ gate_mask = nullptr) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const bool writer = blockIdx.x == 0 && rp == 0;
@@ -430,11 +431,24 @@ __global__ __launch_bounds__(256) void bn_apply(const float4* __restrict__ x, co
         o.z = fmaf(v[u].z, sc.z, sh.z); o.w = fmaf(v[u].w, sc.w, sh.w);
         if (RES && !RAFF) add4(o, w[u]);
         if (RAFF) fma4v(o, w[u], rsc);
+        if (RELU && gate_mask != nullptr)             // the ReLU gate of these four channels as one byte: what the backward reads instead of y
+          gate_mask[static_cast<size_t>(r) * g.C4 + q] = static_cast<unsigned char>((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) |
+                                                                                    (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
         if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         st_nt(y + static_cast<size_t>(r) * g.C4 + q, o);
       }
     }
   }
+}
+
+// The saved output of a residual norm is only read for its SIGN (the ReLU gate).  Round 5: the forward writes that gate as one byte
+// per float4 (bn_apply's gate_mask) and the backward kernels read the byte instead of the 16 bytes of y -- the two passes of a
+// residual norm's backward read 3 + 3 tensors instead of 4 + 4 (the 4-planes-wide block outputs are the largest tensors of the
+// step).  ybyte != 0: `y` points at the mask, element i = gate bits of float4 i; the value returned has the gate's signs.
+__device__ __forceinline__ float4 load_gate_y(const float4* __restrict__ y, size_t i, int ybyte) {
+  if (!ybyte) return y[i];
+  const unsigned m = reinterpret_cast<const unsigned char*>(y)[i];
+  return make_float4((m & 1u) ? 1.f : 0.f, (m & 2u) ? 1.f : 0.f, (m & 4u) ? 1.f : 0.f, (m & 8u) ? 1.f : 0.f);
 }
 
 // dz = dy gated by the ReLU: MASK 0 = no activation, 1 = recompute the pre-activation sign from x
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ 
                                                      const float* __restrict__ save_mean,
                                                      const float* __restrict__ save_invstd,
                                                      float* __restrict__ partial, BnGeom g,
-                                                     unsigned* __restrict__ tickets = nullptr) {
+                                                     unsigned* __restrict__ tickets = nullptr, int ybyte = 0) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 sc = reinterpret_cast<const float4*>(coef)[q];
@@ -493,7 +507,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ 
           a[u].x += b2.x; a[u].y += b2.y; a[u].z += b2.z; a[u].w += b2.w;
         }
         v[u] = x[static_cast<size_t>(r) * g.C4 + q];
-        if (MASK == 2) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
+        if (MASK == 2) o[u] = load_gate_y(y, static_cast<size_t>(r) * g.C4 + q, ybyte);
       }
     }
 #pragma unroll
@@ -591,7 +605,7 @@ template <int MASK, bool DRES>
 __global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, const float4* __restrict__ dy2, const float4* __restrict__ x,
                                                  const float4* __restrict__ y, const float* __restrict__ coef,
                                                  const float* __restrict__ bcoef, float4* __restrict__ dx,
-                                                 float4* __restrict__ dres, BnGeom g, BnBfin fin) {
+                                                 float4* __restrict__ dres, BnGeom g, BnBfin fin, int ybyte = 0) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 sc = reinterpret_cast<const float4*>(coef)[q];
@@ -619,7 +633,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const float4* __restrict__ dy, 
           a[u].x += b2.x; a[u].y += b2.y; a[u].z += b2.z; a[u].w += b2.w;
         }
         v[u] = x[static_cast<size_t>(r) * g.C4 + q];
-        if (MASK == 2) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
+        if (MASK == 2) o[u] = load_gate_y(y, static_cast<size_t>(r) * g.C4 + q, ybyte);
       }
     }
 #pragma unroll
@@ -672,7 +686,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restri
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ mean_d,
                                                           const float* __restrict__ invstd_d, float* __restrict__ partial,
-                                                          BnGeom g, unsigned* __restrict__ tickets = nullptr) {
+                                                          BnGeom g, unsigned* __restrict__ tickets = nullptr, int ybyte = 0) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 mu = reinterpret_cast<const float4*>(mean)[q], is = reinterpret_cast<const float4*>(invstd)[q];
@@ -700,7 +714,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_dual(const float4* __restri
         }
         v[u] = x[static_cast<size_t>(r) * g.C4 + q];
         vd[u] = xd[static_cast<size_t>(r) * g.C4 + q];
-        if (RELU) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
+        if (RELU) o[u] = load_gate_y(y, static_cast<size_t>(r) * g.C4 + q, ybyte);
       }
     }
 #pragma unroll
@@ -766,7 +780,7 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_dx_dual(const float4* __restrict__ dy, const float4* __restrict__ dy2, const float4* __restrict__ x,
                                                       const float4* __restrict__ xd, const float4* __restrict__ y,
                                                       const float* __restrict__ bcoef, float4* __restrict__ dx,
-                                                      float4* __restrict__ dxd, BnGeom g, BnBfin fin, BnBfin fin_d) {
+                                                      float4* __restrict__ dxd, BnGeom g, BnBfin fin, BnBfin fin_d, int ybyte = 0) {
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   float4 A, Bc, Cc, Ad, Bd, Cd;
@@ -810,7 +824,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_dual(const float4* __restrict__
         }
         v[u] = x[static_cast<size_t>(r) * g.C4 + q];
         vd[u] = xd[static_cast<size_t>(r) * g.C4 + q];
-        if (RELU) o[u] = y[static_cast<size_t>(r) * g.C4 + q];
+        if (RELU) o[u] = load_gate_y(y, static_cast<size_t>(r) * g.C4 + q, ybyte);
       }
     }
 #pragma unroll
@@ -858,9 +872,9 @@ void launch_stats(const BnGeom& g, dim3 grid, hipStream_t s, const float4* x, fl
 template <int MASK>
 void launch_bwd_reduce(const BnGeom& g, dim3 grid, hipStream_t s, const float4* dy, const float4* dy2, const float4* x,
                        const float4* y, const float* coef, const float* mean, const float* invstd, float* partial,
-                       unsigned* tickets = nullptr) {
+                       unsigned* tickets = nullptr, int ybyte = 0) {
 #define BN_CALL(T, U) \
-  hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, dy2, x, y, coef, mean, invstd, partial, g, tickets)
+  hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, dy2, x, y, coef, mean, invstd, partial, g, tickets, ybyte)
   BN_DISPATCH_TPB_UNR(BN_CALL);
 #undef BN_CALL
 }
@@ -919,6 +933,19 @@ extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residu
                                              float* save_invstd, float* save_scale_shift, long long M, int C,
                                              const float* stats_partial, int partial_rows, void* workspace,
                                              size_t workspace_bytes, dbevStream_t stream) {
+  return dbev_bn_act_train_forward_mask(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu, y,
+                                        save_mean, save_invstd, save_scale_shift, M, C, stats_partial, partial_rows, nullptr, workspace,
+                                        workspace_bytes, stream);
+}
+
+// ... and with the ReLU gate of a residual norm written as one byte per four channels (relu_mask u8[M * C / 4], NULL: not written):
+// dbev_bn_act_backward3(..., y_is_mask = 1) reads it instead of the saved output
+extern "C" int dbev_bn_act_train_forward_mask(const float* x, const float* residual, const float* gamma, const float* beta,
+                                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                                              float momentum, float eps, int relu, float* y, float* save_mean,
+                                              float* save_invstd, float* save_scale_shift, long long M, int C,
+                                              const float* stats_partial, int partial_rows, unsigned char* relu_mask,
+                                              void* workspace, size_t workspace_bytes, dbevStream_t stream) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
   if (stats_partial != nullptr && partial_rows <= 0) return DBEV_EINVAL;
@@ -970,7 +997,7 @@ extern "C" int dbev_bn_act_train_forward_pre(const float* x, const float* residu
     const int rev = stats_partial != nullptr ? 1 : 0;
     const BnFin nofin{};
     if (residual != nullptr) {
-      if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev, fin, nofin);
+      if (relu) hipLaunchKernelGGL((bn_apply<true, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev, fin, nofin, relu_mask);
       else hipLaunchKernelGGL((bn_apply<true, false>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev, fin, nofin);
     } else {
       if (relu) hipLaunchKernelGGL((bn_apply<false, true>), agrid, dim3(256), 0, s, x4, r4, save_scale_shift, y4, g, none, rev, fin, nofin);
@@ -1061,6 +1088,16 @@ extern "C" int dbev_bn_act_backward2(const float* grad_y, const float* grad_y2, 
                                      const float* save_mean, const float* save_invstd, const float* save_scale_shift,
                                      int relu, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                                      long long M, int C, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  return dbev_bn_act_backward3(grad_y, grad_y2, x, y, 0, gamma, save_mean, save_invstd, save_scale_shift, relu, grad_x, grad_residual,
+                               grad_gamma, grad_beta, M, C, workspace, workspace_bytes, stream);
+}
+
+// y_is_mask != 0: `y` is the byte mask dbev_bn_act_train_forward_mask wrote (u8[M * C / 4]), not the saved output
+extern "C" int dbev_bn_act_backward3(const float* grad_y, const float* grad_y2, const float* x, const void* y, int y_is_mask,
+                                     const float* gamma, const float* save_mean, const float* save_invstd,
+                                     const float* save_scale_shift, int relu, float* grad_x, float* grad_residual, float* grad_gamma,
+                                     float* grad_beta, long long M, int C, void* workspace, size_t workspace_bytes,
+                                     dbevStream_t stream) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
   const size_t need = bn_ws(g).total + sizeof(float) * 3 * static_cast<size_t>(C);
@@ -1082,10 +1119,10 @@ extern "C" int dbev_bn_act_backward2(const float* grad_y, const float* grad_y2, 
   const long long T = 4LL * g.M * C;
   unsigned* tk = bn_ticket_ok(g) ? bn_tickets(1) : nullptr;
   {
-    DbevKt kt(mask == 2 ? DBEV_K_BN_BWD_REDUCE_Y : DBEV_K_BN_BWD_REDUCE, T * (mask == 2 ? 3 : 2), s);
+    DbevKt kt(mask == 2 ? DBEV_K_BN_BWD_REDUCE_Y : DBEV_K_BN_BWD_REDUCE, T * 2 + (mask == 2 ? (y_is_mask ? T / 16 : T) : 0), s);
     if (mask == 0) launch_bwd_reduce<0>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
     else if (mask == 1) launch_bwd_reduce<1>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
-    else launch_bwd_reduce<2>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
+    else launch_bwd_reduce<2>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk, y_is_mask);
   }
   BnBfin fin{};
   if (tk != nullptr) {
@@ -1101,9 +1138,9 @@ extern "C" int dbev_bn_act_backward2(const float* grad_y, const float* grad_y2, 
   float4* dx4 = reinterpret_cast<float4*>(grad_x);
   float4* dr4 = reinterpret_cast<float4*>(grad_residual);
   DbevKt kt(grad_residual != nullptr ? DBEV_K_BN_BWD_DX_RES : DBEV_K_BN_BWD_DX,
-            T * (3 + (mask == 2 ? 1 : 0) + (grad_residual != nullptr && mask != 0 ? 1 : 0)), s);
+            T * (3 + (grad_residual != nullptr && mask != 0 ? 1 : 0)) + (mask == 2 ? (y_is_mask ? T / 16 : T) : 0), s);
   if (grad_residual != nullptr) {
-    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
+    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin, y_is_mask);
     else hipLaunchKernelGGL((bn_bwd_dx<0, true>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
   } else {
     if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx<1, false>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
@@ -1146,6 +1183,23 @@ extern "C" int dbev_bn_dual_train_forward_pre(const float* x, const float* xd, c
                                               float* save_invstd_d, float* save_scale_shift_d, long long M, int C,
                                               const float* stats_partial, int partial_rows, const float* stats_partial_d,
                                               int partial_rows_d, void* workspace, size_t workspace_bytes, dbevStream_t stream) {
+  return dbev_bn_dual_train_forward_mask(x, xd, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, gamma_d, beta_d,
+                                         running_mean_d, running_var_d, num_batches_tracked_d, momentum_d, eps_d, relu, y, save_mean,
+                                         save_invstd, save_scale_shift, save_mean_d, save_invstd_d, save_scale_shift_d, M, C, stats_partial,
+                                         partial_rows, stats_partial_d, partial_rows_d, nullptr, workspace, workspace_bytes, stream);
+}
+
+// ... and with the ReLU gate written as one byte per four channels (relu_mask u8[M * C / 4] or NULL; see dbev_bn_act_train_forward_mask)
+extern "C" int dbev_bn_dual_train_forward_mask(const float* x, const float* xd, const float* gamma, const float* beta,
+                                               float* running_mean, float* running_var, long long* num_batches_tracked,
+                                               float momentum, float eps, const float* gamma_d, const float* beta_d,
+                                               float* running_mean_d, float* running_var_d, long long* num_batches_tracked_d,
+                                               float momentum_d, float eps_d, int relu, float* y, float* save_mean,
+                                               float* save_invstd, float* save_scale_shift, float* save_mean_d,
+                                               float* save_invstd_d, float* save_scale_shift_d, long long M, int C,
+                                               const float* stats_partial, int partial_rows, const float* stats_partial_d,
+                                               int partial_rows_d, unsigned char* relu_mask, void* workspace, size_t workspace_bytes,
+                                               dbevStream_t stream) {
   BnGeom g;
   if (!bn_geom(M, C, &g)) return DBEV_EINVAL;
   if (x == nullptr || xd == nullptr || gamma == nullptr || beta == nullptr || gamma_d == nullptr || beta_d == nullptr ||
@@ -1196,7 +1250,7 @@ extern "C" int dbev_bn_dual_train_forward_pre(const float* x, const float* xd, c
   DbevKt kt(DBEV_K_BN_APPLY_RES, T * 3, s);
   float4* y4 = reinterpret_cast<float4*>(y);
   const int rev = (stats_partial != nullptr && stats_partial_d != nullptr) ? 1 : 0;
-  if (relu) hipLaunchKernelGGL((bn_apply<true, true, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev, fin, fin_d);
+  if (relu) hipLaunchKernelGGL((bn_apply<true, true, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev, fin, fin_d, relu_mask);
   else hipLaunchKernelGGL((bn_apply<true, false, true>), agrid, dim3(256), 0, s, x4, d4, save_scale_shift, y4, g, save_scale_shift_d, rev, fin, fin_d);
   DBEV_LAUNCH_CHECK();
   return 0;
@@ -1215,6 +1269,17 @@ extern "C" int dbev_bn_dual_backward(const float* grad_y, const float* x, const 
 
 extern "C" int dbev_bn_dual_backward2(const float* grad_y, const float* grad_y2, const float* x, const float* xd, const float* y,
                                       const float* gamma, const float* save_mean, const float* save_invstd,
+                                      const float* gamma_d, const float* save_mean_d, const float* save_invstd_d, int relu,
+                                      float* grad_x, float* grad_xd, float* grad_gamma, float* grad_beta,
+                                      float* grad_gamma_d, float* grad_beta_d, long long M, int C, void* workspace,
+                                      size_t workspace_bytes, dbevStream_t stream) {
+  return dbev_bn_dual_backward3(grad_y, grad_y2, x, xd, y, 0, gamma, save_mean, save_invstd, gamma_d, save_mean_d, save_invstd_d, relu,
+                                grad_x, grad_xd, grad_gamma, grad_beta, grad_gamma_d, grad_beta_d, M, C, workspace, workspace_bytes, stream);
+}
+
+// y_is_mask != 0: `y` is the byte mask dbev_bn_dual_train_forward_mask wrote
+extern "C" int dbev_bn_dual_backward3(const float* grad_y, const float* grad_y2, const float* x, const float* xd, const void* y,
+                                      int y_is_mask, const float* gamma, const float* save_mean, const float* save_invstd,
                                       const float* gamma_d, const float* save_mean_d, const float* save_invstd_d, int relu,
                                       float* grad_x, float* grad_xd, float* grad_gamma, float* grad_beta,
                                       float* grad_gamma_d, float* grad_beta_d, long long M, int C, void* workspace,
@@ -1239,11 +1304,11 @@ extern "C" int dbev_bn_dual_backward2(const float* grad_y, const float* grad_y2,
   const float4* y4 = reinterpret_cast<const float4*>(y);
   const long long T = 4LL * g.M * C;
   {
-    DbevKt kt(DBEV_K_BN_BWD_REDUCE_Y, T * (relu ? 4 : 3), s);
+    DbevKt kt(DBEV_K_BN_BWD_REDUCE_Y, T * 3 + (relu ? (y_is_mask ? T / 16 : T) : 0), s);
 #define BN_CALL(TP, U)                                                                                                        \
   do {                                                                                                                        \
     if (relu) hipLaunchKernelGGL((bn_bwd_reduce_dual<true, TP, U>), grid, dim3(TP), 0, s, dy4, dy24, x4, d4, y4, save_mean,         \
-                                 save_invstd, save_mean_d, save_invstd_d, partial, g, tk);                                    \
+                                 save_invstd, save_mean_d, save_invstd_d, partial, g, tk, y_is_mask);                         \
     else hipLaunchKernelGGL((bn_bwd_reduce_dual<false, TP, U>), grid, dim3(TP), 0, s, dy4, dy24, x4, d4, y4, save_mean, save_invstd, \
                             save_mean_d, save_invstd_d, partial, g, tk);                                                      \
   } while (0)
@@ -1263,9 +1328,9 @@ extern "C" int dbev_bn_dual_backward2(const float* grad_y, const float* grad_y2,
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
   const dim3 agrid(static_cast<unsigned>(tiles < cap ? tiles : (cap < 1 ? 1 : cap)), g.GY);
-  DbevKt kt(DBEV_K_BN_BWD_DX_RES, T * (relu ? 6 : 5), s);
+  DbevKt kt(DBEV_K_BN_BWD_DX_RES, T * 5 + (relu ? (y_is_mask ? T / 16 : T) : 0), s);
   if (relu) hipLaunchKernelGGL((bn_bwd_dx_dual<true>), agrid, dim3(256), 0, s, dy4, dy24, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
-                               reinterpret_cast<float4*>(grad_xd), g, fin, fin_d);
+                               reinterpret_cast<float4*>(grad_xd), g, fin, fin_d, y_is_mask);
   else hipLaunchKernelGGL((bn_bwd_dx_dual<false>), agrid, dim3(256), 0, s, dy4, dy24, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
                           reinterpret_cast<float4*>(grad_xd), g, fin, fin_d);
   DBEV_LAUNCH_CHECK();

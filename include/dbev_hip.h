@@ -534,6 +534,38 @@ int dbev_bn_dual_backward2(const float* grad_y, const float* grad_y2, const floa
                            float* grad_gamma, float* grad_beta, float* grad_gamma_d, float* grad_beta_d, long long M, int C,
                            void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Round 5: the ReLU gate of a residual norm as ONE BYTE per four channels.  The backward of `relu(bn(x) + residual)` reads the saved
+ * output only for its sign; the 4x-planes-wide block outputs of the bottlenecks (mmdet3d/models/bricks/res_block.py:102-230,
+ * `out += identity; out = relu(out)`) are the largest tensors of the step, and both backward passes read them.
+ *   dbev_bn_act_train_forward_mask / dbev_bn_dual_train_forward_mask: as the *_pre entries, plus `relu_mask` u8[M * C / 4]
+ *     (NULL: not written): byte i holds the gate bits (bit j = channel 4 i' + j of that pixel positive before the ReLU) of float4 i.
+ *   dbev_bn_act_backward3 / dbev_bn_dual_backward3: as the *_backward2 entries with `y` + `y_is_mask`: y_is_mask != 0 -> `y` is that
+ *     byte array (16 x less traffic than the saved output); 0 -> the saved output, as before.  Results are bit-identical either way.
+ * ---------------------------------------------------------------------------------- */
+int dbev_bn_act_train_forward_mask(const float* x, const float* residual, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, float* y,
+                                   float* save_mean, float* save_invstd, float* save_scale_shift, long long M, int C,
+                                   const float* stats_partial, int partial_rows, unsigned char* relu_mask, void* workspace,
+                                   size_t workspace_bytes, dbevStream_t stream);
+int dbev_bn_act_backward3(const float* grad_y, const float* grad_y2, const float* x, const void* y, int y_is_mask, const float* gamma,
+                          const float* save_mean, const float* save_invstd, const float* save_scale_shift, int relu, float* grad_x,
+                          float* grad_residual, float* grad_gamma, float* grad_beta, long long M, int C, void* workspace,
+                          size_t workspace_bytes, dbevStream_t stream);
+int dbev_bn_dual_train_forward_mask(const float* x, const float* xd, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                    const float* gamma_d, const float* beta_d, float* running_mean_d, float* running_var_d,
+                                    long long* num_batches_tracked_d, float momentum_d, float eps_d, int relu, float* y,
+                                    float* save_mean, float* save_invstd, float* save_scale_shift, float* save_mean_d,
+                                    float* save_invstd_d, float* save_scale_shift_d, long long M, int C, const float* stats_partial,
+                                    int partial_rows, const float* stats_partial_d, int partial_rows_d, unsigned char* relu_mask,
+                                    void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_bn_dual_backward3(const float* grad_y, const float* grad_y2, const float* x, const float* xd, const void* y, int y_is_mask,
+                           const float* gamma, const float* save_mean, const float* save_invstd, const float* gamma_d,
+                           const float* save_mean_d, const float* save_invstd_d, int relu, float* grad_x, float* grad_xd,
+                           float* grad_gamma, float* grad_beta, float* grad_gamma_d, float* grad_beta_d, long long M, int C,
+                           void* workspace, size_t workspace_bytes, dbevStream_t stream);
+
 /* LiDAR sweep -> per-camera sparse depth maps, the depth supervision BEVDepth's img_inputs carry as their last element.
  * Replaces the loader transform PointToMultiViewDepth.__call__ / points2depthmap (mmdet3d/datasets/pipelines/loading.py:18-61).
  *   points f32[n_points, n_feats] (x, y, z first, lidar frame);

@@ -322,3 +322,47 @@ def test_eval_coefficients_are_kept_on_the_module_and_follow_every_change_of_its
     assert c2 is not c1
     bn.load_state_dict({k: torch.rand_like(v.float()).to(v.dtype) + 0.5 if v.is_floating_point() else v for k, v in bn.state_dict().items()})
     assert check() is not c2
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_relu_gate_byte_mask_gives_bit_identical_gradients(dual):
+    """Round 5: the forward of a residual norm writes its ReLU gate as one byte per four channels and both backward passes read the
+    byte instead of the saved output (dbev_bn_act_train_forward_mask / _backward3, the dual entries likewise): every gradient is
+    bit-identical to the path that reads the output (DBEV_BN_GATE_MASK=0), also with the gradient arriving as two addends."""
+    import torch.nn as nn
+    from distill_bev_amd import bn_act as BA
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    shape = (6, 256, 16, 44)
+    cl = lambda: torch.randn(shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    x0, r0, gy, gy2 = cl(), cl(), cl(), cl()
+    outs = []
+    for use_mask in (True, False):
+        BA._state["gate_mask"] = use_mask
+        try:
+            torch.manual_seed(3)
+            bn, bnd = nn.BatchNorm2d(shape[1]).to(dev).train(), nn.BatchNorm2d(shape[1]).to(dev).train()
+            with torch.no_grad():
+                for m in (bn, bnd):
+                    m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3)
+            x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            y = BA.bn_act_dual(x, bn, r, bnd, True, fork=True) if dual else BA.bn_act(x, bn, r, True, fork=True)
+            y2 = BA.forked(y)
+            assert y2 is not y
+            params = [bn.weight, bn.bias] + ([bnd.weight, bnd.bias] if dual else [])
+            grads = torch.autograd.grad([y, y2], [x, r] + params, [gy, gy2])
+            outs.append([y.detach()] + [t.detach() for t in grads])
+        finally:
+            BA._state["gate_mask"] = True
+    assert len(outs[0]) == len(outs[1]) and all(torch.equal(a, b) for a, b in zip(*outs))
+    # and against the unfused op sequence
+    x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+    torch.manual_seed(3)
+    bn, bnd = nn.BatchNorm2d(shape[1]).to(dev).train(), nn.BatchNorm2d(shape[1]).to(dev).train()
+    with torch.no_grad():
+        for m in (bn, bnd):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3)
+    ref = torch.relu(bn(x) + (bnd(r) if dual else r))
+    gx, gr = torch.autograd.grad(ref, [x, r], gy + gy2)
+    assert torch.allclose(outs[0][0], ref.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(outs[0][1], gx, rtol=1e-4, atol=1e-5) and torch.allclose(outs[0][2], gr, rtol=1e-4, atol=1e-5)
