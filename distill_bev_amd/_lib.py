@@ -95,6 +95,8 @@ _SIGNATURES = {
     "dbev_gemm_bf16x6_backward_weight_workspace_bytes": [_ll, _i, _i, _i],
     "dbev_gemm_bf16x6_backward_weight": [_p, _p, _p, _ll, _i, _i, _i, _p, _sz, _p],
     "dbev_channel_sum_nhwc": [_p, _ll, _i, _p, _p, _sz, _p],
+    "dbev_wino_filter_pack_multi": [_p, _i, _ll, _p],
+    "dbev_gemm_bf16x6_pack_multi": [_p, _i, _ll, _p],
     "dbev_subsample2_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "dbev_upsample2_zero_nhwc": [_p, _p, _i, _i, _i, _i, _p],
     "dbev_depth_head_forward": [_p, _p, _p, _p, _ll, _i, _i, _p, _p, _p, _p],

@@ -944,6 +944,22 @@ extern "C" int dbev_gemm_bf16x6_pack_pair(const float* weight, long long stride_
   return 0;
 }
 
+// every trainable 1x1 filter's planes in ONE launch (round 5): blockIdx.z = job; so / sc = strides of the [Cout, Cin] view,
+// kind_a / kind_b = tile width (64 / 128) of the forward / data-gradient planes, 0: skip
+__global__ __launch_bounds__(256) void b6_pack_multi(const dbevPackJob* __restrict__ jobs) {
+  const dbevPackJob j = jobs[blockIdx.z];
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (blockIdx.y == 0) { if (j.kind_a) b6_pack_elem(idx, j.weight, j.so, j.sc, j.Cout, j.Cin, j.kind_a, static_cast<unsigned short*>(j.out_a)); }
+  else if (j.kind_b) b6_pack_elem(idx, j.weight, j.sc, j.so, j.Cin, j.Cout, j.kind_b, static_cast<unsigned short*>(j.out_b));
+}
+
+extern "C" int dbev_gemm_bf16x6_pack_multi(const dbevPackJob* jobs_device, int n_jobs, long long max_units, dbevStream_t stream) {
+  if (jobs_device == nullptr || n_jobs <= 0 || n_jobs > 65535 || max_units <= 0) return DBEV_EINVAL;
+  hipLaunchKernelGGL(b6_pack_multi, dim3(dbev_ceil_div(max_units, 256), 2, n_jobs), dim3(256), 0, dbev_stream(stream), jobs_device);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dbev_gemm_bf16x6_stats_rows(long long M) { return (M > 0 && (M % B6_BM) == 0 && M <= 0x7fffffffLL) ? static_cast<int>(M / B6_BM) : 0; }
 
 extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed, float* y, float* stats_partial, long long M, int K, int N,

@@ -1162,33 +1162,33 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
 
 // part [nsplit][16][Co][C]: the shares of every element are added in a fixed order (four interleaved chains, then pairwise) into
 // share 0's slot -- one thread per (position, co, c), so that a 64 x 64 layer with hundreds of shares still fills the chip ...
-__global__ __launch_bounds__(256) void wino_wgrad_sum(float* __restrict__ part, int nsplit, long long plane16) {
-  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-  if (idx >= plane16) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const float* ps = part + idx;
-  int s = 0;
-  for (; s + 4 <= nsplit; s += 4) {
-    s0 += ps[(s + 0) * plane16];
-    s1 += ps[(s + 1) * plane16];
-    s2 += ps[(s + 2) * plane16];
-    s3 += ps[(s + 3) * plane16];
-  }
-  for (; s < nsplit; ++s) s0 += ps[s * plane16];
-  part[idx] = (s0 + s1) + (s2 + s3);
-}
-
 // ... then grad_w (co, c, a, b) at co*so + c*sc + a*sa + b*sb = G^T dU G per (co, c), dU = share 0's slot [16][Co][C]
+// (round 5: the sum over the shares happens HERE, in wino_wgrad_sum's order -- four interleaved chains, then pairwise -- instead of in
+// a launch of its own: 38 launches per step fewer)
 __global__ __launch_bounds__(256) void wino_wgrad_reduce(const float* __restrict__ part, int C, int Co, float* __restrict__ gw,
-                                                         long long so, long long sc, long long sa, long long sb, int unsigned_z) {
+                                                         long long so, long long sc, long long sa, long long sb, int unsigned_z,
+                                                         int nsplit) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= static_cast<long long>(C) * Co) return;
   const int c = static_cast<int>(idx % C), co = static_cast<int>(idx / C);
   float u[16];
-  const size_t plane = static_cast<size_t>(Co) * C;
+  const size_t plane = static_cast<size_t>(Co) * C, plane16 = 16 * plane;
   const float* ps = part + static_cast<size_t>(co) * C + c;
 #pragma unroll
-  for (int p = 0; p < 16; ++p) u[p] = ps[p * plane];
+  for (int p = 0; p < 16; ++p) {
+    const float* pp = ps + p * plane;
+    if (nsplit <= 1) { u[p] = pp[0]; continue; }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sh = 0;
+    for (; sh + 4 <= nsplit; sh += 4) {
+      s0 += pp[(sh + 0) * plane16];
+      s1 += pp[(sh + 1) * plane16];
+      s2 += pp[(sh + 2) * plane16];
+      s3 += pp[(sh + 3) * plane16];
+    }
+    for (; sh < nsplit; ++sh) s0 += pp[sh * plane16];
+    u[p] = (s0 + s1) + (s2 + s3);
+  }
   if (unsigned_z) {                        // wino_wgrad2 accumulates s_i s_j dU (s_3 = -1): positions (i, 3) and (3, j), i, j < 3
     u[3] = -u[3]; u[7] = -u[7]; u[11] = -u[11]; u[12] = -u[12]; u[13] = -u[13]; u[14] = -u[14];
   }
@@ -1342,6 +1342,27 @@ extern "C" int dbev_wino_filter_pack_pair(const float* weight, long long so, lon
   return 0;
 }
 
+// every trainable layer's filters in ONE launch (round 5): blockIdx.z = job of a device table of dbevPackJob (kind_a / kind_b = the
+// forward / data-gradient kernel codes of dbev_wino_filter_pack_pair, 0: skip; out_a / out_b = its two pack buffers)
+__global__ __launch_bounds__(256) void wino_filter_pack_multi(const dbevPackJob* __restrict__ jobs) {
+  const dbevPackJob j = jobs[blockIdx.z];
+  const int mode = blockIdx.y;
+  const int fmt = mode ? j.kind_b : j.kind_a;
+  if (fmt == 0) return;
+  const int K = mode ? j.Cout : j.Cin, J = mode ? j.Cin : j.Cout;
+  float* U = static_cast<float*>(mode ? j.out_b : j.out_a);
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;      // (the element kernels return past their own range)
+  if (fmt == 2 || fmt == 6) wino_pack_elem(idx, j.weight, j.so, j.sc, j.sa, j.sb, K, J, mode, U + 16LL * K * J);
+  if (fmt == 3 || fmt == 6) wino_pack3_elem(idx, j.weight, j.so, j.sc, j.sa, j.sb, K, J, mode, U);
+}
+
+extern "C" int dbev_wino_filter_pack_multi(const dbevPackJob* jobs_device, int n_jobs, long long max_pairs, dbevStream_t stream) {
+  if (jobs_device == nullptr || n_jobs <= 0 || n_jobs > 65535 || max_pairs <= 0) return DBEV_EINVAL;
+  hipLaunchKernelGGL(wino_filter_pack_multi, dim3(dbev_ceil_div(max_pairs, 256), 2, n_jobs), dim3(256), 0, dbev_stream(stream), jobs_device);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dbev_wino_conv3x3_forward_kernel(int N, int H, int W, int Cin, int Cout) {
   WinoPlan p;
   return wino_plan(N, H, W, Cin, Cout, &p) ? (p.v3 ? 3 : p.n2 > 0 ? 6 : 2) : 0;
@@ -1426,13 +1447,8 @@ extern "C" int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const floa
     hipLaunchKernelGGL(wino_wgrad, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
                        p.nsplit);
   DBEV_LAUNCH_CHECK();
-  const long long plane16 = 16LL * Cin * Cout;
-  if (p.nsplit > 1) {
-    hipLaunchKernelGGL(wino_wgrad_sum, dim3(dbev_ceil_div(plane16, 256)), dim3(256), 0, s, part, p.nsplit, plane16);
-    DBEV_LAUNCH_CHECK();
-  }
   hipLaunchKernelGGL(wino_wgrad_reduce, dim3(dbev_ceil_div(static_cast<long long>(Cin) * Cout, 256)), dim3(256), 0, s, part, Cin, Cout,
-                     grad_weight, so, sc, sa, sb, p.v2);
+                     grad_weight, so, sc, sa, sb, p.v2, p.nsplit);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -415,8 +415,12 @@ class Trainer:
         self.device = device
         self.detector = model.to(device)
         self.detector.train()
+        self.packer = None
         if channels_last:
             self.fused_bn_relu, self.swapped_upsample = to_channels_last(self.detector)
+            if device.type == "cuda":
+                from .packer import WeightPacker
+                self.packer = WeightPacker([self.detector])      # the trainable layers' packed weights: one launch per family and step
         self.wrapper = _TrainWrapper(self.detector)
         self.world_size = world_size
         self.reducer = None
@@ -463,4 +467,6 @@ class Trainer:
         if self.grad_clip:
             nn.utils.clip_grad_norm_(self.params, **self.grad_clip)
         self.optimizer.step()
+        if self.packer is not None:
+            self.packer.repack()                 # (after the step's version bump: the layers find their packs fresh in the next forward)
         return loss.detach(), losses

@@ -668,6 +668,25 @@ int dbev_gemm_bf16x6_backward_weight(const float* x, const float* grad_y, float*
                                      int x_row_stride, void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Round 5: the per-step re-packing of EVERY trainable layer's weights in one launch per kernel family (the reference has no counterpart:
+ * cuDNN consumes `nn.Conv2d.weight` as it is; here the Winograd kernels read G g G^T in their consumption order and the bf16x6 GEMMs the
+ * three bf16 planes of a 1x1 filter, both re-derived after every optimizer step -- 72 launches of 6-8 us per step before).
+ * `jobs_device`: device array of n_jobs dbevPackJob; a job = the arguments of dbev_wino_filter_pack_pair (kind_a / kind_b = forward /
+ * data-gradient kernel codes, 0: skip) resp. dbev_gemm_bf16x6_pack_pair (so / sc = strides of the [Cout, Cin] view, kind_a / kind_b =
+ * tile width 64 / 128 of the forward / data-gradient planes, 0: skip).  max_pairs = max Cin * Cout over the jobs; max_units = max
+ * Cin * Cout / 8.  The buffers are the ones the single-layer entries filled before (same sizes, same contents).
+ * ---------------------------------------------------------------------------------- */
+typedef struct dbevPackJob {
+  const float* weight;
+  long long so, sc, sa, sb;
+  int Cout, Cin, kind_a, kind_b;
+  void* out_a;
+  void* out_b;
+} dbevPackJob;
+int dbev_wino_filter_pack_multi(const dbevPackJob* jobs_device, int n_jobs, long long max_pairs, dbevStream_t stream);
+int dbev_gemm_bf16x6_pack_multi(const dbevPackJob* jobs_device, int n_jobs, long long max_units, dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Stride-2 1x1 convolutions as subsample + GEMM (the `downsample` branch of a stage-first bottleneck: nn.Conv2d(k = 1, stride = 2),
  * mmdet ResNet make_res_layer / mmdet3d/models/bricks/res_block.py:102-230; replaces the library's strided implicit GEMM).
  *   dbev_subsample2_nhwc:      y[n, ho, wo, :] = x[n, 2 ho, 2 wo, :]            x f32[N, H, W, C] channels-last -> y f32[N, H/2, W/2, C]
