@@ -1162,33 +1162,35 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad2(const float* __restrict__ 
 
 // part [nsplit][16][Co][C]: the shares of every element are added in a fixed order (four interleaved chains, then pairwise) into
 // share 0's slot -- one thread per (position, co, c), so that a 64 x 64 layer with hundreds of shares still fills the chip ...
+// (round 5: folding this sum into wino_wgrad_reduce -- one thread per (co, c) walking 16 positions x nsplit shares -- was measured and
+// reverted: 88 us instead of 14 + 5 us per layer; the sum needs the 16 x more threads of its own launch)
+__global__ __launch_bounds__(256) void wino_wgrad_sum(float* __restrict__ part, int nsplit, long long plane16) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= plane16) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* ps = part + idx;
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    s0 += ps[(s + 0) * plane16];
+    s1 += ps[(s + 1) * plane16];
+    s2 += ps[(s + 2) * plane16];
+    s3 += ps[(s + 3) * plane16];
+  }
+  for (; s < nsplit; ++s) s0 += ps[s * plane16];
+  part[idx] = (s0 + s1) + (s2 + s3);
+}
+
 // ... then grad_w (co, c, a, b) at co*so + c*sc + a*sa + b*sb = G^T dU G per (co, c), dU = share 0's slot [16][Co][C]
-// (round 5: the sum over the shares happens HERE, in wino_wgrad_sum's order -- four interleaved chains, then pairwise -- instead of in
-// a launch of its own: 38 launches per step fewer)
 __global__ __launch_bounds__(256) void wino_wgrad_reduce(const float* __restrict__ part, int C, int Co, float* __restrict__ gw,
-                                                         long long so, long long sc, long long sa, long long sb, int unsigned_z,
-                                                         int nsplit) {
+                                                         long long so, long long sc, long long sa, long long sb, int unsigned_z) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= static_cast<long long>(C) * Co) return;
   const int c = static_cast<int>(idx % C), co = static_cast<int>(idx / C);
   float u[16];
-  const size_t plane = static_cast<size_t>(Co) * C, plane16 = 16 * plane;
+  const size_t plane = static_cast<size_t>(Co) * C;
   const float* ps = part + static_cast<size_t>(co) * C + c;
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const float* pp = ps + p * plane;
-    if (nsplit <= 1) { u[p] = pp[0]; continue; }
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int sh = 0;
-    for (; sh + 4 <= nsplit; sh += 4) {
-      s0 += pp[(sh + 0) * plane16];
-      s1 += pp[(sh + 1) * plane16];
-      s2 += pp[(sh + 2) * plane16];
-      s3 += pp[(sh + 3) * plane16];
-    }
-    for (; sh < nsplit; ++sh) s0 += pp[sh * plane16];
-    u[p] = (s0 + s1) + (s2 + s3);
-  }
+  for (int p = 0; p < 16; ++p) u[p] = ps[p * plane];
   if (unsigned_z) {                        // wino_wgrad2 accumulates s_i s_j dU (s_3 = -1): positions (i, 3) and (3, j), i, j < 3
     u[3] = -u[3]; u[7] = -u[7]; u[11] = -u[11]; u[12] = -u[12]; u[13] = -u[13]; u[14] = -u[14];
   }
@@ -1447,8 +1449,13 @@ extern "C" int dbev_wino_conv3x3_backward_weight(const float* x_nhwc, const floa
     hipLaunchKernelGGL(wino_wgrad, dim3(p.grid), dim3(256), 0, s, x_nhwc, grad_y_nhwc, part, N, H, W, Cin, Cout, p.nsb, p.per, p.nblk,
                        p.nsplit);
   DBEV_LAUNCH_CHECK();
+  const long long plane16 = 16LL * Cin * Cout;
+  if (p.nsplit > 1) {
+    hipLaunchKernelGGL(wino_wgrad_sum, dim3(dbev_ceil_div(plane16, 256)), dim3(256), 0, s, part, p.nsplit, plane16);
+    DBEV_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(wino_wgrad_reduce, dim3(dbev_ceil_div(static_cast<long long>(Cin) * Cout, 256)), dim3(256), 0, s, part, Cin, Cout,
-                     grad_weight, so, sc, sa, sb, p.v2, p.nsplit);
+                     grad_weight, so, sc, sa, sb, p.v2);
   DBEV_LAUNCH_CHECK();
   return 0;
 }
