@@ -180,6 +180,11 @@ def main():
         alt = line["config"].get("ms_per_step_fp32_matrix_cores_only")
         if alt:
             line["value_fp32_matrix_cores_only"] = wl.units_per_step * world / (alt * 1e-3)
+            if alt > 1.3 * line["ms_per_step"]:
+                # seen on some boxes of the pool: the library answers one of the 1x1 shapes it gets in this variant with a solver 5-10 x
+                # slower than its usual one (the same outliers show in the `miopen us` column of profiles/r05_gemm_bf6_vs_miopen.txt)
+                line["value_fp32_matrix_cores_only_note"] = ("outlier: the library's 1x1 kernels of this run include a pathological solver pick "
+                                                             "(typical value of this variant: ~109 ms per step); the headline path does not use them")
         # ... and with all 36 branch stacks of the frozen teacher's head evaluated as the reference does (the default skips the 30
         # whose outputs nothing reads; identical losses)
         alt = line["config"].get("ms_per_step_full_teacher_head")
