@@ -248,8 +248,8 @@ def test_full_size_hand_written_dense_kernels_vs_library_path_one_step(full):
             e = float((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-20))
             print("grad rel-L2 %-48s %.3e" % (n, e))
             # (the depth head's gradient arrives through the whole BEV encoder + lift-splat backward: ~20 training-mode norms deep at
-            # a random initialisation; measured 5.2e-3, the layers next to the losses 2e-7 ... 5e-4)
-            assert e <= (2e-2 if "depthnet" in n else 2e-3), (n, e)
+            # a random initialisation; measured 5e-3 ... 6e-3 over several runs, the layers next to the losses 2e-7 ... 7e-4)
+            assert e <= (2e-2 if "depthnet" in n else 5e-3), (n, e)
     worst = max(((float((sa[k] - sb[k]).abs().max() / sb[k].abs().max().clamp_min(1e-6)), k) for k in sa))
     print("running statistics after one step, worst rel-Linf:", worst)
     assert worst[0] <= 1e-5, worst
@@ -287,10 +287,14 @@ def test_full_size_five_step_loss_trajectory_kernels_vs_library_path():
     print("loss trajectory, library:", b)
     assert all(np.isfinite(a)) and all(np.isfinite(b))
     assert abs(a[0] - b[0]) <= 1e-4 * abs(b[0])
-    # the optimizer moves the loss by far more than the two paths differ: steps 1-4 follow the library's trajectory
+    # A random-init 50-layer student is chaotic: two runs of the LIBRARY path alone (MIOpen's atomic split-K weight gradients) drift apart
+    # by ~x4 per step -- measured over several boxes, kernels vs library: step 1 2e-5 ... 1.6e-4, step 2 3e-4 ... 6e-4, step 3 4e-3,
+    # step 4 7e-3 ... 2.3e-2 (library vs library at step 4: 1.2e-2) -- while the optimizer moves the loss by 6-8 % per step.  A stale
+    # weight pack makes step 1 repeat step 0's loss: an 8 % deviation at the step whose bound is 1e-3.
+    bounds = [1e-4, 1e-3, 3e-3, 2e-2, 8e-2]
     for i in range(1, 5):
-        assert abs(a[i] - b[i]) <= 2e-2 * abs(b[i]), (i, a, b)
-        assert abs(a[i] - a[i - 1]) > 10 * abs(a[i] - b[i]) or abs(a[i] - b[i]) <= 1e-3 * abs(b[i]), (i, a, b)
+        assert abs(a[i] - b[i]) <= bounds[i] * abs(b[i]), (i, a, b)
+        assert a[i] < a[i - 1] and b[i] < b[i - 1], (i, a, b)            # both trajectories keep descending at this learning rate
 
 
 def test_full_size_bevformer_distillation_step():
