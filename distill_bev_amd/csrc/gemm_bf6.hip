@@ -338,6 +338,19 @@ __device__ __forceinline__ void b6_split2s(float a, float b, unsigned& p0, unsig
 }
 
 #define B6_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier((mask_), (n_), 0)
+// schedule knobs of b6_fwd2's chunk (dev builds override them: tools/build_variant.sh): VALU instructions per MFMA round, the rounds
+// after which the plane stores of the first / second float4 are placed
+// (measured over the step's twelve 1x1 shapes, tools/kbench_bf6_fwd.py, sum of the forward times: 3 / 9 / 18 -> 1.66 ms, 5 / 6 / 11 -> 1.62 ms,
+// 6 / 5 / 9 -> 1.65, 8 / 4 / 7 and 12 / 3 / 5 -> 1.67: the split a little ahead of the MFMAs, not all of it up front)
+#ifndef B6_VG
+#define B6_VG 5
+#endif
+#ifndef B6_W0
+#define B6_W0 6
+#endif
+#ifndef B6_W1
+#define B6_W1 11
+#endif
 
 template <int BN, bool STATS>
 __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, const unsigned short* __restrict__ Wp,
@@ -484,9 +497,9 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
     B6_SGB(0x100, 3 * TM + 6);                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 12 * TM; ++i) {                                                             \
       B6_SGB(0x008, 1);                                                                                              \
-      B6_SGB(0x002, TM == 2 ? 3 : 6);                                                                                \
+      B6_SGB(0x002, TM == 2 ? B6_VG : 6);                                                                            \
       /* the plane stores follow their split (26 / 52 VALU instructions in), the refill of the register set follows its last reader */ \
-      if (TM == 2 ? (i == 9 || i == 11 || i == 18 || i == 20) : (i == 4 || i == 5 || i == 9 || i == 10)) B6_SGB(0x200, 1); \
+      if (TM == 2 ? (i == B6_W0 || i == B6_W0 + 2 || i == B6_W1 || i == B6_W1 + 2) : (i == 4 || i == 5 || i == 9 || i == 10)) B6_SGB(0x200, 1); \
       if (i == 12 * TM - 3 || i == 12 * TM - 2) B6_SGB(0x020, 1);                                                    \
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: a second library with wino.hip compiled under extra flags (A/B runs through DBEV_HIP_LIB).
-# usage: tools/build_variant.sh <name> [extra hipcc flags...]   ->  distill_bev_amd/libdbev_hip_<name>.so
+# usage: [SRC=gemm_bf6.hip] tools/build_variant.sh <name> [extra hipcc flags...]   ->  distill_bev_amd/libdbev_hip_<name>.so
 set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../distill_bev_amd/csrc"
