@@ -342,6 +342,21 @@ __device__ __forceinline__ void b6_split2s(float a, float b, unsigned& p0, unsig
 // after which the plane stores of the first / second float4 are placed
 // (measured over the step's twelve 1x1 shapes, tools/kbench_bf6_fwd.py, sum of the forward times: 3 / 9 / 18 -> 1.66 ms, 5 / 6 / 11 -> 1.62 ms,
 // 6 / 5 / 9 -> 1.65, 8 / 4 / 7 and 12 / 3 / 5 -> 1.67: the split a little ahead of the MFMAs, not all of it up front)
+// ... and of b6_wgrad2's (128 x 128 tiles): VALU per round, the round around which the first channel's three plane stores sit, the
+// round from which the second channel's follow
+// weight chunks in flight ahead of the one being consumed (ring of four buffers: 2 or 3)
+#ifndef B6_AHEAD
+#define B6_AHEAD 2
+#endif
+#ifndef B6W_VG
+#define B6W_VG 5
+#endif
+#ifndef B6W_H
+#define B6W_H 12
+#endif
+#ifndef B6W_T
+#define B6W_T 20
+#endif
 #ifndef B6_VG
 #define B6_VG 5
 #endif
@@ -449,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
   // prologue: weights of chunks 0, 1 on their way, activations of chunks 0 (staged), 1, 2 (registers)
   B6_DMA_CHUNK(0, 0);
   B6_DMA_CHUNK(1, 1);
+  if (B6_AHEAD == 3) B6_DMA_CHUNK(2, 2);
   B6_LOADA(0, 0);
   B6_LOADA(1, 1);
   B6_STAGEA(0, 0);
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
       _Pragma("unroll") for (int b = 0; b < 2; ++b) bf[b][p] = *reinterpret_cast<const bf16x8*>(br_ + p * BPL + baddr[b]); \
     }                                                                                                                \
     if (((j_) & 1) == 0) B6_STAGEA(1, 1); else B6_STAGEA(0, 0);                                                      \
-    B6_DMA_CHUNK(kc + 2, ((j_) + 2) & 3);                                                                            \
+    B6_DMA_CHUNK(kc + B6_AHEAD, ((j_) + B6_AHEAD) & 3);                                                              \
     if (((j_) & 1) == 0) B6_LOADA(1, kc + 3); else B6_LOADA(0, kc + 3);                                              \
     _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                   \
       const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0, pb = t == 0 || t == 3 || t == 5 ? 0 : (t == 1 || t == 4) ? 1 : 2; \
@@ -846,9 +862,9 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad2(const float* __restrict__ GY
     B6_SGB(0x100, 3 * (NA + NB));                                                                                    \
     _Pragma("unroll") for (int i = 0; i < 6 * NA * NB; ++i) {                                                         \
       B6_SGB(0x008, 1);                                                                                              \
-      B6_SGB(0x002, NA * NB == 4 ? 5 : (NA * NB == 2 ? 10 : 20));                                                    \
-      if (i == 6 * NA * NB / 2 - 2 || i == 6 * NA * NB / 2 || i == 6 * NA * NB / 2 + 2) B6_SGB(0x200, 1);            \
-      if (i >= 6 * NA * NB - 4 && i < 6 * NA * NB - 1) B6_SGB(0x200, 1);                                             \
+      B6_SGB(0x002, NA * NB == 4 ? B6W_VG : (NA * NB == 2 ? 10 : 20));                                               \
+      if (NA * NB == 4 ? (i == B6W_H - 2 || i == B6W_H || i == B6W_H + 2) : (i == 6 * NA * NB / 2 - 2 || i == 6 * NA * NB / 2 || i == 6 * NA * NB / 2 + 2)) B6_SGB(0x200, 1); \
+      if (NA * NB == 4 ? (i >= B6W_T && i < B6W_T + 3) : (i >= 6 * NA * NB - 4 && i < 6 * NA * NB - 1)) B6_SGB(0x200, 1); \
       if (i == 6 * NA * NB - 2 || i == 6 * NA * NB - 1) B6_SGB(0x020, 4);                                            \
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
