@@ -12,7 +12,7 @@ def tm(f, n=30):
     for _ in range(n): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
-for (n, ci, co, h, w) in [(48, 2048, 512, 8, 22), (48, 512, 2048, 8, 22), (48, 1024, 256, 16, 44), (48, 512, 512, 8, 22), (8, 256, 256, 32, 32), (8, 512, 256, 16, 16)]:
+for (n, ci, co, h, w) in [(48, 64, 256, 64, 176), (48, 2048, 512, 8, 22), (48, 512, 2048, 8, 22), (48, 1024, 256, 16, 44), (48, 512, 512, 8, 22), (8, 256, 256, 32, 32), (8, 512, 256, 16, 16)]:
     M = n * h * w
     x = torch.randn((n, ci, h, w), device=dev).contiguous(memory_format=torch.channels_last)
     w2 = torch.randn((co, ci), device=dev) / ci ** 0.5
