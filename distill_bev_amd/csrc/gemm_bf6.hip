@@ -584,7 +584,11 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
     for (int i = 0; i < TM * 8; ++i) {
       const int row = 4 * i + rr;
       const floatx4 v = *reinterpret_cast<const floatx4*>(tw + row * 64 + 4 * c4q);
+#ifdef B6_NT_STORE
+      __builtin_nontemporal_store(v, reinterpret_cast<floatx4*>(yb + static_cast<size_t>(row) * N));
+#else
       *reinterpret_cast<floatx4*>(yb + static_cast<size_t>(row) * N) = v;
+#endif
     }
   }
 }
