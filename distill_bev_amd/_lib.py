@@ -85,6 +85,7 @@ _SIGNATURES = {
     "dbev_grid_sample_bilinear_nhwc": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "dbev_maxpool3x3s2_forward": [_p, _i, _i, _i, _i, _p, _p, _p],
     "dbev_maxpool3x3s2_backward": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "dbev_norm_relu_maxpool3x3s2_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     "dbev_channel_sum_workspace_bytes": [_ll, _i],
     "dbev_gemm_bf16x6_packed_bytes": [_i, _i],
     "dbev_gemm_bf16x6_pack": [_p, _ll, _ll, _i, _i, _i, _p, _p],

@@ -13,8 +13,13 @@ namespace {
 
 struct MpDims { int N, H, W, C4, Ho, Wo; };
 
+// AFFINE (round 5): the pooled tensor is max over the window of relu(x * scale + shift) -- the stem's norm -> ReLU -> pooling in one
+// pass over the convolution's output (coef = scale | shift per channel, the fused norm's coefficient row): the normalised,
+// rectified 554 MB map is neither written nor read back.  Same winners as the three-module sequence (the tie rule sees the same values).
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void maxpool3x3s2_fwd(const float4* __restrict__ x, float4* __restrict__ y,
-                                                        uchar4* __restrict__ tap, MpDims d, long long total) {
+                                                        uchar4* __restrict__ tap, MpDims d, long long total,
+                                                        const float* __restrict__ coef) {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int c = static_cast<int>(t % d.C4);
@@ -25,6 +30,11 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd(const float4* __restrict
   float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   uchar4 w = make_uchar4(0, 0, 0, 0);
   bool first = true;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (AFFINE) {
+    sc = reinterpret_cast<const float4*>(coef)[c];
+    sh = reinterpret_cast<const float4*>(coef + 4 * d.C4)[c];
+  }
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int h = 2 * oh - 1 + kh;
@@ -33,7 +43,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd(const float4* __restrict
     for (int kw = 0; kw < 3; ++kw) {
       const int ww = 2 * ow - 1 + kw;
       if (ww < 0 || ww >= d.W) continue;
-      const float4 v = x[(static_cast<size_t>(n) * d.H + h) * d.W * d.C4 + static_cast<size_t>(ww) * d.C4 + c];
+      float4 v = x[(static_cast<size_t>(n) * d.H + h) * d.W * d.C4 + static_cast<size_t>(ww) * d.C4 + c];
+      if (AFFINE) {                                   // fmaxf(NaN, 0) = 0 as in ATen's relu? no: torch.relu keeps NaN -- keep it here too
+        const float ax = fmaf(v.x, sc.x, sh.x), ay = fmaf(v.y, sc.y, sh.y), az = fmaf(v.z, sc.z, sh.z), aw = fmaf(v.w, sc.w, sh.w);
+        v.x = ax != ax ? ax : fmaxf(ax, 0.f); v.y = ay != ay ? ay : fmaxf(ay, 0.f);
+        v.z = az != az ? az : fmaxf(az, 0.f); v.w = aw != aw ? aw : fmaxf(aw, 0.f);
+      }
       const unsigned char k = static_cast<unsigned char>(3 * kh + kw);
       // ATen: (val > maxval) || isnan(val), maxval starts at -inf with the window's first element as its index
       if (first || v.x > m.x || v.x != v.x) { m.x = v.x; w.x = k; }
@@ -115,9 +130,21 @@ extern "C" int dbev_maxpool3x3s2_forward(const float* x_nhwc, int N, int H, int 
   MpDims d;
   if (!mp_dims(N, H, W, C, &d) || x_nhwc == nullptr || y_nhwc == nullptr || winner == nullptr) return DBEV_EINVAL;
   const long long total = static_cast<long long>(N) * d.Ho * d.Wo * d.C4;
-  hipLaunchKernelGGL(maxpool3x3s2_fwd, dim3(dbev_ceil_div(total, 256)), dim3(256), 0, dbev_stream(stream),
+  hipLaunchKernelGGL(maxpool3x3s2_fwd<false>, dim3(dbev_ceil_div(total, 256)), dim3(256), 0, dbev_stream(stream),
                      reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<float4*>(y_nhwc), reinterpret_cast<uchar4*>(winner), d,
-                     total);
+                     total, static_cast<const float*>(nullptr));
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dbev_norm_relu_maxpool3x3s2_forward(const float* x_nhwc, const float* scale_shift, int N, int H, int W, int C,
+                                                   float* y_nhwc, unsigned char* winner, dbevStream_t stream) {
+  MpDims d;
+  if (!mp_dims(N, H, W, C, &d) || x_nhwc == nullptr || scale_shift == nullptr || y_nhwc == nullptr || winner == nullptr) return DBEV_EINVAL;
+  const long long total = static_cast<long long>(N) * d.Ho * d.Wo * d.C4;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd<true>, dim3(dbev_ceil_div(total, 256)), dim3(256), 0, dbev_stream(stream),
+                     reinterpret_cast<const float4*>(x_nhwc), reinterpret_cast<float4*>(y_nhwc), reinterpret_cast<uchar4*>(winner), d,
+                     total, scale_shift);
   DBEV_LAUNCH_CHECK();
   return 0;
 }

@@ -635,6 +635,13 @@ int dbev_maxpool3x3s2_forward(const float* x_nhwc, int N, int H, int W, int C, f
                               dbevStream_t stream);
 int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* winner, int N, int H, int W, int C, float* grad_x_nhwc,
                                dbevStream_t stream);
+/* Round 5: the stem's norm -> ReLU -> max pooling as ONE pass over the convolution's output (mmdet ResNet.forward: `x = self.conv1(x);
+ * x = self.norm1(x); x = self.relu(x); x = self.maxpool(x)`): y = maxpool3x3s2(relu(x * scale + shift)), scale_shift f32[2 C] = the
+ * coefficient row dbev_bn_act_train_forward_mask(..., y = NULL) leaves in save_scale_shift (training: batch statistics) or
+ * dbev_bn_infer_coef (eval).  winner as dbev_maxpool3x3s2_forward (same tie rule on the same values); the backward is
+ * dbev_maxpool3x3s2_backward followed by dbev_bn_act_backward3 (gate recomputed from x). */
+int dbev_norm_relu_maxpool3x3s2_forward(const float* x_nhwc, const float* scale_shift, int N, int H, int W, int C, float* y_nhwc,
+                                        unsigned char* winner, dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 GEMM of a 1x1 convolution on the BF16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three bf16 values,

@@ -75,3 +75,51 @@ def test_stem_max_pool_kernels_vs_aten_values_ties_and_gradients(N, C, H, W):
     # other geometries / layouts keep the module
     assert max_pool(nn.MaxPool2d(2, 2), xa).grad_fn is not None and type(max_pool(nn.MaxPool2d(2, 2), xa).grad_fn).__name__ != "_MaxPool3x3s2Backward"
     assert type(max_pool(pool, x.to(dev).requires_grad_(True)).grad_fn).__name__ != "_MaxPool3x3s2Backward" or C == 1
+
+
+@pytest.mark.parametrize("N,C,H,W", [(3, 64, 18, 22), (2, 64, 64, 88), (1, 8, 9, 9)])
+def test_stem_norm_relu_max_pool_in_one_pass_equals_the_three_module_sequence(N, C, H, W):
+    """round 5: pool.norm_relu_max_pool = mmdet ResNet's stem tail `norm1 -> relu -> maxpool` (training mode) as the fused norm's
+    statistics + ONE normalise / rectify / pool pass: pooled output bit-equal to the product's own three-kernel sequence (bn_act +
+    max_pool: the same coefficients, the same tie rule on the same values), gradients of the input and of gamma / beta equal to it,
+    running statistics bit-equal; and against the plain torch modules within fp32 round-off."""
+    import torch.nn as nn
+    from distill_bev_amd import bn_act as BA
+    from distill_bev_amd.pool import max_pool, norm_relu_max_pool
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + W)
+    x0 = (torch.randn((N, C, H, W), generator=g) * 2).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    res = []
+    for which in ("fused", "sequence", "torch"):
+        torch.manual_seed(5)
+        bn = nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.uniform_(-1.0, 1.5); bn.bias.normal_(0, 0.5)          # negative scales too: the ReLU must be applied per tap
+        x = x0.clone().requires_grad_(True)
+        if which == "fused":
+            y = norm_relu_max_pool(bn, pool, x)
+            assert type(y.grad_fn).__name__ == "_NormReluMaxPoolBackward"
+        elif which == "sequence":
+            y = max_pool(pool, BA.bn_act(x, bn, None, True))
+        else:
+            y = pool(torch.relu(bn(x)))
+        gx, gw, gb = torch.autograd.grad(y, [x, bn.weight, bn.bias], gy)
+        res.append((y.detach(), gx, gw, gb, bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    f, s, t = res
+    assert torch.equal(f[0], s[0]) and torch.equal(f[4], s[4]) and torch.equal(f[5], s[5]) and f[6] == s[6] == t[6] == 1
+    for a, b in zip(f[1:4], s[1:4]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), float((a - b).abs().max())
+    assert torch.allclose(f[0], t[0], rtol=1e-5, atol=1e-5)
+    for a, b in zip(f[1:4], t[1:4]):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 1e-4
+    assert torch.allclose(f[4], t[4], rtol=1e-6, atol=1e-6) and torch.allclose(f[5], t[5], rtol=1e-5, atol=1e-6)
+    # the detached frame: no autograd, same values
+    with torch.no_grad():
+        torch.manual_seed(5)
+        bn = nn.BatchNorm2d(C).to(dev).train()
+        bn.weight.uniform_(-1.0, 1.5); bn.bias.normal_(0, 0.5)
+        assert torch.equal(norm_relu_max_pool(bn, pool, x0), f[0])
+    # eval-mode norms keep the module sequence
+    assert type(norm_relu_max_pool(bn.eval(), pool, x0.clone().requires_grad_(True)).grad_fn).__name__ != "_NormReluMaxPoolBackward"
