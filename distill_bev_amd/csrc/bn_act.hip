@@ -478,7 +478,11 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ 
                                                      const float* __restrict__ save_mean,
                                                      const float* __restrict__ save_invstd,
                                                      float* __restrict__ partial, BnGeom g,
-                                                     unsigned* __restrict__ tickets = nullptr, int ybyte = 0) {
+                                                     unsigned* __restrict__ tickets = nullptr, int ybyte = 0,
+                                                     float4* __restrict__ dz_out = nullptr) {
+  // dz_out (round 5, residual norms): the gated gradient dz = gate * (dy + dy2) is WRITTEN here -- it is the gradient of the identity
+  // branch anyway (`grad_residual`) -- so that the dx pass reads dz and x instead of dy, dy2, x and the gate: 4 + 3 tensor passes for
+  // the pair instead of 3 + 5 when the gradient arrives as two addends
   const int ql = threadIdx.x % g.CH, rp = threadIdx.x / g.CH;
   const int q = blockIdx.y * g.CH + ql;
   const float4 sc = reinterpret_cast<const float4*>(coef)[q];
@@ -513,6 +517,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const float4* __restrict__ 
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const float4 dz = gate<MASK>(a[u], v[u], o[u], sc, sh);      // rows past M: dy = 0 -> no contribution
+      if (MASK == 2 && dz_out != nullptr) {
+        const int r = r0 + u * stride;
+        if (r < r_end) st_nt(dz_out + static_cast<size_t>(r) * g.C4 + q, dz);
+      }
       float4 xh;
       xh.x = (v[u].x - mu.x) * is.x; xh.y = (v[u].y - mu.y) * is.y;
       xh.z = (v[u].z - mu.z) * is.z; xh.w = (v[u].w - mu.w) * is.w;
@@ -872,9 +880,9 @@ void launch_stats(const BnGeom& g, dim3 grid, hipStream_t s, const float4* x, fl
 template <int MASK>
 void launch_bwd_reduce(const BnGeom& g, dim3 grid, hipStream_t s, const float4* dy, const float4* dy2, const float4* x,
                        const float4* y, const float* coef, const float* mean, const float* invstd, float* partial,
-                       unsigned* tickets = nullptr, int ybyte = 0) {
+                       unsigned* tickets = nullptr, int ybyte = 0, float4* dz_out = nullptr) {
 #define BN_CALL(T, U) \
-  hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, dy2, x, y, coef, mean, invstd, partial, g, tickets, ybyte)
+  hipLaunchKernelGGL((bn_bwd_reduce<MASK, T, U>), grid, dim3(T), 0, s, dy, dy2, x, y, coef, mean, invstd, partial, g, tickets, ybyte, dz_out)
   BN_DISPATCH_TPB_UNR(BN_CALL);
 #undef BN_CALL
 }
@@ -1108,6 +1116,10 @@ extern "C" int dbev_bn_act_backward3(const float* grad_y, const float* grad_y2, 
   // the ReLU gate of the residual variant needs the saved output; without residual it is recomputed from x
   const int mask = !relu ? 0 : (grad_residual != nullptr ? 2 : 1);
   if (mask == 2 && y == nullptr) return DBEV_EINVAL;
+  // residual + ReLU: the reduce pass writes dz (= grad_residual), the dx pass reads it back (see bn_bwd_reduce); DBEV_BN_DZ_FIRST=0: the
+  // round-4 order (dx pass recomputes dz from dy, dy2 and the gate and writes it)
+  static const bool dz_first_on = getenv("DBEV_BN_DZ_FIRST") == nullptr || atoi(getenv("DBEV_BN_DZ_FIRST")) != 0;
+  const bool dz_first = mask == 2 && dz_first_on;
   hipStream_t s = dbev_stream(stream);
   float* partial = static_cast<float*>(workspace);
   float* bcoef = reinterpret_cast<float*>(static_cast<char*>(workspace) + bn_ws(g).total);
@@ -1119,10 +1131,12 @@ extern "C" int dbev_bn_act_backward3(const float* grad_y, const float* grad_y2, 
   const long long T = 4LL * g.M * C;
   unsigned* tk = bn_ticket_ok(g) ? bn_tickets(1) : nullptr;
   {
-    DbevKt kt(mask == 2 ? DBEV_K_BN_BWD_REDUCE_Y : DBEV_K_BN_BWD_REDUCE, T * 2 + (mask == 2 ? (y_is_mask ? T / 16 : T) : 0), s);
+    DbevKt kt(mask == 2 ? DBEV_K_BN_BWD_REDUCE_Y : DBEV_K_BN_BWD_REDUCE,
+              T * (2 + (grad_y2 != nullptr) + dz_first) + (mask == 2 ? (y_is_mask ? T / 16 : T) : 0), s);
     if (mask == 0) launch_bwd_reduce<0>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
     else if (mask == 1) launch_bwd_reduce<1>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk);
-    else launch_bwd_reduce<2>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk, y_is_mask);
+    else launch_bwd_reduce<2>(g, grid, s, dy4, dy24, x4, y4, save_scale_shift, save_mean, save_invstd, partial, tk, y_is_mask,
+                              dz_first ? reinterpret_cast<float4*>(grad_residual) : nullptr);
   }
   BnBfin fin{};
   if (tk != nullptr) {
@@ -1138,8 +1152,11 @@ extern "C" int dbev_bn_act_backward3(const float* grad_y, const float* grad_y2, 
   float4* dx4 = reinterpret_cast<float4*>(grad_x);
   float4* dr4 = reinterpret_cast<float4*>(grad_residual);
   DbevKt kt(grad_residual != nullptr ? DBEV_K_BN_BWD_DX_RES : DBEV_K_BN_BWD_DX,
-            T * (3 + (grad_residual != nullptr && mask != 0 ? 1 : 0)) + (mask == 2 ? (y_is_mask ? T / 16 : T) : 0), s);
-  if (grad_residual != nullptr) {
+            dz_first ? T * 3 : T * (3 + (grad_y2 != nullptr) + (grad_residual != nullptr && mask != 0 ? 1 : 0)) + (mask == 2 ? (y_is_mask ? T / 16 : T) : 0), s);
+  if (dz_first) {                        // dz is in grad_residual: dx = A dz + B x + C, nothing else to read or write
+    hipLaunchKernelGGL((bn_bwd_dx<0, false>), agrid, dim3(256), 0, s, reinterpret_cast<const float4*>(grad_residual),
+                       static_cast<const float4*>(nullptr), x4, y4, save_scale_shift, bcoef, dx4, static_cast<float4*>(nullptr), g, fin);
+  } else if (grad_residual != nullptr) {
     if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx<2, true>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin, y_is_mask);
     else hipLaunchKernelGGL((bn_bwd_dx<0, true>), agrid, dim3(256), 0, s, dy4, dy24, x4, y4, save_scale_shift, bcoef, dx4, dr4, g, fin);
   } else {

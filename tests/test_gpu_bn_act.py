@@ -366,3 +366,39 @@ def test_relu_gate_byte_mask_gives_bit_identical_gradients(dual):
     gx, gr = torch.autograd.grad(ref, [x, r], gy + gy2)
     assert torch.allclose(outs[0][0], ref.detach(), rtol=1e-5, atol=1e-5)
     assert torch.allclose(outs[0][1], gx, rtol=1e-4, atol=1e-5) and torch.allclose(outs[0][2], gr, rtol=1e-4, atol=1e-5)
+
+
+_DZ_SCRIPT = r"""
+import sys, torch, torch.nn as nn
+from distill_bev_amd import bn_act as BA
+dev = torch.device("cuda:0")
+out = []
+for shape, two in (((6, 256, 16, 44), True), ((6, 256, 16, 44), False), ((3, 64, 7, 5), True)):
+    g = torch.Generator().manual_seed(47)
+    cl = lambda: torch.randn(shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    x, r, gy, gy2 = cl().requires_grad_(True), cl().requires_grad_(True), cl(), cl()
+    torch.manual_seed(5)
+    bn = nn.BatchNorm2d(shape[1]).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    y = BA.bn_act(x, bn, r, True, fork=two)
+    outs, gys = ([y, BA.forked(y)], [gy, gy2]) if two else ([y], [gy])
+    out += [t.detach().cpu() for t in torch.autograd.grad(outs, [x, r, bn.weight, bn.bias], gys)]
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_residual_backward_that_writes_dz_in_the_reduce_pass_is_bit_identical_to_the_round4_order(tmp_path):
+    """Round 5: for a residual norm with ReLU the statistics pass of the backward writes dz = gate * (dy + dy2) into `grad_residual`
+    and the dx pass reads it back (7 tensor passes for the pair instead of 8 when two addends arrive); DBEV_BN_DZ_FIRST=0 keeps the
+    round-4 order (dx pass recomputes dz).  The switch is read once per process, so each order runs in its own interpreter: all four
+    gradients of three cases (two addends, one addend, ragged tiny shape) are bit-identical."""
+    import os, subprocess, sys
+    res = []
+    for v in ("1", "0"):
+        p = tmp_path / f"dz{v}.pt"
+        env = dict(os.environ, DBEV_BN_DZ_FIRST=v, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", _DZ_SCRIPT, str(p)], check=True, env=env, timeout=600)
+        res.append(torch.load(p))
+    assert len(res[0]) == 12 and all(torch.equal(a, b) for a, b in zip(*res))
+    assert all(bool(t.isfinite().all()) and float(t.abs().max()) > 0 for t in res[0])
