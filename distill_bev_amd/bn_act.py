@@ -266,11 +266,14 @@ class _Conv1x1Stats(Function):
                    alg_bytes=4 * M * (Ci + Co))
         ctx.save_for_backward(x, w)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)                  # no zero tensor for the (never used) gradient of the statistics output
         return z, part
 
     @staticmethod
     def backward(ctx, gz, _gpart):
         x, w = ctx.saved_tensors
+        if gz is None:
+            return None, None
         gz = gz.contiguous(memory_format=torch.channels_last)
         from .gemm_bf6 import data_gradient, weight_gradient
         gx = data_gradient(gz, w) if ctx.needs_input_grad[0] else None      # bf16x6 GEMMs where they apply, else the library

@@ -189,6 +189,7 @@ class _CenterHeadLoss(torch.autograd.Function):
         ctx.save_for_backward(hm, anno, ind, mask, avg, *heads)
         ctx.cfg = (tuple(ncls), tuple(code_w), float(lw_bbox), float(lw_cls), tuple(flags), (B, H, W))
         ctx.mark_non_differentiable(*sig)
+        ctx.set_materialize_grads(False)                  # no zero maps for the (never used) gradients of the sigmoid outputs
         return (losses, *sig)
 
     @staticmethod
@@ -197,6 +198,8 @@ class _CenterHeadLoss(torch.autograd.Function):
         hm, anno, ind, mask, avg, *heads = ctx.saved_tensors
         ncls, code_w, lw_bbox, lw_cls, flags, (B, H, W) = ctx.cfg
         T = len(ncls)
+        if g_losses is None:
+            return (None,) * (8 + len(heads))
         dev = g_losses.device
         # one zero-filled slab for the 5 regression-head gradients of every task (only object pixels are written),
         # heat-map gradients are fully written by the kernel

@@ -59,12 +59,15 @@ class _Conv1x1(Function):
         ctx.save_for_backward(x, weight)
         if stats:
             ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)              # no zero tensor for the (never used) gradient of the statistics output
             return y, part
         return y
 
     @staticmethod
     def backward(ctx, gy, _gpart=None):
         x, weight = ctx.saved_tensors
+        if gy is None:
+            return None, None, None
         gy = gy.contiguous(memory_format=torch.channels_last)
         dev = gy.device
         N, C, H, W = x.shape

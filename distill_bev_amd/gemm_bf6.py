@@ -218,12 +218,15 @@ class _Conv1x1S2Bf6(Function):
         if stats:
             y, part = product(xs, weight, stats=True)
             ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)              # no zero tensor for the (never used) gradient of the statistics output
             return y, part
         return product(xs, weight)
 
     @staticmethod
     def backward(ctx, gy, _gpart=None):
         xs, weight = ctx.saved_tensors
+        if gy is None:
+            return None, None, None
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -261,6 +264,7 @@ class _Conv1x1Bf6(Function):
         if stats:                                             # (bias-free layers in front of a training-mode norm)
             y, part = product(x, weight, stats=True)
             ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)              # no zero tensor for the (never used) gradient of the statistics output
             return y, part
         y = product(x, weight)
         if bias is not None:
@@ -270,6 +274,8 @@ class _Conv1x1Bf6(Function):
     @staticmethod
     def backward(ctx, gy, _gpart=None):
         x, weight = ctx.saved_tensors
+        if gy is None:
+            return None, None, None, None
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = gb = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]

@@ -223,11 +223,14 @@ class _Conv3x3Wino(Function):
         ctx.has_bias = bias is not None
         if stats:
             ctx.mark_non_differentiable(out[1])
+            ctx.set_materialize_grads(False)              # no zero tensor for the (never used) gradient of the statistics output
         return out
 
     @staticmethod
     def backward(ctx, gy, _gpart=None):
         x, weight = ctx.saved_tensors
+        if gy is None:
+            return None, None, None, None
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
