@@ -25,7 +25,9 @@ FLOP_LOGGED = {"wino_fwd": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32
                "g1_fwd": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "fp32"),
                "g1_wgrad": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "fp32"),
                "b6_fwd": (BF16X6_PEAK_TF, "bf16 MFMA dense peak / 6 (2516.8 / 6)", "fp32_equivalent"),
-               "b6_wgrad": (BF16X6_PEAK_TF, "bf16 MFMA dense peak / 6 (2516.8 / 6)", "fp32_equivalent")}
+               "b6_wgrad": (BF16X6_PEAK_TF, "bf16 MFMA dense peak / 6 (2516.8 / 6)", "fp32_equivalent"),
+               "stem_fwd": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "fp32"),
+               "stem_wgrad": (MFMA_F32_PEAK_TF, "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "fp32")}
 PMC_TRAFFIC = {"bn_apply_res_ratio": (540720.8 * 2 + 540672.0) * 1024 / (3 * 553648128.0),
                # the 3x3 layer 48 x 256 -> 256 x 16 x 44 (a hybrid launch: wino_fwd + wino_fwd3): FETCH_SIZE (49 592.2 + 19 068.0) KB x 2 +
                # WRITE_SIZE (30 072 + 4 224) KB = 175.7 MB per layer against 73.9 MB algorithmic (x, y once + packed filters): the four

@@ -86,6 +86,10 @@ _SIGNATURES = {
     "dbev_maxpool3x3s2_forward": [_p, _i, _i, _i, _i, _p, _p, _p],
     "dbev_maxpool3x3s2_backward": [_p, _p, _i, _i, _i, _i, _p, _p],
     "dbev_norm_relu_maxpool3x3s2_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "dbev_stem7x7s2_stats_rows": [_i, _i, _i],
+    "dbev_stem7x7s2_workspace_bytes": [_i, _i, _i],
+    "dbev_stem7x7s2_forward": [_p, _p, _i, _i, _i, _p, _p, _p, _sz, _p],
+    "dbev_stem7x7s2_backward_weight": [_p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "dbev_channel_sum_workspace_bytes": [_ll, _i],
     "dbev_gemm_bf16x6_packed_bytes": [_i, _i],
     "dbev_gemm_bf16x6_pack": [_p, _ll, _ll, _i, _i, _i, _p, _p],
@@ -162,6 +166,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_wino_filter_floats": ctypes.c_longlong,
+             "dbev_stem7x7s2_workspace_bytes": ctypes.c_longlong,
              "dbev_gemm1x1_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_wino_conv3x3_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_fallback_count": ctypes.c_longlong,
@@ -267,7 +272,8 @@ def call(name, *args, alg_bytes=0):
 
 KERNEL_IDS = {"bn_stats": 1, "bn_finalize": 2, "bn_apply": 3, "bn_apply_res": 4, "bn_bwd_reduce": 5, "bn_bwd_reduce_y": 6,
               "bn_bwd_finalize": 7, "bn_bwd_dx": 8, "bn_bwd_dx_res": 9, "sp_conv_fwd": 10, "msda_fwd": 11, "msda_bwd_sample": 12,
-              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15, "wino_fwd": 16, "wino_wgrad": 17, "g1_fwd": 18, "g1_wgrad": 19, "b6_fwd": 20, "b6_wgrad": 21}        # DBEV_K_* of include/dbev_hip.h
+              "msda_gv_gather": 13, "adapt_mse_fwd": 14, "c1x1_fwd": 15, "wino_fwd": 16, "wino_wgrad": 17, "g1_fwd": 18, "g1_wgrad": 19, "b6_fwd": 20, "b6_wgrad": 21,
+              "stem_fwd": 22, "stem_wgrad": 23}        # DBEV_K_* of include/dbev_hip.h
 
 
 def kernel_timing(which):

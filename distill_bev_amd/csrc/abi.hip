@@ -90,6 +90,8 @@ extern "C" const char* dbev_kernel_name(int kid) {
     case DBEV_K_GEMM1X1_WGRAD: return "g1_wgrad";
     case DBEV_K_B6_FWD: return "b6_fwd";
     case DBEV_K_B6_WGRAD: return "b6_wgrad";
+    case DBEV_K_STEM_FWD: return "stem_fwd";
+    case DBEV_K_STEM_WGRAD: return "stem_wgrad";
     default: return "?";
   }
 }

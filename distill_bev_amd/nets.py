@@ -21,7 +21,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 
 from .bn_act import bn_act, bn_act_dual, conv1x1_bn_ready, conv1x1_stats, forked, split_downsample
-from .pool import max_pool, norm_relu_max_pool
+from .pool import conv_norm_relu_max_pool, max_pool
 from .wino import conv3x3_bn_ready, conv3x3_stats
 from .registry import (MODELS, ConvModule, build_activation_layer, build_conv_layer, build_norm_layer,
                        build_upsample_layer, register_conv)
@@ -230,7 +230,7 @@ class ResNet(nn.Module):
         return getattr(self, self.norm1_name)
 
     def forward(self, x):
-        x = norm_relu_max_pool(self.norm1, self.maxpool, self.conv1(x))      # norm -> ReLU -> pooling: one pass when the kernels take it
+        x = conv_norm_relu_max_pool(self.conv1, self.norm1, self.maxpool, x)      # conv (+ statistics) -> norm / ReLU / pooling in one pass
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

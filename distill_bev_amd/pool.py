@@ -43,7 +43,8 @@ class _NormReluMaxPool(Function):
     recomputed from x (dbev_bn_act_backward3, no residual)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, part=None):
+        # part: per-workgroup channel sums the convolution in front left (stem.stem_conv_stats) -- the statistics pass does not run
         dev = x.device
         N, C, H, W = x.shape
         M = N * H * W
@@ -57,7 +58,7 @@ class _NormReluMaxPool(Function):
         with torch.cuda.device(dev):
             L.call("dbev_bn_act_train_forward_mask", L.ptr(x), None, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
                    L.ptr(nbt), float(momentum or 0.0), float(eps), 1, None, L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), M, C,
-                   None, 0, None, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+                   L.ptr(part), 0 if part is None else int(part.shape[0]), None, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
             L.call("dbev_norm_relu_maxpool3x3s2_forward", L.ptr(x), L.ptr(coef), N, H, W, C, L.ptr(y), L.ptr(win), L.stream_ptr(dev))
         L.touched(running_mean, running_var, nbt)
         ctx.save_for_backward(x, weight, save_mean, save_invstd, coef, win)
@@ -79,7 +80,7 @@ class _NormReluMaxPool(Function):
             L.call("dbev_maxpool3x3s2_backward", L.ptr(gy), L.ptr(win), N, H, W, C, L.ptr(ga), L.stream_ptr(dev))
             L.call("dbev_bn_act_backward3", L.ptr(ga), None, L.ptr(x), None, 0, L.ptr(weight), L.ptr(save_mean), L.ptr(save_invstd),
                    L.ptr(coef), 1, L.ptr(dx), None, L.ptr(dgamma), L.ptr(dbeta), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def _pool_geometry(module):
@@ -88,15 +89,30 @@ def _pool_geometry(module):
             and not module.return_indices)
 
 
-def norm_relu_max_pool(norm, pool, x):
+def _fusable(norm, pool, x):
+    from . import bn_act as BA
+    return (os.environ.get("DBEV_STEM_FUSE", "1") != "0" and _pool_geometry(pool) and BA.eligible(x, norm) and norm.training
+            and norm.running_mean is not None and norm.momentum is not None)
+
+
+def norm_relu_max_pool(norm, pool, x, part=None):
     """pool(relu(norm(x))) -- one fused pass when `norm` is a training-mode BatchNorm2d the fused norm kernels take and `pool` the
     stem's 3x3 / stride-2 pooling; the modules' own sequence (through bn_act / max_pool) otherwise"""
     from . import bn_act as BA
-    if (os.environ.get("DBEV_STEM_FUSE", "1") != "0" and _pool_geometry(pool) and BA.eligible(x, norm) and norm.training
-            and norm.running_mean is not None and norm.momentum is not None):
+    if _fusable(norm, pool, x):
         return _NormReluMaxPool.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.num_batches_tracked,
-                                      norm.momentum, norm.eps)
+                                      norm.momentum, norm.eps, part)
     return max_pool(pool, BA.bn_act(x, norm, None, True))
+
+
+def conv_norm_relu_max_pool(conv, norm, pool, x):
+    """The whole stem, pool(relu(norm(conv(x)))) (mmdet ResNet.forward): the 7x7 convolution on csrc/stem.hip with the norm's
+    statistics in its epilogue when the module and the tensors fit (stem.StemConv2d + a training-mode norm), `conv(x)` otherwise"""
+    from . import stem as S
+    if isinstance(conv, S.StemConv2d) and S.eligible(conv, x) and norm.training and os.environ.get("DBEV_STEM_STATS", "1") != "0":
+        z, part = S.stem_conv_stats(x, conv.weight)
+        return norm_relu_max_pool(norm, pool, z, part if _fusable(norm, pool, z) else None)
+    return norm_relu_max_pool(norm, pool, conv(x))
 
 
 def _pair(v):

@@ -53,7 +53,7 @@ enum {
   DBEV_K_BN_STATS = 1, DBEV_K_BN_FINALIZE, DBEV_K_BN_APPLY, DBEV_K_BN_APPLY_RES, DBEV_K_BN_BWD_REDUCE,
   DBEV_K_BN_BWD_REDUCE_Y, DBEV_K_BN_BWD_FINALIZE, DBEV_K_BN_BWD_DX, DBEV_K_BN_BWD_DX_RES, DBEV_K_SPCONV_FWD,
   DBEV_K_MSDA_FWD, DBEV_K_MSDA_BWD_SAMPLE, DBEV_K_MSDA_GV_GATHER, DBEV_K_ADAPT_MSE_FWD, DBEV_K_CONV1X1_FWD, DBEV_K_WINO_FWD, DBEV_K_WINO_WGRAD,
-  DBEV_K_GEMM1X1_FWD, DBEV_K_GEMM1X1_WGRAD, DBEV_K_B6_FWD, DBEV_K_B6_WGRAD, DBEV_K_COUNT
+  DBEV_K_GEMM1X1_FWD, DBEV_K_GEMM1X1_WGRAD, DBEV_K_B6_FWD, DBEV_K_B6_WGRAD, DBEV_K_STEM_FWD, DBEV_K_STEM_WGRAD, DBEV_K_COUNT
 };
 int dbev_kernel_timing_enable(int mask);
 int dbev_kernel_timing_read(int* kernel_id, float* ms, long long* algorithmic_bytes, int cap);
@@ -642,6 +642,24 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
  * dbev_maxpool3x3s2_backward followed by dbev_bn_act_backward3 (gate recomputed from x). */
 int dbev_norm_relu_maxpool3x3s2_forward(const float* x_nhwc, const float* scale_shift, int N, int H, int W, int C, float* y_nhwc,
                                         unsigned char* winner, dbevStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Round 5: the ResNet stem convolution, nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False) (mmdet ResNet.
+ * _make_stem_layer, `self.conv1`; replaces cuDNN behind it), on the fp32 matrix cores (csrc/stem.hip).  x_nhwc f32[N, H, W, 3],
+ * weight f32[64][7][7][3] (the channels-last memory of the [64, 3, 7, 7] parameter), z_nhwc f32[N, Ho, Wo, 64] with
+ * Ho = (H - 1) / 2 + 1, Wo likewise.  H, W >= 7.
+ *   forward: stats_partial f32[dbev_stem7x7s2_stats_rows(N, H, W)][2][64] = per workgroup the channel sums of z and z^2
+ *     (bn_finalize's partial-row layout, as the other convolutions' epilogues); NULL: not written.
+ *   backward_weight: grad_weight f32[64][7][7][3], every element written; fixed summation order (bit-reproducible).
+ *   workspace: dbev_stem7x7s2_workspace_bytes(N, H, W) bytes for either entry (0: unsupported geometry).
+ * The data gradient (the image's) is not provided: the image has none in the reference's training step.
+ * ---------------------------------------------------------------------------------- */
+int dbev_stem7x7s2_stats_rows(int N, int H, int W);
+long long dbev_stem7x7s2_workspace_bytes(int N, int H, int W);
+int dbev_stem7x7s2_forward(const float* x_nhwc, const float* weight, int N, int H, int W, float* z_nhwc, float* stats_partial,
+                           void* workspace, size_t workspace_bytes, dbevStream_t stream);
+int dbev_stem7x7s2_backward_weight(const float* x_nhwc, const float* grad_z_nhwc, int N, int H, int W, float* grad_weight,
+                                   void* workspace, size_t workspace_bytes, dbevStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 GEMM of a 1x1 convolution on the BF16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three bf16 values,
