@@ -323,7 +323,8 @@ __global__ __launch_bounds__(TPB) void bn_stats(const float4* __restrict__ x, fl
 }
 
 // 4 channels x 64 partial phases per workgroup; fp64 merge in a fixed order.  coef: [0] scale, [1] shift (forward) -- saved for backward.
-__global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ partial, int nbx, int M, int C,
+template <typename PT>
+__global__ __launch_bounds__(256) void bn_finalize(const PT* __restrict__ partial, int nbx, int M, int C,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                                    float momentum, float eps, float* __restrict__ save_mean,
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ par
   if (c < C) {
     int b = ph;
     for (; b + 7 * BN_FIN_PH < nbx; b += 8 * BN_FIN_PH) {      // 16 independent loads in flight: <= 512 partial rows = ONE trip
-      float a[8], q2[8];
+      PT a[8], q2[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         a[u] = partial[(static_cast<size_t>(b + u * BN_FIN_PH) * 2 + 0) * C + c];
@@ -907,6 +908,54 @@ bool bn_ticket_ok(const BnGeom& g) {
   return e != nullptr && atoi(e) != 0 && g.GY <= 2 && g.NBX <= BN_GROUP * BN_MAX_GROUPS;
 }
 
+// Thousands of partial rows (a convolution epilogue leaves one per 128 pixels: 4224 for the first stage of the image backbone) are
+// too many for bn_finalize's C / 4 workgroups -- 28 us for 8.6 MB read as 16-byte pieces.  bn_fold sums `per` consecutive rows of the
+// [nrows][2 C] table (fp64, row order) into one fp64 row: coalesced, one workgroup per 256 columns x `per` rows; bn_finalize<double>
+// then merges the few folded rows exactly as it merges float rows (fp64 sums either way: the result differs from the one-level
+// merge only by fp64 rounding).
+__global__ __launch_bounds__(256) void bn_fold(const float* __restrict__ rows, int nrows, int per, int C2, double* __restrict__ fold) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= C2) return;
+  const int r0 = blockIdx.y * per;
+  const int r1 = r0 + per < nrows ? r0 + per : nrows;
+  double s = 0.0;
+  int r = r0;
+  for (; r + 16 <= r1; r += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = rows[static_cast<size_t>(r + u) * C2 + col];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += static_cast<double>(v[u]);
+  }
+  for (; r < r1; ++r) s += static_cast<double>(rows[static_cast<size_t>(r) * C2 + col]);
+  fold[static_cast<size_t>(blockIdx.y) * C2 + col] = s;
+}
+constexpr int BN_FOLD_MIN_ROWS = 1024, BN_FOLD_PER = 32;
+
+// finalize of one norm from `nrows` partial rows; `scratch` (scratch_bytes): room for the folded rows (the call's own partial-row area,
+// idle when the rows come from a convolution's epilogue)
+void launch_finalize(hipStream_t s, const float* rows, int nrows, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, float* save_mean, float* save_invstd, float* coef,
+                     long long* num_batches_tracked, void* scratch, size_t scratch_bytes) {
+  static const bool fold_on = getenv("DBEV_BN_FOLD") == nullptr || atoi(getenv("DBEV_BN_FOLD")) != 0;
+  const size_t row_bytes = sizeof(double) * 2 * static_cast<size_t>(C);
+  const size_t room = scratch != nullptr && scratch != rows ? scratch_bytes / row_bytes : 0;
+  if (fold_on && nrows >= BN_FOLD_MIN_ROWS && room >= 2) {
+    int per = BN_FOLD_PER;
+    if (static_cast<size_t>(dbev_ceil_div(nrows, per)) > room) per = dbev_ceil_div(nrows, static_cast<int>(room));
+    const int R = dbev_ceil_div(nrows, per);
+    double* fold = static_cast<double*>(scratch);
+    DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nrows * C, s);
+    hipLaunchKernelGGL(bn_fold, dim3(dbev_ceil_div(2 * C, 256), R), dim3(256), 0, s, rows, nrows, per, 2 * C, fold);
+    hipLaunchKernelGGL(bn_finalize<double>, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, fold, R, M, C, gamma, beta, running_mean,
+                       running_var, momentum, eps, save_mean, save_invstd, coef, num_batches_tracked);
+    return;
+  }
+  DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nrows * C, s);
+  hipLaunchKernelGGL(bn_finalize<float>, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, rows, nrows, M, C, gamma, beta, running_mean,
+                     running_var, momentum, eps, save_mean, save_invstd, coef, num_batches_tracked);
+}
+
 struct BnWs { size_t partial, total; };
 BnWs bn_ws(const BnGeom& g) {
   BnWs w;
@@ -983,10 +1032,8 @@ extern "C" int dbev_bn_act_train_forward_mask(const float* x, const float* resid
     fin = BnFin{partial, g.NBX, g.M, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
                 num_batches_tracked};
   } else {
-    DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nrows * C, s);
-    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, rows, nrows, g.M, C, gamma, beta,
-                       running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
-                       num_batches_tracked);
+    launch_finalize(s, rows, nrows, g.M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                    save_scale_shift, num_batches_tracked, partial, sizeof(float) * static_cast<size_t>(g.NBX) * 2 * C);
   }
   if (y == nullptr) {
     DBEV_LAUNCH_CHECK();
@@ -1245,10 +1292,9 @@ extern "C" int dbev_bn_dual_train_forward_mask(const float* x, const float* xd, 
                   save_scale_shift_d, num_batches_tracked_d};
   } else {
     const int nr = stats_partial_d != nullptr ? partial_rows_d : g.NBX;
-    DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nr * C, s);
-    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, stats_partial_d != nullptr ? stats_partial_d : partial_d,
-                       nr, g.M, C, gamma_d, beta_d, running_mean_d, running_var_d, momentum_d, eps_d, save_mean_d, save_invstd_d,
-                       save_scale_shift_d, num_batches_tracked_d);
+    launch_finalize(s, stats_partial_d != nullptr ? stats_partial_d : partial_d, nr, g.M, C, gamma_d, beta_d, running_mean_d, running_var_d,
+                    momentum_d, eps_d, save_mean_d, save_invstd_d, save_scale_shift_d, num_batches_tracked_d, partial_d,
+                    sizeof(float) * static_cast<size_t>(g.NBX) * 2 * C);
   }
   if (stats_partial == nullptr) { DbevKt kt(DBEV_K_BN_STATS, T, s); launch_stats(g, grid, s, x4, partial, tk); }
   if (tk != nullptr) {
@@ -1256,10 +1302,8 @@ extern "C" int dbev_bn_dual_train_forward_mask(const float* x, const float* xd, 
                 num_batches_tracked};
   } else {
     const int nr = stats_partial != nullptr ? partial_rows : g.NBX;
-    DbevKt kt(DBEV_K_BN_FINALIZE, 8LL * nr * C, s);
-    hipLaunchKernelGGL(bn_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, stats_partial != nullptr ? stats_partial : partial,
-                       nr, g.M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, save_scale_shift,
-                       num_batches_tracked);
+    launch_finalize(s, stats_partial != nullptr ? stats_partial : partial, nr, g.M, C, gamma, beta, running_mean, running_var, momentum, eps,
+                    save_mean, save_invstd, save_scale_shift, num_batches_tracked, partial, sizeof(float) * static_cast<size_t>(g.NBX) * 2 * C);
   }
   const long long tiles = (M + static_cast<long long>(g.RP) * BN_ROWS_UNROLL - 1) / (static_cast<long long>(g.RP) * BN_ROWS_UNROLL);
   const long long cap = static_cast<long long>(DBEV_MAX_GRID) * 2 / g.GY;
