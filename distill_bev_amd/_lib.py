@@ -287,7 +287,20 @@ def kernel_timing(which):
         mask = 0
         for k in which:
             mask |= 1 << KERNEL_IDS[k]
+    global _KT_MASK
+    _KT_MASK = mask
     lib().dbev_kernel_timing_enable(mask)
+
+
+_KT_MASK = 0
+
+
+def kernel_timing_active(full=False):
+    """is any host-side timing on (the library's kernel event log or the per-entry-point event brackets)?  HIP-graph capture
+    (graphed.py) steps aside while it is: events are host code.  full=True: is EVERY kernel being logged (mask -1 / brackets on)?"""
+    if full:
+        return _KT_MASK == -1 or bool(_timers)
+    return _KT_MASK != 0 or bool(_timers)
 
 
 def kernel_timing_read():

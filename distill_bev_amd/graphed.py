@@ -1,0 +1,97 @@
+"""HIP-graph replay of a gradient-free, fixed-shape piece of the training step.
+
+The adjacent camera frame of BEVDepth4D goes through the image backbone and neck without a gradient (bevdet_distill_more.py:389-441:
+its BEV map is detached; detectors.extract_img_feat runs it under no_grad): ~330 kernel launches whose host side (module calls,
+autograd.Function.apply, ctypes marshalling) is a pure replayable sequence -- same shapes, same buffers, no host decision depends on
+device data.  `GraphedNoGrad(fn)` captures `fn(x)` into a hipGraph the third time it sees an input signature and replays it
+afterwards: the input is copied into the graph's static input, the output is the graph's static output (valid until the next
+replay).  Measured (tools/fwd_host_vs_gpu.py, tools/ab_env.sh DBEV_GRAPH_ADJ 0 1): the host issues the step's forward in 23.7 ->
+18 ms against 48 ms of GPU time -- the step is NOT host-bound on an idle host, the replay buys 0.2-0.6 ms per step (shorter bubbles
+behind the forward's one synchronising call) and headroom when eight ranks share one host's cores.
+
+What makes a replay equal to an eager call (the owner must guarantee it -- train_step.Trainer does):
+  * the kernels read the layers' packed weights (Winograd filters, bf16 planes) from buffers that are refreshed IN PLACE after every
+    optimizer step (packer.WeightPacker.repack) -- the lazy per-layer re-pack lives in Python and does not run in a replay;
+  * training-mode norms update their running statistics inside the captured kernels (in place, stable addresses);
+  * `valid_token()` -- anything that changes module state behind the graph's back (load_state_dict, train()/eval(), a different
+    parameter tensor) changes the token and the graph is captured again.
+The kernel event log (dbev_kernel_timing_*) is host code: replayed launches are not logged.  Nothing is captured while any timing is
+on, and while EVERY kernel is logged (mask -1, or the per-entry-point brackets: bench.py's instrumented steps) the call runs eagerly."""
+import os
+
+import torch
+
+_ON = os.environ.get("DBEV_GRAPH_ADJ", "1") != "0"
+
+
+def enabled():
+    return _ON
+
+
+class GraphedNoGrad:
+    def __init__(self, fn, token=None, warmup=2, written=None):
+        """written: callable -> the tensors the captured kernels write in place (running statistics): their version counters are
+        moved after every replay, as the eager path's _lib.touched does (the kept eval-mode coefficients are keyed on them)"""
+        self.fn, self.token, self.warmup, self.written = fn, token, warmup, written
+        self.graphs = {}
+        self.replays = self.captures = self.eager = 0
+
+    def reset(self):
+        self.graphs.clear()
+
+    def _eager(self, x):
+        self.eager += 1
+        with torch.no_grad():
+            return self.fn(x)
+
+    def __call__(self, x):
+        from . import _lib as L
+        if not (_ON and x.is_cuda) or torch.cuda.is_current_stream_capturing() or L.kernel_timing_active(full=True):
+            return self._eager(x)                 # (every kernel is being logged: the instrumented steps of bench.py see all launches)
+        tok = self.token() if self.token is not None else None
+        key = (tuple(x.shape), x.dtype, x.device)
+        ent = self.graphs.get(key)
+        if ent is not None and ent["token"] != tok:
+            ent = None
+            self.graphs.pop(key)
+        if ent is None:
+            seen = self.graphs.setdefault(("seen",) + key, {"n": 0})
+            seen["n"] += 1
+            if seen["n"] <= self.warmup or L.kernel_timing_active():
+                return self._eager(x)             # the first calls run eagerly: library plans, MIOpen solutions, lazy packs settle
+            ent = self._capture(x, tok)
+            self.graphs[key] = ent
+        ent["x"].copy_(x)
+        ent["graph"].replay()
+        self.replays += 1
+        if self.written is not None:
+            L.touched(*self.written())
+        return ent["y"]
+
+    def _capture(self, x, tok):
+        static_x = torch.empty_like(x)
+        static_x.copy_(x)
+        torch.cuda.synchronize(x.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            with torch.cuda.graph(graph):
+                y = self.fn(static_x)
+        torch.cuda.synchronize(x.device)
+        self.captures += 1
+        return {"graph": graph, "x": static_x, "y": y, "token": tok}
+
+
+def state_token(*modules):
+    """changes when something a captured graph baked in may have changed: the identity of a parameter / buffer tensor or its storage, a
+    module's training flag.  (Values may change freely -- the graph reads them through the same addresses.)"""
+    t = []
+    for m in modules:
+        if m is None:
+            continue
+        for mod in m.modules():
+            t.append(mod.training)
+        for p in m.parameters():
+            t.append(p.data_ptr())
+        for b in m.buffers():
+            t.append(b.data_ptr())
+    return hash(tuple(t))

@@ -423,6 +423,16 @@ class Trainer:
             if device.type == "cuda":
                 from .packer import WeightPacker
                 self.packer = WeightPacker([self.detector])      # the trainable layers' packed weights: one launch per family and step
+                from . import graphed
+                if graphed.enabled() and hasattr(self.detector, "image_encoder"):
+                    # the gradient-free adjacent frame's backbone + neck as one hipGraph (valid because the packs above are
+                    # refreshed in place after every optimizer step)
+                    det = self.detector
+                    mods = [getattr(det, "img_backbone", None), getattr(det, "img_neck", None)]
+                    stats = lambda: [b for m in mods if m is not None for mod in m.modules()
+                                     if isinstance(mod, nn.modules.batchnorm._BatchNorm) and mod.training and mod.running_mean is not None
+                                     for b in (mod.running_mean, mod.running_var, mod.num_batches_tracked)]
+                    det.adjacent_graph = graphed.GraphedNoGrad(det.image_encoder, token=lambda: graphed.state_token(*mods), written=stats)
         self.wrapper = _TrainWrapper(self.detector)
         self.world_size = world_size
         self.reducer = None
@@ -452,10 +462,12 @@ class Trainer:
         self.params = params
 
     def close(self):
-        """drop the data-parallel reducer's autograd hooks (a Trainer that is discarded while its detector lives on)"""
+        """drop the data-parallel reducer's autograd hooks and the captured graph (a Trainer that is discarded while its detector lives on)"""
         if self.reducer is not None:
             self.reducer.close()
             self.reducer = None
+        if getattr(self.detector, "adjacent_graph", None) is not None:
+            self.detector.adjacent_graph = None      # its replays rely on this trainer's in-place re-packing after every optimizer step
 
     def step(self, batch):
         if self.reducer is not None and self.reducer.dirty():
