@@ -29,10 +29,12 @@ def enabled():
 
 
 class GraphedNoGrad:
-    def __init__(self, fn, token=None, warmup=2, written=None):
-        """written: callable -> the tensors the captured kernels write in place (running statistics): their version counters are
-        moved after every replay, as the eager path's _lib.touched does (the kept eval-mode coefficients are keyed on them)"""
-        self.fn, self.token, self.warmup, self.written = fn, token, warmup, written
+    def __init__(self, fn, token=None, warmup=2, norms=None):
+        """norms: callable -> the training-mode norm modules inside `fn`: the captured kernels update their running statistics in
+        place WITHOUT the version bump the eager path gives them (_lib.touched), so whatever is kept per module keyed on those
+        versions (bn_act's eval-mode coefficients) is dropped after every replay.  (Bumping the versions here instead would trip
+        autograd's saved-tensor check of a stock batch_norm that saved the same buffers in the key frame's forward.)"""
+        self.fn, self.token, self.warmup, self.norms = fn, token, warmup, norms
         self.graphs = {}
         self.replays = self.captures = self.eager = 0
 
@@ -64,8 +66,9 @@ class GraphedNoGrad:
         ent["x"].copy_(x)
         ent["graph"].replay()
         self.replays += 1
-        if self.written is not None:
-            L.touched(*self.written())
+        if self.norms is not None:
+            for m in self.norms():
+                m.__dict__.pop("_dbev_eval_coef", None)
         return ent["y"]
 
     def _capture(self, x, tok):

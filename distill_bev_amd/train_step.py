@@ -429,10 +429,9 @@ class Trainer:
                     # refreshed in place after every optimizer step)
                     det = self.detector
                     mods = [getattr(det, "img_backbone", None), getattr(det, "img_neck", None)]
-                    stats = lambda: [b for m in mods if m is not None for mod in m.modules()
-                                     if isinstance(mod, nn.modules.batchnorm._BatchNorm) and mod.training and mod.running_mean is not None
-                                     for b in (mod.running_mean, mod.running_var, mod.num_batches_tracked)]
-                    det.adjacent_graph = graphed.GraphedNoGrad(det.image_encoder, token=lambda: graphed.state_token(*mods), written=stats)
+                    norms = lambda: [mod for m in mods if m is not None for mod in m.modules()
+                                     if isinstance(mod, nn.modules.batchnorm._BatchNorm)]
+                    det.adjacent_graph = graphed.GraphedNoGrad(det.image_encoder, token=lambda: graphed.state_token(*mods), norms=norms)
         self.wrapper = _TrainWrapper(self.detector)
         self.world_size = world_size
         self.reducer = None

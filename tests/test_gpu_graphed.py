@@ -39,7 +39,7 @@ def test_replay_equals_eager_while_the_weights_move(monkeypatch):
         opt = torch.optim.AdamW(net.parameters(), lr=1e-2, fused=True)
         packer = WeightPacker([net])
         fn = graphed.GraphedNoGrad(lambda t: net(t), token=lambda: graphed.state_token(net),
-                                   written=lambda: [b for b in net.buffers()]) if use_graph else None
+                                   norms=lambda: [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)]) if use_graph else None
         outs = []
         for x in xs:
             with torch.no_grad():
@@ -59,7 +59,7 @@ def test_replay_equals_eager_while_the_weights_move(monkeypatch):
         assert torch.equal(a, b)                               # running statistics / num_batches_tracked: updated inside the replays
 
 
-def test_state_change_recaptures_and_versions_move(monkeypatch):
+def test_state_change_recaptures_and_eval_coefficients_follow_the_replays(monkeypatch):
     from distill_bev_amd import gemm_bf6, graphed, wino
     monkeypatch.setattr(wino, "_MIN_WG", 0)
     monkeypatch.setattr(gemm_bf6, "_MIN_ITEMS", 1)
@@ -67,17 +67,24 @@ def test_state_change_recaptures_and_versions_move(monkeypatch):
     dev = torch.device("cuda:0")
     net = _net(dev, seed=5)
     x = torch.randn((2, 64, 8, 16), device=dev).contiguous(memory_format=torch.channels_last)
-    bufs = lambda: [b for b in net.buffers()]
-    fn = graphed.GraphedNoGrad(lambda t: net(t), token=lambda: graphed.state_token(net), written=bufs, warmup=1)
+    norms = lambda: [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)]
+    fn = graphed.GraphedNoGrad(lambda t: net(t), token=lambda: graphed.state_token(net), norms=norms, warmup=1)
     fn(x)
-    v0 = [b._version for b in bufs()]
-    y1 = fn(x).clone()                                         # captured + replayed
-    assert fn.captures == 1 and fn.replays == 1
-    assert all(b._version > v for b, v in zip(bufs(), v0))     # as the eager path's _lib.touched
+    net.eval()
+    with torch.no_grad():
+        e0 = net(x).clone()                                    # eval-mode coefficients are now kept on the norm modules
+    net.train()
+    fn(x)                                                      # captured + replayed: running statistics move inside the graph
+    y1 = fn(x).clone()
+    assert fn.captures == 1 and fn.replays == 2
     net.eval()                                                 # a training flag the graph baked in: the token changes
     ye = fn(x).clone()
     with torch.no_grad():
         assert torch.equal(ye, net(x))
+    ref = _net(dev, seed=5)                                    # the same sequence without the graph: the eval output after the updates
+    with torch.no_grad():
+        ref.train(); ref(x); ref.eval(); ref(x); ref.train(); ref(x); ref(x); ref.eval()
+        assert torch.equal(ye, ref(x)) and not torch.equal(ye, e0)      # not the coefficients kept before the replays
     assert fn.eager >= 2 or fn.captures == 2
     net.train()
     fn(x); fn(x)
