@@ -367,9 +367,16 @@ __device__ __forceinline__ void b6_split2s(float a, float b, unsigned& p0, unsig
 #define B6_W1 11
 #endif
 
-template <int BN, bool STATS>
+// CONV (round 5): the same GEMM as an IMPLICIT one for nn.Conv2d(C, Co, 3, stride 2, padding 1) -- row m is the output pixel (n, i, j),
+// reduction index k = (ky * 3 + kx) * C + c (the channels-last filter's memory order, so the packed planes come from the ordinary
+// pack of the [Co][9 C] matrix), a 16-wide chunk lies inside one tap: its activation fragment is 16 consecutive channels of input
+// pixel (2 i + ky - 1, 2 j + kx - 1), or zeros outside the map (the load goes to a valid offset and the value is discarded: no
+// branch).  Everything behind the activation fetch -- split, LDS image, weight DMA, schedule, epilogues -- is the 1x1 kernel's.
+struct B6Conv { int H, W, C, Ho, Wo, cshift; };                          // cshift = log2(C / 16) (C a power of two >= 64)
+template <int BN, bool STATS, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, const unsigned short* __restrict__ Wp,
-                                                  float* __restrict__ Y, float* __restrict__ partial, int M, int K, int N, int xs) {
+                                                  float* __restrict__ Y, float* __restrict__ partial, int M, int K, int N, int xs,
+                                                  B6Conv cv = B6Conv{}) {
   constexpr int WN = BN / 64, WM = 4 / WN, TM = B6_BM / WM / 32;            // waves along N / M, 32-row tiles per wave
   constexpr int APL = B6_BM * 32, BPL = BN * 32;                            // bytes of one plane of a chunk
   constexpr int ABUF = 3 * APL, BBUF = 3 * BPL;                             // 12288, 12288 / 6144
@@ -389,8 +396,28 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
 
   const int row0 = tid >> 2, row1 = 64 + (tid >> 2), c4 = tid & 3;
   typedef const __attribute__((address_space(1))) float* gfloat_p;
-  const gfloat_p xb = reinterpret_cast<gfloat_p>(b6_uniform64(reinterpret_cast<unsigned long long>(X + static_cast<size_t>(m0) * xs)));
+  const gfloat_p xb = reinterpret_cast<gfloat_p>(b6_uniform64(reinterpret_cast<unsigned long long>(X + (CONV ? 0 : static_cast<size_t>(m0) * xs))));
   const unsigned xo0 = static_cast<unsigned>(row0 * xs + 4 * c4), xo1 = static_cast<unsigned>(row1 * xs + 4 * c4);
+  int pb0 = 0, pb1 = 0;                                                     // CONV: float offset of tap (0, 0) of the row's pixel (may be < 0)
+  unsigned vm0 = 0, vm1 = 0;                                                //       bit t: tap t lies inside the map
+  if (CONV) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int m = m0 + (q ? row1 : row0);
+      const int j = m % cv.Wo, t = m / cv.Wo;
+      const int i = t % cv.Ho, n = t / cv.Ho;
+      const int pb = ((n * cv.H + 2 * i - 1) * cv.W + 2 * j - 1) * cv.C + 4 * c4;
+      unsigned vm = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = 2 * i + ky - 1, xx = 2 * j + kx - 1;
+          if (yy >= 0 && yy < cv.H && xx >= 0 && xx < cv.W) vm |= 1u << (ky * 3 + kx);
+        }
+      if (q) { pb1 = pb; vm1 = vm; } else { pb0 = pb; vm0 = vm; }
+    }
+  }
   const int aoff0 = row0 * 32 + (((c4 >> 1) ^ ((row0 >> 3) & 1)) * 16) + (c4 & 1) * 8;
   const int aoff1 = row1 * 32 + (((c4 >> 1) ^ ((row1 >> 3) & 1)) * 16) + (c4 & 1) * 8;
   // weight chunks of this column block: LDS-DMA, wave w copies the 1 KB pieces w, w + 4, w + 8 (BN = 128) / piece w and a quarter
@@ -428,12 +455,25 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
     }                                                                                                                \
   } while (0)
   floatx4 xa0_0, xa0_1, xa1_0, xa1_1;                                    // raw activations of two chunks in flight
+  bool xf0_0 = true, xf0_1 = true, xf1_0 = true, xf1_1 = true;           // CONV: ... and whether their tap lies inside the map
 #define B6_LOADA(q_, kc_)                                                                                            \
   do {                                                                                                               \
     const int kq_ = (kc_) < nkc ? (kc_) : nkc - 1;                                                                   \
-    const gfloat_p xc_ = xb + kq_ * B6_KC;                                                                           \
-    xa##q_##_0 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo0);                      \
-    xa##q_##_1 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo1);                      \
+    if (CONV) {                                                                                                      \
+      const int tap_ = kq_ >> cv.cshift;                                                                             \
+      const int ky_ = (tap_ * 11) >> 5;                                                                              \
+      const int toff_ = (ky_ * cv.W + (tap_ - 3 * ky_)) * cv.C + ((kq_ - (tap_ << cv.cshift)) << 4);                 \
+      xf##q_##_0 = (vm0 >> tap_) & 1u;                                                                               \
+      xf##q_##_1 = (vm1 >> tap_) & 1u;                                                                               \
+      const unsigned o0_ = xf##q_##_0 ? static_cast<unsigned>(pb0 + toff_) : static_cast<unsigned>(4 * c4);         \
+      const unsigned o1_ = xf##q_##_1 ? static_cast<unsigned>(pb1 + toff_) : static_cast<unsigned>(4 * c4);         \
+      xa##q_##_0 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xb + o0_);                     \
+      xa##q_##_1 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xb + o1_);                     \
+    } else {                                                                                                         \
+      const gfloat_p xc_ = xb + kq_ * B6_KC;                                                                         \
+      xa##q_##_0 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo0);                    \
+      xa##q_##_1 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo1);                    \
+    }                                                                                                                \
   } while (0)
 #define B6_SPLIT_STORE2(v_, off_)                                                                                    \
   do {                                                                                                               \
@@ -447,6 +487,11 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
 #define B6_STAGEA(q_, buf_)                                                                                          \
   do {                                                                                                               \
     unsigned char* a_ = sA + (buf_) * ABUF;                                                                          \
+    if (CONV) {                                                                                                      \
+      const floatx4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                                      \
+      xa##q_##_0 = xf##q_##_0 ? xa##q_##_0 : z4_;                                                                    \
+      xa##q_##_1 = xf##q_##_1 ? xa##q_##_1 : z4_;                                                                    \
+    }                                                                                                                \
     B6_SPLIT_STORE2(xa##q_##_0, aoff0);                                                                              \
     B6_SPLIT_STORE2(xa##q_##_1, aoff1);                                                                              \
   } while (0)
@@ -1036,6 +1081,46 @@ extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed
 extern "C" int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
                                         int tile_n, dbevStream_t stream) {
   return dbev_gemm_bf16x6_forward_stats(x, packed, y, nullptr, M, K, N, x_row_stride, tile_n, stream);
+}
+
+namespace {
+bool c3s2_ok(int N, int H, int W, int C, int Co) {
+  if (N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 64 || (C & (C - 1)) != 0 || Co <= 0 || Co % 64) return false;   // C = 64, 128, 256 ...
+  const long long M = static_cast<long long>(N) * (H / 2) * (W / 2);
+  return M % B6_BM == 0 && static_cast<long long>(N) * H * W * C < (1LL << 31) && M * Co < (1LL << 31) && b6_ok(M, 9 * C, Co, 9 * C);
+}
+}  // namespace
+
+extern "C" int dbev_conv3x3s2_bf16x6_ok(int N, int H, int W, int C, int Co) { return c3s2_ok(N, H, W, C, Co) ? 1 : 0; }
+
+extern "C" int dbev_conv3x3s2_bf16x6_forward_stats(const float* x_nhwc, const void* packed, float* y_nhwc, float* stats_partial, int N, int H,
+                                                   int W, int C, int Co, int tile_n, dbevStream_t stream) {
+  if (!c3s2_ok(N, H, W, C, Co) || x_nhwc == nullptr || packed == nullptr || y_nhwc == nullptr ||
+      (tile_n != 0 && tile_n != 64 && tile_n != 128) || (tile_n == 128 && (Co % 128) != 0))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  B6Conv cv{H, W, C, H / 2, W / 2, 0};
+  while ((16 << cv.cshift) < C) ++cv.cshift;
+  const int m = N * cv.Ho * cv.Wo, K = 9 * C;
+  const int bn = b6_bn(Co, tile_n);
+  const int grid = dbev_round_xcd((m / B6_BM) * (Co / bn));
+  DbevKt kt(DBEV_K_B6_FWD, 2LL * m * K * Co, s);
+  const unsigned short* pw = static_cast<const unsigned short*>(packed);
+#define B6_GOC(BNV, ST)                                                                                                            \
+  do {                                                                                                                             \
+    constexpr int lds_ = 2 * 3 * B6_BM * 32 + 4 * 3 * BNV * 32;                                                                    \
+    static bool once_ = false;                                                                                                     \
+    if (!once_) {                                                                                                                  \
+      DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b6_fwd2<BNV, ST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
+      once_ = true;                                                                                                                \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((b6_fwd2<BNV, ST, true>), dim3(grid), dim3(256), lds_, s, x_nhwc, pw, y_nhwc, stats_partial, m, K, Co, K, cv); \
+  } while (0)
+  if (bn == 128) { if (stats_partial != nullptr) B6_GOC(128, true); else B6_GOC(128, false); }
+  else { if (stats_partial != nullptr) B6_GOC(64, true); else B6_GOC(64, false); }
+#undef B6_GOC
+  DBEV_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" size_t dbev_gemm_bf16x6_backward_weight_workspace_bytes(long long M, int Cin, int Cout, int x_row_stride) {

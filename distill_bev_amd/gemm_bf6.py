@@ -56,11 +56,21 @@ def eligible(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1
     return weight.shape[1] == C and _nhwc(x) and shape_ok(N * H * W, C, weight.shape[0])
 
 
+def matrix(weight):
+    """the [Cout, K] matrix the GEMM kernels multiply by: a 1x1 filter itself (either memory format), or the channels-last memory
+    [Cout][ky][kx][c] of a k x k filter taken as K = k k Cin columns (a view when the filter is channels-last contiguous)"""
+    Co, Ci, kh, kw = weight.shape
+    if (kh, kw) == (1, 1):
+        return weight.detach().reshape(Co, Ci)
+    return weight.detach().permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci)
+
+
 def packed(weight, transposed=False, tn=128):
     """the three bf16 planes of `weight` [Cout, Cin, 1, 1] in the kernel's LDS image order (dbev_gemm_bf16x6_pack), kept on the weight
     until it changes.  transposed: for the data gradient (rows = input channels, reduction over the output channels)."""
     dev = L.require_cuda(weight)
-    Co, Ci = int(weight.shape[0]), int(weight.shape[1])
+    w2 = matrix(weight)                                       # a view for both memory formats of a 1x1 filter
+    Co, Ci = int(w2.shape[0]), int(w2.shape[1])
     key = (weight._version, weight.data_ptr())
     cache = getattr(weight, "_dbev_bf6_packs", None)
     if cache is None or cache[0] != key:
@@ -76,7 +86,6 @@ def packed(weight, transposed=False, tn=128):
     hit = cache[1].get((bool(transposed), tn))
     if hit is not None:
         return hit
-    w2 = weight.detach().reshape(Co, Ci)                      # a view for both memory formats of a 1x1 filter
     n, k = (Ci, Co) if transposed else (Co, Ci)
     sn, sk = (w2.stride(1), w2.stride(0)) if transposed else (w2.stride(0), w2.stride(1))
     nbytes = int(L.call("dbev_gemm_bf16x6_packed_bytes", n, k))
@@ -305,6 +314,84 @@ def conv1x1(x, weight, bias=None):
     return _Conv1x1Bf6.apply(x, weight, bias)
 
 
+# ---- 3x3 / stride-2 convolutions (conv2 of a stage-first bottleneck): implicit GEMM, forward only ---------------------------------------
+_C3 = os.environ.get("DBEV_BF6_C3S2", "1") != "0"
+
+
+def eligible_c3s2(x, weight, stride=(2, 2), padding=(1, 1), dilation=(1, 1), groups=1):
+    """can `F.conv2d(x, weight, stride=2, padding=1)` (3x3) run as the implicit bf16x6 GEMM?  channels-last fp32 input AND filter (the
+    filter's memory is the [Cout][9 Cin] matrix), the library's geometry rules (dbev_conv3x3s2_bf16x6_ok), a launch that fills the chip"""
+    if not (_ON and _C3 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    if tuple(weight.shape[2:]) != (3, 3) or tuple(stride) != (2, 2) or tuple(padding) != (1, 1) or tuple(dilation) != (1, 1) or groups != 1:
+        return False
+    N, C, H, W = x.shape
+    Co = int(weight.shape[0])
+    if not (weight.shape[1] == C and _nhwc(x) and _nhwc(weight) and L.lib().dbev_conv3x3s2_bf16x6_ok(N, H, W, C, Co)):
+        return False
+    M = N * (H // 2) * (W // 2)
+    return (M // 128) * (Co // tile_n(M, Co)) >= _MIN_ITEMS
+
+
+def product_c3s2(x, weight, stats=False):
+    """conv2d(x, weight, stride 2, padding 1) of channels-last tensors (no autograd) [+ the output's partial statistics rows]"""
+    dev = L.require_cuda(x, weight)
+    N, C, H, W = x.shape
+    Co = int(weight.shape[0])
+    M = N * (H // 2) * (W // 2)
+    tn = tile_n(M, Co)
+    pack = packed(weight, False, tn)
+    y = torch.empty((N, Co, H // 2, W // 2), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    part = torch.empty((int(L.call("dbev_gemm_bf16x6_stats_rows", M)), 2, Co), dtype=torch.float32, device=dev) if stats else None
+    with torch.cuda.device(dev):
+        L.call("dbev_conv3x3s2_bf16x6_forward_stats", L.ptr(x), L.ptr(pack), L.ptr(y), L.ptr(part), N, H, W, C, Co, int(tn), L.stream_ptr(dev))
+    return (y, part) if stats else y
+
+
+class _Conv3x3S2Bf6(Function):
+    """forward on the implicit bf16x6 GEMM; both gradients are the library's (aten.convolution_backward) this round"""
+
+    @staticmethod
+    def forward(ctx, x, weight, stats=False):
+        ctx.save_for_backward(x, weight)
+        if stats:
+            y, part = product_c3s2(x, weight, True)
+            ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)
+            return y, part
+        return product_c3s2(x, weight)
+
+    @staticmethod
+    def backward(ctx, gy, _gpart=None):
+        x, weight = ctx.saved_tensors
+        if gy is None:
+            return None, None, None
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw, None
+
+
+def conv3x3_s2(x, weight):
+    return _Conv3x3S2Bf6.apply(x, weight, False)
+
+
+def conv3x3_s2_stats(x, weight):
+    return _Conv3x3S2Bf6.apply(x, weight, True)
+
+
+class Bf6Conv3x3S2(nn.Conv2d):
+    """nn.Conv2d(3x3, stride 2, padding 1, no bias) whose forward runs on the implicit bf16x6 GEMM when the input qualifies
+    (`eligible_c3s2`); the stock convolution otherwise.  Same parameters and state-dict keys."""
+
+    def forward(self, x):
+        if self.bias is None and eligible_c3s2(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+                return product_c3s2(x, self.weight)
+            return conv3x3_s2(x, self.weight)
+        return super().forward(x)
+
+
 class Bf6Conv2d(nn.Conv2d):
     """nn.Conv2d (1x1, stride 1 or 2, no padding, no bias) whose forward and gradients run on the bf16x6 GEMM when the input qualifies
     (`eligible` / `eligible_s2`: stride 2 = subsample + GEMM); the stock convolution otherwise.  Same parameters and state-dict keys."""
@@ -331,5 +418,10 @@ def use_bf6_convs(model):
         if type(m) is nn.Conv2d and m.kernel_size == (1, 1) and m.stride in ((1, 1), (2, 2)) and m.padding == (0, 0) \
                 and m.dilation == (1, 1) and m.groups == 1 and m.bias is None and m.in_channels % 64 == 0 and m.out_channels % 64 == 0:
             m.__class__ = Bf6Conv2d
+            n += 1
+        elif _C3 and type(m) is nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (2, 2) and m.padding == (1, 1) \
+                and m.dilation == (1, 1) and m.groups == 1 and m.bias is None and m.in_channels >= 64 \
+                and (m.in_channels & (m.in_channels - 1)) == 0 and m.out_channels % 64 == 0:
+            m.__class__ = Bf6Conv3x3S2
             n += 1
     return n

@@ -48,9 +48,17 @@ def _conv1x1_stats(conv, bn, x):
 
 
 def _conv_stats(conv, bn, x):
-    """(conv(x), partial statistics rows or None): the Winograd 3x3 kernel's epilogue takes the following norm's batch statistics"""
+    """(conv(x), partial statistics rows or None): the Winograd 3x3 kernel's epilogue takes the following norm's batch statistics;
+    so does the implicit bf16x6 GEMM of a stride-2 3x3 convolution"""
     if conv3x3_bn_ready(conv, bn, x):
         return conv3x3_stats(x, conv.weight, None)
+    from . import bn_act as BA
+    from . import gemm_bf6 as G
+    if (G._STATS and type(conv) is G.Bf6Conv3x3S2 and conv.bias is None
+            and G.eligible_c3s2(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            and BA._state["enabled"] and type(bn) in BA._BN_TYPES and bn.affine and bn.training and bn.momentum is not None
+            and bn.running_mean is not None and BA._channels_ok(conv.out_channels)):
+        return G.conv3x3_s2_stats(x, conv.weight)
     return conv(x), None
 
 

@@ -29,11 +29,11 @@ assert _JOB.itemsize == 72
 
 class WeightPacker:
     def __init__(self, roots):
-        from .gemm_bf6 import Bf6Conv2d
+        from .gemm_bf6 import Bf6Conv2d, Bf6Conv3x3S2
         from .wino import WinoConv2d
         mods = [m for r in roots if r is not None for m in r.modules()]
         self.wino = [m.weight for m in mods if type(m) is WinoConv2d and m.weight.requires_grad]
-        self.bf6 = [m.weight for m in mods if type(m) is Bf6Conv2d and m.weight.requires_grad]
+        self.bf6 = [m.weight for m in mods if type(m) in (Bf6Conv2d, Bf6Conv3x3S2) and m.weight.requires_grad]
         self._tables = {}                      # family -> (signature, device table, n jobs, max size, per-job (weight, new cache entry maker))
         self.launches = 0
 
@@ -65,12 +65,15 @@ class WeightPacker:
             if hit is None or hit[0][1] != w.data_ptr() or hit[0][0] == w._version:
                 continue
             packs = hit[1]
-            Co, Ci = int(w.shape[0]), int(w.shape[1])
+            from .gemm_bf6 import matrix
+            w2 = matrix(w)                                      # [Cout, K]: the 1x1 filter, or the channels-last memory of a 3x3 one
+            if w2.data_ptr() != w.data_ptr():
+                continue                                        # (not a view: a 3x3 filter that is not channels-last)
+            Co, Ci = int(w2.shape[0]), int(w2.shape[1])
             fwd = [(tn, b) for (tr, tn), b in packs.items() if not tr]
             dgr = [(tn, b) for (tr, tn), b in packs.items() if tr]
             if len(fwd) > 1 or len(dgr) > 1 or not (fwd or dgr):
                 continue                                        # several tile widths in use for one weight: leave it to the lazy path
-            w2 = w.detach().reshape(Co, Ci)
             ka, oa = (fwd[0][0], fwd[0][1].data_ptr()) if fwd else (0, 0)
             kb, ob = (dgr[0][0], dgr[0][1].data_ptr()) if dgr else (0, 0)
             rows.append((w.data_ptr(), w2.stride(0), w2.stride(1), 0, 0, Co, Ci, ka, kb, oa, ob))

@@ -677,6 +677,15 @@ int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long str
 /* the same launch with the BatchNorm statistics of y in its epilogue: stats_partial f32[dbev_gemm_bf16x6_stats_rows(M)][2][N] = per
  * 128-row block the column sums of y and y^2 (bn_finalize's partial-row layout: dbev_bn_act_train_forward_pre(..., pre rows)); NULL: none */
 int dbev_gemm_bf16x6_stats_rows(long long M);
+/* Round 5: nn.Conv2d(C, Co, 3, stride 2, padding 1, bias=False) -- `conv2` of a stage-first ResNet bottleneck (mmdet ResNet / mmdet3d
+ * bricks/res_block.py:102-230; cuDNN behind it) -- as an IMPLICIT bf16x6 GEMM: rows = output pixels, reduction over (ky, kx, c).
+ * x_nhwc f32[N, H, W, C], y_nhwc f32[N, H/2, W/2, Co]; `packed` = dbev_gemm_bf16x6_pack of the filter's channels-last memory
+ * [Co][3][3][C] taken as the matrix [Co][9 C] (stride_n = 9 C, stride_k = 1, N = Co, K = 9 C) with the same tile_n;
+ * stats_partial f32[dbev_gemm_bf16x6_stats_rows(N H/2 W/2)][2][Co] or NULL.  dbev_conv3x3s2_bf16x6_ok: H, W even, C a power of two
+ * >= 64, Co % 64 == 0, N H/2 W/2 % 128 == 0.  (Forward only: both gradients stay with the library this round.) */
+int dbev_conv3x3s2_bf16x6_ok(int N, int H, int W, int C, int Co);
+int dbev_conv3x3s2_bf16x6_forward_stats(const float* x_nhwc, const void* packed, float* y_nhwc, float* stats_partial, int N, int H, int W,
+                                        int C, int Co, int tile_n, dbevStream_t stream);
 int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed, float* y, float* stats_partial, long long M, int K, int N,
                                    int x_row_stride, int tile_n, dbevStream_t stream);
 /* both orientations of a [Cout, Cin] filter (element (o, c) at weight[o * stride_o + c * stride_c]) in ONE launch: the forward planes
