@@ -86,6 +86,8 @@ _SIGNATURES = {
     "dbev_maxpool3x3s2_forward": [_p, _i, _i, _i, _i, _p, _p, _p],
     "dbev_maxpool3x3s2_backward": [_p, _p, _i, _i, _i, _i, _p, _p],
     "dbev_norm_relu_maxpool3x3s2_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "dbev_stem_pool_norm_backward_workspace_bytes": [_i, _i, _i, _i],
+    "dbev_stem_pool_norm_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p],
     "dbev_stem7x7s2_stats_rows": [_i, _i, _i],
     "dbev_stem7x7s2_workspace_bytes": [_i, _i, _i],
     "dbev_stem7x7s2_forward": [_p, _p, _i, _i, _i, _p, _p, _p, _sz, _p],
@@ -169,6 +171,7 @@ _SIGNATURES = {
 _RESTYPES = {"dbev_target_arch": ctypes.c_char_p,
              "dbev_wino_filter_floats": ctypes.c_longlong,
              "dbev_stem7x7s2_workspace_bytes": ctypes.c_longlong,
+             "dbev_stem_pool_norm_backward_workspace_bytes": ctypes.c_size_t,
              "dbev_gemm1x1_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_wino_conv3x3_backward_weight_workspace_bytes": ctypes.c_size_t,
              "dbev_fallback_count": ctypes.c_longlong,

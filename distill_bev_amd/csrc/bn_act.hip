@@ -1214,6 +1214,124 @@ extern "C" int dbev_bn_act_backward3(const float* grad_y, const float* grad_y2, 
   return 0;
 }
 
+namespace {
+
+// ---- the stem's pooling gather + norm backward in two passes (round 5) --------------------------------------------------------------
+// y = maxpool3x3s2(relu(bn(x))) (mmdet ResNet.forward: conv1 -> norm1 -> relu -> maxpool; forward: dbev_norm_relu_maxpool3x3s2_forward).
+// The gradient of the rectified map is a GATHER from the pooled gradient (an input pixel is the winner of at most 2 x 2 windows:
+// csrc/maxpool.hip) -- instead of writing it (554 MB) and reading it twice, both passes of the norm's backward gather it themselves:
+//   sp_reduce: sum dz, sum dz xhat per channel   reads pooled gradient + winners + x
+//   sp_dx:     dx = A dz + B x + Cc              reads the same, writes dx
+// with dz = [x scale + shift > 0] * gathered gradient.  A lane = one float4 of channels of a 2 x 2 block of input pixels, as in
+// maxpool3x3s2_bwd; SP_IT blocks per lane in a fixed order, one partial row per workgroup (merged by bn_bwd_finalize in fp64).
+struct SpDims { int N, H, W, C4, Ho, Wo, Hb, Wb; };
+constexpr int SP_IT = 16;
+
+__device__ __forceinline__ void sp_gather(const float4* __restrict__ gy, const uchar4* __restrict__ tap, const SpDims& d, int n, int i, int j,
+                                          int c, float4 (&g)[2][2]) {
+  float4 v[2][2];
+  uchar4 s[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oh = i + a, ow = j + b;
+      if (oh < d.Ho && ow < d.Wo) {
+        const size_t o = ((static_cast<size_t>(n) * d.Ho + oh) * d.Wo + ow) * d.C4 + c;
+        v[a][b] = gy[o];
+        s[a][b] = tap[o];
+      } else {
+        v[a][b] = f4(0.f);
+        s[a][b] = make_uchar4(255, 255, 255, 255);
+      }
+    }
+#pragma unroll
+  for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 2; ++dw) {
+      float4 acc = f4(0.f);
+#pragma unroll
+      for (int a = 0; a <= dh; ++a)
+#pragma unroll
+        for (int b = 0; b <= dw; ++b) {
+          const int k = 3 * (dh + 1 - 2 * a) + (dw + 1 - 2 * b);       // tap of pixel (2 i + dh, 2 j + dw) in window (i + a, j + b)
+          if (s[a][b].x == k) acc.x += v[a][b].x;
+          if (s[a][b].y == k) acc.y += v[a][b].y;
+          if (s[a][b].z == k) acc.z += v[a][b].z;
+          if (s[a][b].w == k) acc.w += v[a][b].w;
+        }
+      g[dh][dw] = acc;
+    }
+}
+
+template <bool DX>
+__global__ __launch_bounds__(256) void sp_pass(const float4* __restrict__ gy, const uchar4* __restrict__ tap, const float4* __restrict__ x,
+                                               const float* __restrict__ coef, const float* __restrict__ save_mean,
+                                               const float* __restrict__ save_invstd, const float* __restrict__ bcoef,
+                                               float* __restrict__ partial, float4* __restrict__ dx, SpDims d, long long total) {
+  __shared__ float4 red[2][256];
+  const int C = 4 * d.C4;
+  const int c = threadIdx.x % d.C4;                                   // 256 % C4 == 0: a lane keeps its channels over its blocks
+  const float4 sc = reinterpret_cast<const float4*>(coef)[c], sh = reinterpret_cast<const float4*>(coef + C)[c];
+  float4 mu = f4(0.f), is = f4(0.f), A = f4(0.f), Bc = f4(0.f), Cc = f4(0.f);
+  if (DX) {
+    A = reinterpret_cast<const float4*>(bcoef)[c];
+    Bc = reinterpret_cast<const float4*>(bcoef + C)[c];
+    Cc = reinterpret_cast<const float4*>(bcoef + 2 * C)[c];
+  } else {
+    mu = reinterpret_cast<const float4*>(save_mean)[c];
+    is = reinterpret_cast<const float4*>(save_invstd)[c];
+  }
+  float4 s1 = f4(0.f), s2 = f4(0.f);
+  for (int it = 0; it < SP_IT; ++it) {
+    const long long t = (static_cast<long long>(blockIdx.x) * SP_IT + it) * 256 + threadIdx.x;
+    if (t >= total) break;
+    long long p = t / d.C4;
+    const int j = static_cast<int>(p % d.Wb); p /= d.Wb;
+    const int i = static_cast<int>(p % d.Hb);
+    const int n = static_cast<int>(p / d.Hb);
+    float4 g[2][2];
+    sp_gather(gy, tap, d, n, i, j, c, g);
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh) {
+      const int h = 2 * i + dh;
+      if (h >= d.H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int w = 2 * j + dw;
+        if (w >= d.W) continue;
+        const size_t o = ((static_cast<size_t>(n) * d.H + h) * d.W + w) * d.C4 + c;
+        const float4 v = x[o];
+        const float4 dz = gate<1>(g[dh][dw], v, v, sc, sh);
+        if (DX) {
+          float4 r;
+          r.x = fmaf(A.x, dz.x, fmaf(Bc.x, v.x, Cc.x)); r.y = fmaf(A.y, dz.y, fmaf(Bc.y, v.y, Cc.y));
+          r.z = fmaf(A.z, dz.z, fmaf(Bc.z, v.z, Cc.z)); r.w = fmaf(A.w, dz.w, fmaf(Bc.w, v.w, Cc.w));
+          st_nt(dx + o, r);
+        } else {
+          float4 xh;
+          xh.x = (v.x - mu.x) * is.x; xh.y = (v.y - mu.y) * is.y; xh.z = (v.z - mu.z) * is.z; xh.w = (v.w - mu.w) * is.w;
+          add4(s1, dz);
+          fma4v(s2, dz, xh);
+        }
+      }
+    }
+  }
+  if (!DX) {                                                           // the 256 / C4 lanes of a channel quad, in lane order
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < 2 * d.C4) {
+      const int which = threadIdx.x / d.C4, q = threadIdx.x % d.C4;
+      float4 a = red[which][q];
+      for (int l = q + d.C4; l < 256; l += d.C4) add4(a, red[which][l]);
+      reinterpret_cast<float4*>(partial + (static_cast<size_t>(blockIdx.x) * 2 + which) * C)[q] = a;
+    }
+  }
+}
+
+}  // namespace
+
 // ---- dual BatchNorm: y = [relu](bn(x) + bn_d(xd)) ------------------------------------------------------------------------
 extern "C" size_t dbev_bn_dual_workspace_bytes(long long M, int C) {
   BnGeom g;
@@ -1394,6 +1512,53 @@ extern "C" int dbev_bn_dual_backward3(const float* grad_y, const float* grad_y2,
                                reinterpret_cast<float4*>(grad_xd), g, fin, fin_d, y_is_mask);
   else hipLaunchKernelGGL((bn_bwd_dx_dual<false>), agrid, dim3(256), 0, s, dy4, dy24, x4, d4, y4, bcoef, reinterpret_cast<float4*>(grad_x),
                           reinterpret_cast<float4*>(grad_xd), g, fin, fin_d);
+  DBEV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t dbev_stem_pool_norm_backward_workspace_bytes(int N, int H, int W, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || 256 % (C / 4) != 0) return 0;
+  const long long total = static_cast<long long>(N) * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  const long long rows = (total + 256LL * SP_IT - 1) / (256LL * SP_IT);
+  if (rows >= (1LL << 24)) return 0;
+  return sizeof(float) * (static_cast<size_t>(rows) * 2 * C + 3 * static_cast<size_t>(C));
+}
+
+extern "C" int dbev_stem_pool_norm_backward(const float* grad_pooled, const unsigned char* winner, const float* x, const float* gamma,
+                                            const float* save_mean, const float* save_invstd, const float* save_scale_shift, int N, int H,
+                                            int W, int C, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
+                                            size_t workspace_bytes, dbevStream_t stream) {
+  const size_t need = dbev_stem_pool_norm_backward_workspace_bytes(N, H, W, C);
+  if (need == 0 || grad_pooled == nullptr || winner == nullptr || x == nullptr || gamma == nullptr || save_mean == nullptr ||
+      save_invstd == nullptr || save_scale_shift == nullptr || grad_x == nullptr || grad_gamma == nullptr || grad_beta == nullptr ||
+      workspace == nullptr || workspace_bytes < need || static_cast<long long>(N) * H * W >= (1LL << 31))
+    return DBEV_EINVAL;
+  hipStream_t s = dbev_stream(stream);
+  SpDims d{N, H, W, C / 4, (H - 1) / 2 + 1, (W - 1) / 2 + 1, (H + 1) / 2, (W + 1) / 2};
+  const long long total = static_cast<long long>(N) * d.Hb * d.Wb * d.C4;
+  const int rows = static_cast<int>((total + 256LL * SP_IT - 1) / (256LL * SP_IT));
+  float* partial = static_cast<float*>(workspace);
+  float* bcoef = partial + static_cast<size_t>(rows) * 2 * C;
+  const long long M = static_cast<long long>(N) * H * W;
+  const long long T = 4LL * M * C;
+  const float4* g4 = reinterpret_cast<const float4*>(grad_pooled);
+  const uchar4* t4 = reinterpret_cast<const uchar4*>(winner);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  {
+    DbevKt kt(DBEV_K_BN_BWD_REDUCE, T + T / 4 + T / 16, s);
+    hipLaunchKernelGGL((sp_pass<false>), dim3(rows), dim3(256), 0, s, g4, t4, x4, save_scale_shift, save_mean, save_invstd,
+                       static_cast<const float*>(nullptr), partial, static_cast<float4*>(nullptr), d, total);
+  }
+  {
+    DbevKt kt(DBEV_K_BN_BWD_FINALIZE, 8LL * rows * C, s);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(dbev_ceil_div(C, BN_FIN_CH)), dim3(256), 0, s, partial, rows, static_cast<int>(M), C, gamma,
+                       save_mean, save_invstd, grad_gamma, grad_beta, bcoef);
+  }
+  {
+    DbevKt kt(DBEV_K_BN_BWD_DX, 2 * T + T / 4 + T / 16, s);
+    hipLaunchKernelGGL((sp_pass<true>), dim3(rows), dim3(256), 0, s, g4, t4, x4, save_scale_shift, save_mean, save_invstd, bcoef,
+                       static_cast<float*>(nullptr), reinterpret_cast<float4*>(grad_x), d, total);
+  }
   DBEV_LAUNCH_CHECK();
   return 0;
 }

