@@ -345,8 +345,13 @@ class DistillStep(_Base):
                               "peak_TFLOPs": BF16X6_PEAK_TF,
                               "frac": (sum(v["fp32_equivalent_TFLOP_per_step"] for v in b6.values())
                                        / max(sum(v["ms_per_step"] for v in b6.values()) * 1e-3, 1e-12) / BF16X6_PEAK_TF)} if b6 else None,
-                "other_hot_kernels_note": "per-kernel rows (bn_*, wino_*, b6_*, c1x1_fwd): the library's kernel event log; dbev_* rows: "
-                "HIP-event brackets of whole ABI entry points; both over %d extra steps run AFTER the timed region" % n_extra,
+                "other_hot_kernels_note": "per-kernel rows (bn_*, wino_*, b6_*, stem_*, c1x1_fwd): the library's kernel event log; dbev_* rows: "
+                "HIP-event brackets of whole ABI entry points; both over %d extra steps run AFTER the timed region, with the "
+                "gradient-free frame's hipGraph (graphed.py) stepping aside so that every launch is seen" % n_extra,
+                "hip_graph_note": "inside the timed region the gradient-free camera frame's backbone + neck replays as ONE hipGraph "
+                "(distill_bev_amd/graphed.py): its launches carry no event pairs, so `launches_per_step` / `achieved` above are over the "
+                "launches issued from the host (the key frame, the BEV encoder, heads, the teacher) -- the same kernels on the same "
+                "layer shapes; DBEV_GRAPH_ADJ=0 issues everything from the host",
                 "other_hot_kernels": other}
         assert_fracs(out)
         return out
@@ -417,10 +422,14 @@ class DistillStep(_Base):
                 # six exact bf16 x bf16 partial products (three-way split of both operands) on the bf16 matrix cores, sums in fp32:
                 # error vs fp64 at or below the library's fp32 kernels (asserted per shape, tests/test_gpu_gemm_bf6.py).
                 # DBEV_BF6=0 keeps them on the library's fp32-MFMA kernels: that step time is measured beside the headline
-                "conv1x1": "fp32 GEMM as bf16x6 on the bf16 matrix cores (csrc/gemm_bf6.hip): %d modules re-classed, forward + data "
-                           "gradient of layers with >= %d output tiles; weight gradients and the other layers: MIOpen fp32" % (
+                "conv1x1": "fp32 GEMM as bf16x6 on the bf16 matrix cores (csrc/gemm_bf6.hip): %d modules re-classed (1x1, and the 3x3 / "
+                           "stride-2 convolutions as an implicit GEMM, forward only), forward + data gradient of layers with >= %d "
+                           "output tiles; the other layers and gradients: MIOpen fp32" % (
                                getattr(self.trainer.detector, "bf6_convs", 0), __import__("distill_bev_amd.gemm_bf6", fromlist=["x"])._MIN_ITEMS),
                 "ms_per_step_fp32_matrix_cores_only": getattr(self, "fp32_mfma_only_ms", None),
+                "stem_conv": "7x7 / stride-2 stem on fp32 MFMA (csrc/stem.hip): %d modules re-classed, forward + weight gradient" % (
+                    getattr(self.trainer.detector, "stem_convs", 0)),
+                "hip_graph": "gradient-free frame: backbone + neck" if getattr(self.trainer.detector, "adjacent_graph", None) is not None else None,
                 "config_file": "configs/distillbev_centerpoint2bevdepth4d_r50.py",
                 # data parallelism: GradReducer's in-backward bucket launches are OFF by default (DBEV_DDP_OVERLAP=1 turns them on): no
                 # N > 1 RCCL measurement exists to say they help on xGMI.  What one GPU can say (a separate run, tools/ddp_one_rank.sh,
