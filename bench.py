@@ -106,6 +106,9 @@ def main():
 
     for _ in range(warmup):
         wl.step()
+    # untimed, beyond the W warm-up steps and reported as `settle_steps`: the Trainer captures the gradient-free frame's hipGraph on its
+    # third step -- with W < 3 that (slow, synchronising) capture must not fall into the timed region
+    settle = wl.settle() if hasattr(wl, "settle") else 0
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -156,6 +159,7 @@ def main():
             "n_gpus": n_gpus,
             "steps": steps,
             "warmup": warmup,
+            "settle_steps": settle,
             "ms_per_step": 1e3 * dt / steps,
             # rank 0's per-step GPU time between the step-boundary events of the SAME timed region: median, and the means of
             # (up to) four consecutive blocks of steps

@@ -217,6 +217,15 @@ class DistillStep(_Base):
         self.trainer.step(self.batch)
         self.steps_timed = getattr(self, "steps_timed", 0) + 1
 
+    def settle(self):
+        """extra untimed steps until the Trainer's hipGraph of the gradient-free frame exists (at most 3); -> how many were run"""
+        g = getattr(self.trainer.detector, "adjacent_graph", None)
+        n = 0
+        while g is not None and g.captures == 0 and n < 3:
+            self.trainer.step(self.batch)
+            n += 1
+        return n
+
     def begin_timed(self):
         # inside the timed region only the roofline kernel's launches carry an event pair (48 per step); the other
         # kernels / entry points (7000+ calls per 20 steps) are instrumented in EXTRA steps after it (roofline())
