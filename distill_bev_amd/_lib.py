@@ -18,6 +18,7 @@ _lib = None
 _p = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
+_d = ctypes.c_double
 _sz = ctypes.c_size_t
 _ll = ctypes.c_longlong
 
@@ -86,6 +87,8 @@ _SIGNATURES = {
     "dbev_maxpool3x3s2_forward": [_p, _i, _i, _i, _i, _p, _p, _p],
     "dbev_maxpool3x3s2_backward": [_p, _p, _i, _i, _i, _i, _p, _p],
     "dbev_norm_relu_maxpool3x3s2_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "dbev_adamw_chunk_elems": [],
+    "dbev_adamw_multi": [_p, _p, _i, _p, _d, _d, _d, _d, _d, _f, _f, _p],
     "dbev_stem_pool_norm_backward_workspace_bytes": [_i, _i, _i, _i],
     "dbev_stem_pool_norm_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p],
     "dbev_stem7x7s2_stats_rows": [_i, _i, _i],

@@ -643,6 +643,21 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
 int dbev_norm_relu_maxpool3x3s2_forward(const float* x_nhwc, const float* scale_shift, int N, int H, int W, int C, float* y_nhwc,
                                         unsigned char* winner, dbevStream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Round 5: AdamW over many tensors in one launch, the gradient-clipping factor applied as the gradient is read.  Replaces the pair
+ * torch.nn.utils.clip_grad_norm_ (its scaling pass) + torch.optim.AdamW.step the reference's OptimizerHook runs (the recipes under configs/:
+ * optimizer = AdamW(lr, weight_decay), grad_clip = dict(max_norm=35)).
+ *   tensors: device array of dbevAdamTensor (param, grad, exp_avg, exp_avg_sq: fp32, the SAME dense memory order; n elements);
+ *   chunks:  device array of int2 (tensor index, chunk index): chunk c of tensor t covers elements [c, c + 1) * dbev_adamw_chunk_elems();
+ *   grad_scale: device float or NULL -- every gradient value is multiplied by it first (the clip factor min(1, max_norm / (norm + 1e-6)));
+ *   bias_correction1 = 1 - beta1^step, bias_correction2_sqrt = sqrt(1 - beta2^step) of the step being taken.
+ * p -= lr wd p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / bc1) m / (sqrt(v) / bc2_sqrt + eps)
+ * ---------------------------------------------------------------------------------- */
+typedef struct dbevAdamTensor { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long n; } dbevAdamTensor;
+int dbev_adamw_chunk_elems(void);
+int dbev_adamw_multi(const void* tensors, const void* chunks, int n_chunks, const float* grad_scale, double lr, double beta1, double beta2,
+                     double eps, double weight_decay, float bias_correction1, float bias_correction2_sqrt, dbevStream_t stream);
+
 /* Round 5: the backward of that fused forward in two passes -- the pooling's gradient gather (dbev_maxpool3x3s2_backward) happens inside
  * the statistics pass and the dx pass of the norm's backward, the 4 x larger gradient of the rectified map is never written:
  * grad_pooled f32[N, Ho, Wo, C] + winner (of the forward) + x (the convolution's output) -> grad_x f32[N, H, W, C], grad_gamma /
