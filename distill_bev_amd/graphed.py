@@ -37,6 +37,7 @@ class GraphedNoGrad:
         self.fn, self.token, self.warmup, self.norms = fn, token, warmup, norms
         self.graphs = {}
         self.replays = self.captures = self.eager = 0
+        self.failed = None             # the exception of a capture that did not work
 
     def reset(self):
         self.graphs.clear()
@@ -48,8 +49,11 @@ class GraphedNoGrad:
 
     def __call__(self, x):
         from . import _lib as L
-        if not (_ON and x.is_cuda) or torch.cuda.is_current_stream_capturing() or L.kernel_timing_active(full=True):
-            return self._eager(x)                 # (every kernel is being logged: the instrumented steps of bench.py see all launches)
+        if (not (_ON and x.is_cuda) or self.failed is not None or L.CHECK_PACKS or torch.cuda.is_current_stream_capturing()
+                or L.kernel_timing_active(full=True)):
+            # (DBEV_CHECK_PACKS reads fingerprints back to the host: not capturable; every kernel being logged: bench.py's instrumented
+            # steps see all launches)
+            return self._eager(x)
         tok = self.token() if self.token is not None else None
         key = (tuple(x.shape), x.dtype, x.device)
         ent = self.graphs.get(key)
@@ -61,7 +65,12 @@ class GraphedNoGrad:
             seen["n"] += 1
             if seen["n"] <= self.warmup or L.kernel_timing_active():
                 return self._eager(x)             # the first calls run eagerly: library plans, MIOpen solutions, lazy packs settle
-            ent = self._capture(x, tok)
+            try:
+                ent = self._capture(x, tok)
+            except Exception as e:                # a failed capture leaves the stream invalidated on this stack: no quiet way back
+                self.failed = e
+                raise RuntimeError("distill_bev_amd.graphed: hipGraph capture of the gradient-free frame failed "
+                                   f"({type(e).__name__}: {e}); run with DBEV_GRAPH_ADJ=0") from e
             self.graphs[key] = ent
         ent["x"].copy_(x)
         ent["graph"].replay()
