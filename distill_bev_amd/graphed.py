@@ -86,7 +86,8 @@ class GraphedNoGrad:
         torch.cuda.synchronize(x.device)
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad():
-            with torch.cuda.graph(graph):
+            # thread_local: what other threads do meanwhile (a collective's watchdog, a data loader) does not invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 y = self.fn(static_x)
         torch.cuda.synchronize(x.device)
         self.captures += 1
