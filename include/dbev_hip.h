@@ -702,6 +702,11 @@ int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long str
 /* the same launch with the BatchNorm statistics of y in its epilogue: stats_partial f32[dbev_gemm_bf16x6_stats_rows(M)][2][N] = per
  * 128-row block the column sums of y and y^2 (bn_finalize's partial-row layout: dbev_bn_act_train_forward_pre(..., pre rows)); NULL: none */
 int dbev_gemm_bf16x6_stats_rows(long long M);
+/* Round 5: the same product with the activation operand taken as relu(x * scale[k] + shift[k]) (scale_shift f32[2 K] = the coefficient row
+ * of the fused norm: dbev_bn_act_train_forward_mask(..., y = NULL)): `norm2 -> relu -> conv3` of a bottleneck (res_block.py:102-230)
+ * without writing the normalised map.  For paths where nothing else reads that map (no autograd: the detached camera frame). */
+int dbev_gemm_bf16x6_forward_affine_stats(const float* x, const float* scale_shift, const void* packed, float* y, float* stats_partial,
+                                          long long M, int K, int N, int x_row_stride, int tile_n, dbevStream_t stream);
 /* Round 5: nn.Conv2d(C, Co, 3, stride 2, padding 1, bias=False) -- `conv2` of a stage-first ResNet bottleneck (mmdet ResNet / mmdet3d
  * bricks/res_block.py:102-230; cuDNN behind it) -- as an IMPLICIT bf16x6 GEMM: rows = output pixels, reduction over (ky, kx, c).
  * x_nhwc f32[N, H, W, C], y_nhwc f32[N, H/2, W/2, Co]; `packed` = dbev_gemm_bf16x6_pack of the filter's channels-last memory
