@@ -360,7 +360,7 @@ class DistillStep(_Base):
                 "hip_graph_note": "inside the timed region the gradient-free camera frame's backbone + neck replays as ONE hipGraph "
                 "(distill_bev_amd/graphed.py): its launches carry no event pairs, so `launches_per_step` / `achieved` above are over the "
                 "launches issued from the host (the key frame, the BEV encoder, heads, the teacher) -- the same kernels on the same "
-                "layer shapes; DBEV_GRAPH_ADJ=0 issues everything from the host",
+                "layer shapes; DBEV_GRAPH_ADJ=0 issues everything from the host; with --gpus N > 1 the graph is off unless DBEV_GRAPH_ADJ=1",
                 "other_hot_kernels": other}
         assert_fracs(out)
         return out

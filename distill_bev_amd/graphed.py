@@ -22,10 +22,13 @@ import os
 import torch
 
 _ON = os.environ.get("DBEV_GRAPH_ADJ", "1") != "0"
+_FORCED = os.environ.get("DBEV_GRAPH_ADJ") == "1"
 
 
-def enabled():
-    return _ON
+def enabled(world_size=1):
+    """DBEV_GRAPH_ADJ=0: never; =1: always; unset: in single-process runs only -- capture beside a live RCCL communicator (its watchdog
+    thread) is covered by a two-rank test on one GPU (gloo) but has not been run on a multi-GPU node, and a failed capture is fatal"""
+    return _ON and (_FORCED or world_size == 1)
 
 
 class GraphedNoGrad:

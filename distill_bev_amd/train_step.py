@@ -424,7 +424,7 @@ class Trainer:
                 from .packer import WeightPacker
                 self.packer = WeightPacker([self.detector])      # the trainable layers' packed weights: one launch per family and step
                 from . import graphed
-                if graphed.enabled() and hasattr(self.detector, "image_encoder"):
+                if graphed.enabled(world_size) and hasattr(self.detector, "image_encoder"):
                     # the gradient-free adjacent frame's backbone + neck as one hipGraph (valid because the packs above are
                     # refreshed in place after every optimizer step)
                     det = self.detector

@@ -23,6 +23,7 @@ OPTS = {"model.img_view_transformer.data_config.input_size": (64, 176)}
 
 
 def _worker(rank, world, port, out, backend, multi_scale_epoch):
+    os.environ["DBEV_GRAPH_ADJ"] = "1"          # (unset, the hipGraph of the gradient-free frame is a single-process default: force it here)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from distill_bev_amd.train_step import Trainer, build_model, make_batch
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
@@ -39,13 +40,14 @@ def _worker(rank, world, port, out, backend, multi_scale_epoch):
     assert tr.reducer is not None and tr.reducer.world == world
     batch = make_batch(1, np.random.default_rng(100 + rank), dev, n_points=8000, input_size=(64, 176))   # own shard
     losses = []
-    for _ in range(2):
+    for _ in range(4):                       # (from the third step on the gradient-free frame replays as a hipGraph: graphed.py)
         loss, _ = tr.step(batch)
         losses.append(float(loss))
+    g = getattr(tr.detector, "adjacent_graph", None)
     flat = torch.cat([p.detach().reshape(-1) for p in tr.params]).cpu()
     none_grads = sum(p.grad is None for p in tr.params)
     teacher_after = torch.cat([p.detach().reshape(-1) for p in model.teacher_model.parameters()])
-    res = dict(params=flat, losses=losses, none_grads=none_grads, nparams=len(tr.params),
+    res = dict(params=flat, losses=losses, none_grads=none_grads, nparams=len(tr.params), graph=None if g is None else (g.captures, g.replays),
                teacher_same=bool(torch.equal(teacher_before.to(dev), teacher_after)),
                teacher_head=model.teacher_model.pts_bbox_head.task_heads[0].reg[0].conv.weight.detach().cpu())
     gathered = [None] * world
@@ -64,7 +66,10 @@ def test_real_detector_two_ranks_stay_in_lock_step(tmp_path, multi_scale_epoch):
     out = str(tmp_path / "ddp_real.pt")
     mp.spawn(_worker, args=(2, port, out, backend, multi_scale_epoch), nprocs=2, join=True)
     r0, r1 = torch.load(out, weights_only=False)
-    assert torch.equal(r0["params"], r1["params"])                     # identical after 2 steps from different inits
+    assert torch.equal(r0["params"], r1["params"])                     # identical after 4 steps from different inits
+    from distill_bev_amd import graphed
+    if graphed._ON:                                                    # captured and replayed in both ranks, a process group alive
+        assert r0["graph"] == r1["graph"] == (1, 2), (r0["graph"], r1["graph"])
     assert all(np.isfinite(r0["losses"])) and all(np.isfinite(r1["losses"]))
     assert r0["losses"] != r1["losses"]                                # different shards: different local losses
     assert r0["teacher_same"] and r1["teacher_same"]                   # frozen teacher untouched by training ...
