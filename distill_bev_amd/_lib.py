@@ -385,6 +385,38 @@ def ensure_param_version_hook():
 
 
 # ---- debug guard of everything kept per weight ---------------------------------------------------------------------------------------
+# ---- what a captured hipGraph baked in (graphed.py) ---------------------------------------------------------------------------------
+# While DERIVED_LOG is a list, every accessor of a kept weight-derived buffer (wino.packed_pair, wino.folded_pack, gemm_bf6.packed,
+# bn_act._eval_coef) appends (kind, owner, args, tensors) for what it hands out: the kernels captured meanwhile read those buffers
+# through their raw addresses.  graphed.GraphedNoGrad keeps the tensors alive with the graph and, before every replay, calls the same
+# accessor again (`revalidate`): a stale entry is re-derived IN PLACE by the accessor (same buffer -> the replay reads fresh values), a
+# buffer that moved means the graph is captured again.
+DERIVED_LOG = None
+
+
+def note_derived(kind, owner, args, tensors):
+    if DERIVED_LOG is not None:
+        DERIVED_LOG.append((kind, owner, args, tuple(tensors)))
+
+
+def revalidate(kind, owner, args):
+    """-> the tensors the accessor of `kind` hands out NOW for (owner, args) (made fresh on the way, in place where the buffer exists)"""
+    if kind == "wino_pair":
+        from . import wino
+        return tuple(wino.packed_pair(owner, *args))
+    if kind == "wino_folded":
+        from . import wino
+        hit = wino.folded_pack(owner, *args)
+        return (hit[2], hit[3])
+    if kind == "bf6":
+        from . import gemm_bf6
+        return (gemm_bf6.packed(owner, *args),)
+    if kind == "eval_coef":
+        from . import bn_act
+        return (bn_act._eval_coef(owner, *args),)
+    raise DbevHipError(f"revalidate: unknown kind {kind}")
+
+
 # DBEV_CHECK_PACKS=N (N >= 1): every N-th REUSE of a kept derivative of a weight -- packed Winograd filters (wino.packed_pair, the folded
 # conv + norm packs), bf16 planes of a 1x1 filter (gemm_bf6.packed), eval-mode norm coefficients (bn_act._eval_coef) -- re-reads the live
 # source tensors and compares their fingerprint with the one taken when the derivative was made; a mismatch means the weight was written

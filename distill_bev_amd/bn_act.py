@@ -328,7 +328,9 @@ def _eval_coef(bn, dev):
            bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps), str(dev))
     hit = bn.__dict__.get("_dbev_eval_coef")
     if hit is None or hit[0] != key:
-        coef = torch.empty((2 * bn.num_features,), dtype=torch.float32, device=dev)
+        # (a stale entry's tensor is written again, not replaced: a captured hipGraph may read through its address -- graphed.py)
+        reuse = hit is not None and hit[1].numel() == 2 * bn.num_features and hit[1].device == torch.device(dev)
+        coef = hit[1] if reuse else torch.empty((2 * bn.num_features,), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             L.call("dbev_bn_infer_coef", L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                    float(bn.eps), bn.num_features, L.ptr(coef), L.stream_ptr(dev))
@@ -336,6 +338,7 @@ def _eval_coef(bn, dev):
         bn.__dict__["_dbev_eval_coef"] = hit
     else:
         L.check_fingerprint(hit[2], "eval-mode norm coefficients", bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    L.note_derived("eval_coef", bn, (dev,), (hit[1],))
     return hit[1]
 
 

@@ -454,7 +454,7 @@ class BEVDepth4DDistill(CenterPoint):
             # the reference runs the adjacent frame under autograd and then detaches its BEV feature (:440-441): no
             # gradient ever reaches this branch, so its graph (12 GB of saved activations at bs 8) is not recorded
             with torch.set_grad_enabled(torch.is_grad_enabled() and not (self.detach and fi == 1)):
-                graphed = getattr(self, "adjacent_graph", None) if (fi == 1 and not torch.is_grad_enabled()) else None
+                graphed = getattr(self, "adjacent_graph", None) if (fi == 1 and self.training and not torch.is_grad_enabled()) else None
                 x = graphed(im) if graphed is not None else self.image_encoder(im)     # (graphed.py: the gradient-free frame as one hipGraph)
                 Bx, Nx, C, fH, fW = x.shape
                 img_feat, depth_digit, depth = vt.depth_feat_and_prob(x.view(Bx * Nx, C, fH, fW), rot, tran, intrin, post_rot,
@@ -742,7 +742,7 @@ class BEVDet4DDistill(BEVDepth4DDistill):
         for fi, (im, intrin, post_rot, post_tran) in enumerate(zip(imgs, intrins, post_rots, post_trans)):
             tran, rot = trans[0], rots[0]
             with torch.set_grad_enabled(torch.is_grad_enabled() and not (self.detach and fi == 1)):
-                graphed = getattr(self, "adjacent_graph", None) if (fi == 1 and not torch.is_grad_enabled()) else None
+                graphed = getattr(self, "adjacent_graph", None) if (fi == 1 and self.training and not torch.is_grad_enabled()) else None
                 x = graphed(im) if graphed is not None else self.image_encoder(im)     # (graphed.py: the gradient-free frame as one hipGraph)
                 Bx, Nx, C, fH, fW = x.shape
                 x = vt.depthnet(x.view(Bx * Nx, C, fH, fW))

@@ -72,29 +72,51 @@ def packed(weight, transposed=False, tn=128):
     w2 = matrix(weight)                                       # a view for both memory formats of a 1x1 filter
     Co, Ci = int(w2.shape[0]), int(w2.shape[1])
     key = (weight._version, weight.data_ptr())
-    cache = getattr(weight, "_dbev_bf6_packs", None)
-    if cache is None or cache[0] != key:
-        cache = (key, {}, L.fingerprint(weight))
-        try:
-            weight._dbev_bf6_packs = cache
-        except AttributeError:
-            pass
-    else:
-        L.check_fingerprint(cache[2], "bf16 planes of a 1x1 filter", weight)
+    cache = _cache_for(weight, key)
     if (Ci if transposed else Co) % 128:
         tn = 64
-    hit = cache[1].get((bool(transposed), tn))
+    which = (bool(transposed), tn)
+    hit = cache[1].get(which)
     if hit is not None:
+        L.note_derived("bf6", weight, which, (hit,))
         return hit
     n, k = (Ci, Co) if transposed else (Co, Ci)
     sn, sk = (w2.stride(1), w2.stride(0)) if transposed else (w2.stride(0), w2.stride(1))
     nbytes = int(L.call("dbev_gemm_bf16x6_packed_bytes", n, k))
     if nbytes == 0:
         raise L.DbevHipError(f"gemm_bf6: unsupported weight {Co} x {Ci} (transposed={transposed})")
-    buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    buf = _spare(cache, which, nbytes, dev)
     with torch.cuda.device(dev):
         L.call("dbev_gemm_bf16x6_pack", L.ptr(w2), sn, sk, n, k, tn, L.ptr(buf), L.stream_ptr(dev))
-    cache[1][(bool(transposed), tn)] = buf
+    cache[1][which] = buf
+    L.note_derived("bf6", weight, which, (buf,))
+    return buf
+
+
+def _cache_for(weight, key):
+    """the weight's pack cache (key, {(transposed, tile width): planes}, fingerprint, spare buffers) for its CURRENT version.  When the
+    version moved, the stale entry's buffers become the new entry's spares: the next pack of the same kind is written into the same
+    buffer (`_spare`), so the address a captured hipGraph baked in (graphed.py) keeps pointing at fresh planes."""
+    cache = getattr(weight, "_dbev_bf6_packs", None)
+    if cache is None or cache[0] != key:
+        spare = {}
+        if cache is not None and cache[0][1] == key[1]:
+            spare = dict(cache[3]) if len(cache) > 3 else {}
+            spare.update(cache[1])
+        cache = (key, {}, L.fingerprint(weight), spare)
+        try:
+            weight._dbev_bf6_packs = cache
+        except AttributeError:
+            pass
+    else:
+        L.check_fingerprint(cache[2], "bf16 planes of a 1x1 filter", weight)
+    return cache
+
+
+def _spare(cache, which, nbytes, dev):
+    buf = cache[3].pop(which, None) if len(cache) > 3 else None
+    if buf is None or buf.numel() != nbytes or buf.device != torch.device(dev):
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     return buf
 
 
@@ -107,18 +129,18 @@ def pack_both(weight, M):
     cache = getattr(weight, "_dbev_bf6_packs", None)
     if cache is not None and cache[0] == key and (False, tf) in cache[1] and (True, tt) in cache[1]:
         return
-    if cache is None or cache[0] != key:
-        cache = (key, {}, L.fingerprint(weight))
-        try:
-            weight._dbev_bf6_packs = cache
-        except AttributeError:
-            return                                            # no place to keep them: `packed` packs one at a time
+    cache = _cache_for(weight, key)
+    if getattr(weight, "_dbev_bf6_packs", None) is not cache:
+        return                                                # no place to keep them: `packed` packs one at a time
     dev = L.require_cuda(weight)
     w2 = weight.detach().reshape(Co, Ci)
     nf, nt = int(L.call("dbev_gemm_bf16x6_packed_bytes", Co, Ci)), int(L.call("dbev_gemm_bf16x6_packed_bytes", Ci, Co))
     if nf == 0 or nt == 0:
         return
-    bf, bt = torch.empty((nf,), dtype=torch.uint8, device=dev), torch.empty((nt,), dtype=torch.uint8, device=dev)
+    bf = cache[1].get((False, tf))
+    bt = cache[1].get((True, tt))
+    bf = bf if bf is not None else _spare(cache, (False, tf), nf, dev)
+    bt = bt if bt is not None else _spare(cache, (True, tt), nt, dev)
     with torch.cuda.device(dev):
         L.call("dbev_gemm_bf16x6_pack_pair", L.ptr(w2), w2.stride(0), w2.stride(1), Co, Ci, tf, L.ptr(bf), tt, L.ptr(bt), L.stream_ptr(dev))
     cache[1][(False, tf)] = bf

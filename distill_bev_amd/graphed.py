@@ -9,14 +9,23 @@ replay).  Measured (tools/fwd_host_vs_gpu.py, tools/ab_env.sh DBEV_GRAPH_ADJ 0 1
 18 ms against 48 ms of GPU time -- the step is NOT host-bound on an idle host, the replay buys 0.2-0.6 ms per step (shorter bubbles
 behind the forward's one synchronising call) and headroom when eight ranks share one host's cores.
 
-What makes a replay equal to an eager call (the owner must guarantee it -- train_step.Trainer does):
-  * the kernels read the layers' packed weights (Winograd filters, bf16 planes) from buffers that are refreshed IN PLACE after every
-    optimizer step (packer.WeightPacker.repack) -- the lazy per-layer re-pack lives in Python and does not run in a replay;
+What makes a replay equal to an eager call:
+  * the kernels read the layers' derived weight forms (Winograd filter packs, bf16 planes, folded conv + norm packs, eval-mode norm
+    coefficients) through raw addresses.  Every accessor of such a buffer reports what it hands out while the capture runs
+    (_lib.DERIVED_LOG); the graph entry keeps those tensors ALIVE (a replay can never read freed memory) and, before every replay,
+    calls each accessor again (_lib.revalidate): an entry whose source moved on (optimizer step, load_state_dict, any write that
+    bumps the version counter) is re-derived by the accessor INTO THE SAME BUFFER -- stream-ordered before the replay -- and an
+    accessor that hands out a different buffer than the one baked in (a cache dropped by invalidate_eval_coef, a new input size,
+    a weight on new storage) drops the graph: the call runs eagerly and the capture is redone after a fresh warm-up.
+    packer.WeightPacker.repack (one launch per family after the optimizer step, into the same buffers) makes the re-validation a
+    pure host-side check in the training loop; it is an optimisation, not what correctness rests on (DBEV_MULTI_PACK=0 and a packer
+    that skips layers are covered by tests/test_gpu_graphed.py);
   * training-mode norms update their running statistics inside the captured kernels (in place, stable addresses);
-  * `valid_token()` -- anything that changes module state behind the graph's back (load_state_dict, train()/eval(), a different
-    parameter tensor) changes the token and the graph is captured again.
+  * `valid_token()` -- anything that changes module state behind the graph's back (train()/eval(), a different parameter / buffer
+    tensor) changes the token; the graph is dropped and captured again after `warmup` eager calls in the new state.
 The kernel event log (dbev_kernel_timing_*) is host code: replayed launches are not logged.  Nothing is captured while any timing is
-on, and while EVERY kernel is logged (mask -1, or the per-entry-point brackets: bench.py's instrumented steps) the call runs eagerly."""
+on, and while EVERY kernel is logged (mask -1, or the per-entry-point brackets: bench.py's instrumented steps) the call runs eagerly.
+detectors.extract_img_feat uses the graph in TRAINING mode only (validation runs eagerly)."""
 import os
 
 import torch
@@ -33,13 +42,14 @@ def enabled(world_size=1):
 
 class GraphedNoGrad:
     def __init__(self, fn, token=None, warmup=2, norms=None):
-        """norms: callable -> the training-mode norm modules inside `fn`: the captured kernels update their running statistics in
-        place WITHOUT the version bump the eager path gives them (_lib.touched), so whatever is kept per module keyed on those
-        versions (bn_act's eval-mode coefficients) is dropped after every replay.  (Bumping the versions here instead would trip
-        autograd's saved-tensor check of a stock batch_norm that saved the same buffers in the key frame's forward.)"""
+        """norms: callable -> the norm modules inside `fn`: the captured kernels update the running statistics of those in TRAINING
+        mode in place WITHOUT the version bump the eager path gives them (_lib.touched), so the eval-mode coefficients kept per module
+        keyed on those versions (bn_act._eval_coef) are dropped after every replay -- of the training-mode norms only: an eval-mode
+        norm inside the graph has its coefficient tensor baked in.  (Bumping the versions here instead would trip autograd's
+        saved-tensor check of a stock batch_norm that saved the same buffers in the key frame's forward.)"""
         self.fn, self.token, self.warmup, self.norms = fn, token, warmup, norms
         self.graphs = {}
-        self.replays = self.captures = self.eager = 0
+        self.replays = self.captures = self.eager = self.dropped = 0
         self.failed = None             # the exception of a capture that did not work
 
     def reset(self):
@@ -49,6 +59,22 @@ class GraphedNoGrad:
         self.eager += 1
         with torch.no_grad():
             return self.fn(x)
+
+    def _drop(self, key):
+        """forget the captured graph of `key` and start its warm-up again (the next `warmup` calls run eagerly)"""
+        if self.graphs.pop(key, None) is not None:
+            self.dropped += 1
+        self.graphs.pop(("seen",) + key, None)
+
+    @staticmethod
+    def _deps_fresh(ent):
+        """re-validate every derived buffer the capture read (see the module docstring) -> False when one of them moved"""
+        from . import _lib as L
+        for kind, owner, args, ptrs in ent["deps"]:
+            now = L.revalidate(kind, owner, args)
+            if tuple(0 if t is None else t.data_ptr() for t in now) != ptrs:
+                return False
+        return True
 
     def __call__(self, x):
         from . import _lib as L
@@ -61,10 +87,15 @@ class GraphedNoGrad:
         key = (tuple(x.shape), x.dtype, x.device)
         ent = self.graphs.get(key)
         if ent is not None and ent["token"] != tok:
+            self._drop(key)                       # module state changed: the new state gets its own eager warm-up calls
             ent = None
-            self.graphs.pop(key)
+        if ent is not None and not self._deps_fresh(ent):
+            self._drop(key)                       # a baked-in buffer is no longer the layer's: eager now, captured again later
+            ent = None
         if ent is None:
-            seen = self.graphs.setdefault(("seen",) + key, {"n": 0})
+            seen = self.graphs.setdefault(("seen",) + key, {"n": 0, "token": tok})
+            if seen["token"] != tok:
+                seen["n"], seen["token"] = 0, tok
             seen["n"] += 1
             if seen["n"] <= self.warmup or L.kernel_timing_active():
                 return self._eager(x)             # the first calls run eagerly: library plans, MIOpen solutions, lazy packs settle
@@ -80,21 +111,41 @@ class GraphedNoGrad:
         self.replays += 1
         if self.norms is not None:
             for m in self.norms():
-                m.__dict__.pop("_dbev_eval_coef", None)
+                if m.training:
+                    m.__dict__.pop("_dbev_eval_coef", None)
         return ent["y"]
 
     def _capture(self, x, tok):
+        from . import _lib as L
         static_x = torch.empty_like(x)
         static_x.copy_(x)
         torch.cuda.synchronize(x.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad():
-            # thread_local: what other threads do meanwhile (a collective's watchdog, a data loader) does not invalidate the capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                y = self.fn(static_x)
+        log, L.DERIVED_LOG = L.DERIVED_LOG, []
+        try:
+            with torch.no_grad():
+                # thread_local: what other threads do meanwhile (a collective's watchdog, a data loader) does not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    y = self.fn(static_x)
+            noted = L.DERIVED_LOG
+        finally:
+            L.DERIVED_LOG = log
         torch.cuda.synchronize(x.device)
         self.captures += 1
-        return {"graph": graph, "x": static_x, "y": y, "token": tok}
+        deps, keep, seen = [], [], set()
+        for kind, owner, args, tensors in noted:
+            ptrs = tuple(0 if t is None else t.data_ptr() for t in tensors)
+            sig = (kind, id(owner), repr(args) if kind != "wino_folded" else (id(args[0]),) + tuple(args[1:]), ptrs)
+            if sig in seen:
+                continue
+            seen.add(sig)
+            deps.append((kind, owner, args, ptrs))
+            keep.append(tensors)                  # alive as long as the graph: a replay never reads freed memory
+        return {"graph": graph, "x": static_x, "y": y, "token": tok, "deps": deps, "keep": keep}
+
+    def baked_in(self):
+        """[(kind, owner, buffer addresses)] of every captured graph (tests, diagnostics)"""
+        return [(k, o, p) for key, ent in self.graphs.items() if key[0] != "seen" for k, o, _a, p in ent["deps"]]
 
 
 def state_token(*modules):

@@ -9,7 +9,11 @@ caches so that the layers find their packs fresh.  The reference has no counterp
 mmdet3d/models/bricks/res_block.py:102-230).
 
 A layer takes part once it has run (its cache entry records the input size its pack format depends on); layers whose entry is already
-fresh, or whose weight has not been packed yet, are skipped -- the lazy path stays the fallback for everything.
+fresh, or whose weight has not been packed yet, are skipped -- the lazy path stays the fallback for everything, and it writes a stale
+entry's buffers again instead of replacing them (wino.packed_pair, gemm_bf6._cache_for), so a pack buffer keeps its address for the
+life of its weight's storage either way.  `repack()` returns the weights it left STALE to the lazy path (`self.skipped`; empty in the
+bench recipe, asserted by tests/test_gpu_graphed.py): a captured hipGraph re-validates what it baked in before every replay
+(graphed.GraphedNoGrad), which is where such a layer is refreshed.
 """
 import os
 
@@ -36,13 +40,17 @@ class WeightPacker:
         self.bf6 = [m.weight for m in mods if type(m) in (Bf6Conv2d, Bf6Conv3x3S2) and m.weight.requires_grad]
         self._tables = {}                      # family -> (signature, device table, n jobs, max size, per-job (weight, new cache entry maker))
         self.launches = 0
+        self.skipped = []                      # of the last repack(): stale weights left to the lazy path, with the reason
 
     # ---- one family ------------------------------------------------------------------------------------------------------------
     def _wino_jobs(self):
         rows, fix = [], []
         for w in self.wino:
             hit = getattr(w, "_dbev_wino_pair", None)
-            if hit is None or hit[0][1] != w.data_ptr():
+            if hit is None:
+                continue                                        # never packed: the layer has not run yet
+            if hit[0][1] != w.data_ptr():
+                self.skipped.append((w, "wino: the weight's storage moved"))
                 continue
             (ver, ptr, N, H, W), fwd, dgrad = hit[0], hit[1], hit[2]
             if ver == w._version:
@@ -51,6 +59,7 @@ class WeightPacker:
             fk = int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, C, Co))
             dk = int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, Co, C)) if dgrad is not None else 0
             if fk == 0:
+                self.skipped.append((w, "wino: no forward kernel for the recorded input size"))
                 continue
             so, sc, sa, sb = w.stride()
             rows.append((w.data_ptr(), so, sc, sa, sb, Co, C, fk, dk, fwd.data_ptr(), 0 if dgrad is None else dgrad.data_ptr()))
@@ -62,22 +71,27 @@ class WeightPacker:
         rows, fix = [], []
         for w in self.bf6:
             hit = getattr(w, "_dbev_bf6_packs", None)
-            if hit is None or hit[0][1] != w.data_ptr() or hit[0][0] == w._version:
+            if hit is None or hit[0][0] == w._version and hit[0][1] == w.data_ptr():
+                continue                                        # never packed / already fresh
+            if hit[0][1] != w.data_ptr():
+                self.skipped.append((w, "bf6: the weight's storage moved"))
                 continue
-            packs = hit[1]
+            packs, spare = hit[1], (hit[3] if len(hit) > 3 else {})
             from .gemm_bf6 import matrix
             w2 = matrix(w)                                      # [Cout, K]: the 1x1 filter, or the channels-last memory of a 3x3 one
             if w2.data_ptr() != w.data_ptr():
-                continue                                        # (not a view: a 3x3 filter that is not channels-last)
+                self.skipped.append((w, "bf6: a k x k filter that is not channels-last (no matrix view)"))
+                continue
             Co, Ci = int(w2.shape[0]), int(w2.shape[1])
             fwd = [(tn, b) for (tr, tn), b in packs.items() if not tr]
             dgr = [(tn, b) for (tr, tn), b in packs.items() if tr]
             if len(fwd) > 1 or len(dgr) > 1 or not (fwd or dgr):
-                continue                                        # several tile widths in use for one weight: leave it to the lazy path
+                self.skipped.append((w, "bf6: several tile widths in use for one weight" if (fwd or dgr) else "bf6: an entry without packs"))
+                continue
             ka, oa = (fwd[0][0], fwd[0][1].data_ptr()) if fwd else (0, 0)
             kb, ob = (dgr[0][0], dgr[0][1].data_ptr()) if dgr else (0, 0)
             rows.append((w.data_ptr(), w2.stride(0), w2.stride(1), 0, 0, Co, Ci, ka, kb, oa, ob))
-            fix.append((w, "_dbev_bf6_packs", lambda w=w, packs=packs: ((w._version, w.data_ptr()), packs, L.fingerprint(w))))
+            fix.append((w, "_dbev_bf6_packs", lambda w=w, packs=packs, spare=spare: ((w._version, w.data_ptr()), packs, L.fingerprint(w), spare)))
         return rows, fix, max((r[5] * r[6] // 8 for r in rows), default=0)
 
     def _run(self, family, entry, rows, fix, size, dev):
@@ -100,14 +114,17 @@ class WeightPacker:
 
     @torch.no_grad()
     def repack(self):
-        """call after the optimizer step (the version counters of the updated weights have moved)"""
+        """call after the optimizer step (the version counters of the updated weights have moved) -> the stale weights it did NOT
+        re-pack (left to the lazy path, which refreshes their buffers in place at the layer's next use)"""
+        self.skipped = []
         if not _ON:
-            return
+            return self.skipped
         ws = self.wino or self.bf6
         if not ws or not ws[0].is_cuda:
-            return
+            return self.skipped
         dev = ws[0].device
         rows, fix, size = self._wino_jobs()
         self._run("wino", "dbev_wino_filter_pack_multi", rows, fix, size, dev)
         rows, fix, size = self._bf6_jobs()
         self._run("bf6", "dbev_gemm_bf16x6_pack_multi", rows, fix, size, dev)
+        return self.skipped

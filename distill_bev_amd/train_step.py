@@ -425,8 +425,9 @@ class Trainer:
                 self.packer = WeightPacker([self.detector])      # the trainable layers' packed weights: one launch per family and step
                 from . import graphed
                 if graphed.enabled(world_size) and hasattr(self.detector, "image_encoder"):
-                    # the gradient-free adjacent frame's backbone + neck as one hipGraph (valid because the packs above are
-                    # refreshed in place after every optimizer step)
+                    # the gradient-free adjacent frame's backbone + neck as one hipGraph.  It re-validates every derived weight buffer
+                    # it baked in before each replay (graphed.py); with the packs above refreshed in place after every optimizer
+                    # step that check finds everything fresh
                     det = self.detector
                     mods = [getattr(det, "img_backbone", None), getattr(det, "img_neck", None)]
                     norms = lambda: [mod for m in mods if m is not None for mod in m.modules()
@@ -475,7 +476,7 @@ class Trainer:
             self.reducer.close()
             self.reducer = None
         if getattr(self.detector, "adjacent_graph", None) is not None:
-            self.detector.adjacent_graph = None      # its replays rely on this trainer's in-place re-packing after every optimizer step
+            self.detector.adjacent_graph = None      # (installed by this trainer: goes with it)
 
     def step(self, batch):
         if self.reducer is not None and self.reducer.dirty():

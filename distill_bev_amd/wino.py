@@ -55,10 +55,11 @@ def _blocks(N, H, W):
     return N * min(-(-th // 8) * -(-tw // 8), -(-th // 4) * -(-tw // 16))
 
 
-def pack_filters(weight, data_gradient=False, for_input=None):
+def pack_filters(weight, data_gradient=False, for_input=None, out=None):
     """G g G^T of every (co, c) filter in the kernels' consumption orders (dbev_wino_filter_pack).  `for_input`: shape [N, K, H, W] of
     the tensor the packed filters will be applied to -- only the format of the forward kernel that layer gets is written (the other
-    slot of the buffer stays uninitialised); None: both formats."""
+    slot of the buffer stays uninitialised); None: both formats.  out: a buffer of an earlier call for the same layer, written again
+    (a captured hipGraph may be reading through its address: graphed.py)."""
     dev = L.require_cuda(weight)
     Co, C = weight.shape[:2]
     K, J = (Co, C) if data_gradient else (C, Co)
@@ -70,7 +71,7 @@ def pack_filters(weight, data_gradient=False, for_input=None):
     n = int(L.call("dbev_wino_filter_floats", K, J))
     if n == 0:
         raise L.DbevHipError(f"wino: unsupported channel counts {C} -> {Co} (data_gradient={data_gradient})")
-    packed = torch.empty((n,), dtype=torch.float32, device=dev)
+    packed = out if (out is not None and out.numel() == n and out.device == dev) else torch.empty((n,), dtype=torch.float32, device=dev)
     so, sc, sa, sb = weight.stride()
     with torch.cuda.device(dev):
         L.call("dbev_wino_filter_pack", L.ptr(weight), so, sc, sa, sb, Co, C, flags, L.ptr(packed), L.stream_ptr(dev))
@@ -93,15 +94,22 @@ def packed_pair(weight, x_shape, want_dgrad):
         L.check_fingerprint(hit[3], "Winograd filter pack", weight)
         fwd, dgrad = hit[1], hit[2]
         if dgrad is not None or not want_dgrad:
+            L.note_derived("wino_pair", weight, ((N, C, H, W), want_dgrad), (fwd, dgrad))
             return fwd, dgrad
+    # a STALE entry of the same storage and input size (the weight's version moved: an optimizer step, load_state_dict): its buffers
+    # are written again rather than replaced -- their addresses stay what a captured hipGraph (graphed.py) baked in
+    old_f = old_d = None
+    if hit is not None and hit[0] != key and hit[0][1:] == key[1:] and hit[1].device == dev:
+        old_f, old_d = hit[1], hit[2]
+        want_dgrad = want_dgrad or old_d is not None         # (a kept data-gradient pack is refreshed with its forward pack)
     fk = 0 if fwd is not None else int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, C, Co))
     dk = int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, Co, C)) if want_dgrad else 0
     if fwd is None:
         if fk == 0:
             raise L.DbevHipError(f"wino: unsupported layer {C} -> {Co} at {H} x {W}")
-        fwd = torch.empty((int(L.call("dbev_wino_filter_floats", C, Co)),), dtype=torch.float32, device=dev)
+        fwd = old_f if old_f is not None else torch.empty((int(L.call("dbev_wino_filter_floats", C, Co)),), dtype=torch.float32, device=dev)
     if dk:
-        dgrad = torch.empty((int(L.call("dbev_wino_filter_floats", Co, C)),), dtype=torch.float32, device=dev)
+        dgrad = old_d if old_d is not None else torch.empty((int(L.call("dbev_wino_filter_floats", Co, C)),), dtype=torch.float32, device=dev)
     so, sc, sa, sb = weight.stride()
     with torch.cuda.device(dev):
         L.call("dbev_wino_filter_pack_pair", L.ptr(weight), so, sc, sa, sb, Co, C, fk, dk, L.ptr(fwd), L.ptr(dgrad), L.stream_ptr(dev))
@@ -109,6 +117,7 @@ def packed_pair(weight, x_shape, want_dgrad):
         weight._dbev_wino_pair = (key, fwd, dgrad, L.fingerprint(weight))
     except AttributeError:                                  # a tensor type without instance attributes: no reuse, still correct
         pass
+    L.note_derived("wino_pair", weight, ((N, C, H, W), want_dgrad), (fwd, dgrad))
     return fwd, dgrad
 
 
@@ -154,28 +163,42 @@ def fold_ready(conv, norm, x):
             and worthwhile(x, conv.out_channels))
 
 
-def conv_norm_relu_eval(x, conv, norm):
-    """relu(norm(conv(x))) for a `fold_ready` triple: the norm's scale goes into the filters before they are transformed and packed
-    (kept until the convolution's or the norm's tensors change), its shift (+ the scaled convolution bias) is the kernel's bias, the
-    ReLU its output flag -- no normalisation pass over the output."""
+def folded_pack(conv, norm, x_shape, dev):
+    """-> (key, norm coefficient key, packed filters with the norm's scale folded in, bias = the norm's shift (+ the scaled convolution
+    bias), fingerprint) of a `fold_ready` pair, kept on the convolution until its or the norm's tensors change; a stale entry is
+    re-derived INTO ITS BUFFERS (stable addresses for a captured hipGraph: graphed.py)"""
     from . import bn_act as BA
-    dev = x.device
-    coef = BA._eval_coef(norm, dev)                          # scale | shift; a new tensor object whenever the norm's tensors change
+    coef = BA._eval_coef(norm, dev)                          # scale | shift
+    ckey = norm.__dict__["_dbev_eval_coef"][0]               # changes whenever one of the norm's four tensors does
     w = conv.weight
-    N, _, H, W = x.shape
+    N, _, H, W = (int(v) for v in x_shape)
     key = (w._version, w.data_ptr(), None if conv.bias is None else conv.bias._version, N, H, W)
     hit = conv.__dict__.get("_dbev_wino_folded")
-    if hit is None or hit[0] != key or hit[1] is not coef:
+    if hit is None or hit[0] != key or hit[1] != ckey:
         Co = conv.out_channels
+        reuse = hit is not None and hit[0][1] == key[1] and hit[0][3:] == key[3:] and hit[2].device == torch.device(dev)
         with torch.no_grad():
             scale, shift = coef[:Co], coef[Co:]
             wf = w.detach() * scale.view(Co, 1, 1, 1)
             b = (shift if conv.bias is None else shift + conv.bias.detach() * scale).contiguous()
-            U = pack_filters(wf, False, x.shape)
-        hit = (key, coef, U, b, L.fingerprint(w, conv.bias))
+            U = pack_filters(wf, False, x_shape, out=hit[2] if reuse else None)
+            if reuse:
+                b = hit[3].copy_(b)
+            elif b.data_ptr() == coef.data_ptr() or b._base is not None:
+                b = b.clone()                                # own storage: the coefficient tensor is rewritten in place when the norm moves
+        hit = (key, ckey, U, b, L.fingerprint(w, conv.bias))
         conv.__dict__["_dbev_wino_folded"] = hit
     else:
         L.check_fingerprint(hit[4], "folded convolution + norm filter pack", w, conv.bias)
+    L.note_derived("wino_folded", conv, (norm, (N, int(x_shape[1]), H, W), dev), (hit[2], hit[3]))
+    return hit
+
+
+def conv_norm_relu_eval(x, conv, norm):
+    """relu(norm(conv(x))) for a `fold_ready` triple: the norm's scale goes into the filters before they are transformed and packed
+    (kept until the convolution's or the norm's tensors change), its shift (+ the scaled convolution bias) is the kernel's bias, the
+    ReLU its output flag -- no normalisation pass over the output."""
+    hit = folded_pack(conv, norm, x.shape, x.device)
     return conv_packed(x, hit[2], conv.out_channels, hit[3], relu=True)
 
 

@@ -56,12 +56,12 @@ def test_multi_pack_equals_lazy_packs_and_is_used(monkeypatch):
                             refd = wino.pack_filters(w.detach(), True, (N, Co, H, W))
                             assert torch.equal(wino.conv_packed(gin, dgrad, C), wino.conv_packed(gin, refd, C))
                     for w in packer.bf6:
-                        key, packs, fp = w._dbev_bf6_packs
+                        key, packs, fp = w._dbev_bf6_packs[:3]
                         assert key[0] == w._version and packs
                         for (tr, tn), buf in list(packs.items()):
                             del w._dbev_bf6_packs                     # force a fresh single-layer pack to compare with
                             assert torch.equal(buf, gemm_bf6.packed(w, tr, tn))
-                            w._dbev_bf6_packs = (key, packs, fp)
+                            w._dbev_bf6_packs = (key, packs, fp, {})
             ys.append(y.detach().clone())
         if packer is not None:
             assert packer.launches == 6                               # two families x three steps, nothing left to the lazy path
