@@ -33,10 +33,12 @@ PMC_TRAFFIC = {"bn_apply_res_ratio": (540720.8 * 2 + 540672.0) * 1024 / (3 * 553
                # WRITE_SIZE (30 072 + 4 224) KB = 175.7 MB per layer against 73.9 MB algorithmic (x, y once + packed filters): the four
                # 64-channel blocks of a tile block each fetch its patch (16- / 32-byte pieces; the x 2 read correction is the guide's for
                # wide reads and is conservative here); writes = the output
-               "wino_fwd_ratio": ((49592.2 + 19068.0) * 2 + 30072.0 + 4224.0) * 1024 / (4.0 * 48 * 16 * 44 * 512 + 4.0 * 16 * 256 * 256),
-               "wino_source": "profiles/r04_pmc_wino_FETCH_SIZE.txt (x2 gfx950 wide-read correction) + profiles/r04_pmc_wino_WRITE_SIZE.txt, "
-                              "separate --pmc passes of wino_fwd at 48x256x16x44 -> 256; traffic = mean algorithmic bytes of the timed "
-                              "launches x that measured ratio (not collected live)",
+               "wino_fwd_ratio": ((49594.1 + 19068.0) * 2 + 30072.0 + 4224.0) * 1024 / (4.0 * 48 * 16 * 44 * 512 + 4.0 * 16 * 256 * 256),
+               "wino_source": "profiles/r06_pmc_wino.txt (re-taken in round 6: FETCH_SIZE 49 594.1 + 19 068.0 KB, WRITE_SIZE 30 072 + 4 224 KB -- "
+                              "unchanged from round 4; x2 gfx950 wide-read correction on the reads), separate --pmc passes of the hybrid "
+                              "wino_fwd + wino_fwd3 launch at 48x256x16x44 -> 256; traffic = mean algorithmic bytes of the timed launches x "
+                              "that measured ratio (not collected live).  Per shape: 2.3x (256 ch), 1.27x (128), 1.04x (64): every 64-channel "
+                              "block of a tile block fetches the patch, L2 -> fabric traffic at 0.6-1.3 TB/s, not what limits the kernel",
                "source": "profiles/r03_pmc_FETCH_SIZE.txt (x2 gfx950 wide-read correction) + profiles/r03_pmc_WRITE_SIZE.txt, separate "
                          "--pmc passes at the kernel's largest shape (48x256x64x176); traffic = algorithmic bytes of the timed "
                          "launches x that measured ratio (not collected live)"}

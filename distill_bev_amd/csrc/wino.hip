@@ -26,6 +26,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -407,6 +409,397 @@ __global__ __launch_bounds__(256, 1) void wino_fwd(const float* __restrict__ X, 
     if (tid < 128) {
       const int which = tid >> 6, c = tid & 63;
       partial[(static_cast<size_t>(tb) * 2 + which) * Co + 64 * cb + c] = red[(which * 2 + 0) * 64 + c] + red[(which * 2 + 1) * 64 + c];
+    }
+  }
+}
+
+// ---- the convolution, persistent workgroups (round 6) ------------------------------------------------------------------------------
+// Counters of wino_fwd on the image backbone's 48-image shapes (profiles/r06_pmc_wino.txt; clock 2.4-2.5 GHz by GRBM_GUI_ACTIVE -- no
+// throttling in the spaced runs): the matrix pipe is busy 0.84 / 0.78 / 0.65 of the cycles a CU has a workgroup (256 / 128 / 64 input
+// channels: ~7 us per work item are prologue -- zeroing, the first DMA round trip, the first transform -- and epilogue, whatever the
+// item's length), and a CU HAS a workgroup only 0.74-0.79 of the launch (turnover between workgroups, the partly filled last round).
+// Same main loop, but ONE workgroup per CU that walks work items (tile block x 64-channel block):
+//  * items come from eight queues, one per XCD (the items of an XCD's queue are neighbours: the four channel blocks of a tile block
+//    fetch the same patch, from ONE L2), a device counter each; the first item of a workgroup is its own by position, the counter
+//    for item i + 1 is bumped under item i's first k group; a workgroup whose queue is empty finishes its item, then takes from
+//    the queues that still have work, so the last round is shared by all 256 CUs whatever the split;
+//  * behind the last k group of an item the patch stages 0 / 1 and the first filter chunk of the NEXT item are requested, then the
+//    output transform and the stores of this item run under that round trip -- the prologue's latency is gone;
+//  * patch slots outside the image are zeroed per item by the lanes the DMA skips (the item's edge mask is constant over its stages);
+//  * the wait for the next item's first stages leaves this item's 64 stores in flight (vmcnt counts loads and stores in issue order,
+//    the stores are the youngest), and the barriers between the stores and the next k group do not drain it.
+// The last workgroup out resets the counters (a set of counters per launch in flight: g_wino_queue).  Results are bit-identical to
+// wino_fwd's: same per-item arithmetic in the same order.
+// dev builds (-DDBEV_WINO_ABLATE): shader-clock stamps of workgroup 0 between the phases of an item, summed over its items
+#ifdef DBEV_WINO_ABLATE
+__device__ unsigned long long g_wp_prof[16];
+#define WP_T0() unsigned long long wp_t_ = __builtin_amdgcn_s_memtime(), wp_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  const unsigned long long wp_c0_ = wp_t_, wp_r0_ = __builtin_amdgcn_s_memrealtime()
+#define WP_STAMP(i_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); wp_acc_[i_] += n_ - wp_t_; wp_t_ = n_; if ((i_) == 6) ++wp_acc_[7]; } while (0)
+#define WP_DUMP() do { if (blockIdx.x == 0 && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) g_wp_prof[i_] = wp_acc_[i_];          \
+    g_wp_prof[8] += __builtin_amdgcn_s_memtime() - wp_c0_; g_wp_prof[9] += __builtin_amdgcn_s_memrealtime() - wp_r0_;            \
+    g_wp_prof[10] += wp_acc_[7]; g_wp_prof[11] += 1; } } while (0)    /* [8..11]: summed over launches: shader cycles, 100 MHz ticks, items, launches */
+#else
+#define WP_T0()
+#define WP_STAMP(i_)
+#define WP_DUMP()
+#endif
+constexpr int WQ_SETS = 64, WQ_INTS = 16;                  // [8 queue counters, 1 exit counter, padding]
+__device__ int g_wino_queue[WQ_SETS * WQ_INTS];
+
+template <int BH, int BW, bool STATS>
+__global__ __launch_bounds__(256, 1) void wino_fwdp(const float* __restrict__ X, const float* __restrict__ U, const float* __restrict__ bias,
+                                                    float* __restrict__ Y, float* __restrict__ partial, int N, int H, int W, int C,
+                                                    int Co, int ntb, int dbg, int qset) {
+  constexpr int PW = 2 * BW + 2, PH = 2 * BH + 2, NPIX = PW * PH;
+  constexpr int NPC = (NPIX + 31) / 32;                   // patch DMA pieces (32 pixels x 32 bytes = 1 KB each)
+  constexpr int PBUF = NPC * 256;                         // floats per patch stage buffer
+  constexpr int VBUF = 16 * 64 * 8;                       // floats per transformed-input buffer
+  __shared__ __attribute__((aligned(16))) float smem[2 * PBUF + 2 * VBUF + 2 * WN_UCHUNK];
+  __shared__ int s_item;
+  float* sP = smem;
+  float* sV = smem + 2 * PBUF;
+  float* sU = sV + 2 * VBUF;
+  const bool relu = (dbg >> 16) & 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mi = w & 1, ni = w >> 1, half = lane >> 5, l31 = lane & 31;
+  const int ncb = Co / 64;
+  const int TH = H >> 1, TW = W >> 1;
+  const int NBW = (TW + BW - 1) / BW, NBH = (TH + BH - 1) / BH;
+  const int nkg = C / 8;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int nitems = ntb * ncb;
+  const int qper = (nitems + DBEV_NUM_XCD - 1) / DBEV_NUM_XCD;
+  const int q0 = blockIdx.x % DBEV_NUM_XCD;
+  int* const ctr = g_wino_queue + qset * WQ_INTS;
+  // Queue q = items [q qper, (q + 1) qper).  The workgroups of XCD q (blockIdx % 8 == q: placement is a speed assumption only) take their
+  // FIRST item without asking: workgroup j of the queue (j = blockIdx / 8) owns local index j; the head counter hands out the local
+  // indices from nown = (workgroups of the queue) on.  A workgroup whose queue is empty looks at the other heads (one 64-byte read)
+  // and bumps the first queue that still has items.
+  const int nown = (static_cast<int>(gridDim.x) - q0 + DBEV_NUM_XCD - 1) / DBEV_NUM_XCD;
+  const int myend = min(nitems, (q0 + 1) * qper) - q0 * qper;         // local indices of my queue: [0, myend)
+  auto steal = [&]() -> int {
+    for (int k = 1; k < DBEV_NUM_XCD; ++k) {
+      const int q = (q0 + k) % DBEV_NUM_XCD;
+      const int beg = q * qper, cnt = min(nitems, beg + qper) - beg;
+      const int wgs = (static_cast<int>(gridDim.x) - q + DBEV_NUM_XCD - 1) / DBEV_NUM_XCD;
+      if (cnt <= wgs) continue;
+      if (__hip_atomic_load(ctr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + wgs >= cnt) continue;
+      const int v = atomicAdd(ctr + q, 1) + wgs;
+      if (v < cnt) return beg + v;
+    }
+    return -1;
+  };
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_ptr_t)smem)));
+  const unsigned uvoff = lane * 16;
+#define WN_DMA(voff_, sbase_, ldsaddr_)                                                                              \
+  do {                                                                                                               \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"  \
+                 : "=&s"(keep_) : "v"(voff_), "s"(ldsaddr_), "s"(sbase_) : "memory");                                \
+  } while (0)
+#define WN_DMA_PATCH(i_, st_, buf_)                                                                                  \
+  do {                                                                                                               \
+    if (pok[i_]) {                                                                                                   \
+      const unsigned long long sb_ = ximg + static_cast<unsigned long long>(st_) * 32ull;                            \
+      const unsigned la_ = lds0 + static_cast<unsigned>(((buf_) * PBUF + (wu + 4 * (i_)) * 256) * 4);                \
+      WN_DMA(pvoff[i_], sb_, la_);                                                                                   \
+    }                                                                                                                \
+  } while (0)
+#define WN_DMA_U(i_, kg_, buf_)                                                                                      \
+  do {                                                                                                               \
+    const unsigned long long sb_ = ucb + (static_cast<unsigned long long>(kg_) * WN_UCHUNK + (8 * wu + (i_)) * 256) * 4ull; \
+    const unsigned la_ = lds0 + static_cast<unsigned>((2 * PBUF + 2 * VBUF + (buf_) * WN_UCHUNK + (8 * wu + (i_)) * 256) * 4); \
+    WN_DMA(uvoff, sb_, la_);                                                                                         \
+  } while (0)
+#define WN_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+  // gfx9 counts loads AND stores in vmcnt, in issue order, and __syncthreads() drains it: between an item's output stores and the next
+  // item's first k group the barriers are bare (LDS traffic only) and the wait for the next item's first stages -- requested BEFORE the
+  // stores -- leaves the youngest 63 operations (the stores) in flight
+#define WP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  // geometry of item it_: channel block, tile block -> image, first tile; the DMA lanes' pixel offsets and edge mask; then the zeros
+  // of the masked slots (both stage buffers) and the requests for stages 0, 1 and the first filter chunk
+  unsigned pvoff[3];
+  bool pok[3];
+  unsigned long long ximg = 0, ucb = 0;
+  int cb = 0, tb = 0, n = 0, th0 = 0, tw0 = 0;
+#define WP_START(it_)                                                                                                \
+  do {                                                                                                               \
+    cb = (it_) % ncb; tb = (it_) / ncb;                                                                              \
+    const int bw_ = tb % NBW, bh_ = (tb / NBW) % NBH;                                                                \
+    n = tb / (NBW * NBH); th0 = bh_ * BH; tw0 = bw_ * BW;                                                            \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                  \
+      const int pix = 32 * (wu + 4 * i) + (lane >> 1);                                                               \
+      const int pr = pix / PW, pc = pix - pr * PW;                                                                   \
+      const int h = 2 * th0 - 1 + pr, x = 2 * tw0 - 1 + pc;                                                          \
+      const bool in_patch = (wu + 4 * i) < NPC && pix < NPIX;                                                        \
+      pok[i] = in_patch && h >= 0 && h < H && x >= 0 && x < W;                                                       \
+      pvoff[i] = pok[i] ? static_cast<unsigned>(((h * W + x) * C + 4 * (lane & 1)) * 4) : 0u;                        \
+      if (in_patch && !pok[i]) {                                                                                     \
+        float4* z_ = reinterpret_cast<float4*>(sP + (wu + 4 * i) * 256 + lane * 4);                                  \
+        z_[0] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                     \
+        z_[PBUF / 4] = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+      }                                                                                                              \
+    }                                                                                                                \
+    ximg = uniform64(reinterpret_cast<unsigned long long>(X + static_cast<size_t>(n) * H * W * C));                  \
+    ucb = uniform64(reinterpret_cast<unsigned long long>(U + static_cast<size_t>(cb) * nkg * WN_UCHUNK));            \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) WN_DMA_PATCH(i, 0, 0);                                             \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) WN_DMA_PATCH(i, nkg > 1 ? 1 : 0, 1);                               \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) WN_DMA_U(i, 0, 0);                                                 \
+  } while (0)
+
+  const int tt = tid >> 2, kq = tid & 3;
+  const int ttr = tt / BW, ttc = tt - ttr * BW;
+  const int tsrc = ((2 * ttr) * PW + 2 * ttc) * 8 + 2 * kq;
+  const int tdst = tt * 8 + 2 * kq;
+  const int aoff = (32 * mi + l31) * 8 + 4 * half;
+  const int boff = (ni * 64 + lane) * 4;
+
+  const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  floatx2 d[4][4], T[4][4];
+#define WN_DREAD(ptr_, a_, b_) d[a_][b_] = *reinterpret_cast<const floatx2*>((ptr_) + ((a_) * PW + (b_)) * 8)
+#define WN_TOP(i_, b_) T[i_][b_] = (i_) == 0 ? pk_sub(d[0][b_], d[2][b_]) : (i_) == 1 ? pk_add(d[1][b_], d[2][b_]) : (i_) == 2 ? pk_sub(d[2][b_], d[1][b_]) : pk_sub(d[1][b_], d[3][b_])
+#define WN_VCOL(i_, j_) \
+  ((j_) == 0 ? pk_sub(T[i_][0], T[i_][2]) : (j_) == 1 ? pk_add(T[i_][1], T[i_][2]) : (j_) == 2 ? pk_sub(T[i_][2], T[i_][1]) : pk_sub(T[i_][1], T[i_][3]))
+#define WN_VSTORE(dst_, i_, j_, v_) *reinterpret_cast<floatx2*>((dst_) + (4 * (i_) + (j_)) * 512) = (v_)
+#define WN_VOUT(dst_, i_, j_) WN_VSTORE(dst_, i_, j_, WN_VCOL(i_, j_))
+  floatx2 vo[8];
+
+  // prologue of the workgroup: zero the patch buffers once, take the first item
+  for (int i = tid; i < 2 * PBUF / 4; i += 256) reinterpret_cast<float4*>(sP)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  int item = static_cast<int>(blockIdx.x) / DBEV_NUM_XCD < myend ? q0 * qper + static_cast<int>(blockIdx.x) / DBEV_NUM_XCD : -1;
+  if (item < 0) {                                                 // (more workgroups than items in my queue: help elsewhere)
+    if (tid == 0) s_item = steal();
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(s_item);
+  }
+  if (item >= 0) WP_START(item);
+
+  bool fast_prev = false;
+  WP_T0();
+  while (item >= 0) {
+    // stages 0 / 1 and the first filters of `item` are in flight (requested by WP_START: above, or behind the previous item's loop)
+    if (fast_prev) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");   // the 64 stores of the previous item's epilogue are the youngest
+    else WN_WAIT_VM();
+    WP_BARRIER();
+    WP_STAMP(0);                                                  // waited for this item's first stages
+    const int co = 64 * cb + 32 * ni + l31;
+    float bco = bias != nullptr ? bias[co] : 0.f;                 // (its wait sits behind the first k group)
+    // the bump of my queue's head for the item after this one, by lane 0 of wave 0, as ONE instruction whose result nobody looks at
+    // before the wait at the end of the first k group (a compiler-visible atomic is waited for on the spot: ~1 us in front of the barrier)
+    int vnext = 0;
+    if (wu == 0) {
+      const unsigned long long cq_ = reinterpret_cast<unsigned long long>(ctr + q0);
+      asm volatile("s_mov_b64 s[2:3], exec\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %0, 1\n\tglobal_atomic_add %0, %1, %0, %2 sc0\n\ts_mov_b64 exec, s[2:3]"
+                   : "=&v"(vnext) : "v"(0), "s"(cq_) : "s2", "s3", "memory");
+    }
+    {
+      const float* ps = sP + tsrc;
+      float* vd = sV + tdst;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) WN_DREAD(ps, a, b2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) WN_TOP(i, b2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) WN_VOUT(vd, i, j);
+    }
+    WP_BARRIER();
+    WP_STAMP(1);                                                  // first transform
+
+    // one k group; FIRST_: the item's first -- its MFMAs start the 16 accumulators from the constant 0 (no zeroing pass, and no
+    // accumulator value is carried from one item to the next: the compiler shuffled and spilled the tuples when one was)
+#define WP_KGROUP(FIRST_, kg_)                                                                                        \
+    do {                                                                                                             \
+      const int cur = (kg_) & 1, nxt = cur ^ 1;                                                                      \
+      const int kgn = min((kg_) + 1, nkg - 1), stn = min((kg_) + 2, nkg - 1);                                        \
+      const float* ps = sP + nxt * PBUF + tsrc;                                                                      \
+      float* vd = sV + nxt * VBUF + tdst;                                                                            \
+      const float4* ap = reinterpret_cast<const float4*>(sV + cur * VBUF + aoff);                                    \
+      const float4* bp = reinterpret_cast<const float4*>(sU + cur * WN_UCHUNK + boff);                               \
+      float4 av = ap[0], bv = bp[0], an = av, bn = bv;                                                               \
+      _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                                               \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+          const int sl = 4 * p + e;                                                                                  \
+          const float a_ = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;                                     \
+          const float b_ = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;                                     \
+          if ((FIRST_) && e == 0) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, zero16, 0, 0, 0);            \
+          else acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, acc[p], 0, 0, 0);                               \
+          if (e == 0 && p < 15) { an = ap[(p + 1) * 128]; bn = bp[(p + 1) * 128]; }                                  \
+          if (sl >= 1 && sl < 17) { const int q = sl - 1; WN_DREAD(ps, q >> 2, q & 3); }                             \
+          if (sl == 20) {                                                                                            \
+            _Pragma("unroll") for (int q = 0; q < 16; ++q) WN_TOP(q >> 2, q & 3);                                    \
+          }                                                                                                          \
+          if (sl == 24 || sl == 34) {                                                                                \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) vo[q] = WN_VCOL((sl == 24 ? 0 : 2) + (q >> 2), q & 3);     \
+          }                                                                                                          \
+          if (sl >= 25 && sl < 33) { const int q = sl - 25; WN_VSTORE(vd, q >> 2, q & 3, vo[q]); }                   \
+          if (sl >= 35 && sl < 43) { const int q = sl - 35; WN_VSTORE(vd, 2 + (q >> 2), q & 3, vo[q]); }             \
+          if (sl >= 2 && sl < 10) WN_DMA_U(sl - 2, kgn, nxt);                                                        \
+          if (sl >= 10 && sl < 13) WN_DMA_PATCH(sl - 10, stn, cur);                                                  \
+          __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                            \
+        av = an; bv = bn;                                                                                            \
+      }                                                                                                              \
+      WN_WAIT_VM();                                                                                                  \
+      __syncthreads();                                                                                               \
+    } while (0)
+    // an accumulator element where the output transform consumes it: read from its AGPR THERE (left to the compiler, all 256 are copied
+    // to VGPRs right behind the main loop and everything else that lives across the item loop is spilled; the last MFMA is thousands
+    // of cycles back: no hazard for the hand-written read)
+#define WP_AR(x_) ({ float v_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v_) : "a"(x_)); v_; })
+    floatx16 acc[16];
+    WP_KGROUP(true, 0);
+    asm volatile("" : "+v"(vnext), "+v"(bco));                    // (both have landed: the k group ended with vmcnt(0))
+    WP_STAMP(2);                                                  // first k group
+    for (int kg = 1; kg < nkg; ++kg) WP_KGROUP(false, kg);
+    WP_STAMP(3);                                                  // the other k groups
+#undef WP_KGROUP
+
+    // this item's geometry for the epilogue; the next item (its requests go out before the epilogue's stores)
+    const int e_cb = cb, e_tb = tb, e_n = n, e_th0 = th0, e_tw0 = tw0;
+    // the next item: my queue's, known already -- its first stages are requested before this item's stores --, or, once my queue is
+    // empty, somebody else's: looked for AFTER this item's output is on its way
+    if (tid == 0) s_item = vnext + nown < myend ? q0 * qper + vnext + nown : -1;
+    __syncthreads();
+    int next = __builtin_amdgcn_readfirstlane(s_item);
+    const bool late = next < 0;
+    WP_STAMP(4);                                                  // next item index
+    if (!late) WP_START(next);
+    __builtin_amdgcn_sched_barrier(0);
+    WP_STAMP(5);                                                  // next item's geometry and requests
+
+    // output transform + store: register r of every accumulator = tile ti = (r & 3) + 8 (r >> 2) + 4 half of this wave's 32, channel l31
+    float s1 = 0.f, s2 = 0.f;
+    fast_prev = e_th0 + BH <= TH && e_tw0 + BW <= TW;
+    if (fast_prev) {
+      static_assert(BW == 8 || BW == 16, "tile (row, column) of register r below");
+      unsigned long long yb[8];
+      yb[0] = uniform64(reinterpret_cast<unsigned long long>(Y + static_cast<size_t>(e_n) * H * W * Co));
+      yb[1] = yb[0] + static_cast<unsigned long long>(Co) * 4ull;
+      yb[2] = yb[0] + static_cast<unsigned long long>(W) * Co * 4ull;
+      yb[3] = yb[2] + static_cast<unsigned long long>(Co) * 4ull;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yb[4 + i] = yb[i] + static_cast<unsigned long long>(Co) * 8ull;
+#define WN_ST(voff_, val_, sbase_) asm volatile("global_store_dword %0, %1, %2" :: "v"(voff_), "v"(val_), "s"(sbase_) : "memory")
+      // (opaque copies: everything below that depends only on the lane and the layer would otherwise be hoisted out of the item loop and
+      // kept -- spilled -- across the main loop, its reloads then waiting between the stores)
+      int Wq = W, Coq = Co;
+      asm volatile("" : "+s"(Wq), "+s"(Coq));
+      const int tr0 = (BW == 8 ? 4 : 2) * mi, tc0 = 4 * half;
+      const unsigned voff0 = static_cast<unsigned>(((2 * (e_th0 + tr0) * Wq + 2 * (e_tw0 + tc0)) * Coq + co) * 4);
+      const unsigned rowstep = static_cast<unsigned>(2 * Wq * Coq * 4), colstep = static_cast<unsigned>(2 * Coq * 4);
+      const floatx2 b2 = {bco, bco};
+      floatx2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int dr = BW == 8 ? (r >> 2) : (r >> 3), dc = BW == 8 ? (r & 3) : (r & 3) + 8 * ((r >> 2) & 1);
+        floatx2 s0[4], s1r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const floatx2 a0 = {WP_AR(acc[0 + j][r]), WP_AR(acc[0 + j][r + 1])}, a1 = {WP_AR(acc[4 + j][r]), WP_AR(acc[4 + j][r + 1])};
+          const floatx2 a2 = {WP_AR(acc[8 + j][r]), WP_AR(acc[8 + j][r + 1])}, a3 = {WP_AR(acc[12 + j][r]), WP_AR(acc[12 + j][r + 1])};
+          s0[j] = pk_add(pk_add(a0, a1), a2);
+          s1r[j] = pk_sub(pk_sub(a1, a2), a3);
+        }
+        floatx2 y00 = pk_add(pk_add(pk_add(s0[0], s0[1]), s0[2]), b2), y01 = pk_add(pk_sub(pk_sub(s0[1], s0[2]), s0[3]), b2);
+        floatx2 y10 = pk_add(pk_add(pk_add(s1r[0], s1r[1]), s1r[2]), b2), y11 = pk_add(pk_sub(pk_sub(s1r[1], s1r[2]), s1r[3]), b2);
+        if (relu) {
+          y00.x = fmaxf(y00.x, 0.f); y00.y = fmaxf(y00.y, 0.f); y01.x = fmaxf(y01.x, 0.f); y01.y = fmaxf(y01.y, 0.f);
+          y10.x = fmaxf(y10.x, 0.f); y10.y = fmaxf(y10.y, 0.f); y11.x = fmaxf(y11.x, 0.f); y11.y = fmaxf(y11.y, 0.f);
+        }
+        const unsigned vo_ = voff0 + dr * rowstep + dc * colstep;
+        WN_ST(vo_, y00.x, yb[0]); WN_ST(vo_, y00.y, yb[4]);
+        WN_ST(vo_, y01.x, yb[1]); WN_ST(vo_, y01.y, yb[5]);
+        WN_ST(vo_, y10.x, yb[2]); WN_ST(vo_, y10.y, yb[6]);
+        WN_ST(vo_, y11.x, yb[3]); WN_ST(vo_, y11.y, yb[7]);
+        if (STATS) {
+          t1 = pk_add(t1, pk_add(pk_add(y00, y01), pk_add(y10, y11)));
+          t2 = pk_fma(y00, y00, t2); t2 = pk_fma(y01, y01, t2); t2 = pk_fma(y10, y10, t2); t2 = pk_fma(y11, y11, t2);
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // (the accumulator reads of the next pair stay here: register pressure)
+      }
+      s1 = t1.x + t1.y; s2 = t2.x + t2.y;
+#undef WN_ST
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int tr = t / BW, tc = t - tr * BW;
+        const int th = e_th0 + tr, tw = e_tw0 + tc;
+        float s0[4], s1r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float m0 = WP_AR(acc[0 + j][r]), m1 = WP_AR(acc[4 + j][r]), m2 = WP_AR(acc[8 + j][r]), m3 = WP_AR(acc[12 + j][r]);
+          s0[j] = (m0 + m1) + m2;
+          s1r[j] = (m1 - m2) - m3;
+        }
+        float y00 = (s0[0] + s0[1]) + s0[2] + bco, y01 = (s0[1] - s0[2]) - s0[3] + bco;
+        float y10 = (s1r[0] + s1r[1]) + s1r[2] + bco, y11 = (s1r[1] - s1r[2]) - s1r[3] + bco;
+        if (relu) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (th < TH && tw < TW) {
+          float* yp = Y + (static_cast<size_t>(e_n * H + 2 * th) * W + 2 * tw) * Co + co;
+          yp[0] = y00;
+          yp[Co] = y01;
+          yp[static_cast<size_t>(W) * Co] = y10;
+          yp[static_cast<size_t>(W) * Co + Co] = y11;
+          if (STATS) {
+            s1 += (y00 + y01) + (y10 + y11);
+            s2 = fmaf(y00, y00, s2); s2 = fmaf(y01, y01, s2); s2 = fmaf(y10, y10, s2); s2 = fmaf(y11, y11, s2);
+          }
+        }
+      }
+    }
+    if (STATS) {
+      float* red = sV + VBUF;                                      // [2 which][2 mi][64 channels]: V buffer 1 is idle until the next item's first k group
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (half == 0) {
+        red[(0 * 2 + mi) * 64 + 32 * ni + l31] = s1;
+        red[(1 * 2 + mi) * 64 + 32 * ni + l31] = s2;
+      }
+      WP_BARRIER();
+      if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        partial[(static_cast<size_t>(e_tb) * 2 + which) * Co + 64 * e_cb + c] = red[(which * 2 + 0) * 64 + c] + red[(which * 2 + 1) * 64 + c];
+      }
+    }
+    WP_STAMP(6);                                                  // output transform, stores, statistics
+    if (late) {
+      if (tid == 0) s_item = steal();
+      __syncthreads();
+      next = __builtin_amdgcn_readfirstlane(s_item);
+      if (next >= 0) WP_START(next);
+      fast_prev = false;                                          // (requests behind the stores: wait for everything)
+    }
+    item = next;
+  }
+  WP_DUMP();
+#undef WP_BARRIER
+#undef WP_AR
+#undef WN_DREAD
+#undef WN_TOP
+#undef WN_VOUT
+#undef WN_VCOL
+#undef WN_VSTORE
+#undef WN_DMA
+#undef WN_DMA_PATCH
+#undef WN_DMA_U
+#undef WN_WAIT_VM
+#undef WP_START
+  // the last workgroup out leaves the counters at zero for the next launch that gets this set
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(ctr + DBEV_NUM_XCD, 1) == static_cast<int>(gridDim.x) - 1) {
+#pragma unroll
+      for (int q = 0; q <= DBEV_NUM_XCD; ++q) atomicExch(ctr + q, 0);
     }
   }
 }
@@ -1238,10 +1631,13 @@ bool wino_wg_plan(int N, int H, int W, int C, int Co, WinoWgPlan* p) {
   return true;
 }
 
+std::atomic<unsigned> g_wq_seq{0};            // launches of wino_fwdp take the counter sets of g_wino_queue in turn
+
 int wino_dbg() { static const int v = getenv("DBEV_WINO_DBG") ? atoi(getenv("DBEV_WINO_DBG")) : 0; return v; }
 
 struct WinoPlan {
   int bh, bw, ntb, ncb, grid, v3;
+  int persist;                                 // wino_fwdp: one workgroup per CU walking all (tile block, channel block) items
   int n2;                                      // > 0: hybrid -- wino_fwd runs tile blocks [0, n2) (whole rounds), wino_fwd3 the rest
   int bh3, bw3, tb3_first, ntb3, grid3;        // the wino_fwd3 part of a hybrid launch (its 32-tile blocks from tb3_first on)
 };
@@ -1263,9 +1659,9 @@ bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
   // Which kernel (measured, profiles/r04_wino_vs_miopen.txt): wino_fwd (64-tile items, one per CU) is 10-17 % faster per tile once the
   // chip is full; wino_fwd3 (32-tile items, two per CU) wins where wino_fwd would leave CUs idle: under ~200 items (64 items: 98 vs
   // 129 us, 128: 55 vs 69), and when a second round would be at most half full (384 items: 247 vs 264 us)
-  const int ver = wino_fwd_version();
+  const int ver = wino_fwd_version();                      // 2 / 3 / 4 force wino_fwd / wino_fwd3 / wino_fwdp (tests, A/B runs)
   const long long items = nb64 * p->ncb;
-  p->v3 = ver == 3 || (C % 8) != 0 || (ver != 2 && (items <= 192 || (items > 256 && items <= 384)));
+  p->v3 = ver == 3 || (C % 8) != 0 || (ver != 2 && ver != 4 && (items <= 192 || (items > 256 && items <= 384)));
   if (p->v3) {                                   // 32-tile blocks: 4 x 8 or 2 x 16
     const long long w48 = static_cast<long long>((TH + 3) / 4) * ((TW + 7) / 8), w216 = static_cast<long long>((TH + 1) / 2) * ((TW + 15) / 16);
     if (w216 < w48) { p->bh = 2; p->bw = 16; p->ntb = static_cast<int>(w216) * N; }
@@ -1279,6 +1675,18 @@ bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
   // round for it.  wino_fwd then runs only the whole rounds (tile blocks [0, n2), n2 a multiple of a block row), and the remaining tile
   // rows go to wino_fwd3 as 32-tile items, two per CU: <= 256 of them take ~0.58 of a round, <= 512 ~1.16 (profiles/r04_wino_vs_miopen.txt).
   p->n2 = 0;
+  // Persistent workgroups (round 6, wino_fwdp): no workgroup turnover, the next item's first stages requested under this item's output
+  // transform, the last round shared by all CUs.  MEASURED NEUTRAL TO SLIGHTLY SLOWER (profiles/r06_wino_persistent.txt: per layer
+  // -3 ... +10 %, the step 101.0 -> 101.4 ms): what it removes (turnover, the prologue's round trip) it pays back in item hand-over
+  // (~12 k shader cycles per item against ~10 k of prologue + epilogue + turnover before), and the kernel runs at the clock the power
+  // limit leaves (2.15 GHz in the step, measured by this kernel's own stamps) either way.  Off by default; DBEV_WINO_PERSIST=1 /
+  // DBEV_WINO_FWD_V=4 select it (tests, the clock probe tools/wino_clock_in_step.py).
+  static const int persist_on = getenv("DBEV_WINO_PERSIST") ? atoi(getenv("DBEV_WINO_PERSIST")) : 0;
+  p->persist = !p->v3 && ((ver == 0 && persist_on && items > DBEV_NUM_CU) || ver == 4);
+  if (p->persist) {
+    p->grid = DBEV_NUM_CU;
+    return true;
+  }
   static const int hybrid_on = getenv("DBEV_WINO_HYBRID") ? atoi(getenv("DBEV_WINO_HYBRID")) : 1;
   if (!p->v3 && ver == 0 && hybrid_on && (TH % p->bh) == 0) {
     const int nbw = (TW + p->bw - 1) / p->bw;
@@ -1302,6 +1710,12 @@ bool wino_plan(int N, int H, int W, int C, int Co, WinoPlan* p) {
 }
 
 }  // namespace
+
+#ifdef DBEV_WINO_ABLATE
+extern "C" int dbev_wino_prof_read(unsigned long long* out16) {      // dev builds only: not part of the ABI
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wp_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" long long dbev_wino_filter_floats(int K, int J) {
   if (K <= 0 || J <= 0 || (K % 4) || (J % 64)) return 0;
@@ -1390,6 +1804,9 @@ extern "C" int dbev_wino_conv3x3_forward_act(const float* x_nhwc, const float* p
 #define WN_GO3(BHV, BWV, ST)                                                                                                      \
   hipLaunchKernelGGL((wino_fwd3<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
                      Cin, Cout, p.ntb, wino_dbg() | (relu ? 1 << 16 : 0), 0)
+#define WN_GOP(BHV, BWV, ST)                                                                                                      \
+  hipLaunchKernelGGL((wino_fwdp<BHV, BWV, ST>), dim3(p.grid), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc, stats_partial, N, H, W, \
+                     Cin, Cout, p.ntb, wino_dbg() | (relu ? 1 << 16 : 0), static_cast<int>(g_wq_seq.fetch_add(1) % WQ_SETS))
 #define WN_GO3T(BHV, BWV, ST)                     /* the tail of a hybrid launch: blocks tb3_first.. , statistics rows behind wino_fwd's */ \
   hipLaunchKernelGGL((wino_fwd3<BHV, BWV, ST>), dim3(p.grid3), dim3(256), 0, s, x_nhwc, packed, bias, y_nhwc,                        \
                      stats_partial != nullptr ? stats_partial + static_cast<size_t>(p.n2) * 2 * Cout : nullptr, N, H, W, Cin, Cout,  \
@@ -1397,6 +1814,10 @@ extern "C" int dbev_wino_conv3x3_forward_act(const float* x_nhwc, const float* p
   if (p.v3) {
     if (p.bw == 8) { if (stats_partial != nullptr) WN_GO3(4, 8, true); else WN_GO3(4, 8, false); }
     else { if (stats_partial != nullptr) WN_GO3(2, 16, true); else WN_GO3(2, 16, false); }
+  } else if (p.persist) {
+    packed += 16LL * Cin * Cout;                            // wino_fwd's format: the second half of the packed buffer
+    if (p.bw == 8) { if (stats_partial != nullptr) WN_GOP(8, 8, true); else WN_GOP(8, 8, false); }
+    else { if (stats_partial != nullptr) WN_GOP(4, 16, true); else WN_GOP(4, 16, false); }
   } else {
     if (p.n2 > 0) {                                         // hybrid: the rows wino_fwd leaves (launched first: it owns fewer CUs per item)
       if (p.bw3 == 8) { if (stats_partial != nullptr) WN_GO3T(4, 8, true); else WN_GO3T(4, 8, false); }
@@ -1409,6 +1830,7 @@ extern "C" int dbev_wino_conv3x3_forward_act(const float* x_nhwc, const float* p
 #undef WN_GO
 #undef WN_GO3
 #undef WN_GO3T
+#undef WN_GOP
   DBEV_LAUNCH_CHECK();
   return 0;
 }

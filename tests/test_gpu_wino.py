@@ -170,32 +170,59 @@ def test_frozen_conv_norm_relu_stack_is_one_launch_per_pair():
     assert float((out.detach() - outr.detach()).abs().max()) <= 1e-4 * float(outr.detach().abs().max()) and xg.grad is not None
 
 
-def test_hybrid_launch_whole_rounds_on_one_kernel_the_tail_on_the_other():
-    """576 work items = 2.25 rounds of 256 CUs: wino_fwd runs the whole rounds, wino_fwd3 the remaining tile rows (kernel code 6, both
-    filter formats); output, statistics rows and gradients as for any other layer"""
-    import os
-    from distill_bev_amd import wino, _lib as L
-    if os.environ.get("DBEV_WINO_FWD_V", "0") != "0" or os.environ.get("DBEV_WINO_HYBRID", "1") == "0":
-        pytest.skip("a forward kernel is forced by the environment (A/B runs)")
-    N, C, Co, H, W = 48, 64, 256, 16, 44
-    assert int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, C, Co)) == 6
-    x, w, b = _mk(N, C, Co, H, W, 31, True)
-    y, part = wino.conv_packed(x, wino.pack_filters(w, False, x.shape), Co, b, stats=True)
-    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
-    scale = float(ref.abs().max())
-    assert float((y.double() - ref).abs().max()) <= 2e-5 * scale
-    assert part.shape[0] == wino.stats_rows(x.shape, Co)
-    s = part.double().sum(0)
-    assert torch.allclose(s[0], ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * scale)
-    assert torch.allclose(s[1], (ref ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * scale * scale)
-    xg = x.clone().requires_grad_(True)
-    wg = w.clone().requires_grad_(True)
-    wino.conv3x3(xg, wg, b).backward(torch.ones_like(y))
-    xr = x.double().requires_grad_(True)
-    wr = w.double().requires_grad_(True)
-    F.conv2d(xr, wr, b.double(), 1, 1).backward(torch.ones_like(ref))
-    assert float((xg.grad.double() - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
-    assert float((wg.grad.double() - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max())
+_LAYER_CODE = """
+import sys, torch, torch.nn.functional as F
+from distill_bev_amd import wino, _lib as L
+dev = torch.device('cuda:0')
+N, C, Co, H, W = 48, 64, 256, 16, 44
+g = torch.Generator().manual_seed(31)
+x = torch.randn((N, C, H, W), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+w = (torch.randn((Co, C, 3, 3), generator=g) / (3.0 * C ** 0.5)).to(dev).contiguous(memory_format=torch.channels_last)
+b = torch.randn((Co,), generator=g).to(dev)
+code = int(L.call("dbev_wino_conv3x3_forward_kernel", N, H, W, C, Co))
+y, part = wino.conv_packed(x, wino.pack_filters(w, False, x.shape), Co, b, stats=True)
+ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+scale = float(ref.abs().max())
+assert float((y.double() - ref).abs().max()) <= 2e-5 * scale
+assert part.shape[0] == wino.stats_rows(x.shape, Co)
+s = part.double().sum(0)
+assert torch.allclose(s[0], ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * scale)
+assert torch.allclose(s[1], (ref ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * scale * scale)
+for _ in range(3):                                     # work items are handed out dynamically: the result must not depend on who got which
+    y2, part2 = wino.conv_packed(x, wino.pack_filters(w, False, x.shape), Co, b, stats=True)
+    assert torch.equal(y, y2) and torch.equal(part, part2)
+xg = x.clone().requires_grad_(True)
+wg = w.clone().requires_grad_(True)
+wino.conv3x3(xg, wg, b).backward(torch.ones_like(y))
+xr = x.double().requires_grad_(True)
+wr = w.double().requires_grad_(True)
+F.conv2d(xr, wr, b.double(), 1, 1).backward(torch.ones_like(ref))
+assert float((xg.grad.double() - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
+assert float((wg.grad.double() - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max())
+torch.save(dict(y=y.cpu(), part_sum=part.double().sum(0).cpu(), gx=xg.grad.cpu()), sys.argv[1])
+print('OK code', code)
+"""
+
+
+def test_persistent_hybrid_and_plain_launches_of_a_2_25_round_layer(tmp_path):
+    """576 work items = 2.25 rounds of 256 CUs, three ways (the choice is read once per process: a subprocess each): persistent
+    workgroups walking per-XCD item queues (wino_fwdp, kernel code 2: DBEV_WINO_PERSIST=1; measured neutral, off by default), the
+    default hybrid (wino_fwd for the whole rounds, wino_fwd3 for the remaining tile rows, code 6) and plain wino_fwd
+    (DBEV_WINO_FWD_V=2): each against fp64
+    (output, statistics rows, both gradients), repeated launches bit-identical, and the three outputs bit-identical to each other (the
+    per-item arithmetic is the same whichever workgroup runs it)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("DBEV_WINO_FWD_V", "DBEV_WINO_PERSIST", "DBEV_WINO_HYBRID")}
+    outs = {}
+    for name, env, code in (("persistent", {"DBEV_WINO_PERSIST": "1"}, 2), ("hybrid", {}, 6), ("plain", {"DBEV_WINO_FWD_V": "2"}, 2)):
+        f = str(tmp_path / (name + ".pt"))
+        r = subprocess.run([sys.executable, "-c", _LAYER_CODE, f], env=dict(base, **env), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0 and "OK code %d" % code in r.stdout, (name, r.stdout[-500:], r.stderr[-1500:])
+        outs[name] = torch.load(f)
+    assert torch.equal(outs["persistent"]["y"], outs["plain"]["y"])      # (the data gradient's 144 items go to another kernel by default)
+    assert torch.equal(outs["hybrid"]["y"], outs["plain"]["y"])
+    assert torch.allclose(outs["persistent"]["part_sum"], outs["hybrid"]["part_sum"], rtol=1e-6)      # (row layouts differ: the sums agree)
 
 
 @pytest.mark.parametrize("block", ["basic", "bottleneck"])
@@ -251,7 +278,9 @@ def test_small_grids_stay_on_the_library_kernel():
 
 
 def test_both_forward_kernels():
-    """DBEV_WINO_FWD_V forces one of the two forward kernels (64-tile workgroups, one per CU / 32-tile workgroups, two per CU); both
+    """DBEV_WINO_FWD_V forces one of the three forward kernels (2: 64-tile workgroups, one per CU; 3: 32-tile workgroups, two per CU;
+    4: persistent 64-tile workgroups walking the item queues -- here with far fewer items than CUs, so most workgroups leave at once
+    and queues get emptied by their neighbours); each
     against fp64 on every test shape, in a subprocess each (the choice is read once per process)."""
     import subprocess, sys, os
     code = """
@@ -269,7 +298,7 @@ for N, C, Co, H, W in [(2, 16, 64, 16, 16), (3, 64, 64, 16, 44), (2, 32, 128, 8,
     assert torch.allclose(part.double().sum(0)[0], y.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
 print('OK')
 """
-    for v in ("2", "3"):
+    for v in ("2", "3", "4"):
         env = dict(os.environ, DBEV_WINO_FWD_V=v)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "OK" in r.stdout, (v, r.stdout[-500:], r.stderr[-1500:])
