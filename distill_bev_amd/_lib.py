@@ -87,8 +87,6 @@ _SIGNATURES = {
     "dbev_maxpool3x3s2_forward": [_p, _i, _i, _i, _i, _p, _p, _p],
     "dbev_maxpool3x3s2_backward": [_p, _p, _i, _i, _i, _i, _p, _p],
     "dbev_norm_relu_maxpool3x3s2_forward": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
-    "dbev_adamw_chunk_elems": [],
-    "dbev_adamw_multi": [_p, _p, _i, _p, _d, _d, _d, _d, _d, _f, _f, _p],
     "dbev_stem_pool_norm_backward_workspace_bytes": [_i, _i, _i, _i],
     "dbev_stem_pool_norm_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p],
     "dbev_stem7x7s2_stats_rows": [_i, _i, _i],
@@ -101,7 +99,6 @@ _SIGNATURES = {
     "dbev_gemm_bf16x6_pack_pair": [_p, _ll, _ll, _i, _i, _i, _p, _i, _p, _p],
     "dbev_gemm_bf16x6_forward": [_p, _p, _p, _ll, _i, _i, _i, _i, _p],
     "dbev_gemm_bf16x6_forward_stats": [_p, _p, _p, _p, _ll, _i, _i, _i, _i, _p],
-    "dbev_gemm_bf16x6_forward_affine_stats": [_p, _p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _p],
     "dbev_conv3x3s2_bf16x6_ok": [_i, _i, _i, _i, _i],
     "dbev_conv3x3s2_bf16x6_forward_stats": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dbev_gemm_bf16x6_stats_rows": [_ll],

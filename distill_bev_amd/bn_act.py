@@ -386,26 +386,6 @@ def bn_act(x, bn, residual=None, relu=True, pre=None, fork=False):
     return F.relu(out) if relu else out
 
 
-def train_coef(x, bn, pre=None):
-    """statistics + finalize of a training-mode norm WITHOUT the apply pass: updates the running statistics exactly as bn_act does and
-    returns the coefficient row scale | shift (f32[2 C]) with y = x * scale + shift.  No autograd (callers: paths without a gradient
-    that apply the norm inside their own kernel -- gemm_bf6.product_affine).  `pre`: partial statistics rows of x, as for bn_act."""
-    dev = x.device
-    N, C, H, W = x.shape
-    M = N * H * W
-    save_mean = torch.empty((C,), dtype=torch.float32, device=dev)
-    save_invstd = torch.empty((C,), dtype=torch.float32, device=dev)
-    coef = torch.empty((2 * C,), dtype=torch.float32, device=dev)
-    ws = torch.empty((L.lib().dbev_bn_act_workspace_bytes(M, C) + 12 * C,), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        L.call("dbev_bn_act_train_forward_mask", L.ptr(x), None, L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
-               L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked), float(bn.momentum or 0.0), float(bn.eps), 1, None, L.ptr(save_mean),
-               L.ptr(save_invstd), L.ptr(coef), M, C, L.ptr(pre), 0 if pre is None else int(pre.shape[0]), None, L.ptr(ws), ws.numel(),
-               L.stream_ptr(dev))
-    L.touched(bn.running_mean, bn.running_var, bn.num_batches_tracked)
-    return coef
-
-
 class BatchNormAct2d(nn.BatchNorm2d):
     """nn.BatchNorm2d that also applies the ReLU which followed it in the reference's module list
     (parameters, buffers and state-dict keys are those of the BatchNorm2d it replaces)."""

@@ -373,13 +373,13 @@ __device__ __forceinline__ void b6_split2s(float a, float b, unsigned& p0, unsig
 // pixel (2 i + ky - 1, 2 j + kx - 1), or zeros outside the map (the load goes to a valid offset and the value is discarded: no
 // branch).  Everything behind the activation fetch -- split, LDS image, weight DMA, schedule, epilogues -- is the 1x1 kernel's.
 struct B6Conv { int H, W, C, Ho, Wo, cshift; };                          // cshift = log2(C / 16) (C a power of two >= 64)
-// AFF (round 5): the activation operand is relu(x * scale[k] + shift[k]) of what is in memory (coef = scale | shift, f32[2 K]) -- the
-// norm + ReLU in front of a 1x1 convolution applied as its operand is fetched (fmaf, then fmaxf: bn_apply's arithmetic), so that the
-// normalised map is never written.  Used where nothing else reads that map: the gradient-free camera frame (nets.Bottleneck).
-template <int BN, bool STATS, bool CONV = false, bool AFF = false>
+// (Round 5 also carried an AFF variant -- relu(x * scale[k] + shift[k]) applied as the operand is fetched, the norm in front of the
+// convolution never written -- for the gradient-free frame: bit-equal, measured neutral (the eight extra VALU instructions per fetched
+// float4 cost the VALU-co-limited GEMM what the pass cost the norm); retired in round 6 with its ABI entry.)
+template <int BN, bool STATS, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, const unsigned short* __restrict__ Wp,
                                                   float* __restrict__ Y, float* __restrict__ partial, int M, int K, int N, int xs,
-                                                  B6Conv cv = B6Conv{}, const float* __restrict__ coef = nullptr) {
+                                                  B6Conv cv = B6Conv{}) {
   constexpr int WN = BN / 64, WM = 4 / WN, TM = B6_BM / WM / 32;            // waves along N / M, 32-row tiles per wave
   constexpr int APL = B6_BM * 32, BPL = BN * 32;                            // bytes of one plane of a chunk
   constexpr int ABUF = 3 * APL, BBUF = 3 * BPL;                             // 12288, 12288 / 6144
@@ -459,7 +459,6 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
   } while (0)
   floatx4 xa0_0, xa0_1, xa1_0, xa1_1;                                    // raw activations of two chunks in flight
   bool xf0_0 = true, xf0_1 = true, xf1_0 = true, xf1_1 = true;           // CONV: ... and whether their tap lies inside the map
-  floatx4 xc0_s, xc0_h, xc1_s, xc1_h;                                    // AFF: scale / shift of the thread's four channels of those chunks
 #define B6_LOADA(q_, kc_)                                                                                            \
   do {                                                                                                               \
     const int kq_ = (kc_) < nkc ? (kc_) : nkc - 1;                                                                   \
@@ -477,10 +476,6 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
       const gfloat_p xc_ = xb + kq_ * B6_KC;                                                                         \
       xa##q_##_0 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo0);                    \
       xa##q_##_1 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo1);                    \
-      if (AFF) {                                                                                                     \
-        xc##q_##_s = *reinterpret_cast<const floatx4*>(coef + kq_ * B6_KC + 4 * c4);                                 \
-        xc##q_##_h = *reinterpret_cast<const floatx4*>(coef + K + kq_ * B6_KC + 4 * c4);                             \
-      }                                                                                                              \
     }                                                                                                                \
   } while (0)
 #define B6_SPLIT_STORE2(v_, off_)                                                                                    \
@@ -499,12 +494,6 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
       const floatx4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                                      \
       xa##q_##_0 = xf##q_##_0 ? xa##q_##_0 : z4_;                                                                    \
       xa##q_##_1 = xf##q_##_1 ? xa##q_##_1 : z4_;                                                                    \
-    }                                                                                                                \
-    if (AFF) {                                                                                                       \
-      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                             \
-        xa##q_##_0[e_] = fmaxf(fmaf(xa##q_##_0[e_], xc##q_##_s[e_], xc##q_##_h[e_]), 0.f);                           \
-        xa##q_##_1[e_] = fmaxf(fmaf(xa##q_##_1[e_], xc##q_##_s[e_], xc##q_##_h[e_]), 0.f);                           \
-      }                                                                                                              \
     }                                                                                                                \
     B6_SPLIT_STORE2(xa##q_##_0, aoff0);                                                                              \
     B6_SPLIT_STORE2(xa##q_##_1, aoff1);                                                                              \
@@ -1095,37 +1084,6 @@ extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed
 extern "C" int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
                                         int tile_n, dbevStream_t stream) {
   return dbev_gemm_bf16x6_forward_stats(x, packed, y, nullptr, M, K, N, x_row_stride, tile_n, stream);
-}
-
-extern "C" int dbev_gemm_bf16x6_forward_affine_stats(const float* x, const float* scale_shift, const void* packed, float* y,
-                                                     float* stats_partial, long long M, int K, int N, int x_row_stride, int tile_n,
-                                                     dbevStream_t stream) {
-  if (!b6_ok(M, K, N, x_row_stride) || x == nullptr || scale_shift == nullptr || packed == nullptr || y == nullptr ||
-      (tile_n != 0 && tile_n != 64 && tile_n != 128) || (tile_n == 128 && (N % 128) != 0))
-    return DBEV_EINVAL;
-  hipStream_t s = dbev_stream(stream);
-  const int m = static_cast<int>(M);
-  const int bn = b6_bn(N, tile_n);
-  const int grid = dbev_round_xcd((m / B6_BM) * (N / bn));
-  DbevKt kt(DBEV_K_B6_FWD, 2LL * M * K * N, s);
-  const unsigned short* pw = static_cast<const unsigned short*>(packed);
-#define B6_GOA(BNV, ST)                                                                                                            \
-  do {                                                                                                                             \
-    constexpr int lds_ = 2 * 3 * B6_BM * 32 + 4 * 3 * BNV * 32;                                                                    \
-    static bool once_ = false;                                                                                                     \
-    if (!once_) {                                                                                                                  \
-      DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b6_fwd2<BNV, ST, false, true>),                              \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_));                                        \
-      once_ = true;                                                                                                                \
-    }                                                                                                                              \
-    hipLaunchKernelGGL((b6_fwd2<BNV, ST, false, true>), dim3(grid), dim3(256), lds_, s, x, pw, y, stats_partial, m, K, N,         \
-                       x_row_stride, B6Conv{}, scale_shift);                                                                       \
-  } while (0)
-  if (bn == 128) { if (stats_partial != nullptr) B6_GOA(128, true); else B6_GOA(128, false); }
-  else { if (stats_partial != nullptr) B6_GOA(64, true); else B6_GOA(64, false); }
-#undef B6_GOA
-  DBEV_LAUNCH_CHECK();
-  return 0;
 }
 
 namespace {

@@ -160,27 +160,6 @@ def gemm(x, pack, Cout, tn, stats=False):
     return (y, part) if stats else y
 
 
-# opt-in: measured neutral in the step (the fetch-side fmaf / fmaxf cost the GEMM what the apply pass cost the norm: docs/design/08_round5.md)
-_AFF = os.environ.get("DBEV_BF6_AFFINE", "0") == "1"
-
-
-def product_affine(x, coef, weight, stats=False):
-    """conv1x1(relu(x * scale + shift), weight) with coef = scale | shift (f32[2 Cin], bn_act.train_coef): the norm + ReLU in front of
-    the convolution applied as the GEMM fetches its operand -- the normalised map is not written.  No autograd."""
-    dev = L.require_cuda(x, weight, coef)
-    n, K, H, W = x.shape
-    M = n * H * W
-    Cout = int(weight.shape[0])
-    tn = tile_n(M, Cout)
-    pack = packed(weight, False, tn)
-    y = torch.empty((n, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-    part = torch.empty((int(L.call("dbev_gemm_bf16x6_stats_rows", M)), 2, Cout), dtype=torch.float32, device=dev) if stats else None
-    with torch.cuda.device(dev):
-        L.call("dbev_gemm_bf16x6_forward_affine_stats", L.ptr(x), L.ptr(coef), L.ptr(pack), L.ptr(y), L.ptr(part), M, K, Cout, K, int(tn),
-               L.stream_ptr(dev))
-    return (y, part) if stats else y
-
-
 def product(x, weight, transposed=False, stats=False):
     """x [N, K, H, W] channels-last times the 1x1 filter `weight` [Cout, Cin, 1, 1] (transposed: its transpose, the data gradient's
     operand) -> channels-last; no autograd.  The tile width follows the layer's row count (`tile_n`), the pack is made for it."""

@@ -47,21 +47,6 @@ def _conv1x1_stats(conv, bn, x):
     return conv(x), None
 
 
-def _norm_relu_conv1x1_stats(z, pz, bn, conv, bn_next):
-    """conv(relu(bn(z))) without writing the normalised map, for a path with no gradient: statistics + finalize of the training-mode
-    norm `bn` (bn_act.train_coef: running statistics as usual), then the bf16x6 GEMM applies scale / shift / ReLU as it fetches its
-    operand and leaves the statistics of ITS output for `bn_next`.  -> (conv output, partial rows) or (None, None): not applicable"""
-    from . import bn_act as BA
-    from . import gemm_bf6 as G
-    ok = lambda m: (type(m) in BA._BN_TYPES and m.affine and m.training and m.momentum is not None and m.running_mean is not None)
-    if not (G._AFF and G._STATS and BA._state["enabled"] and ok(bn) and ok(bn_next) and conv.bias is None and BA.eligible(z, bn)
-            and tuple(conv.stride) == (1, 1) and G.eligible(z, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
-            and BA._channels_ok(conv.out_channels)):
-        return None, None
-    coef = BA.train_coef(z, bn, pz)
-    return G.product_affine(z, coef, conv.weight, stats=True)
-
-
 def _conv_stats(conv, bn, x):
     """(conv(x), partial statistics rows or None): the Winograd 3x3 kernel's epilogue takes the following norm's batch statistics;
     so does the implicit bf16x6 GEMM of a stride-2 3x3 convolution"""
@@ -173,12 +158,8 @@ class Bottleneck(nn.Module):
         out = bn_act(z1, n1, None, True, pre=p1)
         n2 = getattr(self, self.norm2_name)
         z2, p2 = _conv_stats(self.conv2, n2, out)
-        z3 = None
-        if not torch.is_grad_enabled():
-            z3, p3 = _norm_relu_conv1x1_stats(z2, p2, n2, self.conv3, n3)     # the detached frame: norm2 + ReLU inside conv3's operand fetch
-        if z3 is None:
-            out = bn_act(z2, n2, None, True, pre=p2)
-            z3, p3 = _conv1x1_stats(self.conv3, n3, out)
+        out = bn_act(z2, n2, None, True, pre=p2)
+        z3, p3 = _conv1x1_stats(self.conv3, n3, out)
         ds = split_downsample(self.downsample)
         if ds is not None:
             zd, pd = _conv1x1_stats(ds[0], ds[1], xi)

@@ -455,16 +455,9 @@ class Trainer:
         opt = dict(cfg.get("optimizer", dict(type="AdamW", lr=2e-4, weight_decay=0.01)))
         assert opt.pop("type") == "AdamW"
         params = [p for p in self.detector.parameters() if p.requires_grad]
-        if device.type == "cuda" and os.environ.get("DBEV_ADAMW", "0") == "1":
-            # opt-in: torch.optim.AdamW (fused) with its step as ONE launch per parameter group and the clip factor applied inside it
-            # (csrc/adamw.hip, optim.MultiTensorAdamW: bit-identical updates, 0.67 + 0.14 -> 0.25 ms of GPU work).  Off by default: the end
-            # of the step is not where the step's time goes -- alternating A/B runs show no difference (docs/design/08_round5.md)
-            from .optim import MultiTensorAdamW
-            self.optimizer = MultiTensorAdamW(param_groups(self.detector, opt), **opt)
-            self.fused_clip = os.environ.get("DBEV_FUSED_CLIP", "1") != "0"
-        else:
-            self.optimizer = torch.optim.AdamW(param_groups(self.detector, opt), **opt, fused=(device.type == "cuda"))
-            self.fused_clip = False
+        # (round 5's one-launch AdamW with the clip factor inside -- bit-identical, 0 ms gained in alternating A/B runs -- was retired in
+        # round 6: docs/design/09_round6.md)
+        self.optimizer = torch.optim.AdamW(param_groups(self.detector, opt), **opt, fused=(device.type == "cuda"))
         oc = cfg.get("optimizer_config", {}) or {}
         gc = oc.get("grad_clip", None)
         self.grad_clip = dict(gc) if gc else None
@@ -487,16 +480,9 @@ class Trainer:
         loss.backward()
         if self.reducer is not None:
             self.reducer.all_reduce_grads()
-        if self.grad_clip and self.fused_clip:
-            # mmcv's OptimizerHook: clip_grad_norm_ then step.  Here the clip factor goes INTO the step (the gradient values are scaled as
-            # the optimizer reads them, p.grad keeps the unclipped values): one pass over the gradients less
-            from .optim import clip_factor
-            _total, c = clip_factor(self.params, **self.grad_clip)
-            self.optimizer.step(grad_scale=c)
-        else:
-            if self.grad_clip:
-                nn.utils.clip_grad_norm_(self.params, **self.grad_clip)
-            self.optimizer.step()
+        if self.grad_clip:
+            nn.utils.clip_grad_norm_(self.params, **self.grad_clip)
+        self.optimizer.step()
         if self.packer is not None:
             self.packer.repack()                 # (after the step's version bump: the layers find their packs fresh in the next forward)
         return loss.detach(), losses

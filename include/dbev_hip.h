@@ -643,21 +643,6 @@ int dbev_maxpool3x3s2_backward(const float* grad_y_nhwc, const unsigned char* wi
 int dbev_norm_relu_maxpool3x3s2_forward(const float* x_nhwc, const float* scale_shift, int N, int H, int W, int C, float* y_nhwc,
                                         unsigned char* winner, dbevStream_t stream);
 
-/* ------------------------------------------------------------------------------------
- * Round 5: AdamW over many tensors in one launch, the gradient-clipping factor applied as the gradient is read.  Replaces the pair
- * torch.nn.utils.clip_grad_norm_ (its scaling pass) + torch.optim.AdamW.step the reference's OptimizerHook runs (the recipes under configs/:
- * optimizer = AdamW(lr, weight_decay), grad_clip = dict(max_norm=35)).
- *   tensors: device array of dbevAdamTensor (param, grad, exp_avg, exp_avg_sq: fp32, the SAME dense memory order; n elements);
- *   chunks:  device array of int2 (tensor index, chunk index): chunk c of tensor t covers elements [c, c + 1) * dbev_adamw_chunk_elems();
- *   grad_scale: device float or NULL -- every gradient value is multiplied by it first (the clip factor min(1, max_norm / (norm + 1e-6)));
- *   bias_correction1 = 1 - beta1^step, bias_correction2_sqrt = sqrt(1 - beta2^step) of the step being taken.
- * p -= lr wd p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / bc1) m / (sqrt(v) / bc2_sqrt + eps)
- * ---------------------------------------------------------------------------------- */
-typedef struct dbevAdamTensor { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long n; } dbevAdamTensor;
-int dbev_adamw_chunk_elems(void);
-int dbev_adamw_multi(const void* tensors, const void* chunks, int n_chunks, const float* grad_scale, double lr, double beta1, double beta2,
-                     double eps, double weight_decay, float bias_correction1, float bias_correction2_sqrt, dbevStream_t stream);
-
 /* Round 5: the backward of that fused forward in two passes -- the pooling's gradient gather (dbev_maxpool3x3s2_backward) happens inside
  * the statistics pass and the dx pass of the norm's backward, the 4 x larger gradient of the rectified map is never written:
  * grad_pooled f32[N, Ho, Wo, C] + winner (of the forward) + x (the convolution's output) -> grad_x f32[N, H, W, C], grad_gamma /
@@ -702,11 +687,6 @@ int dbev_gemm_bf16x6_pack(const float* weight, long long stride_n, long long str
 /* the same launch with the BatchNorm statistics of y in its epilogue: stats_partial f32[dbev_gemm_bf16x6_stats_rows(M)][2][N] = per
  * 128-row block the column sums of y and y^2 (bn_finalize's partial-row layout: dbev_bn_act_train_forward_pre(..., pre rows)); NULL: none */
 int dbev_gemm_bf16x6_stats_rows(long long M);
-/* Round 5: the same product with the activation operand taken as relu(x * scale[k] + shift[k]) (scale_shift f32[2 K] = the coefficient row
- * of the fused norm: dbev_bn_act_train_forward_mask(..., y = NULL)): `norm2 -> relu -> conv3` of a bottleneck (res_block.py:102-230)
- * without writing the normalised map.  For paths where nothing else reads that map (no autograd: the detached camera frame). */
-int dbev_gemm_bf16x6_forward_affine_stats(const float* x, const float* scale_shift, const void* packed, float* y, float* stats_partial,
-                                          long long M, int K, int N, int x_row_stride, int tile_n, dbevStream_t stream);
 /* Round 5: nn.Conv2d(C, Co, 3, stride 2, padding 1, bias=False) -- `conv2` of a stage-first ResNet bottleneck (mmdet ResNet / mmdet3d
  * bricks/res_block.py:102-230; cuDNN behind it) -- as an IMPLICIT bf16x6 GEMM: rows = output pixels, reduction over (ky, kx, c).
  * x_nhwc f32[N, H, W, C], y_nhwc f32[N, H/2, W/2, Co]; `packed` = dbev_gemm_bf16x6_pack of the filter's channels-last memory

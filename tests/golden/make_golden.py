@@ -3,7 +3,12 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [lss] [voxel] [fgmask] [pillars] [gauss]
+    python tests/golden/make_golden.py [section ...]        (no argument: every section)
+
+Several sections (or none named) run as ONE SUBPROCESS PER SECTION: the sections install different stand-ins for the reference's
+un-vendored imports into sys.modules / patch module state (bevformer_step followed by bevdepth_step in one interpreter died with a
+KeyError in round 5); a fresh interpreter per section is what each was written and verified in.  DBEV_GOLDEN_OUT=<dir> writes the
+fixtures there instead of tests/golden/ (tests/test_golden_recipe.py regenerates two sections that way and compares bit for bit).
 
 Each section imports (or compiles) the reference's own implementation of one
 hot-path function, runs it on small seeded inputs and stores inputs + outputs
@@ -26,7 +31,7 @@ from distill_bev_amd import synthetic as syn  # noqa: E402
 
 
 def _save(name, **arrs):
-    path = os.path.join(HERE, name)
+    path = os.path.join(os.environ.get("DBEV_GOLDEN_OUT") or HERE, name)
     np.savez_compressed(path, **arrs)
     shapes = {k: getattr(v, "shape", None) for k, v in arrs.items() if "__" not in k}
     print("wrote", path, shapes, f"+ {len(arrs) - len(shapes)} state-dict / prefixed arrays")
@@ -1209,5 +1214,14 @@ SECTIONS = {"lss": make_lss, "voxel": make_voxel, "pillars": make_pillars, "fgma
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(SECTIONS)
-    for s in which:
-        SECTIONS[s]()
+    unknown = [s for s in which if s not in SECTIONS]
+    if unknown:
+        sys.exit(f"make_golden.py: unknown section(s) {unknown}; known: {sorted(SECTIONS)}")
+    if len(which) == 1:
+        SECTIONS[which[0]]()
+    else:                                     # one interpreter per section (see the module docstring)
+        import subprocess
+        for s in which:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), s])
+            if r.returncode != 0:
+                sys.exit(f"make_golden.py: section {s} failed (exit code {r.returncode})")

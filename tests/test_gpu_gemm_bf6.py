@@ -328,32 +328,3 @@ def test_stride2_module_vs_fp64(n, ci, co, h, w, monkeypatch):
     xo = x[:, :, : h - 1].contiguous(memory_format=torch.channels_last)
     assert not G.eligible_s2(xo, conv.weight)
     assert torch.allclose(conv(xo), F.conv2d(xo, conv.weight, stride=2), rtol=1e-4, atol=1e-5)
-
-
-def test_norm_relu_inside_the_operand_fetch_equals_the_separate_pass(monkeypatch):
-    """round 5: conv1x1(relu(bn(z))) for a path without a gradient -- statistics + finalize of the norm (bn_act.train_coef), scale /
-    shift / ReLU applied as the GEMM fetches its operand (dbev_gemm_bf16x6_forward_affine_stats): output, statistics rows and the
-    norm's running statistics bit-equal to bn_act (apply pass) + the plain product (nets.Bottleneck takes that path under no_grad with
-    DBEV_BF6_AFFINE=1: measured neutral, so opt-in)."""
-    from distill_bev_amd import bn_act as BA
-    from distill_bev_amd import gemm_bf6 as G
-    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(11)
-    for (N, C, Co, H, W) in [(4, 64, 256, 16, 32), (2, 128, 128, 16, 16), (8, 256, 64, 8, 16)]:
-        z = (torch.randn((N, C, H, W), generator=g) * 2.0 + 0.3).to(dev).contiguous(memory_format=torch.channels_last)
-        w = (torch.randn((Co, C, 1, 1), generator=g) / C ** 0.5).to(dev)
-        outs = []
-        for fused in (True, False):
-            torch.manual_seed(1)
-            bn = torch.nn.BatchNorm2d(C).to(dev).train()
-            with torch.no_grad():
-                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
-                if fused:
-                    y, part = G.product_affine(z, BA.train_coef(z, bn), w, stats=True)
-                else:
-                    y, part = G.product(BA.bn_act(z, bn, None, True), w, stats=True)
-            outs.append((y, part, bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
-        for a, b in zip(outs[0][:4], outs[1][:4]):
-            assert torch.equal(a, b)
-        assert outs[0][4] == outs[1][4] == 1

@@ -28,14 +28,9 @@ for it in range(6):
     tr.optimizer.zero_grad(set_to_none=True)
     loss.backward()
     e[2].record(); t2 = time.perf_counter()
-    if tr.grad_clip and getattr(tr, "fused_clip", False):
-        from distill_bev_amd.optim import clip_factor
-        _t, c = clip_factor(tr.params, **tr.grad_clip)
-        tr.optimizer.step(grad_scale=c)
-    else:
-        if tr.grad_clip:
-            nn.utils.clip_grad_norm_(tr.params, **tr.grad_clip)
-        tr.optimizer.step()
+    if tr.grad_clip:
+        nn.utils.clip_grad_norm_(tr.params, **tr.grad_clip)
+    tr.optimizer.step()
     if tr.packer is not None:
         tr.packer.repack()
     e[3].record(); t3 = time.perf_counter()
