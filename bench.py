@@ -56,6 +56,64 @@ def _flush_c_stdio():
         pass
 
 
+class _ClockSampler:
+    """the shader clock (sclk) of the benchmarked GPU, read from the driver's sysfs files by a background thread every 50 ms while the
+    timed region runs: fractions of the 2.4 GHz peaks in `roofline` are fractions of a clock the board does not hold under the matrix
+    kernels (power limit).  The in-kernel figure (s_memtime / s_memrealtime under the Winograd forward in this step: 2.15 GHz) is in
+    profiles/r06_wino_persistent.txt.  -> {"median_mhz", "min_mhz", "max_mhz", "samples", "source"} or {"unavailable": why}"""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.samples, self.source, self.why, self._stop, self._thread = [], None, None, threading.Event(), None
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            want = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1), getattr(props, "pci_device_id", 0))
+            cands = []
+            for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+                real = os.path.realpath(os.path.dirname(f))
+                cands.append((f, want in real))
+            hit = [f for f, ok in cands if ok] or ([cands[0][0]] if len(cands) == 1 else [])
+            if not hit:
+                self.why = "no pp_dpm_sclk file matches the device (%d candidates)" % len(cands)
+                return
+            self.source = hit[0]
+            self._thread = threading.Thread(target=self._run, daemon=True)
+        except Exception as e:
+            self.why = f"{type(e).__name__}: {e}"
+
+    def _read(self):
+        for ln in open(self.source).read().splitlines():
+            if ln.rstrip().endswith("*"):
+                return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                v = self._read()
+                if v:
+                    self.samples.append(v)
+            except Exception as e:
+                self.why = f"{type(e).__name__}: {e}"
+                return
+            self._stop.wait(0.05)
+
+    def start(self):
+        if self._thread is not None:
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+        if not self.samples:
+            return {"unavailable": self.why or "no sample inside the timed region", "source": self.source}
+        a = np.asarray(self.samples)
+        return {"median_mhz": float(np.median(a)), "min_mhz": float(a.min()), "max_mhz": float(a.max()), "samples": int(a.size),
+                "source": self.source, "nominal_mhz_of_the_peaks": 2400.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +177,9 @@ def main():
     # the wall-clock figure -- the board's power state moves a single 20-step average by ~5 % box to box and run to run, the
     # median over blocks of steps says how much of `ms_per_step` is that
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    clock = _ClockSampler(dev) if rank == 0 else None
+    if clock is not None:
+        clock.start()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(steps):
@@ -128,6 +189,7 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    shader_clock = clock.stop() if clock is not None else None
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -165,6 +227,7 @@ def main():
             # (up to) four consecutive blocks of steps
             "ms_per_step_median": float(np.median(per_step)) if per_step else None,
             "ms_per_step_blocks": [float(np.mean(b)) for b in np.array_split(np.asarray(per_step), min(4, max(steps, 1))) if len(b)],
+            "shader_clock": shader_clock,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -194,6 +257,9 @@ def main():
         alt = line["config"].get("ms_per_step_full_teacher_head")
         if alt:
             line["value_full_teacher_head"] = wl.units_per_step * world / (alt * 1e-3)
+        alt = line["config"].get("ms_per_step_ddp_configuration")
+        if isinstance(alt, float):
+            line["value_ddp_configuration"] = wl.units_per_step * world / (alt * 1e-3)
         if line["ms_per_step_median"]:
             line["value_median_step"] = wl.units_per_step * world / (line["ms_per_step_median"] * 1e-3)
     if dist.is_initialized():

@@ -293,6 +293,11 @@ class DistillStep(_Base):
                 self.fp32_mfma_only_ms = (time.perf_counter() - t0) / 5 * 1e3
             finally:
                 gemm_bf6._ON = True
+        # the configuration `--gpus N > 1` times -- the gradient reducer active, the hipGraph of the gradient-free frame off -- on THIS GPU:
+        # a one-rank RCCL group, the reducer's pack / all-reduce / unpack machinery on 217 MB of gradients; 1 warm-up + 5 timed steps,
+        # outside the timed region (the first multi-GPU run must not time a configuration no line ever reported)
+        if self.world == 1 and self.trainer.reducer is None and not plain and os.environ.get("DBEV_BENCH_DDP_LEG", "1") != "0":
+            self.ddp_config_ms = self._ddp_leg()
         rt, rf = self._fam(roof)                    # seconds, Winograd-domain FLOPs (the log's work field) of the timed launches
         ach = rf / rt / 1e12
         other = {}
@@ -366,6 +371,37 @@ class DistillStep(_Base):
                 "other_hot_kernels": other}
         assert_fracs(out)
         return out
+
+    def _ddp_leg(self):
+        import torch.distributed as dist
+        from distill_bev_amd.train_step import GradReducer
+        tr = self.trainer
+        made_pg = False
+        try:
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=self.dev)
+                made_pg = True
+            graph, tr.detector.adjacent_graph = getattr(tr.detector, "adjacent_graph", None), None
+            tr.reducer = GradReducer([p for p in tr.detector.parameters() if p.requires_grad], list(tr.detector.buffers()), bucket_mb=32)
+            try:
+                self.step()
+                torch.cuda.synchronize(self.dev)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    self.step()
+                torch.cuda.synchronize(self.dev)
+                return (time.perf_counter() - t0) / 5 * 1e3
+            finally:
+                tr.reducer.close()
+                tr.reducer = None
+                tr.detector.adjacent_graph = graph
+        except Exception as e:                       # (a box without a usable RCCL: the headline does not depend on this leg)
+            return f"unavailable: {type(e).__name__}: {e}"
+        finally:
+            if made_pg:
+                dist.destroy_process_group()
 
     def cpu_baseline(self):
         """The same training step with the reference's op sequence on the host cores
@@ -445,6 +481,8 @@ class DistillStep(_Base):
                 # data parallelism: GradReducer's in-backward bucket launches are OFF by default (DBEV_DDP_OVERLAP=1 turns them on): no
                 # N > 1 RCCL measurement exists to say they help on xGMI.  What one GPU can say (a separate run, tools/ddp_one_rank.sh,
                 # NOT this process): the step with the reducer active on a world-size-1 RCCL group vs the plain step
+                # this GPU, the multi-GPU configuration: reducer active on a one-rank RCCL group, hipGraph off (what bench.py --gpus N > 1 runs)
+                "ms_per_step_ddp_configuration": getattr(self, "ddp_config_ms", None),
                 "ddp_overlap_default": "off" if os.environ.get("DBEV_DDP_OVERLAP", "0") != "1" else "on (DBEV_DDP_OVERLAP=1)",
                 "ddp_one_rank_probe": _ddp_probe()}
 

@@ -102,7 +102,7 @@ def test_filter_pack_is_the_winograd_transform_of_each_filter():
 
 def test_paired_pack_matches_the_single_direction_packs_and_is_reused():
     """dbev_wino_filter_pack_pair writes, in one launch, exactly what the two single-direction packs write in the slot of the kernel
-    each direction gets; the pair stays attached to the weight until its version changes"""
+    each direction gets; the pair stays attached to the weight, and is written again in place when the weight's version changes"""
     from distill_bev_amd import wino, _lib as L
     for (N, C, Co, H, W) in [(2, 64, 128, 16, 16), (48, 64, 64, 16, 44), (1, 64, 64, 8, 8)]:
         x, w, _ = _mk(N, C, Co, H, W, 21, False)
@@ -115,9 +115,11 @@ def test_paired_pack_matches_the_single_direction_packs_and_is_reused():
             assert torch.equal(pack[sl], ref[sl])
         again = wino.packed_pair(w, x.shape, True)
         assert again[0] is fwd and again[1] is dg                       # same version: the attached pair
-        w.add_(1.0)                                                     # in-place update (the optimizer's): new version, new pack
+        before = fwd[sl].clone()
+        w.add_(1.0)                                                     # in-place update (the optimizer's): new version ...
         f2, d2 = wino.packed_pair(w, x.shape, True)
-        assert f2 is not fwd and not torch.equal(f2[sl], fwd[sl])
+        # ... re-packed INTO THE SAME BUFFERS (round 6: a captured hipGraph may be reading through their addresses, graphed.py)
+        assert f2 is fwd and d2 is dg and not torch.equal(f2[sl], before)
         y = wino.conv3x3(x, w)
         assert torch.allclose(y, F.conv2d(x, w, None, 1, 1), atol=2e-5 * float(y.abs().max()))
     # forward first without the data gradient, then the missing direction alone
