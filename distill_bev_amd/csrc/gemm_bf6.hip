@@ -376,6 +376,7 @@ struct B6Conv { int H, W, C, Ho, Wo, cshift; };                          // cshi
 // (Round 5 also carried an AFF variant -- relu(x * scale[k] + shift[k]) applied as the operand is fetched, the norm in front of the
 // convolution never written -- for the gradient-free frame: bit-equal, measured neutral (the eight extra VALU instructions per fetched
 // float4 cost the VALU-co-limited GEMM what the pass cost the norm); retired in round 6 with its ABI entry.)
+typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
 template <int BN, bool STATS, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, const unsigned short* __restrict__ Wp,
                                                   float* __restrict__ Y, float* __restrict__ partial, int M, int K, int N, int xs,
@@ -393,13 +394,20 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
   const int nblk = N / BN;
   const int L = xcd_block();
   const int nb = L % nblk, mb = L / nblk;
-  if (mb >= M / B6_BM) return;
+  if (mb >= (M + B6_BM - 1) / B6_BM) return;
   const int m0 = mb * B6_BM, n0 = nb * BN;
   const int nkc = K / B6_KC;
+  // Round 6: M need not be a multiple of 128 (the BEVFormer recipe's 928 x 1600 images give 58 x 100 and 29 x 50 maps).  The 1x1 path
+  // reads X and writes Y through BUFFER descriptors of this row block's valid rows: a row past M loads zeros (so its outputs and its
+  // share of the statistics are exact zeros) and its stores are dropped by the bounds check -- no instruction added anywhere.
+  const int vrows = min(B6_BM, M - m0);
 
   const int row0 = tid >> 2, row1 = 64 + (tid >> 2), c4 = tid & 3;
   typedef const __attribute__((address_space(1))) float* gfloat_p;
   const gfloat_p xb = reinterpret_cast<gfloat_p>(b6_uniform64(reinterpret_cast<unsigned long long>(X + (CONV ? 0 : static_cast<size_t>(m0) * xs))));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(reinterpret_cast<const float*>(b6_uniform64(reinterpret_cast<unsigned long long>(X + static_cast<size_t>(m0) * xs)))), 0,
+      vrows * xs * 4, 0x00020000);
   const unsigned xo0 = static_cast<unsigned>(row0 * xs + 4 * c4), xo1 = static_cast<unsigned>(row1 * xs + 4 * c4);
   int pb0 = 0, pb1 = 0;                                                     // CONV: float offset of tap (0, 0) of the row's pixel (may be < 0)
   unsigned vm0 = 0, vm1 = 0;                                                //       bit t: tap t lies inside the map
@@ -418,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
           const int yy = 2 * i + ky - 1, xx = 2 * j + kx - 1;
           if (yy >= 0 && yy < cv.H && xx >= 0 && xx < cv.W) vm |= 1u << (ky * 3 + kx);
         }
+      if (m >= M) vm = 0;                                                    // (round 6: a row past M has no tap inside the map: zeros)
       if (q) { pb1 = pb; vm1 = vm; } else { pb0 = pb; vm0 = vm; }
     }
   }
@@ -473,9 +482,8 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
       xa##q_##_0 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xb + o0_);                     \
       xa##q_##_1 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xb + o1_);                     \
     } else {                                                                                                         \
-      const gfloat_p xc_ = xb + kq_ * B6_KC;                                                                         \
-      xa##q_##_0 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo0);                    \
-      xa##q_##_1 = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(xc_ + xo1);                    \
+      xa##q_##_0 = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xrs, 4 * xo0, kq_ * (B6_KC * 4), 0)); \
+      xa##q_##_1 = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xrs, 4 * xo1, kq_ * (B6_KC * 4), 0)); \
     }                                                                                                                \
   } while (0)
 #define B6_SPLIT_STORE2(v_, off_)                                                                                    \
@@ -627,16 +635,15 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
         for (int r = 0; r < 16; ++r) tw[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + b * 32 + l31] = tot[a][b][r];
     // (the wave reads only what it wrote itself: the compiler's lgkmcnt wait orders the two phases)
     const int rr = lane >> 4, c4q = lane & 15;                               // 4 rows per instruction, 16 lanes x float4 per row
-    float* yb = Y + static_cast<size_t>(m0 + wm * TM * 32) * N + n0 + wn * 64 + 4 * c4q;
+    // (a buffer descriptor of the block's VALID rows: the stores of rows past M are dropped by the hardware's bounds check)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<float*>(b6_uniform64(reinterpret_cast<unsigned long long>(Y + static_cast<size_t>(m0) * N))), 0, vrows * N * 4, 0x00020000);
+    const unsigned yo = static_cast<unsigned>(((wm * TM * 32 + rr) * N + n0 + wn * 64 + 4 * c4q) * 4);
 #pragma unroll
     for (int i = 0; i < TM * 8; ++i) {
       const int row = 4 * i + rr;
       const floatx4 v = *reinterpret_cast<const floatx4*>(tw + row * 64 + 4 * c4q);
-#ifdef B6_NT_STORE
-      __builtin_nontemporal_store(v, reinterpret_cast<floatx4*>(yb + static_cast<size_t>(row) * N));
-#else
-      *reinterpret_cast<floatx4*>(yb + static_cast<size_t>(row) * N) = v;
-#endif
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), yrs, yo + static_cast<unsigned>(4 * i * N * 4), 0, 0);
     }
   }
 }
@@ -808,7 +815,10 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad2(const float* __restrict__ GY
   if (split >= nsplit) return;
   const int co0 = (tile / tiles_n) * TA, ci0 = (tile % tiles_n) * TB;
   const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
-  const int nch = (mend - mbeg) / B6_KC;                                    // a multiple of 8
+  // Round 6: M (and so the last share) need not be a multiple of 128 pixels -- the operands are read through BUFFER descriptors of the
+  // share's valid rows, a pixel past the end loads zeros and adds nothing; whole groups of 8 chunks as before
+  const int nrows = mend - mbeg;
+  const int nch = (nrows + 8 * B6_KC - 1) / (8 * B6_KC) * 8;
 
   // staging role: operand (gradient rows = output channels | input rows = input channels), pixel group pg (8 pixels), channel pair cp
   const bool isB = tid >= TA;
@@ -816,7 +826,12 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad2(const float* __restrict__ GY
   const bool stage = (TA + TB == 256) || st < (isB ? TB : TA);      // 128 x 128 tiles: every thread stages (no branch in the chunk body)
   const int pg = st & 1, cp = st >> 1;                                      // (consecutive lanes: the two pixel groups of one channel pair)
   const int sstride = isB ? xs : Co;
-  const float* src = (isB ? X + ci0 : GY + co0) + static_cast<size_t>(mbeg + 8 * pg) * sstride + 2 * cp;
+  const float* src0 = (isB ? X + ci0 : GY + co0) + static_cast<size_t>(mbeg) * sstride;     // (uniform per wave: TA is a multiple of 64)
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(reinterpret_cast<const float*>(b6_uniform64(reinterpret_cast<unsigned long long>(src0)))), 0,
+      __builtin_amdgcn_readfirstlane(nrows * sstride * 4), 0x00020000);
+  const unsigned svoff = static_cast<unsigned>((8 * pg * sstride + 2 * cp) * 4);              // byte offset of (pixel 8 pg, channel 2 cp)
+  const unsigned srow = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(sstride * 4));
   unsigned char* sbase = smem + (isB ? 3 * PLA : 0);
   const int PL = isB ? PLB : PLA;
   int soff[2];
@@ -826,19 +841,20 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad2(const float* __restrict__ GY
     soff[c] = row * 32 + ((pg ^ ((row >> 3) & 1)) * 16);
   }
   floatx2 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;      // two chunks in flight
+#define B6W2_LD1(k_) __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(srs, svoff + (k_) * srow, so_, 0))
 #define B6W2_LOAD(q_, ch_)                                                                                           \
   do {                                                                                                               \
     const int cq_ = (ch_) < nch ? (ch_) : nch - 1;                                                                   \
-    const float* p_ = src + static_cast<size_t>(cq_) * B6_KC * sstride;                                              \
+    const unsigned so_ = static_cast<unsigned>(cq_) * B6_KC * srow;                                                  \
     if (stage) {                                                                                                     \
-      r##q_##0 = *reinterpret_cast<const floatx2*>(p_);                                                              \
-      r##q_##1 = *reinterpret_cast<const floatx2*>(p_ + sstride);                                                    \
-      r##q_##2 = *reinterpret_cast<const floatx2*>(p_ + 2 * sstride);                                                \
-      r##q_##3 = *reinterpret_cast<const floatx2*>(p_ + 3 * sstride);                                                \
-      r##q_##4 = *reinterpret_cast<const floatx2*>(p_ + 4 * sstride);                                                \
-      r##q_##5 = *reinterpret_cast<const floatx2*>(p_ + 5 * sstride);                                                \
-      r##q_##6 = *reinterpret_cast<const floatx2*>(p_ + 6 * sstride);                                                \
-      r##q_##7 = *reinterpret_cast<const floatx2*>(p_ + 7 * sstride);                                                \
+      r##q_##0 = B6W2_LD1(0);                                                                                        \
+      r##q_##1 = B6W2_LD1(1);                                                                                        \
+      r##q_##2 = B6W2_LD1(2);                                                                                        \
+      r##q_##3 = B6W2_LD1(3);                                                                                        \
+      r##q_##4 = B6W2_LD1(4);                                                                                        \
+      r##q_##5 = B6W2_LD1(5);                                                                                        \
+      r##q_##6 = B6W2_LD1(6);                                                                                        \
+      r##q_##7 = B6W2_LD1(7);                                                                                        \
     }                                                                                                                \
   } while (0)
   // channel c_ of the pair: its 8 pixel values -> one 16-byte piece per plane
@@ -937,6 +953,7 @@ __global__ __launch_bounds__(256, 2) void b6_wgrad2(const float* __restrict__ GY
 #undef B6W2_STAGE
 #undef B6W2_STAGE1
 #undef B6W2_LOAD
+#undef B6W2_LD1
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -967,12 +984,12 @@ __global__ __launch_bounds__(256) void b6_wsum(const float* __restrict__ part, i
 struct B6WPlan { int nsplit, rows, grid, ta, tb; };
 
 bool b6w_plan(long long M, int Ci, int Co, int xs, B6WPlan* p) {
-  if (M <= 0 || (M % B6W_KC) || M > 0x7fffffffLL || Ci <= 0 || (Ci % 64) || Co <= 0 || (Co % 64) || xs < Ci || (xs % 4)) return false;
+  if (M <= 0 || M > 0x7fffffffLL - 128 || M * static_cast<long long>(xs > Co ? xs : Co) * 4 >= (1LL << 32) || Ci <= 0 || (Ci % 64) || Co <= 0 || (Co % 64) || xs < Ci || (xs % 4)) return false;
   p->ta = (Co % 128) == 0 ? 128 : 64;
   p->tb = (Ci % 128) == 0 ? 128 : 64;
   const int tiles = (Co / p->ta) * (Ci / p->tb);
   long long ns = (2 * DBEV_NUM_CU) / tiles;                  // two workgroups per CU, one round
-  const long long chunks = M / B6W_KC;
+  const long long chunks = (M + B6W_KC - 1) / B6W_KC;         // (round 6: the last chunk may be partly past M -- zeros)
   if (ns > chunks / 8) ns = chunks / 8;                      // a share reduces at least 8 chunks
   if (ns < 1) ns = 1;
   long long per = (chunks + ns - 1) / ns;
@@ -988,7 +1005,7 @@ bool b6w_plan(long long M, int Ci, int Co, int xs, B6WPlan* p) {
 int b6_bn(int N, int tile_n) { return (tile_n == 64 || (N % 128) != 0) ? 64 : 128; }
 
 bool b6_ok(long long M, int K, int N, int xs) {
-  return M > 0 && (M % B6_BM) == 0 && M <= 0x7fffffffLL && K > 0 && (K % 64) == 0 && N > 0 && (N % 64) == 0 && xs >= K && (xs % 4) == 0 &&
+  return M > 0 && M <= 0x7fffffffLL - B6_BM && K > 0 && (K % 64) == 0 && N > 0 && (N % 64) == 0 && xs >= K && (xs % 4) == 0 &&
          M * static_cast<long long>(xs > N ? xs : N) < (1LL << 40);
 }
 
@@ -1041,7 +1058,7 @@ extern "C" int dbev_gemm_bf16x6_pack_multi(const dbevPackJob* jobs_device, int n
   return 0;
 }
 
-extern "C" int dbev_gemm_bf16x6_stats_rows(long long M) { return (M > 0 && (M % B6_BM) == 0 && M <= 0x7fffffffLL) ? static_cast<int>(M / B6_BM) : 0; }
+extern "C" int dbev_gemm_bf16x6_stats_rows(long long M) { return (M > 0 && M <= 0x7fffffffLL - B6_BM) ? static_cast<int>((M + B6_BM - 1) / B6_BM) : 0; }
 
 extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed, float* y, float* stats_partial, long long M, int K, int N,
                                               int x_row_stride, int tile_n, dbevStream_t stream) {
@@ -1051,11 +1068,12 @@ extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed
   hipStream_t s = dbev_stream(stream);
   const int m = static_cast<int>(M);
   const int bn = b6_bn(N, tile_n);
-  const int grid = dbev_round_xcd((m / B6_BM) * (N / bn));
+  const int grid = dbev_round_xcd(((m + B6_BM - 1) / B6_BM) * (N / bn));
   DbevKt kt(DBEV_K_B6_FWD, 2LL * M * K * N, s);                  // the log's work field: fp32-equivalent FLOPs
   static const int dbg = getenv("DBEV_BF6_DBG") ? atoi(getenv("DBEV_BF6_DBG")) : 0;
   const unsigned short* pw = static_cast<const unsigned short*>(packed);
   static const int ver = getenv("DBEV_BF6_V") ? atoi(getenv("DBEV_BF6_V")) : 2;          // 1: the round-4 kernel (A/B runs)
+  if (ver != 2 && (M % B6_BM) != 0) return DBEV_EINVAL;           // (the round-4 kernel takes whole 128-row blocks only)
   if (ver == 2) {
 #define B6_GO2(BNV, ST)                                                                                                            \
   do {                                                                                                                             \
@@ -1090,7 +1108,7 @@ namespace {
 bool c3s2_ok(int N, int H, int W, int C, int Co) {
   if (N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 64 || (C & (C - 1)) != 0 || Co <= 0 || Co % 64) return false;   // C = 64, 128, 256 ...
   const long long M = static_cast<long long>(N) * (H / 2) * (W / 2);
-  return M % B6_BM == 0 && static_cast<long long>(N) * H * W * C < (1LL << 31) && M * Co < (1LL << 31) && b6_ok(M, 9 * C, Co, 9 * C);
+  return static_cast<long long>(N) * H * W * C < (1LL << 31) && M * Co < (1LL << 31) && b6_ok(M, 9 * C, Co, 9 * C);
 }
 }  // namespace
 
@@ -1106,7 +1124,7 @@ extern "C" int dbev_conv3x3s2_bf16x6_forward_stats(const float* x_nhwc, const vo
   while ((16 << cv.cshift) < C) ++cv.cshift;
   const int m = N * cv.Ho * cv.Wo, K = 9 * C;
   const int bn = b6_bn(Co, tile_n);
-  const int grid = dbev_round_xcd((m / B6_BM) * (Co / bn));
+  const int grid = dbev_round_xcd(((m + B6_BM - 1) / B6_BM) * (Co / bn));
   DbevKt kt(DBEV_K_B6_FWD, 2LL * m * K * Co, s);
   const unsigned short* pw = static_cast<const unsigned short*>(packed);
 #define B6_GOC(BNV, ST)                                                                                                            \
@@ -1142,7 +1160,8 @@ extern "C" int dbev_gemm_bf16x6_backward_weight(const float* x, const float* gra
   float* part = static_cast<float*>(workspace);
   DbevKt kt(DBEV_K_B6_WGRAD, 2LL * M * Cin * Cout, s);
   static const int ver = getenv("DBEV_BF6_WV") ? atoi(getenv("DBEV_BF6_WV")) : 2;         // 1: the round-4 kernel (A/B runs)
-  const bool v2 = ver == 2 && (M % 128) == 0 && (p.rows % 128) == 0;
+  if (ver != 2 && (M % 128) != 0) return DBEV_EINVAL;                                    // (the round-4 kernel has no partial chunks)
+  const bool v2 = ver == 2;
 #define B6W_GO(TAV, TBV)                                                                                                          \
   do {                                                                                                                            \
     if (v2) hipLaunchKernelGGL((b6_wgrad2<TAV, TBV>), dim3(p.grid), dim3(256), 0, s, grad_y, x, p.nsplit > 1 ? part : grad_weight, \

@@ -7,7 +7,7 @@ and the sums are kept in fp32: max |y - fp64| / max |y| = 2-4e-7 on the step's l
 (5e-7-1e-6; tests/test_gpu_gemm_bf6.py asserts it per shape).  On gfx950 the bf16 matrix pipe is 16 x as fast as the fp32 one, so six
 bf16 instructions replace eight fp32 ones in 0.38 of the time.
 
-``conv1x1(x, weight)`` is ``F.conv2d(x, weight)`` for channels-last fp32 device tensors with N*H*W % 128 == 0, Cin % 64 == 0,
+``conv1x1(x, weight)`` is ``F.conv2d(x, weight)`` for channels-last fp32 device tensors with Cin % 64 == 0,
 Cout % 64 == 0, differentiable: the data gradient is the same kernel on grad_y with the transposed weight view, the weight gradient
 its own kernel (both operands split on the fly).  Layers that would leave half of the chip idle (fewer than `_MIN_ITEMS` output tiles) stay with the library."""
 import os
@@ -37,14 +37,15 @@ def tile_n(M, N):
     8 x 22 maps of the last ResNet stage have 66 row blocks"""
     if N % 128:
         return 64
-    return 128 if (M // 128) * (N // 128) >= _MIN_ITEMS else 64
+    return 128 if -(-M // 128) * (N // 128) >= _MIN_ITEMS else 64
 
 
 def shape_ok(M, K, N):
-    """can the kernels take Y[M, N] = X[M, K] W[N, K]^T, and does the launch fill the chip?"""
-    if M <= 0 or M % 128 or K % 64 or N % 64 or K <= 0 or N <= 0:
+    """can the kernels take Y[M, N] = X[M, K] W[N, K]^T, and does the launch fill the chip?  (M: any row count since round 6 -- the
+    last 128-row block is read and written through bounds-checked buffer descriptors)"""
+    if M <= 0 or K % 64 or N % 64 or K <= 0 or N <= 0:
         return False
-    return (M // 128) * (N // tile_n(M, N)) >= _MIN_ITEMS
+    return -(-M // 128) * (N // tile_n(M, N)) >= _MIN_ITEMS
 
 
 def eligible(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1):
@@ -352,7 +353,7 @@ def eligible_c3s2(x, weight, stride=(2, 2), padding=(1, 1), dilation=(1, 1), gro
     if not (weight.shape[1] == C and _nhwc(x) and _nhwc(weight) and L.lib().dbev_conv3x3s2_bf16x6_ok(N, H, W, C, Co)):
         return False
     M = N * (H // 2) * (W // 2)
-    return (M // 128) * (Co // tile_n(M, Co)) >= _MIN_ITEMS
+    return -(-M // 128) * (Co // tile_n(M, Co)) >= _MIN_ITEMS
 
 
 def product_c3s2(x, weight, stats=False):

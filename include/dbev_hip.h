@@ -675,7 +675,9 @@ int dbev_stem7x7s2_backward_weight(const float* x_nhwc, const float* grad_z_nhwc
  * fp32 GEMM of a 1x1 convolution on the BF16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three bf16 values,
  * six exact partial products per product, fp32 accumulation; csrc/gemm_bf6.hip).  Replaces cuDNN behind nn.Conv2d(k=1) of
  * mmdet3d/models/bricks/res_block.py:102-230 / necks/fpn.py:10-204 like dbev_gemm1x1_forward does.
- *   y[M, N] = x[M, K] * weight[N, K]^T,  x rows of x_row_stride floats, y row-major; M % 128 == 0, K % 64 == 0, N % 64 == 0.
+ *   y[M, N] = x[M, K] * weight[N, K]^T,  x rows of x_row_stride floats, y row-major; K % 64 == 0, N % 64 == 0, M any
+ *   positive row count (round 6: the last 128-row block goes through bounds-checked buffer descriptors -- rows past M load zeros, their
+ *   stores are dropped; the weight gradient likewise reads pixels past M as zeros).
  * dbev_gemm_bf16x6_pack splits the weight (element (n, k) at weight[n * stride_n + k * stride_k]: the transposed view serves the data
  * gradient) into `packed` (dbev_gemm_bf16x6_packed_bytes(N, K) bytes; 0: unsupported shape) once per weight version.  tile_n: columns
  * of a workgroup tile, the SAME value for the pack and the launches that use it: 0 = 128 when N % 128 == 0 else 64; 64 doubles the
@@ -692,7 +694,7 @@ int dbev_gemm_bf16x6_stats_rows(long long M);
  * x_nhwc f32[N, H, W, C], y_nhwc f32[N, H/2, W/2, Co]; `packed` = dbev_gemm_bf16x6_pack of the filter's channels-last memory
  * [Co][3][3][C] taken as the matrix [Co][9 C] (stride_n = 9 C, stride_k = 1, N = Co, K = 9 C) with the same tile_n;
  * stats_partial f32[dbev_gemm_bf16x6_stats_rows(N H/2 W/2)][2][Co] or NULL.  dbev_conv3x3s2_bf16x6_ok: H, W even, C a power of two
- * >= 64, Co % 64 == 0, N H/2 W/2 % 128 == 0.  (Forward only: both gradients stay with the library this round.) */
+ * >= 64, Co % 64 == 0.  (Forward only: both gradients stay with the library this round.) */
 int dbev_conv3x3s2_bf16x6_ok(int N, int H, int W, int C, int Co);
 int dbev_conv3x3s2_bf16x6_forward_stats(const float* x_nhwc, const void* packed, float* y_nhwc, float* stats_partial, int N, int H, int W,
                                         int C, int Co, int tile_n, dbevStream_t stream);

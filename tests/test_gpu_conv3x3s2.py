@@ -8,7 +8,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(2, 64, 16, 32, 128), (4, 128, 16, 16, 128), (1, 256, 32, 16, 64), (6, 128, 64, 176, 128)]
+SHAPES = [(2, 64, 16, 32, 128), (4, 128, 16, 16, 128), (1, 256, 32, 16, 64), (6, 128, 64, 176, 128),
+          (3, 128, 58, 100, 128), (1, 64, 10, 6, 64), (5, 256, 14, 18, 192)]      # round 6: N H/2 W/2 no multiple of 128
 
 
 def _data(N, C, H, W, Co, seed=0):

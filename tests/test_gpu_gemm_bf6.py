@@ -64,7 +64,9 @@ def test_signed_inputs_and_extreme_magnitudes(monkeypatch):
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(4, 64, 256, 16, 16), (2, 256, 64, 32, 16), (2, 128, 128, 16, 16), (3, 256, 384, 16, 24),
-                                         (2, 1024, 128, 8, 16), (2, 64, 64, 32, 32), (2, 192, 320, 16, 16)])
+                                         (2, 1024, 128, 8, 16), (2, 64, 64, 32, 32), (2, 192, 320, 16, 16),
+                                         # round 6: pixel counts that are no multiple of 128 (the BEVFormer recipe's 58 x 100 / 29 x 50 maps):
+                                         (3, 256, 128, 29, 50), (1, 128, 256, 58, 100), (2, 64, 192, 7, 9), (1, 320, 64, 5, 27)])
 def test_module_gradients_vs_fp64(n, ci, co, h, w, monkeypatch):
     """forward, data gradient and weight gradient (all four tile shapes: 128 / 64 output x 128 / 64 input channels) on the bf16x6 kernels"""
     from distill_bev_amd import gemm_bf6 as G
@@ -108,9 +110,10 @@ def test_small_layers_stay_with_the_library_and_packs_follow_the_weight():
     assert torch.equal(m(x), F.conv2d(x, m.weight))
     p1 = G.packed(m.weight)
     assert G.packed(m.weight) is p1
+    before = p1.clone()
     with torch.no_grad():
-        m.weight.mul_(2.0)                                       # version counter moves: a new pack
-    assert G.packed(m.weight) is not p1
+        m.weight.mul_(2.0)                                       # version counter moves: packed again -- into the SAME buffer (round 6)
+    assert G.packed(m.weight) is p1 and not torch.equal(p1, before)
     from distill_bev_amd.bn_act import invalidate_eval_coef
     p2 = G.packed(m.weight)
     m.weight.data.mul_(0.5)                                      # a write the version counter does not see ...
@@ -328,3 +331,37 @@ def test_stride2_module_vs_fp64(n, ci, co, h, w, monkeypatch):
     xo = x[:, :, : h - 1].contiguous(memory_format=torch.channels_last)
     assert not G.eligible_s2(xo, conv.weight)
     assert torch.allclose(conv(xo), F.conv2d(xo, conv.weight, stride=2), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(18, 256, 1024, 29, 50), (3, 64, 128, 7, 9), (1, 128, 64, 1, 129), (2, 512, 256, 58, 100)])
+def test_rows_past_the_last_block_load_zeros_and_store_nothing(n, ci, co, h, w, monkeypatch):
+    """round 6: M = N H W of any size.  The last 128-row block is read and written through buffer descriptors of its valid rows: the output
+    (and the memory BEHIND it: a guard band) is what the library computes / untouched, the statistics rows count ceil(M / 128) and sum
+    to the column sums of y exactly as for full blocks, and the weight gradient reads pixels past M as zeros"""
+    from distill_bev_amd import gemm_bf6 as G, _lib as L
+    monkeypatch.setattr(G, "_MIN_ITEMS", 1)
+    monkeypatch.setattr(G, "_MIN_WGRAD_ROWS", 1)
+    x, wt = _mk(n, ci, co, h, w, 13)
+    M = n * h * w
+    assert M % 128 != 0 and G.eligible(x, wt)
+    y, part = G.product(x, wt, stats=True)
+    ref = F.conv2d(x.double(), wt.double())
+    lib = F.conv2d(x, wt)
+    assert _err(y, ref) <= 1.25 * _err(lib, ref) + 1e-7
+    assert part.shape[0] == -(-M // 128)
+    s = part.double().sum(0)
+    yy = y.double().permute(0, 2, 3, 1).reshape(-1, co)
+    assert torch.allclose(s[0], yy.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(s[1], (yy * yy).sum(0), rtol=1e-5, atol=1e-3)
+    # guard band: the launch writes M rows and not one float more
+    tn = G.tile_n(M, co)
+    buf = torch.full((M * co + 128 * co,), 7.25, device=DEV)
+    with torch.cuda.device(DEV):
+        L.call("dbev_gemm_bf16x6_forward_stats", L.ptr(x), L.ptr(G.packed(wt, False, tn)), L.ptr(buf), None, M, ci, co, ci, int(tn), L.stream_ptr(DEV))
+    assert torch.equal(buf[:M * co].view(n, h, w, co).permute(0, 3, 1, 2), y) and bool((buf[M * co:] == 7.25).all())
+    # weight gradient: fixed order, equal to fp64 within the library's error
+    gy = torch.randn_like(y)
+    g1 = G.weight_gradient(x, gy, wt)
+    assert g1 is not None and torch.equal(g1, G.weight_gradient(x, gy, wt))
+    gref = torch.einsum("nohw,nihw->oi", gy.double(), x.double())
+    glib = torch.ops.aten.convolution_backward(gy, x, wt, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert _err(g1.reshape(co, ci), gref) <= 1.25 * _err(glib.reshape(co, ci), gref) + 1e-7

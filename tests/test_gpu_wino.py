@@ -211,8 +211,8 @@ def test_persistent_hybrid_and_plain_launches_of_a_2_25_round_layer(tmp_path):
     workgroups walking per-XCD item queues (wino_fwdp, kernel code 2: DBEV_WINO_PERSIST=1; measured neutral, off by default), the
     default hybrid (wino_fwd for the whole rounds, wino_fwd3 for the remaining tile rows, code 6) and plain wino_fwd
     (DBEV_WINO_FWD_V=2): each against fp64
-    (output, statistics rows, both gradients), repeated launches bit-identical, and the three outputs bit-identical to each other (the
-    per-item arithmetic is the same whichever workgroup runs it)"""
+    (output, statistics rows, both gradients), repeated launches bit-identical, the persistent kernel's output bit-identical to plain
+    wino_fwd's (the per-item arithmetic is the same whichever workgroup runs it), the hybrid's equal to rounding"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = {k: v for k, v in os.environ.items() if k not in ("DBEV_WINO_FWD_V", "DBEV_WINO_PERSIST", "DBEV_WINO_HYBRID")}
@@ -223,7 +223,9 @@ def test_persistent_hybrid_and_plain_launches_of_a_2_25_round_layer(tmp_path):
         assert r.returncode == 0 and "OK code %d" % code in r.stdout, (name, r.stdout[-500:], r.stderr[-1500:])
         outs[name] = torch.load(f)
     assert torch.equal(outs["persistent"]["y"], outs["plain"]["y"])      # (the data gradient's 144 items go to another kernel by default)
-    assert torch.equal(outs["hybrid"]["y"], outs["plain"]["y"])
+    # (the hybrid's tail rows run on wino_fwd3, whose two position halves meet in a different summation order: equal to rounding)
+    d = (outs["hybrid"]["y"] - outs["plain"]["y"]).abs().max()
+    assert float(d) <= 2e-6 * float(outs["plain"]["y"].abs().max()) and not torch.equal(outs["hybrid"]["y"], torch.zeros_like(outs["hybrid"]["y"]))
     assert torch.allclose(outs["persistent"]["part_sum"], outs["hybrid"]["part_sum"], rtol=1e-6)      # (row layouts differ: the sums agree)
 
 
