@@ -313,15 +313,22 @@ def test_eval_coefficients_are_kept_on_the_module_and_follow_every_change_of_its
         return bn.__dict__["_dbev_eval_coef"][1]
     c0 = check()
     assert check() is c0                                        # unchanged module: the kept tensor is reused
+    # every change below re-derives the coefficients INTO THE SAME TENSOR (round 6: a captured hipGraph may read through its address,
+    # graphed.py) -- check() has compared the values with torch's batch_norm each time
+    v0 = c0.clone()
     bn.train(); BA.bn_act(x * 3 + 1, bn, None, True)            # running statistics move (in-kernel update)
     c1 = check()
-    assert c1 is not c0
+    assert c1 is c0 and not torch.equal(c1, v0)
+    v1 = c1.clone()
     with torch.no_grad():
         bn.weight.mul_(1.5); bn.bias.add_(0.25)                 # optimizer-style in-place parameter update
     c2 = check()
-    assert c2 is not c1
+    assert c2 is c0 and not torch.equal(c2, v1)
+    v2 = c2.clone()
     bn.load_state_dict({k: torch.rand_like(v.float()).to(v.dtype) + 0.5 if v.is_floating_point() else v for k, v in bn.state_dict().items()})
-    assert check() is not c2
+    assert check() is c0 and not torch.equal(c0, v2)
+    BA.invalidate_eval_coef(bn)                                 # the documented invalidation drops the tensor: a new one next time
+    assert check() is not c0
 
 
 @pytest.mark.parametrize("dual", [False, True])
