@@ -60,6 +60,8 @@ def eligible(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1
 def matrix(weight):
     """the [Cout, K] matrix the GEMM kernels multiply by: a 1x1 filter itself (either memory format), or the channels-last memory
     [Cout][ky][kx][c] of a k x k filter taken as K = k k Cin columns (a view when the filter is channels-last contiguous)"""
+    if weight.dim() == 2:                                    # nn.Linear's [out_features, in_features]
+        return weight.detach()
     Co, Ci, kh, kw = weight.shape
     if (kh, kw) == (1, 1):
         return weight.detach().reshape(Co, Ci)
@@ -197,7 +199,7 @@ def weight_gradient(x, gy, weight):
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         L.call("dbev_gemm_bf16x6_backward_weight", L.ptr(x), L.ptr(gy), L.ptr(gw2), M, Ci, Co, Ci, L.ptr(ws), nbytes, L.stream_ptr(dev))
-    return gw2.view(Co, Ci, 1, 1)                           # [Co, Ci] in memory: contiguous in both memory formats of a 1x1 filter
+    return gw2.view(weight.shape)                           # [Co, Ci] in memory: contiguous in both memory formats of a 1x1 filter (and a Linear's 2-D weight)
 
 
 # ---- stride-2 1x1 convolutions: subsample + GEMM (csrc/stride2.hip) -------------------------------------------------------------------
@@ -429,6 +431,91 @@ class Bf6Conv2d(nn.Conv2d):
                 return product(subsample2(x), self.weight)
             return conv1x1_s2(x, self.weight)
         return super().forward(x)
+
+
+# ---- nn.Linear on [tokens, C] (round 6): the transformer's projections and FFNs of the BEVFormer recipe -----------------------------------
+_LIN = os.environ.get("DBEV_BF6_LINEAR", "1") != "0"
+
+
+def _rows_as_nhwc(x2):
+    """[M, K] row-major -> the same memory as a channels-last [1, K, M, 1] tensor (a view): the GEMM kernels' activation operand"""
+    M, K = x2.shape
+    return x2.view(1, M, 1, K).permute(0, 3, 1, 2)
+
+
+def eligible_linear(x, weight):
+    """can `F.linear(x, weight)` run on the bf16x6 GEMM?  fp32 device tensors, in / out features multiples of 64, enough rows to fill the
+    chip (`shape_ok`: the decoder's 900 queries stay with the library, the encoder's 200 x 200 BEV queries come here)"""
+    if not (_ON and _LIN and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.dim() >= 2):
+        return False
+    N, K = weight.shape
+    if x.shape[-1] != K or not weight.is_contiguous():
+        return False
+    M = x.numel() // K
+    return M * max(K, N) < 2 ** 31 and shape_ok(M, K, N)
+
+
+class _LinearBf6(Function):
+    """F.linear(x2, weight, bias) for x2 [M, K] contiguous: forward and both gradients on the bf16x6 kernels (the library where a shape
+    rule says no), bias added in a separate pass / its gradient a column sum -- torch.nn.Linear's semantics (transformer_modules/*.py of
+    the reference call plain nn.Linear)"""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        M, K = x2.shape
+        N = int(weight.shape[0])
+        if ctx.needs_input_grad[0] and shape_ok(M, N, K):
+            pack_both(weight, M)
+        y = product(_rows_as_nhwc(x2), weight).permute(0, 2, 3, 1).reshape(M, N)      # (a view of the channels-last output)
+        if bias is not None:
+            y.add_(bias)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        M, N = gy.shape
+        gx = gw = gb = None
+        g4 = _rows_as_nhwc(gy)
+        if ctx.needs_input_grad[0]:
+            g = data_gradient(g4, weight)
+            gx = g.permute(0, 2, 3, 1).reshape(M, -1) if g is not None else gy @ weight
+        if ctx.needs_input_grad[1]:
+            gw = weight_gradient(_rows_as_nhwc(x2), g4, weight)
+            if gw is None:
+                gw = gy.t() @ x2
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            from . import colsum
+            gb = colsum.channel_sum(gy) if colsum.eligible(gy) else gy.sum(0)
+        return gx, gw, gb
+
+
+class Bf6Linear(nn.Linear):
+    """nn.Linear whose product runs on the bf16x6 GEMM when `eligible_linear`; torch's otherwise.  Same parameters and state-dict keys."""
+
+    def forward(self, x):
+        if eligible_linear(x, self.weight):
+            K = self.in_features
+            x2 = x.reshape(-1, K)
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            return _LinearBf6.apply(x2, self.weight, self.bias).view(*x.shape[:-1], self.out_features)
+        return super().forward(x)
+
+
+def use_bf6_linears(model):
+    """Re-class the plain nn.Linear modules with in / out features multiples of 64; returns how many.  Idempotent."""
+    if not (_ON and _LIN):
+        return 0
+    n = 0
+    for m in model.modules():
+        if type(m) is nn.Linear and m.in_features % 64 == 0 and m.out_features % 64 == 0:
+            m.__class__ = Bf6Linear
+            n += 1
+    return n
 
 
 def use_bf6_convs(model):

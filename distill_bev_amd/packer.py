@@ -33,11 +33,11 @@ assert _JOB.itemsize == 72
 
 class WeightPacker:
     def __init__(self, roots):
-        from .gemm_bf6 import Bf6Conv2d, Bf6Conv3x3S2
+        from .gemm_bf6 import Bf6Conv2d, Bf6Conv3x3S2, Bf6Linear
         from .wino import WinoConv2d
         mods = [m for r in roots if r is not None for m in r.modules()]
         self.wino = [m.weight for m in mods if type(m) is WinoConv2d and m.weight.requires_grad]
-        self.bf6 = [m.weight for m in mods if type(m) in (Bf6Conv2d, Bf6Conv3x3S2) and m.weight.requires_grad]
+        self.bf6 = [m.weight for m in mods if type(m) in (Bf6Conv2d, Bf6Conv3x3S2, Bf6Linear) and m.weight.requires_grad]
         self._tables = {}                      # family -> (signature, device table, n jobs, max size, per-job (weight, new cache entry maker))
         self.launches = 0
         self.skipped = []                      # of the last repack(): stale weights left to the lazy path, with the reason

@@ -146,6 +146,8 @@ def accelerate_modules(detector):
         detector.batched_branches = sum(plan_branches(m) for r in roots for m in r.modules() if isinstance(m, CenterHead))
     from .gemm_bf6 import use_bf6_convs
     detector.bf6_convs = sum(use_bf6_convs(r) for r in roots)          # bias-free 1x1 convolutions: fp32 GEMM on the bf16 matrix cores (bf16x6)
+    from .gemm_bf6 import use_bf6_linears
+    detector.bf6_linears = sum(use_bf6_linears(r) for r in roots)      # nn.Linear on [tokens, C] with enough tokens (the BEVFormer encoder)
     from .stem import use_stem_convs
     detector.stem_convs = sum(use_stem_convs(r) for r in roots)        # the image backbone's 7x7 / stride-2 stem: fp32 MFMA kernel of its own
     from .colsum import use_bias_sum_convs

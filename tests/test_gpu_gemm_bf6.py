@@ -365,3 +365,36 @@ def test_rows_past_the_last_block_load_zeros_and_store_nothing(n, ci, co, h, w, 
     gref = torch.einsum("nohw,nihw->oi", gy.double(), x.double())
     glib = torch.ops.aten.convolution_backward(gy, x, wt, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
     assert _err(g1.reshape(co, ci), gref) <= 1.25 * _err(glib.reshape(co, ci), gref) + 1e-7
+
+
+@pytest.mark.parametrize("shape,ci,co", [((40000,), 256, 512), ((2, 20000), 512, 256), ((1, 40000), 256, 128), ((3, 7001), 256, 64)])
+def test_linear_on_tokens_vs_fp64(shape, ci, co, monkeypatch):
+    """round 6: nn.Linear on [tokens, C] (the BEVFormer encoder's projections and FFNs, transformer_modules/*.py) re-classed to
+    Bf6Linear: output, input gradient, weight gradient and bias gradient against fp64, no worse than torch's fp32 linear; few tokens
+    (the decoder's 900 queries) stay with the library; same parameters and state-dict keys"""
+    from distill_bev_amd import gemm_bf6 as G
+    torch.manual_seed(5)
+    lin = nn.Sequential(nn.Linear(ci, co)).to(DEV)
+    ref = nn.Sequential(nn.Linear(ci, co)).to(DEV)
+    ref.load_state_dict(lin.state_dict())
+    assert G.use_bf6_linears(lin) == 1 and type(lin[0]) is G.Bf6Linear and G.use_bf6_linears(lin) == 0
+    assert list(lin.state_dict()) == ["0.weight", "0.bias"]
+    x = torch.randn(shape + (ci,), device=DEV)
+    assert G.eligible_linear(x, lin[0].weight)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y, yr = lin(xa), ref(xb)
+    gy = torch.randn_like(y)
+    y.backward(gy); yr.backward(gy)
+    xd = x.double().requires_grad_(True)
+    wd, bd = ref[0].weight.detach().double().requires_grad_(True), ref[0].bias.detach().double().requires_grad_(True)
+    yd = F.linear(xd, wd, bd)
+    yd.backward(gy.double())
+    assert y.shape == yr.shape
+    for got, lib, want in ((y.detach(), yr.detach(), yd.detach()), (xa.grad, xb.grad, xd.grad), (lin[0].weight.grad, ref[0].weight.grad, wd.grad),
+                           (lin[0].bias.grad, ref[0].bias.grad, bd.grad)):
+        assert _err(got, want) <= 1.25 * _err(lib, want) + 2e-7, (_err(got, want), _err(lib, want))
+    with torch.no_grad():
+        assert torch.equal(lin(x), y.detach())
+    few = torch.randn((900, ci), device=DEV)                                   # the decoder's query count: below the fill threshold
+    assert not G.eligible_linear(few, lin[0].weight)
+    assert torch.equal(lin(few), ref(few))
