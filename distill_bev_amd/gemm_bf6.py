@@ -443,6 +443,19 @@ def _rows_as_nhwc(x2):
     return x2.view(1, M, 1, K).permute(0, 3, 1, 2)
 
 
+def _rows_product(x2, weight, transposed):
+    """x2 [M, K] row-major times weight[N, K]^T (transposed: times weight [K', N'] itself, the data gradient) -> [M, N] row-major"""
+    dev = L.require_cuda(x2, weight)
+    M, K = x2.shape
+    cout = int(weight.shape[1 if transposed else 0])
+    tn = tile_n(M, cout)
+    pack = packed(weight, transposed, tn)
+    y = torch.empty((M, cout), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dbev_gemm_bf16x6_forward_stats", L.ptr(x2), L.ptr(pack), L.ptr(y), None, M, K, cout, K, int(tn), L.stream_ptr(dev))
+    return y
+
+
 def eligible_linear(x, weight):
     """can `F.linear(x, weight)` run on the bf16x6 GEMM?  fp32 device tensors, in / out features multiples of 64, enough rows to fill the
     chip (`shape_ok`: the decoder's 900 queries stay with the library, the encoder's 200 x 200 BEV queries come here)"""
@@ -466,7 +479,7 @@ class _LinearBf6(Function):
         N = int(weight.shape[0])
         if ctx.needs_input_grad[0] and shape_ok(M, N, K):
             pack_both(weight, M)
-        y = product(_rows_as_nhwc(x2), weight).permute(0, 2, 3, 1).reshape(M, N)      # (a view of the channels-last output)
+        y = _rows_product(x2, weight, False)                  # [M, N] row-major, its own storage (autograd forbids returning a view)
         if bias is not None:
             y.add_(bias)
         ctx.save_for_backward(x2, weight)
@@ -481,8 +494,8 @@ class _LinearBf6(Function):
         gx = gw = gb = None
         g4 = _rows_as_nhwc(gy)
         if ctx.needs_input_grad[0]:
-            g = data_gradient(g4, weight)
-            gx = g.permute(0, 2, 3, 1).reshape(M, -1) if g is not None else gy @ weight
+            K = int(weight.shape[1])
+            gx = _rows_product(gy, weight, True) if shape_ok(M, N, K) else gy @ weight
         if ctx.needs_input_grad[1]:
             gw = weight_gradient(_rows_as_nhwc(x2), g4, weight)
             if gw is None:
