@@ -99,6 +99,7 @@ _SIGNATURES = {
     "dbev_gemm_bf16x6_pack_pair": [_p, _ll, _ll, _i, _i, _i, _p, _i, _p, _p],
     "dbev_gemm_bf16x6_forward": [_p, _p, _p, _ll, _i, _i, _i, _i, _p],
     "dbev_gemm_bf16x6_forward_stats": [_p, _p, _p, _p, _ll, _i, _i, _i, _i, _p],
+    "dbev_gemm_bf16x6_forward_bias": [_p, _p, _p, _p, _ll, _i, _i, _i, _i, _p],
     "dbev_conv3x3s2_bf16x6_ok": [_i, _i, _i, _i, _i],
     "dbev_conv3x3s2_bf16x6_forward_stats": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dbev_gemm_bf16x6_stats_rows": [_ll],

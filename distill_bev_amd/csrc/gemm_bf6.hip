@@ -380,7 +380,7 @@ typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
 template <int BN, bool STATS, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, const unsigned short* __restrict__ Wp,
                                                   float* __restrict__ Y, float* __restrict__ partial, int M, int K, int N, int xs,
-                                                  B6Conv cv = B6Conv{}) {
+                                                  B6Conv cv = B6Conv{}, const float* __restrict__ bias = nullptr) {
   constexpr int WN = BN / 64, WM = 4 / WN, TM = B6_BM / WM / 32;            // waves along N / M, 32-row tiles per wave
   constexpr int APL = B6_BM * 32, BPL = BN * 32;                            // bytes of one plane of a chunk
   constexpr int ABUF = 3 * APL, BBUF = 3 * BPL;                             // 12288, 12288 / 6144
@@ -593,6 +593,16 @@ __global__ __launch_bounds__(256, 2) void b6_fwd2(const float* __restrict__ X, c
 #undef B6_DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped prefetches of the last chunks: no DMA may outlive the workgroup's LDS
   __syncthreads();                                           // ... nor land in the LDS another wave re-uses for its output tile below
+  if (bias != nullptr) {                                     // round 6: y = x W^T + bias (nn.Linear / a biased 1x1 convolution) without a pass of its own
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float bv = bias[n0 + (wn * 2 + b) * 32 + l31];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[a][b][r] = b6_add(tot[a][b][r], bv);
+    }
+  }
   if (STATS) {
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
@@ -1060,8 +1070,24 @@ extern "C" int dbev_gemm_bf16x6_pack_multi(const dbevPackJob* jobs_device, int n
 
 extern "C" int dbev_gemm_bf16x6_stats_rows(long long M) { return (M > 0 && M <= 0x7fffffffLL - B6_BM) ? static_cast<int>((M + B6_BM - 1) / B6_BM) : 0; }
 
+namespace {
+int b6_forward(const float* x, const void* packed, const float* bias, float* y, float* stats_partial, long long M, int K, int N,
+               int x_row_stride, int tile_n, dbevStream_t stream);
+}
+
 extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed, float* y, float* stats_partial, long long M, int K, int N,
                                               int x_row_stride, int tile_n, dbevStream_t stream) {
+  return b6_forward(x, packed, nullptr, y, stats_partial, M, K, N, x_row_stride, tile_n, stream);
+}
+
+extern "C" int dbev_gemm_bf16x6_forward_bias(const float* x, const void* packed, const float* bias, float* y, long long M, int K, int N,
+                                             int x_row_stride, int tile_n, dbevStream_t stream) {
+  return b6_forward(x, packed, bias, y, nullptr, M, K, N, x_row_stride, tile_n, stream);
+}
+
+namespace {
+int b6_forward(const float* x, const void* packed, const float* bias, float* y, float* stats_partial, long long M, int K, int N,
+               int x_row_stride, int tile_n, dbevStream_t stream) {
   if (!b6_ok(M, K, N, x_row_stride) || x == nullptr || packed == nullptr || y == nullptr || (tile_n != 0 && tile_n != 64 && tile_n != 128) ||
       (tile_n == 128 && (N % 128) != 0))
     return DBEV_EINVAL;
@@ -1073,7 +1099,7 @@ extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed
   static const int dbg = getenv("DBEV_BF6_DBG") ? atoi(getenv("DBEV_BF6_DBG")) : 0;
   const unsigned short* pw = static_cast<const unsigned short*>(packed);
   static const int ver = getenv("DBEV_BF6_V") ? atoi(getenv("DBEV_BF6_V")) : 2;          // 1: the round-4 kernel (A/B runs)
-  if (ver != 2 && (M % B6_BM) != 0) return DBEV_EINVAL;           // (the round-4 kernel takes whole 128-row blocks only)
+  if (ver != 2 && ((M % B6_BM) != 0 || bias != nullptr)) return DBEV_EINVAL;   // (the round-4 kernel: whole 128-row blocks, no bias)
   if (ver == 2) {
 #define B6_GO2(BNV, ST)                                                                                                            \
   do {                                                                                                                             \
@@ -1083,7 +1109,8 @@ extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed
       DBEV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b6_fwd2<BNV, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_)); \
       once_ = true;                                                                                                                \
     }                                                                                                                              \
-    hipLaunchKernelGGL((b6_fwd2<BNV, ST>), dim3(grid), dim3(256), lds_, s, x, pw, y, stats_partial, m, K, N, x_row_stride);        \
+    hipLaunchKernelGGL((b6_fwd2<BNV, ST>), dim3(grid), dim3(256), lds_, s, x, pw, y, stats_partial, m, K, N, x_row_stride,         \
+                       B6Conv{}, bias);                                                                                           \
   } while (0)
     if (bn == 128) { if (stats_partial != nullptr) B6_GO2(128, true); else B6_GO2(128, false); }
     else { if (stats_partial != nullptr) B6_GO2(64, true); else B6_GO2(64, false); }
@@ -1098,6 +1125,7 @@ extern "C" int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed
   DBEV_LAUNCH_CHECK();
   return 0;
 }
+}  // namespace
 
 extern "C" int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride,
                                         int tile_n, dbevStream_t stream) {

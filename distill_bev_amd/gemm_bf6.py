@@ -150,7 +150,7 @@ def pack_both(weight, M):
     cache[1][(True, tt)] = bt
 
 
-def gemm(x, pack, Cout, tn, stats=False):
+def gemm(x, pack, Cout, tn, stats=False, bias=None):
     """x [N, K, H, W] channels-last -> [N, Cout, H, W] channels-last with weight planes packed for tile width `tn` (`product` pairs
     the pack and the launch); stats: also the partial BatchNorm statistics rows f32[M / 128, 2, Cout] of the output (kernel epilogue)"""
     dev = L.require_cuda(x, pack)
@@ -159,16 +159,19 @@ def gemm(x, pack, Cout, tn, stats=False):
     y = torch.empty((n, Cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     part = torch.empty((int(L.call("dbev_gemm_bf16x6_stats_rows", M)), 2, Cout), dtype=torch.float32, device=dev) if stats else None
     with torch.cuda.device(dev):
-        L.call("dbev_gemm_bf16x6_forward_stats", L.ptr(x), L.ptr(pack), L.ptr(y), L.ptr(part), M, K, Cout, K, int(tn), L.stream_ptr(dev))
+        if bias is not None and not stats:                    # (round 6: the bias in the kernel's epilogue)
+            L.call("dbev_gemm_bf16x6_forward_bias", L.ptr(x), L.ptr(pack), L.ptr(bias), L.ptr(y), M, K, Cout, K, int(tn), L.stream_ptr(dev))
+        else:
+            L.call("dbev_gemm_bf16x6_forward_stats", L.ptr(x), L.ptr(pack), L.ptr(y), L.ptr(part), M, K, Cout, K, int(tn), L.stream_ptr(dev))
     return (y, part) if stats else y
 
 
-def product(x, weight, transposed=False, stats=False):
+def product(x, weight, transposed=False, stats=False, bias=None):
     """x [N, K, H, W] channels-last times the 1x1 filter `weight` [Cout, Cin, 1, 1] (transposed: its transpose, the data gradient's
     operand) -> channels-last; no autograd.  The tile width follows the layer's row count (`tile_n`), the pack is made for it."""
     cout = int(weight.shape[1 if transposed else 0])
     tn = tile_n(x.shape[0] * x.shape[2] * x.shape[3], cout)
-    return gemm(x, packed(weight, transposed, tn), cout, tn, stats)
+    return gemm(x, packed(weight, transposed, tn), cout, tn, stats, bias)
 
 
 def data_gradient(gy, weight):
@@ -300,9 +303,10 @@ class _Conv1x1Bf6(Function):
             ctx.mark_non_differentiable(part)
             ctx.set_materialize_grads(False)              # no zero tensor for the (never used) gradient of the statistics output
             return y, part
-        y = product(x, weight)
-        if bias is not None:
-            y.add_(bias.view(1, -1, 1, 1))                    # the separate bias pass ATen runs behind the library's convolution
+        fused = _BIAS and bias is not None and bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous()
+        y = product(x, weight, bias=bias if fused else None)  # (round 6: the bias in the GEMM's epilogue, not a pass of its own)
+        if bias is not None and not fused:
+            y.add_(bias.view(1, -1, 1, 1))
         return y
 
     @staticmethod
@@ -435,6 +439,7 @@ class Bf6Conv2d(nn.Conv2d):
 
 # ---- nn.Linear on [tokens, C] (round 6): the transformer's projections and FFNs of the BEVFormer recipe -----------------------------------
 _LIN = os.environ.get("DBEV_BF6_LINEAR", "1") != "0"
+_BIAS = os.environ.get("DBEV_BF6_BIAS", "1") != "0"          # the bias in the GEMM's epilogue (0: a separate pass, for A/B runs)
 
 
 def _rows_as_nhwc(x2):
@@ -443,16 +448,20 @@ def _rows_as_nhwc(x2):
     return x2.view(1, M, 1, K).permute(0, 3, 1, 2)
 
 
-def _rows_product(x2, weight, transposed):
-    """x2 [M, K] row-major times weight[N, K]^T (transposed: times weight [K', N'] itself, the data gradient) -> [M, N] row-major"""
-    dev = L.require_cuda(x2, weight)
+def _rows_product(x2, weight, transposed, bias=None):
+    """x2 [M, K] row-major times weight[N, K]^T (+ bias[N], in the kernel's epilogue; transposed: times weight [K', N'] itself, the data
+    gradient) -> [M, N] row-major"""
+    dev = L.require_cuda(x2, weight, bias)
     M, K = x2.shape
     cout = int(weight.shape[1 if transposed else 0])
     tn = tile_n(M, cout)
     pack = packed(weight, transposed, tn)
     y = torch.empty((M, cout), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        L.call("dbev_gemm_bf16x6_forward_stats", L.ptr(x2), L.ptr(pack), L.ptr(y), None, M, K, cout, K, int(tn), L.stream_ptr(dev))
+        if bias is not None:
+            L.call("dbev_gemm_bf16x6_forward_bias", L.ptr(x2), L.ptr(pack), L.ptr(bias), L.ptr(y), M, K, cout, K, int(tn), L.stream_ptr(dev))
+        else:
+            L.call("dbev_gemm_bf16x6_forward_stats", L.ptr(x2), L.ptr(pack), L.ptr(y), None, M, K, cout, K, int(tn), L.stream_ptr(dev))
     return y
 
 
@@ -479,8 +488,10 @@ class _LinearBf6(Function):
         N = int(weight.shape[0])
         if ctx.needs_input_grad[0] and shape_ok(M, N, K):
             pack_both(weight, M)
-        y = _rows_product(x2, weight, False)                  # [M, N] row-major, its own storage (autograd forbids returning a view)
-        if bias is not None:
+        # [M, N] row-major, its own storage (autograd forbids returning a view); the bias in the kernel's epilogue
+        fused = _BIAS and bias is not None and bias.is_contiguous() and bias.dtype == torch.float32
+        y = _rows_product(x2, weight, False, bias if fused else None)
+        if bias is not None and not fused:
             y.add_(bias)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None

@@ -704,6 +704,11 @@ int dbev_gemm_bf16x6_forward_stats(const float* x, const void* packed, float* y,
  * (N = Cout, K = Cin, tile_fwd) and the data gradient's (N = Cin, K = Cout, tile_dgrad) */
 int dbev_gemm_bf16x6_pack_pair(const float* weight, long long stride_o, long long stride_c, int Cout, int Cin, int tile_fwd,
                                void* packed_fwd, int tile_dgrad, void* packed_dgrad, dbevStream_t stream);
+/* Round 6: y = x weight^T + bias[N] with the bias added in the kernel's epilogue (no pass of its own): torch.nn.Linear on [tokens, C] rows
+ * (the BEVFormer encoder's projections and FFNs, projects/mmdet3d_plugin/bevformer/modules/: encoder.py, spatial_cross_attention.py, temporal_self_attention.py)
+ * and biased 1x1 convolutions. */
+int dbev_gemm_bf16x6_forward_bias(const float* x, const void* packed, const float* bias, float* y, long long M, int K, int N,
+                                  int x_row_stride, int tile_n, dbevStream_t stream);
 int dbev_gemm_bf16x6_forward(const float* x, const void* packed, float* y, long long M, int K, int N, int x_row_stride, int tile_n,
                              dbevStream_t stream);
 /* weight gradient of the same layer, grad_weight[Cout, Cin] = sum_m grad_y[m, Cout] * x[m, Cin] (both operands split on the fly,
