@@ -129,13 +129,14 @@ class _BNActTrain(Function):
                    L.ptr(gmask), L.ptr(ws), ws.numel(), L.stream_ptr(dev),
                    alg_bytes=4 * M * C * (3 + (residual is not None) - (pre is not None)))     # x (stats), x (apply) [+ res] + y
         L.touched(running_mean, running_var, nbt)
-        ctx.gmask = gmask
         y2 = _alias(y) if fork else None
         # both handles of a forked output are SAVED (whether or not the backward reads y): they share one storage but have separate
         # version counters, so an in-place op on either handle (`feat += ...`, `relu_`) would silently change what the other handle's
         # consumer saved for its backward -- saved, autograd's version check turns that into its usual "modified by an inplace
         # operation" error when this node's backward unpacks them.  Contract: forked outputs are never written in place.
-        ctx.save_for_backward(x, y if (need_y or fork) else None, weight, save_mean, save_invstd, coef, y2)
+        # (the gate mask travels through save_for_backward like everything else the backward reads: saved-tensor hooks / offloading see
+        # it -- ADVICE r5; when it exists the backward does not read y, which stays saved only as a forked handle, see above)
+        ctx.save_for_backward(x, y if ((need_y and gmask is None) or fork) else None, weight, save_mean, save_invstd, coef, y2, gmask)
         ctx.cfg = (M, C, bool(relu), residual is not None, need_y)
         if fork:
             ctx.set_materialize_grads(False)
@@ -144,7 +145,7 @@ class _BNActTrain(Function):
 
     @staticmethod
     def backward(ctx, dy, dy2=None):
-        x, y, weight, save_mean, save_invstd, coef, _y2 = ctx.saved_tensors      # unpacking checks the versions of both handles
+        x, y, weight, save_mean, save_invstd, coef, _y2, gmask = ctx.saved_tensors      # unpacking checks the versions of both handles
         M, C, relu, has_res, need_y = ctx.cfg
         if not need_y:
             y = None
@@ -160,7 +161,7 @@ class _BNActTrain(Function):
         nbytes = L.lib().dbev_bn_act_workspace_bytes(M, C)
         ws = torch.empty((nbytes + 12 * C,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            gm = ctx.gmask if need_y else None
+            gm = gmask if need_y else None
             L.call("dbev_bn_act_backward3", L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(y if gm is None else gm), int(gm is not None),
                    L.ptr(weight), L.ptr(save_mean), L.ptr(save_invstd), L.ptr(coef), int(relu), L.ptr(dx), L.ptr(dres), L.ptr(dgamma),
                    L.ptr(dbeta), M, C, L.ptr(ws), ws.numel(), L.stream_ptr(dev),
@@ -184,7 +185,6 @@ class _BNDualTrain(Function):
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         gmask = (torch.empty((M * C // 4,), dtype=torch.uint8, device=dev)
                  if relu and _state["gate_mask"] and any(ctx.needs_input_grad[:4]) else None)     # see _BNActTrain.forward
-        ctx.gmask = gmask
         with torch.cuda.device(dev):
             L.call("dbev_bn_dual_train_forward_mask", L.ptr(x), L.ptr(xd), L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), L.ptr(nbt),
                    float(mom or 0.0), float(eps), L.ptr(wd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), L.ptr(nbtd), float(momd or 0.0),
@@ -194,7 +194,7 @@ class _BNDualTrain(Function):
                    alg_bytes=4 * M * C * (5 - (pre is not None) - (pre_d is not None)))
         L.touched(rm, rv, nbt, rmd, rvd, nbtd)
         y2 = _alias(y) if fork else None
-        ctx.save_for_backward(x, xd, y if (relu or fork) else None, w, wd, stats, y2)     # both handles saved: see _BNActTrain.forward
+        ctx.save_for_backward(x, xd, y if ((relu and gmask is None) or fork) else None, w, wd, stats, y2, gmask)     # both handles saved: see _BNActTrain.forward
         ctx.cfg = (M, C, bool(relu))
         if fork:
             ctx.set_materialize_grads(False)
@@ -203,7 +203,7 @@ class _BNDualTrain(Function):
 
     @staticmethod
     def backward(ctx, dy, dy2=None):
-        x, xd, y, w, wd, stats, _y2 = ctx.saved_tensors
+        x, xd, y, w, wd, stats, _y2, gmask = ctx.saved_tensors
         M, C, relu = ctx.cfg
         if not relu:
             y = None
@@ -216,7 +216,7 @@ class _BNDualTrain(Function):
         nbytes = L.lib().dbev_bn_dual_workspace_bytes(M, C)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            gm = ctx.gmask if relu else None
+            gm = gmask if relu else None
             L.call("dbev_bn_dual_backward3", L.ptr(dy), L.ptr(dy2), L.ptr(x), L.ptr(xd), L.ptr(y if gm is None else gm), int(gm is not None),
                    L.ptr(w), L.ptr(stats[0]),
                    L.ptr(stats[1]), L.ptr(wd), L.ptr(stats[4]), L.ptr(stats[5]), int(relu), L.ptr(dx), L.ptr(dxd), L.ptr(g[0]),
