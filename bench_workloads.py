@@ -377,6 +377,12 @@ class DistillStep(_Base):
         from distill_bev_amd.train_step import GradReducer
         tr = self.trainer
         made_pg = False
+        # RCCL prints a version banner through C stdio when its first communicator comes up: this leg must not put anything on the
+        # process's stdout (bench.py's contract: ONE JSON line) -- file descriptor 1 points at stderr while the leg runs
+        import sys
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         try:
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -402,6 +408,14 @@ class DistillStep(_Base):
         finally:
             if made_pg:
                 dist.destroy_process_group()
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     def cpu_baseline(self):
         """The same training step with the reference's op sequence on the host cores
