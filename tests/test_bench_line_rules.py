@@ -44,3 +44,32 @@ def test_weight_packer_is_a_no_op_without_device_weights():
     assert p.wino == [] and p.bf6 == []
     p.repack()
     assert p.launches == 0
+
+
+def test_shader_clock_sampler_reads_the_starred_level_and_reports_why_when_it_cannot(tmp_path):
+    """round 6: bench.py samples the driver's pp_dpm_sclk during the timed region (the current level is the starred line)"""
+    import time
+    import bench
+    f = tmp_path / "pp_dpm_sclk"
+    f.write_text("0: 132Mhz\n1: 2174Mhz *\n")
+    s = bench._ClockSampler.__new__(bench._ClockSampler)
+    import threading
+    s.samples, s.source, s.why, s._stop = [], str(f), None, threading.Event()
+    s._thread = threading.Thread(target=s._run, daemon=True)
+    assert s._read() == 2174.0
+    s.start()
+    time.sleep(0.12)
+    f.write_text("0: 132Mhz *\n1: 2174Mhz\n")
+    time.sleep(0.12)
+    out = s.stop()
+    assert out["samples"] >= 2 and out["max_mhz"] == 2174.0 and out["min_mhz"] == 132.0 and out["nominal_mhz_of_the_peaks"] == 2400.0
+    s2 = bench._ClockSampler.__new__(bench._ClockSampler)
+    s2.samples, s2.source, s2.why, s2._stop, s2._thread = [], None, "no pp_dpm_sclk file matches the device (0 candidates)", threading.Event(), None
+    assert "unavailable" in s2.stop()
+
+
+def test_packer_reports_what_it_skipped_as_an_empty_list_without_device_weights():
+    import torch.nn as nn
+    from distill_bev_amd.packer import WeightPacker
+    p = WeightPacker([nn.Sequential(nn.Conv2d(64, 64, 1))])
+    assert p.repack() == [] and p.skipped == []
